@@ -1,0 +1,256 @@
+/*
+ * q4_oracle.c -- CPU restatement of fastLLaMa's ggml Q4_0/Q4_1 x Q8_0 hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it; the product (fastllama_amd/) never does.
+ *
+ * Parity status: PINNED.  Every function below is checked bit-for-bit (integers, scales)
+ * or to 0 ulp (float dots) against the reference itself, compiled out-of-tree by
+ * oracle/Makefile into oracle/_ref/ (tests/test_oracle_pinning.py), and against the golden
+ * vectors that build produced (tests/golden/, generator tests/golden/make_golden.py).
+ *
+ * The arithmetic restated here is what the reference executes in its default x86 build
+ * (gcc -O3 -march=native => the __AVX2__ branches of lib/ggml.c), written as plain scalar C
+ * that models the 8 float lanes of a __m256 explicitly so the float summation ORDER is the
+ * reference's.  Compile with -ffp-contract=off: every fused multiply-add below is spelled
+ * fmaf() where (and only where) the reference build fuses.
+ *
+ * All citations are file:line into /root/reference.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define QK 32 /* elements per block for Q4_0, Q4_1 and Q8_0: lib/ggml.c:589,596,619 */
+
+/* lib/ggml.c:590-595 */
+typedef struct { float d; uint8_t qs[QK / 2]; } orc_block_q4_0;           /* 20 B */
+/* lib/ggml.c:597-603 */
+typedef struct { float d; float m; uint8_t qs[QK / 2]; } orc_block_q4_1;  /* 24 B */
+/* lib/ggml.c:620-626 */
+typedef struct { float d; float s; int8_t qs[QK]; } orc_block_q8_0;       /* 40 B */
+
+_Static_assert(sizeof(orc_block_q4_0) == 20, "q4_0 block");
+_Static_assert(sizeof(orc_block_q4_1) == 24, "q4_1 block");
+_Static_assert(sizeof(orc_block_q8_0) == 40, "q8_0 block");
+
+/* ------------------------------------------------------------------------------------------
+ * Weight quantizers (used only to MAKE synthetic inputs; lib/ggml.c:630-664 and :917-956,
+ * the *_reference variants that ggml_quantize_q4_0/1 call, lib/ggml.c:12122-12166).
+ * ---------------------------------------------------------------------------------------- */
+void orc_quantize_row_q4_0(const float *x, void *vy, int k) {
+    orc_block_q4_0 *y = (orc_block_q4_0 *)vy;
+    for (int b = 0; b < k / QK; ++b) {
+        float amax = 0.0f;
+        for (int l = 0; l < QK; ++l) {
+            const float a = fabsf(x[b * QK + l]);
+            if (a > amax) amax = a;                         /* MAX(amax, fabsf(v)) :637-640 */
+        }
+        const float d = amax / 7.0f;                         /* (1<<3)-1          :642 */
+        const float id = d != 0.0f ? 1.0f / d : 0.0f;        /* :643 */
+        y[b].d = d;
+        for (int l = 0; l < QK; l += 2) {
+            const uint8_t lo = (uint8_t)((int8_t)roundf(x[b * QK + l] * id) + 8);      /* :651 */
+            const uint8_t hi = (uint8_t)((int8_t)roundf(x[b * QK + l + 1] * id) + 8);  /* :652 */
+            y[b].qs[l / 2] = (uint8_t)(lo | (hi << 4));      /* element 2j -> LOW nibble :657 */
+        }
+    }
+}
+
+void orc_quantize_row_q4_1(const float *x, void *vy, int k) {
+    orc_block_q4_1 *y = (orc_block_q4_1 *)vy;
+    for (int b = 0; b < k / QK; ++b) {
+        float mn = FLT_MAX, mx = -FLT_MAX;                   /* :926-933 */
+        for (int l = 0; l < QK; ++l) {
+            const float v = x[b * QK + l];
+            if (v < mn) mn = v;
+            if (v > mx) mx = v;
+        }
+        const float d = (mx - mn) / 15.0f;                   /* :935 */
+        const float id = d != 0.0f ? 1.0f / d : 0.0f;
+        y[b].d = d;
+        y[b].m = mn;
+        for (int l = 0; l < QK; l += 2) {
+            const uint8_t lo = (uint8_t)roundf((x[b * QK + l] - mn) * id);             /* :942-946 */
+            const uint8_t hi = (uint8_t)roundf((x[b * QK + l + 1] - mn) * id);
+            y[b].qs[l / 2] = (uint8_t)(lo | (hi << 4));
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a4: quantize_row_q8_0, AVX2 flavour lib/ggml.c:1341-1403 + the `s` fix-up :1433-1440.
+ *   maxScalar = max |x|                     :1350-1360
+ *   d  = maxScalar / 127.f                  :1363
+ *   id = maxScalar != 0 ? 127.f/maxScalar:0 :1365   (NOT 1/d as the scalar :1261 does)
+ *   q  = cvtps_epi32(round_nearest(x*id))   :1369-1385  round-half-to-even
+ *   s  = d * (float)sum(q)                  :1433-1440
+ * ---------------------------------------------------------------------------------------- */
+void orc_quantize_row_q8_0(const float *x, void *vy, int k) {
+    orc_block_q8_0 *y = (orc_block_q8_0 *)vy;
+    for (int b = 0; b < k / QK; ++b) {
+        float amax = 0.0f;
+        for (int l = 0; l < QK; ++l) {
+            const float a = fabsf(x[b * QK + l]);
+            if (a > amax) amax = a;
+        }
+        const float d = amax / 127.0f;
+        const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
+        y[b].d = d;
+        int sum = 0;
+        for (int l = 0; l < QK; ++l) {
+            const float v = x[b * QK + l] * id;
+            const int q = (int)nearbyintf(v);   /* default FP env = round-half-even, as _MM_ROUND_NEAREST */
+            y[b].qs[l] = (int8_t)q;              /* |q| <= 127 always, packs never saturate */
+            sum += q;
+        }
+        y[b].s = d * (float)sum;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a7: dequantizers.  AVX2 flavour lib/ggml.c:1449-1482 (Q4_0: (nib-8)*d) and :1567-1597
+ * (Q4_1: nib*d + m).  In the reference's gcc -O3 build the Q4_1 `_mm256_add_ps(_mm256_mul_ps())`
+ * pair at :1593 is written with intrinsics that GCC lowers to plain vector * and +, which its
+ * default -ffp-contract=fast then fuses into one vfmadd (checked in oracle/_ref/ggml.o) =>
+ * fmaf here.  Element 2j is the low nibble of byte j (bytes_from_nibbles_32, :453-469).
+ * ---------------------------------------------------------------------------------------- */
+void orc_dequantize_row_q4_0(const void *vx, float *y, int k) {
+    const orc_block_q4_0 *x = (const orc_block_q4_0 *)vx;
+    for (int b = 0; b < k / QK; ++b) {
+        const float d = x[b].d;
+        for (int j = 0; j < QK / 2; ++j) {
+            const int lo = (x[b].qs[j] & 0x0F) - 8;
+            const int hi = (x[b].qs[j] >> 4) - 8;
+            y[b * QK + 2 * j + 0] = (float)lo * d;
+            y[b * QK + 2 * j + 1] = (float)hi * d;
+        }
+    }
+}
+
+void orc_dequantize_row_q4_1(const void *vx, float *y, int k) {
+    const orc_block_q4_1 *x = (const orc_block_q4_1 *)vx;
+    for (int b = 0; b < k / QK; ++b) {
+        const float d = x[b].d, m = x[b].m;
+        for (int j = 0; j < QK / 2; ++j) {
+            const int lo = x[b].qs[j] & 0x0F;
+            const int hi = x[b].qs[j] >> 4;
+            y[b * QK + 2 * j + 0] = fmaf((float)lo, d, m);
+            y[b * QK + 2 * j + 1] = fmaf((float)hi, d, m);
+        }
+    }
+}
+
+/* 8-lane horizontal sum exactly as lib/ggml.c:2482-2487 / :2682-2687:
+ *   res[k] = acc[k+4] + acc[k]  (extractf128 + add_ps)
+ *   res[k] = res[k] + res[k+2]  (movehl)       k = 0,1
+ *   out    = res[0] + res[1]    (movehdup + add_ss)                                      */
+static inline float orc_hsum8(const float acc[8]) {
+    float r0 = acc[4] + acc[0], r1 = acc[5] + acc[1], r2 = acc[6] + acc[2], r3 = acc[7] + acc[3];
+    r0 = r0 + r2;
+    r1 = r1 + r3;
+    return r0 + r1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a5: ggml_vec_dot_q4_0_q8_0, AVX2 branch lib/ggml.c:2445-2487.
+ * Per block: d = d_w * d_x (f32 mul, :2452); the 32 int8 products are reduced by
+ * maddubs+madd to 8 int32 lanes, lane j = sum of elements 4j..4j+3 (:2468-2472);
+ * acc[j] = fma(d, (float)lane_j, acc[j]) (:2478).
+ * ---------------------------------------------------------------------------------------- */
+void orc_vec_dot_q4_0_q8_0(int n, float *s, const void *vx, const void *vy) {
+    const orc_block_q4_0 *x = (const orc_block_q4_0 *)vx;
+    const orc_block_q8_0 *y = (const orc_block_q8_0 *)vy;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < n / QK; ++b) {
+        const float d = x[b].d * y[b].d;
+        for (int j = 0; j < 8; ++j) {
+            int isum = 0;
+            for (int e = 4 * j; e < 4 * j + 4; ++e) {
+                const int nib = (e & 1) ? (x[b].qs[e >> 1] >> 4) : (x[b].qs[e >> 1] & 0x0F);
+                isum += (nib - 8) * (int)y[b].qs[e];
+            }
+            acc[j] = fmaf(d, (float)isum, acc[j]);
+        }
+    }
+    *s = orc_hsum8(acc);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a6: ggml_vec_dot_q4_1_q8_0, AVX2 branch lib/ggml.c:2639-2689.
+ * As a5 with unsigned nibbles, plus the scalar side-sum  summs += m_w * s_x  (:2651), which
+ * the reference's gcc build contracts to one vfmadd231ss (oracle/_ref disassembly) => fmaf.
+ * Result = hsum(acc) + summs (:2689).
+ * ---------------------------------------------------------------------------------------- */
+void orc_vec_dot_q4_1_q8_0(int n, float *s, const void *vx, const void *vy) {
+    const orc_block_q4_1 *x = (const orc_block_q4_1 *)vx;
+    const orc_block_q8_0 *y = (const orc_block_q8_0 *)vy;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float summs = 0.0f;
+    for (int b = 0; b < n / QK; ++b) {
+        summs = fmaf(x[b].m, y[b].s, summs);
+        const float d = x[b].d * y[b].d;
+        for (int j = 0; j < 8; ++j) {
+            int isum = 0;
+            for (int e = 4 * j; e < 4 * j + 4; ++e) {
+                const int nib = (e & 1) ? (x[b].qs[e >> 1] >> 4) : (x[b].qs[e >> 1] & 0x0F);
+                isum += nib * (int)y[b].qs[e];
+            }
+            acc[j] = fmaf(d, (float)isum, acc[j]);
+        }
+    }
+    *s = orc_hsum8(acc) + summs;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a9: ggml_compute_forward_mul_mat_q_f32, lib/ggml.c:7928-8176 (non-BLAS path).
+ *   INIT    :8105-8119  every activation row x[n][0..K) -> Q8_0 into a work buffer
+ *   COMPUTE :8127-8163  y[n][m] = vec_dot_q(K, W row m, q8 row n); W rows split over threads
+ * type: 2 = Q4_0, 3 = Q4_1 (include/ggml.h:200-212).  W is M rows of K/32 AoS blocks;
+ * x is N rows of K f32; y is N rows of M f32 (dst ne0 = M).  Returns 0, or -1 on bad args.
+ * Each output is produced by exactly one thread in a fixed order, so the result does not
+ * depend on n_threads (same property as the reference).
+ * ---------------------------------------------------------------------------------------- */
+int orc_mul_mat_q_f32(int type, const void *W, const float *x, float *y,
+                      int M, int K, int N, int n_threads) {
+    if ((type != 2 && type != 3) || K % 64 != 0 || M <= 0 || N <= 0) return -1;  /* nb%2==0 :2372 */
+    const size_t wrow = (size_t)(K / QK) * (type == 2 ? sizeof(orc_block_q4_0) : sizeof(orc_block_q4_1));
+    const size_t qrow = (size_t)(K / QK) * sizeof(orc_block_q8_0);
+    char *wdata = (char *)malloc(qrow * (size_t)N);
+    if (!wdata) return -1;
+    for (int n = 0; n < N; ++n)                     /* INIT is serial on thread 0 in the reference */
+        orc_quantize_row_q8_0(x + (size_t)n * K, wdata + (size_t)n * qrow, K);
+    if (n_threads < 1) n_threads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+#endif
+    for (int m = 0; m < M; ++m) {
+        const char *wr = (const char *)W + (size_t)m * wrow;
+        for (int n = 0; n < N; ++n) {
+            float *out = y + (size_t)n * M + m;
+            if (type == 2) orc_vec_dot_q4_0_q8_0(K, out, wr, wdata + (size_t)n * qrow);
+            else           orc_vec_dot_q4_1_q8_0(K, out, wr, wdata + (size_t)n * qrow);
+        }
+    }
+    free(wdata);
+    return 0;
+}
+
+/* Whole-matrix helpers used to build synthetic weights (row length k = K, lib/ggml.c:12122). */
+void orc_quantize_q4(int type, const float *src, void *dst, int64_t nelem, int K) {
+    const size_t bsz = type == 2 ? sizeof(orc_block_q4_0) : sizeof(orc_block_q4_1);
+    const int64_t rows = nelem / K;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t r = 0; r < rows; ++r) {
+        char *o = (char *)dst + (size_t)r * (size_t)(K / QK) * bsz;
+        if (type == 2) orc_quantize_row_q4_0(src + r * K, o, K);
+        else           orc_quantize_row_q4_1(src + r * K, o, K);
+    }
+}
