@@ -1,0 +1,7 @@
+#!/bin/bash
+# build.sh -- compile libfastllama_hip.so for gfx950 (cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")"
+SRCS=$(ls fastllama_amd/csrc/*.hip fastllama_amd/csrc/*.cpp)
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Iinclude \
+      -o fastllama_amd/libfastllama_hip.so $SRCS "$@"

@@ -1,0 +1,41 @@
+// q4_kernels.h -- host-callable launchers of the HIP kernels (internal C++ interface; the public
+// C-ABI is include/fastllama_hip.h, implemented in capi.cpp on top of these).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "q4_layout.h"
+
+namespace fl {
+
+// ---- weights: AoS blocks (reference file layout, device) <-> QW16 ----
+hipError_t repack_to_qw16(int type, const void *aos_dev, int M, int K, uint32_t *qs, float *d, float *m,
+                          int *bad_scale_flag_dev, hipStream_t st);
+hipError_t unpack_from_qw16(int type, const uint32_t *qs, const float *d, const float *m, int M, int K,
+                            void *aos_dev, hipStream_t st);
+
+// ---- a4: quantize_row_q8_0 (lib/ggml.c:1299-1441), three output layouts ----
+// x: N rows of K floats, row stride ldx (elements).
+hipError_t quantize_q8_aos(const float *x, int ldx, int N, int K, void *aos_dev, hipStream_t st);
+hipError_t quantize_q8_qa16(const float *x, int ldx, int N, int K, const fl_qact &out, hipStream_t st);
+hipError_t quantize_q8_qa1(const float *x, int ldx, int N, int K, const fl_qact &out, hipStream_t st);
+// QA16 / QA1 workspace -> reference AoS block_q8_0 (parity tests of the internal quantizers)
+hipError_t export_qa16_to_aos(const fl_qact &in, int N, int K, void *aos_dev, hipStream_t st);
+hipError_t export_qa1_to_aos(const fl_qact &in, int N, int K, void *aos_dev, hipStream_t st);
+
+// ---- a7: dequantize_row_q4_{0,1} on AoS blocks (lib/ggml.c:1443-1665) ----
+hipError_t dequantize_aos(int type, const void *aos_dev, float *y, int64_t k, hipStream_t st);
+// dequantize selected rows of a QW16 tensor (get_rows_q, lib/ggml.c:8333-8360)
+hipError_t get_rows_qw16(const fl_qtensor &W, const int *rows_dev, int nrows, float *y, int ldy, hipStream_t st);
+
+// ---- a5/a6: ggml_vec_dot_q4_{0,1}_q8_0 on AoS operands (lib/ggml.c:2368-2714) ----
+hipError_t vec_dot_aos(int type, int n, float *s_dev, const void *x_aos, const void *y_aos, hipStream_t st);
+
+// ---- a9: mul_mat_q_f32 compute phase on QW16 x QA* ----
+// y: N rows of M floats, row stride ldy.
+hipError_t gemv_q4(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st);
+hipError_t gemm_q4_mfma(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st);
+hipError_t gemm_q4_naive(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st);
+
+size_t qact_bytes_q(int N, int K);      // bytes of the q plane for N columns (padded to 16)
+size_t qact_bytes_scale(int N, int K);  // bytes of one scale plane
+
+}  // namespace fl

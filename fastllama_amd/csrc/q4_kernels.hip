@@ -1,0 +1,799 @@
+// q4_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for fastLLaMa's Q4_0/Q4_1 x Q8_0
+// "quantize activations, integer block dot, scale" matmul path.
+//
+// Reference semantics being reproduced (all file:line into /root/reference):
+//   quantize_row_q8_0                  lib/ggml.c:1299-1441   (AVX2 flavour :1341-1403, s :1433-1440)
+//   ggml_vec_dot_q4_0_q8_0             lib/ggml.c:2368-2559
+//   ggml_vec_dot_q4_1_q8_0             lib/ggml.c:2561-2714
+//   dequantize_row_q4_0 / _q4_1        lib/ggml.c:1443-1665
+//   ggml_compute_forward_mul_mat_q_f32 lib/ggml.c:7928-8176
+//
+// Exactness contract: everything integer (Q8_0 quants, block dots) and every scale (d, s) is
+// bit-identical to the reference; the only freedom taken is the ORDER in which the per-block f32
+// terms d_w*d_x*isum are added (the reference itself adds them in 8 interleaved partial sums).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "q4_kernels.h"
+
+namespace fl {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int qw16_pos(int r, int g) { return g ^ (((r >> 3) & 1) << 1); }
+
+// unpack one stored nibble dword (8 weights of k-group g) into two int8x4 dwords:
+//   lo = elements 0,2,4,6   hi = elements 1,3,5,7 of the group
+// Q4_0: values are 16*(nib-8) (stored nibbles are nib^8, see q4_layout.h); Q4_1: values are nib.
+template <int TYPE>
+__device__ __forceinline__ void unpack_nibbles(uint32_t v, uint32_t &lo, uint32_t &hi) {
+    if (TYPE == FL_TYPE_Q4_0) {
+        lo = (v << 4) & 0xF0F0F0F0u;
+        hi = v & 0xF0F0F0F0u;
+    } else {
+        lo = v & 0x0F0F0F0Fu;
+        hi = (v >> 4) & 0x0F0F0F0Fu;
+    }
+}
+
+__device__ __forceinline__ int dot8(uint32_t wlo, uint32_t whi, uint32_t xlo, uint32_t xhi, int acc) {
+    acc = __builtin_amdgcn_sdot4((int)wlo, (int)xlo, acc, false);
+    acc = __builtin_amdgcn_sdot4((int)whi, (int)xhi, acc, false);
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights: AoS <-> QW16
+// ------------------------------------------------------------------------------------------------
+template <int TYPE>
+__global__ void repack_qw16_kernel(const uint32_t *__restrict__ aos, int M, int M16, int KB,
+                                   uint32_t *__restrict__ qs, float *__restrict__ d, float *__restrict__ mm,
+                                   int *bad) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (row, block)
+    if (idx >= (int64_t)M16 * KB) return;
+    // iterate in OUTPUT order so the 16-byte stores coalesce: idx = ((grp*KB + b)*16 + r)
+    const int r = (int)(idx & 15);
+    const int64_t gb = idx >> 4;
+    const int b = (int)(gb % KB);
+    const int grp = (int)(gb / KB);
+    const int row = grp * 16 + r;
+    constexpr int WPB = TYPE == FL_TYPE_Q4_0 ? 5 : 6;  // 32-bit words per AoS block
+    uint32_t w[4] = {0, 0, 0, 0};
+    float dv = 0.f, mv = 0.f;
+    if (row < M) {
+        const uint32_t *p = aos + ((int64_t)row * KB + b) * WPB;
+        dv = __uint_as_float(p[0]);
+        if (TYPE == FL_TYPE_Q4_1) mv = __uint_as_float(p[1]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) w[g] = p[WPB - 4 + g];
+        if (TYPE == FL_TYPE_Q4_0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) w[g] ^= 0x88888888u;
+            if (dv != 0.f && fabsf(dv) < 1.8807909613156600e-37f /* 2^-122 */) atomicOr(bad, 1);
+            dv *= 0.0625f;
+        }
+    }
+    uint4 o;
+    uint32_t *op = &o.x;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) op[qw16_pos(r, g)] = w[g];
+    reinterpret_cast<uint4 *>(qs)[idx] = o;
+    d[idx] = dv;
+    if (TYPE == FL_TYPE_Q4_1) mm[idx] = mv;
+}
+
+template <int TYPE>
+__global__ void unpack_qw16_kernel(const uint32_t *__restrict__ qs, const float *__restrict__ d,
+                                   const float *__restrict__ mm, int M, int KB, uint32_t *__restrict__ aos) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (row, block)
+    if (idx >= (int64_t)M * KB) return;
+    const int b = (int)(idx % KB);
+    const int row = (int)(idx / KB);
+    const int grp = row >> 4, r = row & 15;
+    const int64_t src = ((int64_t)grp * KB + b) * 16 + r;
+    constexpr int WPB = TYPE == FL_TYPE_Q4_0 ? 5 : 6;
+    uint32_t *p = aos + idx * WPB;
+    const uint4 v = reinterpret_cast<const uint4 *>(qs)[src];
+    const uint32_t *vp = &v.x;
+    float dv = d[src];
+    if (TYPE == FL_TYPE_Q4_0) dv *= 16.0f;
+    p[0] = __float_as_uint(dv);
+    if (TYPE == FL_TYPE_Q4_1) p[1] = __float_as_uint(mm[src]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        uint32_t w = vp[qw16_pos(r, g)];
+        if (TYPE == FL_TYPE_Q4_0) w ^= 0x88888888u;
+        p[WPB - 4 + g] = w;
+    }
+}
+
+hipError_t repack_to_qw16(int type, const void *aos, int M, int K, uint32_t *qs, float *d, float *m,
+                          int *bad, hipStream_t st) {
+    const int M16 = fl_roundup(M, 16), KB = K / FL_QK;
+    const int64_t total = (int64_t)M16 * KB;
+    const int grid = (int)((total + 255) / 256);
+    if (type == FL_TYPE_Q4_0)
+        hipLaunchKernelGGL(repack_qw16_kernel<FL_TYPE_Q4_0>, dim3(grid), dim3(256), 0, st,
+                           (const uint32_t *)aos, M, M16, KB, qs, d, m, bad);
+    else
+        hipLaunchKernelGGL(repack_qw16_kernel<FL_TYPE_Q4_1>, dim3(grid), dim3(256), 0, st,
+                           (const uint32_t *)aos, M, M16, KB, qs, d, m, bad);
+    return hipGetLastError();
+}
+
+hipError_t unpack_from_qw16(int type, const uint32_t *qs, const float *d, const float *m, int M, int K,
+                            void *aos, hipStream_t st) {
+    const int KB = K / FL_QK;
+    const int64_t total = (int64_t)M * KB;
+    const int grid = (int)((total + 255) / 256);
+    if (type == FL_TYPE_Q4_0)
+        hipLaunchKernelGGL(unpack_qw16_kernel<FL_TYPE_Q4_0>, dim3(grid), dim3(256), 0, st, qs, d, m, M, KB,
+                           (uint32_t *)aos);
+    else
+        hipLaunchKernelGGL(unpack_qw16_kernel<FL_TYPE_Q4_1>, dim3(grid), dim3(256), 0, st, qs, d, m, M, KB,
+                           (uint32_t *)aos);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// a4: quantize_row_q8_0.  One thread per 8 consecutive elements, 4 adjacent lanes per 32-block.
+//   amax -> d = amax/127, id = amax ? 127/amax : 0 -> q = rint(x*id) (half-even) -> s = d*sum(q)
+// ------------------------------------------------------------------------------------------------
+enum { Q8_AOS = 0, Q8_QA16 = 1, Q8_QA1 = 2 };
+
+struct Q8Quad {
+    uint32_t w_nat[2];   // q0..q3 | q4..q7            (reference order)
+    uint32_t w_perm[2];  // q0,q2,q4,q6 | q1,q3,q5,q7  (MFMA / dot4 order)
+    float d, s;
+};
+
+__device__ __forceinline__ Q8Quad quantize_group8(const float v[8]) {
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    const float d = __fdiv_rn(amax, 127.0f);
+    const float id = amax != 0.0f ? __fdiv_rn(127.0f, amax) : 0.0f;
+    int q[8];
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        q[i] = (int)rintf(__fmul_rn(v[i], id));
+        sum += q[i];
+    }
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    Q8Quad o;
+    o.d = d;
+    o.s = __fmul_rn(d, (float)sum);
+    auto pk = [](int a, int b, int c, int e) -> uint32_t {
+        return (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(c & 0xFF) << 16) |
+               ((uint32_t)(e & 0xFF) << 24);
+    };
+    o.w_nat[0] = pk(q[0], q[1], q[2], q[3]);
+    o.w_nat[1] = pk(q[4], q[5], q[6], q[7]);
+    o.w_perm[0] = pk(q[0], q[2], q[4], q[6]);
+    o.w_perm[1] = pk(q[1], q[3], q[5], q[7]);
+    return o;
+}
+
+template <int LAYOUT>
+__global__ void quantize_q8_kernel(const float *__restrict__ x, int ldx, int N, int NP, int K,
+                                   int8_t *__restrict__ q, float *__restrict__ d, float *__restrict__ s,
+                                   uint32_t *__restrict__ aos) {
+    const int gpr = K >> 3;  // 8-element groups per row
+    const int KB = K >> 5;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)NP * gpr;  // multiple of 4; whole quads are in or out of range
+    const bool live = gid < total;
+    const int n = live ? (int)(gid / gpr) : 0;
+    const int kg = live ? (int)(gid % gpr) : 0;
+    float v[8];
+    if (live && n < N) {
+        const float4 a = *reinterpret_cast<const float4 *>(x + (int64_t)n * ldx + kg * 8);
+        const float4 c = *reinterpret_cast<const float4 *>(x + (int64_t)n * ldx + kg * 8 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    }
+    const Q8Quad o = quantize_group8(v);
+    if (!live) return;
+    const int b = kg >> 2, g = kg & 3;
+    if (LAYOUT == Q8_AOS) {
+        // block_q8_0 {float d; float s; int8 qs[32]} = 10 words, lib/ggml.c:620-626
+        uint32_t *p = aos + ((int64_t)n * KB + b) * 10;
+        p[2 + g * 2] = o.w_nat[0];
+        p[3 + g * 2] = o.w_nat[1];
+        if (g == 0) {
+            p[0] = __float_as_uint(o.d);
+            p[1] = __float_as_uint(o.s);
+        }
+    } else if (LAYOUT == Q8_QA16) {
+        const int grp = n >> 4, c = n & 15;
+        const int64_t cb = ((int64_t)grp * KB + b) * 16 + c;  // (group, block, col)
+        uint2 w = make_uint2(o.w_perm[0], o.w_perm[1]);
+        *reinterpret_cast<uint2 *>(q + cb * 32 + qw16_pos(c, g) * 8) = w;
+        if (g == 0) {
+            d[cb] = o.d;
+            s[cb] = o.s;
+        }
+    } else {
+        const int64_t vb = (int64_t)n * KB + b;
+        uint2 w = make_uint2(o.w_perm[0], o.w_perm[1]);
+        *reinterpret_cast<uint2 *>(q + vb * 32 + g * 8) = w;
+        if (g == 0) {
+            d[vb] = o.d;
+            s[vb] = o.s;
+        }
+    }
+}
+
+size_t qact_bytes_q(int N, int K) { return (size_t)fl_roundup(N, 16) * (size_t)K; }
+size_t qact_bytes_scale(int N, int K) { return (size_t)fl_roundup(N, 16) * (size_t)(K / FL_QK) * sizeof(float); }
+
+template <int LAYOUT>
+static hipError_t launch_quantize(const float *x, int ldx, int N, int NP, int K, int8_t *q, float *d, float *s,
+                                  void *aos, hipStream_t st) {
+    const int64_t total = (int64_t)NP * (K >> 3);
+    const int grid = (int)((total + 255) / 256);
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(quantize_q8_kernel<LAYOUT>, dim3(grid), dim3(256), 0, st, x, ldx, N, NP, K, q, d, s,
+                       (uint32_t *)aos);
+    return hipGetLastError();
+}
+
+hipError_t quantize_q8_aos(const float *x, int ldx, int N, int K, void *aos, hipStream_t st) {
+    return launch_quantize<Q8_AOS>(x, ldx, N, N, K, nullptr, nullptr, nullptr, aos, st);
+}
+hipError_t quantize_q8_qa16(const float *x, int ldx, int N, int K, const fl_qact &o, hipStream_t st) {
+    return launch_quantize<Q8_QA16>(x, ldx, N, fl_roundup(N, 16), K, o.q, o.d, o.s, nullptr, st);
+}
+hipError_t quantize_q8_qa1(const float *x, int ldx, int N, int K, const fl_qact &o, hipStream_t st) {
+    return launch_quantize<Q8_QA1>(x, ldx, N, N, K, o.q, o.d, o.s, nullptr, st);
+}
+
+template <int LAYOUT>
+__global__ void export_q8_kernel(const int8_t *__restrict__ q, const float *__restrict__ d,
+                                 const float *__restrict__ s, int N, int K, uint32_t *__restrict__ aos) {
+    const int gpr = K >> 3, KB = K >> 5;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)N * gpr) return;
+    const int n = (int)(gid / gpr), kg = (int)(gid % gpr);
+    const int b = kg >> 2, g = kg & 3;
+    int64_t sb;
+    uint2 w;
+    if (LAYOUT == Q8_QA16) {
+        const int grp = n >> 4, c = n & 15;
+        sb = ((int64_t)grp * KB + b) * 16 + c;
+        w = *reinterpret_cast<const uint2 *>(q + sb * 32 + qw16_pos(c, g) * 8);
+    } else {
+        sb = (int64_t)n * KB + b;
+        w = *reinterpret_cast<const uint2 *>(q + sb * 32 + g * 8);
+    }
+    // undo the even/odd split: w.x = e0,e2,e4,e6  w.y = e1,e3,e5,e7
+    auto by = [](uint32_t v, int i) -> uint32_t { return (v >> (8 * i)) & 0xFFu; };
+    const uint32_t n0 = by(w.x, 0) | (by(w.y, 0) << 8) | (by(w.x, 1) << 16) | (by(w.y, 1) << 24);
+    const uint32_t n1 = by(w.x, 2) | (by(w.y, 2) << 8) | (by(w.x, 3) << 16) | (by(w.y, 3) << 24);
+    uint32_t *p = aos + ((int64_t)n * KB + b) * 10;
+    p[2 + g * 2] = n0;
+    p[3 + g * 2] = n1;
+    if (g == 0) {
+        p[0] = __float_as_uint(d[sb]);
+        p[1] = __float_as_uint(s[sb]);
+    }
+}
+
+hipError_t export_qa16_to_aos(const fl_qact &in, int N, int K, void *aos, hipStream_t st) {
+    const int64_t total = (int64_t)N * (K >> 3);
+    hipLaunchKernelGGL(export_q8_kernel<Q8_QA16>, dim3((int)((total + 255) / 256)), dim3(256), 0, st, in.q, in.d,
+                       in.s, N, K, (uint32_t *)aos);
+    return hipGetLastError();
+}
+hipError_t export_qa1_to_aos(const fl_qact &in, int N, int K, void *aos, hipStream_t st) {
+    const int64_t total = (int64_t)N * (K >> 3);
+    hipLaunchKernelGGL(export_q8_kernel<Q8_QA1>, dim3((int)((total + 255) / 256)), dim3(256), 0, st, in.q, in.d,
+                       in.s, N, K, (uint32_t *)aos);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// a7: dequantize_row_q4_{0,1} on AoS blocks.  One thread per nibble dword (8 weights).
+//   Q4_0: (nib-8)*d          lib/ggml.c:1449-1482
+//   Q4_1: fma(nib, d, m)     lib/ggml.c:1567-1597 (the reference's gcc build fuses mul+add)
+// ------------------------------------------------------------------------------------------------
+template <int TYPE>
+__global__ void dequantize_aos_kernel(const uint32_t *__restrict__ aos, float *__restrict__ y, int64_t ngroups) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= ngroups) return;
+    constexpr int WPB = TYPE == FL_TYPE_Q4_0 ? 5 : 6;
+    const int64_t blk = gid >> 2;
+    const int g = (int)(gid & 3);
+    const uint32_t *p = aos + blk * WPB;
+    const float d = __uint_as_float(p[0]);
+    const float m = TYPE == FL_TYPE_Q4_1 ? __uint_as_float(p[1]) : 0.f;
+    const uint32_t v = p[WPB - 4 + g];
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int lo = (v >> (8 * j)) & 0xF, hi = (v >> (8 * j + 4)) & 0xF;
+        if (TYPE == FL_TYPE_Q4_0) {
+            o[2 * j] = __fmul_rn((float)(lo - 8), d);
+            o[2 * j + 1] = __fmul_rn((float)(hi - 8), d);
+        } else {
+            o[2 * j] = __fmaf_rn((float)lo, d, m);
+            o[2 * j + 1] = __fmaf_rn((float)hi, d, m);
+        }
+    }
+    float4 *yp = reinterpret_cast<float4 *>(y + gid * 8);
+    yp[0] = make_float4(o[0], o[1], o[2], o[3]);
+    yp[1] = make_float4(o[4], o[5], o[6], o[7]);
+}
+
+hipError_t dequantize_aos(int type, const void *aos, float *y, int64_t k, hipStream_t st) {
+    const int64_t ngroups = k >> 3;
+    const int grid = (int)((ngroups + 255) / 256);
+    if (grid == 0) return hipSuccess;
+    if (type == FL_TYPE_Q4_0)
+        hipLaunchKernelGGL(dequantize_aos_kernel<FL_TYPE_Q4_0>, dim3(grid), dim3(256), 0, st,
+                           (const uint32_t *)aos, y, ngroups);
+    else
+        hipLaunchKernelGGL(dequantize_aos_kernel<FL_TYPE_Q4_1>, dim3(grid), dim3(256), 0, st,
+                           (const uint32_t *)aos, y, ngroups);
+    return hipGetLastError();
+}
+
+// get_rows_q (token embedding): dequantize rows[i] of a QW16 tensor.  lib/ggml.c:8333-8360
+template <int TYPE>
+__global__ void get_rows_qw16_kernel(const uint32_t *__restrict__ qs, const float *__restrict__ d,
+                                     const float *__restrict__ mm, const int *__restrict__ rows, int nrows,
+                                     int M, int KB, float *__restrict__ y, int ldy) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int gpr = KB * 4;
+    if (gid >= (int64_t)nrows * gpr) return;
+    const int i = (int)(gid / gpr), kg = (int)(gid % gpr);
+    const int b = kg >> 2, g = kg & 3;
+    int row = rows[i];
+    row = row < 0 ? 0 : (row >= M ? M - 1 : row);
+    const int grp = row >> 4, r = row & 15;
+    const int64_t src = ((int64_t)grp * KB + b) * 16 + r;
+    const uint32_t v = qs[src * 4 + qw16_pos(r, g)];
+    float o[8];
+    if (TYPE == FL_TYPE_Q4_0) {
+        const float dv = d[src] * 16.0f;  // undo the exact /16 of the repack
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lo = ((int)(v << (28 - 8 * j))) >> 28;  // stored nibble is two's-complement (nib-8)
+            const int hi = ((int)(v << (24 - 8 * j))) >> 28;
+            o[2 * j] = __fmul_rn((float)lo, dv);
+            o[2 * j + 1] = __fmul_rn((float)hi, dv);
+        }
+    } else {
+        const float dv = d[src], mv = mm[src];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lo = (v >> (8 * j)) & 0xF, hi = (v >> (8 * j + 4)) & 0xF;
+            o[2 * j] = __fmaf_rn((float)lo, dv, mv);
+            o[2 * j + 1] = __fmaf_rn((float)hi, dv, mv);
+        }
+    }
+    float4 *yp = reinterpret_cast<float4 *>(y + (int64_t)i * ldy + kg * 8);
+    yp[0] = make_float4(o[0], o[1], o[2], o[3]);
+    yp[1] = make_float4(o[4], o[5], o[6], o[7]);
+}
+
+hipError_t get_rows_qw16(const fl_qtensor &W, const int *rows, int nrows, float *y, int ldy, hipStream_t st) {
+    const int64_t total = (int64_t)nrows * W.KB * 4;
+    const int grid = (int)((total + 255) / 256);
+    if (grid == 0) return hipSuccess;
+    if (W.type == FL_TYPE_Q4_0)
+        hipLaunchKernelGGL(get_rows_qw16_kernel<FL_TYPE_Q4_0>, dim3(grid), dim3(256), 0, st, W.qs, W.d, W.m, rows,
+                           nrows, W.M, W.KB, y, ldy);
+    else
+        hipLaunchKernelGGL(get_rows_qw16_kernel<FL_TYPE_Q4_1>, dim3(grid), dim3(256), 0, st, W.qs, W.d, W.m, rows,
+                           nrows, W.M, W.KB, y, ldy);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// a5/a6 on AoS operands: the quantize_fns_t::vec_dot_q mirror (one dot, one workgroup).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int TYPE>
+__global__ __launch_bounds__(256) void vec_dot_aos_kernel(int nb, float *__restrict__ out,
+                                                          const uint32_t *__restrict__ xw,
+                                                          const uint32_t *__restrict__ yq) {
+    constexpr int WPB = TYPE == FL_TYPE_Q4_0 ? 5 : 6;
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+        const uint32_t *pw = xw + (int64_t)b * WPB;
+        const uint32_t *px = yq + (int64_t)b * 10;
+        const float dw = __uint_as_float(pw[0]);
+        const float dx = __uint_as_float(px[0]);
+        int isum = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t v = pw[WPB - 4 + g];
+            const uint32_t x0 = px[2 + 2 * g], x1 = px[3 + 2 * g];  // natural order q0..q3 | q4..q7
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int lo = (v >> (8 * j)) & 0xF, hi = (v >> (8 * j + 4)) & 0xF;
+                const uint32_t xs = j < 2 ? x0 : x1;
+                const int q0 = (int)(int8_t)((xs >> (16 * (j & 1))) & 0xFF);
+                const int q1 = (int)(int8_t)((xs >> (16 * (j & 1) + 8)) & 0xFF);
+                if (TYPE == FL_TYPE_Q4_0) isum += (lo - 8) * q0 + (hi - 8) * q1;
+                else isum += lo * q0 + hi * q1;
+            }
+        }
+        acc = __fmaf_rn(__fmul_rn(dw, dx), (float)isum, acc);
+        if (TYPE == FL_TYPE_Q4_1) acc = __fmaf_rn(__uint_as_float(pw[1]), __uint_as_float(px[1]), acc);
+    }
+    __shared__ float part[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+hipError_t vec_dot_aos(int type, int n, float *s, const void *x, const void *y, hipStream_t st) {
+    if (type == FL_TYPE_Q4_0)
+        hipLaunchKernelGGL(vec_dot_aos_kernel<FL_TYPE_Q4_0>, dim3(1), dim3(256), 0, st, n / FL_QK, s,
+                           (const uint32_t *)x, (const uint32_t *)y);
+    else
+        hipLaunchKernelGGL(vec_dot_aos_kernel<FL_TYPE_Q4_1>, dim3(1), dim3(256), 0, st, n / FL_QK, s,
+                           (const uint32_t *)x, (const uint32_t *)y);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// a9 decode path (N <= 8): wavefront-dot GEMV, HBM-bound.
+//
+// One 256-thread workgroup (4 waves) owns one 16-row group of W.  A wave-wide 16-byte load covers
+// (16 rows) x (4 consecutive blocks) = 1 KiB contiguous of QW16; lane = row + 16*(block&3).  The four
+// waves stride over the block-quads of the row, every lane keeps one f32 partial per column, then
+// lanes {r, r+16, r+32, r+48} and the four waves are summed.
+// Per lane and block: 12 VALU unpack + NC*(8 v_dot4 + cvt + mul + fma).
+// ------------------------------------------------------------------------------------------------
+template <int TYPE, int NC>
+__global__ __launch_bounds__(256) void gemv_q4_kernel(const uint4 *__restrict__ qs, const float *__restrict__ dW,
+                                                      const float *__restrict__ mW,
+                                                      const int8_t *__restrict__ xq, const float *__restrict__ xd,
+                                                      const float *__restrict__ xs, int N, int M, int KB,
+                                                      float *__restrict__ y, int ldy) {
+    const int grp = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, bq = lane >> 4;
+    const int xswap = ((r >> 3) & 1) * 16;  // rows 8..15 keep k-groups {2,3} first (qw16_pos)
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+
+    const int nquads = (KB + 3) >> 2;
+    const int64_t gbase = (int64_t)grp * KB;
+    constexpr int U = NC <= 2 ? 4 : 2;  // block-quads in flight per wave
+    for (int q0 = wave * U; q0 < nquads; q0 += 4 * U) {
+        uint4 w[U];
+        float dw[U], mw[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = (q0 + u) * 4 + bq;
+            ok[u] = (q0 + u) < nquads && b < KB;
+            const int64_t idx = (gbase + (ok[u] ? b : 0)) * 16 + r;
+            w[u] = qs[idx];
+            dw[u] = dW[idx];
+            mw[u] = TYPE == FL_TYPE_Q4_1 ? mW[idx] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            const int b = (q0 + u) * 4 + bq;
+            uint32_t lo[4], hi[4];
+            unpack_nibbles<TYPE>(w[u].x, lo[0], hi[0]);
+            unpack_nibbles<TYPE>(w[u].y, lo[1], hi[1]);
+            unpack_nibbles<TYPE>(w[u].z, lo[2], hi[2]);
+            unpack_nibbles<TYPE>(w[u].w, lo[3], hi[3]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int n = c < N ? c : 0;
+                const int8_t *xb = xq + ((int64_t)n * KB + b) * 32;
+                const uint4 xa = *reinterpret_cast<const uint4 *>(xb + xswap);
+                const uint4 xc = *reinterpret_cast<const uint4 *>(xb + (16 - xswap));
+                int isum = 0;
+                isum = dot8(lo[0], hi[0], xa.x, xa.y, isum);
+                isum = dot8(lo[1], hi[1], xa.z, xa.w, isum);
+                isum = dot8(lo[2], hi[2], xc.x, xc.y, isum);
+                isum = dot8(lo[3], hi[3], xc.z, xc.w, isum);
+                const float dx = xd[(int64_t)n * KB + b];
+                acc[c] = __fmaf_rn(__fmul_rn(dw[u], dx), (float)isum, acc[c]);
+                if (TYPE == FL_TYPE_Q4_1) acc[c] = __fmaf_rn(mw[u], xs[(int64_t)n * KB + b], acc[c]);
+            }
+        }
+    }
+    __shared__ float part[4][NC][16];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float v = acc[c];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 16) part[wave][c][lane] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 * NC) {
+        const int c = threadIdx.x >> 4, rr = threadIdx.x & 15;
+        const int row = grp * 16 + rr;
+        if (c < N && row < M)
+            y[(int64_t)c * ldy + row] = (part[0][c][rr] + part[1][c][rr]) + (part[2][c][rr] + part[3][c][rr]);
+    }
+}
+
+template <int TYPE>
+static hipError_t launch_gemv(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st) {
+    const dim3 grid(W.M16 / 16), block(256);
+    const uint4 *qs = reinterpret_cast<const uint4 *>(W.qs);
+#define FL_GEMV(NC)                                                                                         \
+    hipLaunchKernelGGL((gemv_q4_kernel<TYPE, NC>), grid, block, 0, st, qs, W.d, W.m, xq.q, xq.d, xq.s, N, W.M, \
+                       W.KB, y, ldy)
+    if (N == 1) FL_GEMV(1);
+    else if (N == 2) FL_GEMV(2);
+    else if (N <= 4) FL_GEMV(4);
+    else FL_GEMV(8);
+#undef FL_GEMV
+    return hipGetLastError();
+}
+
+hipError_t gemv_q4(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st) {
+    if (N < 1 || N > 8) return hipErrorInvalidValue;
+    return W.type == FL_TYPE_Q4_0 ? launch_gemv<FL_TYPE_Q4_0>(W, xq, N, y, ldy, st)
+                                  : launch_gemv<FL_TYPE_Q4_1>(W, xq, N, y, ldy, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a9, straightforward device version (one thread per output) -- used by tests to cross-check the
+// MFMA kernel on the device itself.  QW16 x QA16.
+// ------------------------------------------------------------------------------------------------
+template <int TYPE>
+__global__ void gemm_q4_naive_kernel(const uint32_t *__restrict__ qs, const float *__restrict__ dW,
+                                     const float *__restrict__ mW, const int8_t *__restrict__ xq,
+                                     const float *__restrict__ xd, const float *__restrict__ xs, int N, int M,
+                                     int KB, float *__restrict__ y, int ldy) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = blockIdx.y;
+    if (row >= M || n >= N) return;
+    const int grp = row >> 4, r = row & 15, ng = n >> 4, c = n & 15;
+    float acc = 0.f;
+    for (int b = 0; b < KB; ++b) {
+        const int64_t wi = ((int64_t)grp * KB + b) * 16 + r;
+        const int64_t xi = ((int64_t)ng * KB + b) * 16 + c;
+        int isum = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint32_t lo, hi;
+            unpack_nibbles<TYPE>(qs[wi * 4 + qw16_pos(r, g)], lo, hi);
+            const uint2 xv = *reinterpret_cast<const uint2 *>(xq + xi * 32 + qw16_pos(c, g) * 8);
+            isum = dot8(lo, hi, xv.x, xv.y, isum);
+        }
+        acc = __fmaf_rn(__fmul_rn(dW[wi], xd[xi]), (float)isum, acc);
+        if (TYPE == FL_TYPE_Q4_1) acc = __fmaf_rn(mW[wi], xs[xi], acc);
+    }
+    y[(int64_t)n * ldy + row] = acc;
+}
+
+hipError_t gemm_q4_naive(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st) {
+    const dim3 grid((W.M + 255) / 256, N), block(256);
+    if (W.type == FL_TYPE_Q4_0)
+        hipLaunchKernelGGL(gemm_q4_naive_kernel<FL_TYPE_Q4_0>, grid, block, 0, st, W.qs, W.d, W.m, xq.q, xq.d, xq.s,
+                           N, W.M, W.KB, y, ldy);
+    else
+        hipLaunchKernelGGL(gemm_q4_naive_kernel<FL_TYPE_Q4_1>, grid, block, 0, st, W.qs, W.d, W.m, xq.q, xq.d, xq.s,
+                           N, W.M, W.KB, y, ldy);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// a9 prefill path (N >= 9): exact-integer MFMA GEMM.
+//
+//   One MFMA K-step == one 32-element quant block:  v_mfma_i32_16x16x32_i8 (A = 16 W rows, B = 16
+//   activation columns) gives the 16x16 block dots exactly; the VALU epilogue applies the per-block
+//   scales:  acc[m][n] += float(isum) * (d_w[m,b] * d_x[n,b])   (+ m_w[m,b]*s_x[n,b] for Q4_1).
+//
+//   Workgroup 256 threads = 4 waves (2 x 2), tile BM x BN = 128 x 128, K-step = 4 blocks (128).
+//   Wave tile 64 x 64 = 4 x 4 MFMA tiles, 64 f32 accumulators.
+//   LDS stage (single image of the QW16 / QA16 global order, so all fills are 16-byte linear copies):
+//       A  [8 row-groups][4 blocks][16 rows][16 B]     8 KiB     packed nibbles
+//       dW [8][4][16] f32 (+ mW for Q4_1)              2 (+2) KiB
+//       B  [8 col-groups][4 blocks][16 cols][32 B]    16 KiB     int8
+//       dX [8][4][16] f32 (+ sX for Q4_1)              2 (+2) KiB
+//   Two stages are double-buffered: the global loads of step t+1 are issued before the MFMAs of
+//   step t and written to the other stage after them.
+// ------------------------------------------------------------------------------------------------
+constexpr int GM_BM = 128, GM_BN = 128, GM_KB = 4;
+constexpr int GM_A_BYTES = 8 * GM_KB * 256;       // 8192
+constexpr int GM_S_BYTES = 8 * GM_KB * 64;        // 2048
+constexpr int GM_B_BYTES = 8 * GM_KB * 512;       // 16384
+constexpr int GM_STAGE_BYTES = GM_A_BYTES + GM_B_BYTES + 4 * GM_S_BYTES;  // 32768
+
+template <int TYPE>
+__global__ __launch_bounds__(256, 2) void gemm_q4_mfma_kernel(
+    const uint4 *__restrict__ qs, const float *__restrict__ dW, const float *__restrict__ mW,
+    const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs, int N, int M,
+    int MG /* row groups */, int NG /* col groups */, int KB, float *__restrict__ y, int ldy) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    // XCD-aware tile order: consecutive tiles of one N-panel share their W rows' L2.
+    const int tiles_m = (MG + 7) >> 3, tiles_n = (NG + 7) >> 3;
+    int bid = blockIdx.x;
+    {
+        const int nwg = tiles_m * tiles_n;
+        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;  // bijective remap
+    }
+    const int tn = bid % tiles_n, tm = bid / tiles_n;
+    const int mg0 = tm * 8, ng0 = tn * 8;
+
+    v4f acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    // ---- staging registers: A 2 x uint4, B 4 x uint4, scales: 1 x uint4 (threads 0..127: dW | 128..255: dX),
+    //      Q4_1: + 1 x uint4 (mW | sX)
+    uint4 ra[2], rb[4], rs, rs2;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    auto load_stage = [&](int kb0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {  // A: 8 chunks of 1 KiB, chunk = group
+            const int ch = (tid >> 6) + i * 4, e = tid & 63;  // e: uint4 index inside the chunk = (b, row)
+            const int g = mg0 + ch, b = kb0 + (e >> 4);
+            ra[i] = (g < MG && b < KB) ? qs[((int64_t)g * KB + kb0) * 16 + e] : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // B: 8 chunks of 2 KiB
+            const int ch = (tid >> 7) + i * 2, e = tid & 127;  // e: uint4 index = (b, col, half)
+            const int g = ng0 + ch, b = kb0 + (e >> 5);
+            rb[i] = (g < NG && b < KB)
+                        ? *reinterpret_cast<const uint4 *>(xq + (((int64_t)g * KB + kb0) * 16) * 32 + e * 16)
+                        : zero4;
+        }
+        {  // scales: 8 chunks of 256 B per plane; 16 uint4 per chunk
+            const int t = tid & 127, ch = t >> 4, e = t & 15;  // e: uint4 index = (b, 4 rows)
+            const int b = kb0 + (e >> 2);
+            if (tid < 128) {
+                const int g = mg0 + ch;
+                const bool ok = g < MG && b < KB;
+                const int64_t off = ((int64_t)g * KB + kb0) * 16 + e * 4;
+                rs = ok ? *reinterpret_cast<const uint4 *>(dW + off) : zero4;
+                if (TYPE == FL_TYPE_Q4_1) rs2 = ok ? *reinterpret_cast<const uint4 *>(mW + off) : zero4;
+            } else {
+                const int g = ng0 + ch;
+                const bool ok = g < NG && b < KB;
+                const int64_t off = ((int64_t)g * KB + kb0) * 16 + e * 4;
+                rs = ok ? *reinterpret_cast<const uint4 *>(xd + off) : zero4;
+                if (TYPE == FL_TYPE_Q4_1) rs2 = ok ? *reinterpret_cast<const uint4 *>(xs + off) : zero4;
+            }
+        }
+    };
+    auto store_stage = [&](int st) {
+        unsigned char *base = smem + st * GM_STAGE_BYTES;
+        uint4 *sa = reinterpret_cast<uint4 *>(base);
+        uint4 *sb = reinterpret_cast<uint4 *>(base + GM_A_BYTES);
+        uint4 *ss = reinterpret_cast<uint4 *>(base + GM_A_BYTES + GM_B_BYTES);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) sa[((tid >> 6) + i * 4) * 64 + (tid & 63)] = ra[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sb[((tid >> 7) + i * 2) * 128 + (tid & 127)] = rb[i];
+        // plane order: dW | dX | mW | sX, each 2 KiB = 128 uint4
+        ss[(tid < 128 ? 0 : 128) + (tid & 127)] = rs;
+        if (TYPE == FL_TYPE_Q4_1) ss[256 + (tid < 128 ? 0 : 128) + (tid & 127)] = rs2;
+    };
+
+    const int nsteps = (KB + GM_KB - 1) / GM_KB;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+
+    for (int t = 0; t < nsteps; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nsteps) load_stage((t + 1) * GM_KB);
+
+        const unsigned char *base = smem + cur * GM_STAGE_BYTES;
+        const uint32_t *sa = reinterpret_cast<const uint32_t *>(base);
+        const unsigned char *sb = base + GM_A_BYTES;
+        const float *sdw = reinterpret_cast<const float *>(base + GM_A_BYTES + GM_B_BYTES);
+        const float *sdx = sdw + 512;
+        const float *smw = sdw + 1024;
+        const float *ssx = sdw + 1536;
+
+#pragma unroll 1
+        for (int b = 0; b < GM_KB; ++b) {
+            long afrag[4], bfrag[4];
+            v4f dwv[4], mwv[4];
+            float dxv[4], sxv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int g = wm * 4 + i;
+                const uint32_t v = sa[((g * GM_KB + b) * 16 + l15) * 4 + qw16_pos(l15, lg)];
+                uint32_t lo, hi;
+                unpack_nibbles<TYPE>(v, lo, hi);
+                afrag[i] = (long)(((uint64_t)hi << 32) | lo);
+                dwv[i] = *reinterpret_cast<const v4f *>(sdw + (g * GM_KB + b) * 16 + lg * 4);
+                if (TYPE == FL_TYPE_Q4_1) mwv[i] = *reinterpret_cast<const v4f *>(smw + (g * GM_KB + b) * 16 + lg * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int g = wn * 4 + j;
+                bfrag[j] = *reinterpret_cast<const long *>(sb + ((g * GM_KB + b) * 16 + l15) * 32 +
+                                                           qw16_pos(l15, lg) * 8);
+                dxv[j] = sdx[(g * GM_KB + b) * 16 + l15];
+                if (TYPE == FL_TYPE_Q4_1) sxv[j] = ssx[(g * GM_KB + b) * 16 + l15];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const v4i z = {0, 0, 0, 0};
+                    const v4i isum = __builtin_amdgcn_mfma_i32_16x16x32_i8(afrag[i], bfrag[j], z, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc[i][j][r] = __fmaf_rn(__fmul_rn(dwv[i][r], dxv[j]), (float)isum[r], acc[i][j][r]);
+                        if (TYPE == FL_TYPE_Q4_1) acc[i][j][r] = __fmaf_rn(mwv[i][r], sxv[j], acc[i][j][r]);
+                    }
+                }
+            }
+        }
+        if (t + 1 < nsteps) store_stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds rows m = 16*g + 4*lg + {0..3} of column n = 16*h + l15  -> one 16-byte store
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row0 = (mg0 + wm * 4 + i) * 16 + lg * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = (ng0 + wn * 4 + j) * 16 + l15;
+            if (n < N && row0 < M) {
+                float *p = y + (int64_t)n * ldy + row0;
+                if (row0 + 3 < M) {
+                    *reinterpret_cast<v4f *>(p) = acc[i][j];
+                } else {
+                    for (int r = 0; r < 4 && row0 + r < M; ++r) p[r] = acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
+hipError_t gemm_q4_mfma(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st) {
+    const int MG = W.M16 / 16, NG = fl_roundup(N, 16) / 16;
+    const int tiles = ((MG + 7) / 8) * ((NG + 7) / 8);
+    const size_t lds = 2 * GM_STAGE_BYTES;
+    if ((ldy & 3) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return hipErrorInvalidValue;
+    if (W.type == FL_TYPE_Q4_0) {
+        hipLaunchKernelGGL(gemm_q4_mfma_kernel<FL_TYPE_Q4_0>, dim3(tiles), dim3(256), lds, st,
+                           reinterpret_cast<const uint4 *>(W.qs), W.d, W.m, xq.q, xq.d, xq.s, N, W.M, MG, NG, W.KB, y,
+                           ldy);
+    } else {
+        hipLaunchKernelGGL(gemm_q4_mfma_kernel<FL_TYPE_Q4_1>, dim3(tiles), dim3(256), lds, st,
+                           reinterpret_cast<const uint4 *>(W.qs), W.d, W.m, xq.q, xq.d, xq.s, N, W.M, MG, NG, W.KB, y,
+                           ldy);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace fl

@@ -1,0 +1,68 @@
+// q4_layout.h -- device-resident data layouts of the MI355X Q4_0/Q4_1 x Q8_0 path.
+//
+// The reference keeps weights as arrays of 20-byte (Q4_0) / 24-byte (Q4_1) AoS blocks and the
+// quantized activations as 40-byte AoS Q8_0 blocks (/root/reference/lib/ggml.c:590-626).  Neither
+// is 16-byte aligned, so at upload (the Model::load hook, lib/llama.cpp:105) weights are repacked
+// LOSSLESSLY into the SoA layouts below; fl_qtensor_download() inverts the repack bit-for-bit.
+//
+// ---------------------------------------------------------------------------------------------
+// QW16 -- weights.  Rows are grouped by 16 (one MFMA M-tile); inside a group the 32-element
+// quant blocks are block-major, so that (group, 4 consecutive blocks) is ONE contiguous KiB:
+//
+//   qs : uint32 [M16/16][KB][16 rows][4 dwords]     M16 = roundup(M,16), KB = K/32
+//   d  : float  [M16/16][KB][16 rows]               Q4_0: d_w/16 (see below); Q4_1: d_w
+//   m  : float  [M16/16][KB][16 rows]               Q4_1 only: m_w
+//
+//   * dword g (0..3) of a reference block holds elements 8g..8g+7 (byte j = elements 2j | 2j+1<<4,
+//     lib/ggml.c:657).  It is stored at dword position  p = g ^ (((row>>3)&1)<<1)  so that the
+//     per-lane ds_read_b32 of an MFMA A-fragment (lane = row + 16*g) is LDS-bank-conflict free.
+//   * Q4_0 nibbles are stored XOR 8: a nibble is then the 4-bit two's-complement of (nib-8), and
+//     (v<<4)&0xF0F0F0F0 / v&0xF0F0F0F0 are int8 vectors holding 16*(nib-8) -- 3 VALU ops per 8
+//     weights, no subtract.  The factor 16 is taken back exactly by storing d_w/16 (a power-of-two
+//     scaling, exact for every normal float; |d_w| < 2^-122 is rejected at upload).
+//   * Q4_1 nibbles are stored as they are (0..15 are valid non-negative int8).
+//   * rows M..M16-1 are zero (nibble value 0 after the transform, scale 0).
+//
+// QA16 -- quantized activations for the MFMA (N >= 9) path, columns grouped by 16:
+//
+//   q  : int8  [N16/16][KB][16 cols][32]
+//   d  : float [N16/16][KB][16 cols]                d_x           (lib/ggml.c:1363)
+//   s  : float [N16/16][KB][16 cols]                d_x * sum(q)  (lib/ggml.c:1433-1440)
+//
+//   * the 32 int8 of a block are 4 k-groups of 8; group g sits at 8-byte position
+//     p = g ^ (((col>>3)&1)<<1) (bank-conflict-free ds_read_b64 of the MFMA B-fragment) and holds
+//     elements 8g+{0,2,4,6,1,3,5,7} -- the order in which the nibble unpack above yields them.
+//
+// QA1 -- quantized activations for the wave-dot (N <= 8) path, one vector:
+//
+//   q  : int8  [KB][32]   (groups at their natural position, same in-group order as QA16)
+//   d  : float [KB],  s : float [KB]
+//
+// The integer dot over a block is invariant under any permutation of k applied to both operands,
+// so none of this changes a result bit.
+#pragma once
+#include <stdint.h>
+
+#define FL_QK 32
+#define FL_TYPE_Q4_0 2   // enum ggml_type, /root/reference/include/ggml.h:200-212
+#define FL_TYPE_Q4_1 3
+
+struct fl_qtensor {
+    int type;            // FL_TYPE_Q4_0 | FL_TYPE_Q4_1
+    int M, K;            // logical rows / row length
+    int M16, KB;         // roundup(M,16), K/32
+    uint32_t *qs;        // device, QW16
+    float *d;            // device
+    float *m;            // device (Q4_1) or nullptr
+    int owns;            // 1: qs/d/m were hipMalloc'ed by the library
+};
+
+// Quantized-activation workspace (either QA16 or QA1 depending on the consumer).
+struct fl_qact {
+    int8_t *q;
+    float *d;
+    float *s;
+    int N, N16, KB;
+};
+
+static inline int fl_roundup(int x, int a) { return (x + a - 1) / a * a; }

@@ -1,0 +1,112 @@
+"""ctypes binding of the kernel-level C-ABI (include/fastllama_hip.h) of libfastllama_hip.so.
+
+This module is plumbing only: it loads the shared object that ``build.sh`` / ``__graft_entry__.build()``
+produce in-tree and declares the prototypes.  There is NO fallback: if the library is missing, or no
+gfx950 device is visible when a compute entry point is called, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libfastllama_hip.so")
+
+FL_OK, FL_EINVAL, FL_EHIP, FL_ENOMEM, FL_ENODEV = 0, -1, -2, -3, -4
+Q4_0, Q4_1 = 2, 3
+BLOCK_BYTES = {Q4_0: 20, Q4_1: 24}
+Q8_BLOCK_BYTES = 40
+QK = 32
+
+
+class FastLlamaHipError(RuntimeError):
+    pass
+
+
+_ROW_DEQ = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)
+_ROW_Q = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)
+_DOT = C.CFUNCTYPE(None, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+
+
+class QuantizeFns(C.Structure):
+    """fl_quantize_fns_t -- field-for-field the reference's quantize_fns_t (include/ggml.h:854-860)."""
+    _fields_ = [("dequantize_row_q", _ROW_DEQ), ("quantize_row_q", _ROW_Q),
+                ("quantize_row_q_reference", _ROW_Q), ("quantize_row_q_dot", _ROW_Q),
+                ("vec_dot_q", _DOT)]
+
+
+_PROTOS = {
+    # name: (restype, [argtypes])
+    "fl_device_count": (C.c_int, []),
+    "fl_init": (C.c_int, [C.c_int]),
+    "fl_last_error": (C.c_char_p, []),
+    "fl_device_name": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "fl_version": (C.c_char_p, []),
+    "fl_malloc": (C.c_void_p, [C.c_size_t]),
+    "fl_free": (C.c_int, [C.c_void_p]),
+    "fl_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "fl_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "fl_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "fl_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    "fl_stream_synchronize": (C.c_int, [C.c_void_p]),
+    "fl_stream_create": (C.c_void_p, []),
+    "fl_stream_destroy": (C.c_int, [C.c_void_p]),
+    "fl_event_create": (C.c_void_p, []),
+    "fl_event_destroy": (C.c_int, [C.c_void_p]),
+    "fl_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fl_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "fl_qtensor_upload": (C.c_void_p, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "fl_qtensor_from_device": (C.c_void_p, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "fl_qtensor_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fl_qtensor_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "fl_qtensor_device_bytes": (C.c_size_t, [C.c_void_p]),
+    "fl_qtensor_free": (None, [C.c_void_p]),
+    "fl_quantize_row_q8_0": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "fl_dequantize_row_q4_0": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "fl_dequantize_row_q4_1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "fl_vec_dot_q4_0_q8_0": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fl_vec_dot_q4_1_q8_0": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fl_get_quantize_fn": (QuantizeFns, [C.c_size_t]),
+    "fl_qact_create": (C.c_void_p, [C.c_int, C.c_int]),
+    "fl_qact_free": (None, [C.c_void_p]),
+    "fl_quantize_q8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "fl_qact_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fl_mul_mat_q": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "fl_mul_mat_q_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "fl_debug_mul_mat_q": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "fl_debug_qact_layout": (C.c_int, [C.c_void_p]),
+    "fl_quantize_q8_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load(path: str | None = None) -> C.CDLL:
+    """Load libfastllama_hip.so (once) and declare every prototype of include/fastllama_hip.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise FastLlamaHipError(
+            f"{p} is missing: run ./build.sh (or __graft_entry__.build()). "
+            "fastllama_amd has no CPU fallback.")
+    lib = C.CDLL(p)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != FL_OK:
+        msg = load().fl_last_error().decode(errors="replace")
+        raise FastLlamaHipError(f"{what or 'libfastllama_hip'} failed (rc={rc}): {msg}")
+
+
+def require_device(device: int = 0) -> None:
+    """Raise unless a gfx950 device is usable -- the product path never falls back to the CPU."""
+    check(load().fl_init(device), "fl_init")

@@ -1,0 +1,140 @@
+/*
+ * fastllama_hip.h -- kernel-level C-ABI of libfastllama_hip.so (MI355X / gfx950).
+ *
+ * This is the SECONDARY (operator) boundary of SURVEY.md section 8(b): a device-side replacement for the
+ * reference's `quantize_fns_t` plug-in table and for `ggml_compute_forward_mul_mat_q_f32`.
+ * The PRIMARY boundary (the 17 `llama_*` symbols of interfaces/c/fastllama.h) is declared in
+ * include/fastllama.h and exported by the same shared object.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no torch / C++ types cross this boundary.
+ *   - every pointer named *_dev is a DEVICE pointer (hipMalloc / torch.cuda memory); *_host is host.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream, which is also torch's default).
+ *   - functions return FL_OK (0) or a negative FL_E* code; fl_last_error() holds the message.
+ *     (The reference's row functions return void and GGML_ASSERT -> abort(), lib/ggml.c:138-144; an error
+ *     code is the only deliberate deviation, see INTEGRATION.md.)
+ *   - one caller thread per device at a time, exactly like the reference (no internal locking,
+ *     SURVEY.md section 8(b) "Threading").
+ *
+ * All "replaces" citations are file:line into the reference tree (/root/reference).
+ */
+#ifndef FASTLLAMA_HIP_H
+#define FASTLLAMA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FL_OK 0
+#define FL_EINVAL (-1)  /* bad argument (shape, alignment, type)                        */
+#define FL_EHIP (-2)    /* a HIP runtime call failed                                     */
+#define FL_ENOMEM (-3)  /* device or host allocation failed                              */
+#define FL_ENODEV (-4)  /* no gfx950 device / HIP runtime unavailable -- never a CPU fallback */
+
+#define FL_TYPE_Q4_0 2 /* enum ggml_type GGML_TYPE_Q4_0, include/ggml.h:200-212 */
+#define FL_TYPE_Q4_1 3 /* GGML_TYPE_Q4_1 */
+
+/* ---------------------------------------------------------------- runtime ---------------------- */
+/* replaces: nothing in the reference (CPU only); hook point is FastLlama::Params::build,
+ * lib/bridge.cpp:110-150 ("bridge.cpp device init" in BASELINE.json). */
+int fl_device_count(void);
+int fl_init(int device);                 /* hipSetDevice + sanity check that the device is gfx950 */
+const char *fl_last_error(void);
+int fl_device_name(char *buf, size_t n);
+const char *fl_version(void);
+
+void *fl_malloc(size_t bytes);           /* device memory; NULL on failure */
+int fl_free(void *p_dev);
+int fl_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int fl_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int fl_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
+int fl_memset(void *dst_dev, int value, size_t bytes, void *stream);
+int fl_stream_synchronize(void *stream);
+void *fl_stream_create(void);
+int fl_stream_destroy(void *stream);
+
+/* HIP events on the stream the kernels are launched on (bench.py's live timing) */
+void *fl_event_create(void);
+int fl_event_destroy(void *ev);
+int fl_event_record(void *ev, void *stream);
+int fl_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises `stop` */
+
+/* ---------------------------------------------------------------- weights ---------------------- */
+/* A Q4_0 / Q4_1 matrix W[M rows][K], resident in HBM in the repacked QW16 layout
+ * (fastllama_amd/csrc/q4_layout.h).  Input is the reference's own byte layout: M rows of K/32
+ * consecutive block_q4_0 (20 B) / block_q4_1 (24 B), lib/ggml.c:590-603 -- i.e. a GGML/GGJT tensor
+ * payload as is.  The repack is lossless: fl_qtensor_download returns the input bytes.
+ * replaces: the host-resident `ggml_tensor` weights created in Model::load, lib/llama.cpp:223-258. */
+typedef struct fl_qtensor fl_qtensor;
+fl_qtensor *fl_qtensor_upload(int type, const void *blocks_host, int M, int K, void *stream);
+fl_qtensor *fl_qtensor_from_device(int type, const void *blocks_dev, int M, int K, void *stream);
+int fl_qtensor_download(const fl_qtensor *W, void *blocks_host, void *stream);
+int fl_qtensor_info(const fl_qtensor *W, int *type, int *M, int *K);
+size_t fl_qtensor_device_bytes(const fl_qtensor *W);
+void fl_qtensor_free(fl_qtensor *W);
+
+/* ---------------------------------------------------------------- quantize_fns_t mirror -------- */
+/* Same five entry points, same argument meaning as `quantize_fns_t` (include/ggml.h:850-862,
+ * table lib/ggml.c:1731-1767), operating on DEVICE buffers that use the reference's AoS block
+ * layouts, so outputs can be diffed byte-for-byte against the CPU functions.
+ *
+ *   dequantize_row_q(x, y, k)   replaces dequantize_row_q4_0 / _q4_1   lib/ggml.c:1443,1561
+ *   quantize_row_q_dot(x, y, k) replaces quantize_row_q8_0             lib/ggml.c:1299
+ *   vec_dot_q(n, s, x, y)       replaces ggml_vec_dot_q4_0_q8_0 / _q4_1_q8_0  lib/ggml.c:2368,2561
+ *
+ * quantize_row_q / quantize_row_q_reference (f32 -> Q4 weights) are offline tooling in the
+ * reference (quantize CLI, LoRA requant) and are not on the eval path: they are NULL in the table. */
+int fl_quantize_row_q8_0(const float *x_dev, void *y_dev /* block_q8_0[k/32] */, int k, void *stream);
+int fl_dequantize_row_q4_0(const void *x_dev /* block_q4_0[k/32] */, float *y_dev, int k, void *stream);
+int fl_dequantize_row_q4_1(const void *x_dev /* block_q4_1[k/32] */, float *y_dev, int k, void *stream);
+int fl_vec_dot_q4_0_q8_0(int n, float *s_dev, const void *x_dev, const void *y_dev, void *stream);
+int fl_vec_dot_q4_1_q8_0(int n, float *s_dev, const void *x_dev, const void *y_dev, void *stream);
+
+typedef void (*fl_dequantize_row_q_t)(const void *x_dev, float *y_dev, int k);
+typedef void (*fl_quantize_row_q_t)(const float *x_dev, void *y_dev, int k);
+typedef void (*fl_vec_dot_q_t)(const int n, float *s_dev, const void *x_dev, const void *y_dev);
+typedef struct {
+    fl_dequantize_row_q_t dequantize_row_q;
+    fl_quantize_row_q_t quantize_row_q;            /* NULL */
+    fl_quantize_row_q_t quantize_row_q_reference;  /* NULL */
+    fl_quantize_row_q_t quantize_row_q_dot;
+    fl_vec_dot_q_t vec_dot_q;
+} fl_quantize_fns_t;
+/* replaces ggml_internal_get_quantize_fn, lib/ggml.c:1769-1773.  Table entries run on the null
+ * stream and synchronise it before returning (they mirror synchronous CPU functions). */
+fl_quantize_fns_t fl_get_quantize_fn(size_t type);
+
+/* ---------------------------------------------------------------- the op ----------------------- */
+/* Quantized activations (the reference's `params->wdata` Q8_0 scratch, lib/ggml.c:8105-8119,
+ * sized at :10949).  INIT and COMPUTE are separate entry points so that one quantized x feeds
+ * wq/wk/wv (and w1/w3), which the reference re-quantizes per matmul. */
+typedef struct fl_qact fl_qact;
+fl_qact *fl_qact_create(int max_N, int K);
+void fl_qact_free(fl_qact *a);
+/* INIT phase: x_dev is N rows of K floats, row stride ldx elements (16-byte aligned rows). */
+int fl_quantize_q8(fl_qact *a, const float *x_dev, int ldx, int N, int K, void *stream);
+/* copy the workspace out as the reference's block_q8_0[N][K/32] (parity tests) */
+int fl_qact_export(const fl_qact *a, void *blocks_dev, void *stream);
+/* COMPUTE phase: y_dev[n*ldy + m] = vec_dot_q(K, W row m, q8 row n), n < N, m < M.
+ * N <= 8 runs the wave-dot GEMV, N >= 9 the exact-integer MFMA GEMM. */
+int fl_mul_mat_q(const fl_qtensor *W, const fl_qact *a, float *y_dev, int ldy, void *stream);
+
+/* replaces ggml_compute_forward_mul_mat_q_f32 (lib/ggml.c:7928-8176) = INIT + COMPUTE, for
+ * `dst = ggml_mul_mat(W, x)`: x_dev is N rows of K floats (ne10 = K, ne11 = N), y_dev is N rows of M
+ * floats (ne0 = M, ne1 = N), both contiguous-row with the given strides.  Uses an internal
+ * grow-on-demand workspace (do not call while a hipGraph capture is active). */
+int fl_mul_mat_q_f32(const fl_qtensor *W, const float *x_dev, int ldx, float *y_dev, int ldy, int N, void *stream);
+
+/* test hooks: force one kernel family regardless of N (N must suit the layout of `a`) */
+int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a, float *y_dev, int ldy, int which /*0 naive,1 mfma,2 gemv*/,
+                       void *stream);
+int fl_debug_qact_layout(const fl_qact *a); /* 16 = QA16, 1 = QA1 */
+int fl_quantize_q8_layout(fl_qact *a, const float *x_dev, int ldx, int N, int K, int layout, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTLLAMA_HIP_H */

@@ -1,0 +1,34 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+
+
+def _gpu_available() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` on a box without a GPU must FAIL loudly rather than silently pass: only skip when the
+    # user did not ask for gpu tests explicitly.
+    if _gpu_available():
+        return
+    asked = "gpu" in (config.getoption("-m") or "") and "not gpu" not in (config.getoption("-m") or "")
+    if asked:
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container (run with gpurun)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)

@@ -1,0 +1,69 @@
+"""CPU: the C-ABI shared library loads and exports every symbol the headers declare.
+No compute is attempted here (there is no GPU in this container and no CPU fallback in the product).
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "fastllama_amd", "libfastllama_hip.so")
+
+
+def _declared(header, prefix):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    names = set(re.findall(r"\b(%s\w+)\s*\(" % prefix, txt))
+    return {n for n in names if not n.endswith("_t")}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        subprocess.check_call([os.path.join(ROOT, "build.sh")])
+    return ctypes.CDLL(LIB)
+
+
+def test_kernel_abi_symbols_exported(lib):
+    names = _declared("fastllama_hip.h", "fl_")
+    assert len(names) >= 30
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_python_binding_covers_header():
+    from fastllama_amd import hip
+    names = _declared("fastllama_hip.h", "fl_")
+    assert names == set(hip._PROTOS), names ^ set(hip._PROTOS)
+    hip.load()
+
+
+def test_no_device_means_loud_failure(lib):
+    """Without a GPU the product refuses to compute (FL_ENODEV) -- it never falls back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from fastllama_amd import hip
+    L = hip.load()
+    assert L.fl_device_count() == 0
+    assert L.fl_init(0) == hip.FL_ENODEV
+    assert b"no CPU fallback" in L.fl_last_error()
+    assert not L.fl_malloc(64)
+    assert not L.fl_qact_create(4, 64)
+    with pytest.raises(hip.FastLlamaHipError):
+        hip.require_device(0)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under fastllama_amd/ may reference it."""
+    bad = []
+    for dp, _, fns in os.walk(os.path.join(ROOT, "fastllama_amd")):
+        for fn in fns:
+            if fn.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dp, fn), errors="replace").read()
+                if re.search(r"^\s*(import|from)\s+oracle\b|liboracle|orc_|oracle/_ref", src, flags=re.M):
+                    bad.append(fn)
+    assert not bad, bad
