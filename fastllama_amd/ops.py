@@ -40,6 +40,8 @@ class QTensor:
         lib = hip.load()
         hip.require_device(torch.cuda.current_device())
         self.qtype, self.M, self.K = qtype, M, K
+        if qtype not in BLOCK_BYTES:
+            raise hip.FastLlamaHipError(f"type {qtype} is not Q4_0 (2) / Q4_1 (3)")
         nbytes = M * (K // QK) * BLOCK_BYTES[qtype]
         if isinstance(blocks, torch.Tensor) and blocks.is_cuda:
             assert blocks.numel() * blocks.element_size() == nbytes
