@@ -187,7 +187,7 @@ fl_qtensor *fl_qtensor_from_device(int type, const void *blocks_dev, int M, int 
     int bad = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, S(stream));
     if (e == hipSuccess) e = hipStreamSynchronize(S(stream));
-    if (flag) hipFree(flag);
+    if (flag) (void)hipFree(flag);
     if (e != hipSuccess) {
         hip_fail(e, "fl_qtensor_from_device");
         fl_qtensor_free(W);
@@ -214,7 +214,7 @@ fl_qtensor *fl_qtensor_upload(int type, const void *blocks_host, int M, int K, v
     fl_qtensor *W = nullptr;
     if (e == hipSuccess) W = fl_qtensor_from_device(type, tmp, M, K, stream);
     else hip_fail(e, "hipMemcpy(H2D)");
-    hipFree(tmp);
+    (void)hipFree(tmp);
     return W;
 }
 
@@ -226,7 +226,7 @@ int fl_qtensor_download(const fl_qtensor *W, void *blocks_host, void *stream) {
     hipError_t e = unpack_from_qw16(W->type, W->qs, W->d, W->m, W->M, W->K, tmp, S(stream));
     if (e == hipSuccess) e = hipMemcpyAsync(blocks_host, tmp, bytes, hipMemcpyDeviceToHost, S(stream));
     if (e == hipSuccess) e = hipStreamSynchronize(S(stream));
-    hipFree(tmp);
+    (void)hipFree(tmp);
     if (e != hipSuccess) return hip_fail(e, "fl_qtensor_download");
     return FL_OK;
 }
@@ -248,9 +248,9 @@ size_t fl_qtensor_device_bytes(const fl_qtensor *W) {
 void fl_qtensor_free(fl_qtensor *W) {
     if (!W) return;
     if (W->owns) {
-        if (W->qs) hipFree(W->qs);
-        if (W->d) hipFree(W->d);
-        if (W->m) hipFree(W->m);
+        if (W->qs) (void)hipFree(W->qs);
+        if (W->d) (void)hipFree(W->d);
+        if (W->m) (void)hipFree(W->m);
     }
     delete W;
 }
@@ -305,7 +305,7 @@ static void tbl_check(int rc, const char *fn) {
         fprintf(stderr, "%s: %s\n", fn, fl_last_error());
         abort();
     }
-    hipStreamSynchronize(nullptr);
+    (void)hipStreamSynchronize(nullptr);
 }
 static void tbl_deq_q4_0(const void *x, float *y, int k) { tbl_check(fl_dequantize_row_q4_0(x, y, k, nullptr), __func__); }
 static void tbl_deq_q4_1(const void *x, float *y, int k) { tbl_check(fl_dequantize_row_q4_1(x, y, k, nullptr), __func__); }
@@ -360,9 +360,9 @@ fl_qact *fl_qact_create(int max_N, int K) {
 
 void fl_qact_free(fl_qact *a) {
     if (!a) return;
-    if (a->q) hipFree(a->q);
-    if (a->d) hipFree(a->d);
-    if (a->s) hipFree(a->s);
+    if (a->q) (void)hipFree(a->q);
+    if (a->d) (void)hipFree(a->d);
+    if (a->s) (void)hipFree(a->s);
     delete static_cast<fl_qact_impl *>(a);
 }
 
@@ -447,7 +447,7 @@ int fl_mul_mat_q_f32(const fl_qtensor *W, const float *x, int ldx, float *y, int
     const size_t need = (size_t)fl_roundup(N, 16) * W->K;
     if (!g_ws || need > g_ws_elems) {
         if (g_ws) {
-            hipDeviceSynchronize();
+            (void)hipDeviceSynchronize();
             fl_qact_free(g_ws);
         }
         g_ws = fl_qact_create(fl_roundup(N, 16), W->K);

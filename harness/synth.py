@@ -1,0 +1,83 @@
+"""Synthetic LLaMA-shaped Q4_0 / Q4_1 weights, generated ON THE GPU with torch (harness only).
+
+Follows the weight recipe of SURVEY.md section 8(d): f32 ~ N(0, 0.02^2) per tensor, quantized per
+32-element block with the rule of the reference's quantize_row_q4_{0,1}_reference
+(/root/reference/lib/ggml.c:630-664, :917-956: d = amax/7, q = roundf(x/d)+8  |  d = (max-min)/15,
+q = roundf((x-min)/d)), packed into the reference's AoS block bytes (element 2j -> low nibble).
+The CPU oracle's quantizer (oracle.Port.quantize_q4) is the bit-exact one used by the parity tests;
+this torch version exists so that 4-40 GB of bench weights take seconds instead of minutes.
+"""
+from __future__ import annotations
+
+import torch
+
+Q4_0, Q4_1 = 2, 3
+BLOCK_BYTES = {Q4_0: 20, Q4_1: 24}
+
+# n_embd, n_head, n_layer, n_ff (n_ff from lib/llama.cpp:129 with n_mult = 256), n_vocab
+MODELS = {
+    "7B": dict(n_embd=4096, n_head=32, n_layer=32, n_ff=11008, n_vocab=32000),
+    "13B": dict(n_embd=5120, n_head=40, n_layer=40, n_ff=13824, n_vocab=32000),
+    "30B": dict(n_embd=6656, n_head=52, n_layer=60, n_ff=17920, n_vocab=32000),
+    "65B": dict(n_embd=8192, n_head=64, n_layer=80, n_ff=22016, n_vocab=32000),
+    # tiny shape for smoke tests (same structure, every K a multiple of 64)
+    "tiny": dict(n_embd=256, n_head=4, n_layer=2, n_ff=704, n_vocab=512),
+}
+
+
+def layer_matmuls(cfg):
+    """(name, M, K) of the 7 quantized matmuls of one layer, in eval order (lib/llama.cpp:328-435)."""
+    E, F = cfg["n_embd"], cfg["n_ff"]
+    return [("wq", E, E), ("wk", E, E), ("wv", E, E), ("wo", E, E), ("w3", F, E), ("w1", F, E), ("w2", E, F)]
+
+
+def algorithmic_work(cfg, N, qtype=Q4_0):
+    """bytes = M*K/32*B_blk + 4*N*K + 4*N*M, flops = 2*M*K*N, summed over the
+    7*n_layer + 1 quantized matmuls of one eval."""
+    bb = BLOCK_BYTES[qtype]
+    mats = [(M, K) for _, M, K in layer_matmuls(cfg)] * cfg["n_layer"] + [(cfg["n_vocab"], cfg["n_embd"])]
+    wbytes = sum(M * K // 32 * bb for M, K in mats)
+    abytes = sum(4 * N * K + 4 * N * M for M, K in mats)
+    flops = sum(2 * M * K * N for M, K in mats)
+    return dict(weight_bytes=wbytes, act_bytes=abytes, bytes=wbytes + abytes, flops=flops, n_matmuls=len(mats))
+
+
+def _roundf(x):
+    """C roundf: half away from zero."""
+    return torch.sign(x) * torch.floor(torch.abs(x) + 0.5)
+
+
+@torch.no_grad()
+def quantize_q4_torch(w: torch.Tensor, qtype: int) -> torch.Tensor:
+    """f32 [M, K] (device) -> uint8 [M, K/32*block_bytes] AoS blocks (device)."""
+    M, K = w.shape
+    b = w.view(M, K // 32, 32)
+    if qtype == Q4_0:
+        amax = b.abs().amax(-1, keepdim=True)
+        d = amax / 7.0
+        inv = torch.where(d != 0, 1.0 / d, torch.zeros_like(d))
+        q = (_roundf(b * inv).to(torch.int32) + 8).clamp_(0, 15).to(torch.uint8)
+        head = d.contiguous().view(torch.uint8).view(M, K // 32, 4)
+    else:
+        mn = b.amin(-1, keepdim=True)
+        mx = b.amax(-1, keepdim=True)
+        d = (mx - mn) / 15.0
+        inv = torch.where(d != 0, 1.0 / d, torch.zeros_like(d))
+        q = _roundf((b - mn) * inv).to(torch.int32).clamp_(0, 15).to(torch.uint8)
+        head = torch.cat([d.contiguous().view(torch.uint8).view(M, K // 32, 4),
+                          mn.contiguous().view(torch.uint8).view(M, K // 32, 4)], dim=-1)
+    packed = q[..., 0::2] | (q[..., 1::2] << 4)
+    return torch.cat([head, packed], dim=-1).reshape(M, -1).contiguous()
+
+
+@torch.no_grad()
+def synth_q4(M: int, K: int, qtype: int, seed: int, device="cuda", scale: float = 0.02) -> torch.Tensor:
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty((M, K // 32 * BLOCK_BYTES[qtype]), dtype=torch.uint8, device=device)
+    rows = max(16, min(M, (1 << 26) // K))          # generate in <=256 MiB f32 slabs
+    for r0 in range(0, M, rows):
+        r1 = min(M, r0 + rows)
+        w = torch.randn((r1 - r0, K), generator=g, device=device, dtype=torch.float32) * scale
+        out[r0:r1] = quantize_q4_torch(w, qtype)
+    return out
