@@ -14,36 +14,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "q4_kernels.h"
+#include "q4_device.h"
 
 namespace fl {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-// ------------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int qw16_pos(int r, int g) { return g ^ (((r >> 3) & 1) << 1); }
-
-// unpack one stored nibble dword (8 weights of k-group g) into two int8x4 dwords:
-//   lo = elements 0,2,4,6   hi = elements 1,3,5,7 of the group
-// Q4_0: values are 16*(nib-8) (stored nibbles are nib^8, see q4_layout.h); Q4_1: values are nib.
-template <int TYPE>
-__device__ __forceinline__ void unpack_nibbles(uint32_t v, uint32_t &lo, uint32_t &hi) {
-    if (TYPE == FL_TYPE_Q4_0) {
-        lo = (v << 4) & 0xF0F0F0F0u;
-        hi = v & 0xF0F0F0F0u;
-    } else {
-        lo = v & 0x0F0F0F0Fu;
-        hi = (v >> 4) & 0x0F0F0F0Fu;
-    }
-}
-
-__device__ __forceinline__ int dot8(uint32_t wlo, uint32_t whi, uint32_t xlo, uint32_t xhi, int acc) {
-    acc = __builtin_amdgcn_sdot4((int)wlo, (int)xlo, acc, false);
-    acc = __builtin_amdgcn_sdot4((int)whi, (int)xhi, acc, false);
-    return acc;
-}
 
 // ------------------------------------------------------------------------------------------------
 // weights: AoS <-> QW16
@@ -597,202 +570,6 @@ hipError_t gemm_q4_naive(const fl_qtensor &W, const fl_qact &xq, int N, float *y
     else
         hipLaunchKernelGGL(gemm_q4_naive_kernel<FL_TYPE_Q4_1>, grid, block, 0, st, W.qs, W.d, W.m, xq.q, xq.d, xq.s,
                            N, W.M, W.KB, y, ldy);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
-// a9 prefill path (N >= 9): exact-integer MFMA GEMM.
-//
-//   One MFMA K-step == one 32-element quant block:  v_mfma_i32_16x16x32_i8 (A = 16 W rows, B = 16
-//   activation columns) gives the 16x16 block dots exactly; the VALU epilogue applies the per-block
-//   scales:  acc[m][n] += float(isum) * (d_w[m,b] * d_x[n,b])   (+ m_w[m,b]*s_x[n,b] for Q4_1).
-//
-//   Workgroup 256 threads = 4 waves (2 x 2), tile BM x BN = 128 x 128, K-step = 4 blocks (128).
-//   Wave tile 64 x 64 = 4 x 4 MFMA tiles, 64 f32 accumulators.
-//   LDS stage (single image of the QW16 / QA16 global order, so all fills are 16-byte linear copies):
-//       A  [8 row-groups][4 blocks][16 rows][16 B]     8 KiB     packed nibbles
-//       dW [8][4][16] f32 (+ mW for Q4_1)              2 (+2) KiB
-//       B  [8 col-groups][4 blocks][16 cols][32 B]    16 KiB     int8
-//       dX [8][4][16] f32 (+ sX for Q4_1)              2 (+2) KiB
-//   Two stages are double-buffered: the global loads of step t+1 are issued before the MFMAs of
-//   step t and written to the other stage after them.
-// ------------------------------------------------------------------------------------------------
-constexpr int GM_BM = 128, GM_BN = 128, GM_KB = 4;
-constexpr int GM_A_BYTES = 8 * GM_KB * 256;       // 8192
-constexpr int GM_S_BYTES = 8 * GM_KB * 64;        // 2048
-constexpr int GM_B_BYTES = 8 * GM_KB * 512;       // 16384
-constexpr int GM_STAGE_BYTES = GM_A_BYTES + GM_B_BYTES + 4 * GM_S_BYTES;  // 32768
-
-template <int TYPE>
-__global__ __launch_bounds__(256, 2) void gemm_q4_mfma_kernel(
-    const uint4 *__restrict__ qs, const float *__restrict__ dW, const float *__restrict__ mW,
-    const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs, int N, int M,
-    int MG /* row groups */, int NG /* col groups */, int KB, float *__restrict__ y, int ldy) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l15 = lane & 15, lg = lane >> 4;
-
-    // XCD-aware tile order: consecutive tiles of one N-panel share their W rows' L2.
-    const int tiles_m = (MG + 7) >> 3, tiles_n = (NG + 7) >> 3;
-    int bid = blockIdx.x;
-    {
-        const int nwg = tiles_m * tiles_n;
-        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, k = bid >> 3;
-        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;  // bijective remap
-    }
-    const int tn = bid % tiles_n, tm = bid / tiles_n;
-    const int mg0 = tm * 8, ng0 = tn * 8;
-
-    v4f acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
-
-    // ---- staging registers: A 2 x uint4, B 4 x uint4, scales: 1 x uint4 (threads 0..127: dW | 128..255: dX),
-    //      Q4_1: + 1 x uint4 (mW | sX)
-    uint4 ra[2], rb[4], rs, rs2;
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-
-    auto load_stage = [&](int kb0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {  // A: 8 chunks of 1 KiB, chunk = group
-            const int ch = (tid >> 6) + i * 4, e = tid & 63;  // e: uint4 index inside the chunk = (b, row)
-            const int g = mg0 + ch, b = kb0 + (e >> 4);
-            ra[i] = (g < MG && b < KB) ? qs[((int64_t)g * KB + kb0) * 16 + e] : zero4;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {  // B: 8 chunks of 2 KiB
-            const int ch = (tid >> 7) + i * 2, e = tid & 127;  // e: uint4 index = (b, col, half)
-            const int g = ng0 + ch, b = kb0 + (e >> 5);
-            rb[i] = (g < NG && b < KB)
-                        ? *reinterpret_cast<const uint4 *>(xq + (((int64_t)g * KB + kb0) * 16) * 32 + e * 16)
-                        : zero4;
-        }
-        {  // scales: 8 chunks of 256 B per plane; 16 uint4 per chunk
-            const int t = tid & 127, ch = t >> 4, e = t & 15;  // e: uint4 index = (b, 4 rows)
-            const int b = kb0 + (e >> 2);
-            if (tid < 128) {
-                const int g = mg0 + ch;
-                const bool ok = g < MG && b < KB;
-                const int64_t off = ((int64_t)g * KB + kb0) * 16 + e * 4;
-                rs = ok ? *reinterpret_cast<const uint4 *>(dW + off) : zero4;
-                if (TYPE == FL_TYPE_Q4_1) rs2 = ok ? *reinterpret_cast<const uint4 *>(mW + off) : zero4;
-            } else {
-                const int g = ng0 + ch;
-                const bool ok = g < NG && b < KB;
-                const int64_t off = ((int64_t)g * KB + kb0) * 16 + e * 4;
-                rs = ok ? *reinterpret_cast<const uint4 *>(xd + off) : zero4;
-                if (TYPE == FL_TYPE_Q4_1) rs2 = ok ? *reinterpret_cast<const uint4 *>(xs + off) : zero4;
-            }
-        }
-    };
-    auto store_stage = [&](int st) {
-        unsigned char *base = smem + st * GM_STAGE_BYTES;
-        uint4 *sa = reinterpret_cast<uint4 *>(base);
-        uint4 *sb = reinterpret_cast<uint4 *>(base + GM_A_BYTES);
-        uint4 *ss = reinterpret_cast<uint4 *>(base + GM_A_BYTES + GM_B_BYTES);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) sa[((tid >> 6) + i * 4) * 64 + (tid & 63)] = ra[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sb[((tid >> 7) + i * 2) * 128 + (tid & 127)] = rb[i];
-        // plane order: dW | dX | mW | sX, each 2 KiB = 128 uint4
-        ss[(tid < 128 ? 0 : 128) + (tid & 127)] = rs;
-        if (TYPE == FL_TYPE_Q4_1) ss[256 + (tid < 128 ? 0 : 128) + (tid & 127)] = rs2;
-    };
-
-    const int nsteps = (KB + GM_KB - 1) / GM_KB;
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
-
-    for (int t = 0; t < nsteps; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nsteps) load_stage((t + 1) * GM_KB);
-
-        const unsigned char *base = smem + cur * GM_STAGE_BYTES;
-        const uint32_t *sa = reinterpret_cast<const uint32_t *>(base);
-        const unsigned char *sb = base + GM_A_BYTES;
-        const float *sdw = reinterpret_cast<const float *>(base + GM_A_BYTES + GM_B_BYTES);
-        const float *sdx = sdw + 512;
-        const float *smw = sdw + 1024;
-        const float *ssx = sdw + 1536;
-
-#pragma unroll 1
-        for (int b = 0; b < GM_KB; ++b) {
-            long afrag[4], bfrag[4];
-            v4f dwv[4], mwv[4];
-            float dxv[4], sxv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int g = wm * 4 + i;
-                const uint32_t v = sa[((g * GM_KB + b) * 16 + l15) * 4 + qw16_pos(l15, lg)];
-                uint32_t lo, hi;
-                unpack_nibbles<TYPE>(v, lo, hi);
-                afrag[i] = (long)(((uint64_t)hi << 32) | lo);
-                dwv[i] = *reinterpret_cast<const v4f *>(sdw + (g * GM_KB + b) * 16 + lg * 4);
-                if (TYPE == FL_TYPE_Q4_1) mwv[i] = *reinterpret_cast<const v4f *>(smw + (g * GM_KB + b) * 16 + lg * 4);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int g = wn * 4 + j;
-                bfrag[j] = *reinterpret_cast<const long *>(sb + ((g * GM_KB + b) * 16 + l15) * 32 +
-                                                           qw16_pos(l15, lg) * 8);
-                dxv[j] = sdx[(g * GM_KB + b) * 16 + l15];
-                if (TYPE == FL_TYPE_Q4_1) sxv[j] = ssx[(g * GM_KB + b) * 16 + l15];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const v4i z = {0, 0, 0, 0};
-                    const v4i isum = __builtin_amdgcn_mfma_i32_16x16x32_i8(afrag[i], bfrag[j], z, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        acc[i][j][r] = __fmaf_rn(__fmul_rn(dwv[i][r], dxv[j]), (float)isum[r], acc[i][j][r]);
-                        if (TYPE == FL_TYPE_Q4_1) acc[i][j][r] = __fmaf_rn(mwv[i][r], sxv[j], acc[i][j][r]);
-                    }
-                }
-            }
-        }
-        if (t + 1 < nsteps) store_stage(cur ^ 1);
-        __syncthreads();
-    }
-
-    // epilogue: lane holds rows m = 16*g + 4*lg + {0..3} of column n = 16*h + l15  -> one 16-byte store
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row0 = (mg0 + wm * 4 + i) * 16 + lg * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = (ng0 + wn * 4 + j) * 16 + l15;
-            if (n < N && row0 < M) {
-                float *p = y + (int64_t)n * ldy + row0;
-                if (row0 + 3 < M) {
-                    *reinterpret_cast<v4f *>(p) = acc[i][j];
-                } else {
-                    for (int r = 0; r < 4 && row0 + r < M; ++r) p[r] = acc[i][j][r];
-                }
-            }
-        }
-    }
-}
-
-hipError_t gemm_q4_mfma(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st) {
-    const int MG = W.M16 / 16, NG = fl_roundup(N, 16) / 16;
-    const int tiles = ((MG + 7) / 8) * ((NG + 7) / 8);
-    const size_t lds = 2 * GM_STAGE_BYTES;
-    if ((ldy & 3) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return hipErrorInvalidValue;
-    if (W.type == FL_TYPE_Q4_0) {
-        hipLaunchKernelGGL(gemm_q4_mfma_kernel<FL_TYPE_Q4_0>, dim3(tiles), dim3(256), lds, st,
-                           reinterpret_cast<const uint4 *>(W.qs), W.d, W.m, xq.q, xq.d, xq.s, N, W.M, MG, NG, W.KB, y,
-                           ldy);
-    } else {
-        hipLaunchKernelGGL(gemm_q4_mfma_kernel<FL_TYPE_Q4_1>, dim3(tiles), dim3(256), lds, st,
-                           reinterpret_cast<const uint4 *>(W.qs), W.d, W.m, xq.q, xq.d, xq.s, N, W.M, MG, NG, W.KB, y,
-                           ldy);
-    }
     return hipGetLastError();
 }
 
