@@ -43,6 +43,7 @@ int ensure_device() {
 
 }  // namespace fl
 
+namespace fl { extern int g_gemm_force_cfg; }
 using namespace fl;
 
 #define FL_HIP(call)                                   \
@@ -385,6 +386,11 @@ int fl_quantize_q8_layout(fl_qact *a_, const float *x, int ldx, int N, int K, in
 
 int fl_quantize_q8(fl_qact *a, const float *x, int ldx, int N, int K, void *st) {
     return fl_quantize_q8_layout(a, x, ldx, N, K, N <= 8 ? 1 : 16, st);
+}
+
+int fl_debug_set(int what, int value) {
+    if (what == 0) fl::g_gemm_force_cfg = value;
+    return FL_OK;
 }
 
 int fl_debug_qact_layout(const fl_qact *a) { return a ? static_cast<const fl_qact_impl *>(a)->layout : 0; }

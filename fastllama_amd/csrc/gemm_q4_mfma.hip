@@ -6,16 +6,23 @@
 //
 // One MFMA K-step is exactly one 32-element quant block: v_mfma_i32_16x16x32_i8 (A = 16 W rows,
 // B = 16 activation columns) produces the 16x16 block dots exactly.  The per-block scale product cannot
-// be folded into integer operands, so the f32 scale-accumulate is a VALU epilogue of 1/32 of the MACs
-// -- which on gfx950 is the co-critical resource (12 lane-ops per 16-cycle MFMA).  Design points:
+// be folded into integer operands, so the f32 scale-accumulate is a VALU epilogue of 1/32 of the MACs.
+// Measured on MI355X (profiles/): that epilogue, not the MFMA, bounds the kernel -- 12 f32 lane-ops
+// (6 packed VALU instructions, ~4 cycles each) per 16-cycle MFMA -- so the design is built around
+// keeping the VALU pipe of every SIMD saturated:
 //
 //   * int -> float without v_cvt: the MFMA's C input is the constant 0x4B400000 (= 1.5*2^23 as f32
-//     bits); D = magic + isum, reinterpreted as f32, IS 12582912 + isum exactly (|isum| < 2^22), so one
-//     (packable) v_sub_f32 replaces v_cvt_f32_i32.  Epilogue = pk_add, pk_mul, pk_fma per 2 outputs.
-//   * the MFMA of tile t+1 is issued before the epilogue of tile t (software pipeline in one wave).
-//   * QW16 / QA16 make every LDS fill a linear 16-byte copy -> global_load_lds (no staging VGPRs),
-//     two LDS stages; fragment reads are bank-conflict free by construction (q4_layout.h).
-//   * workgroup tile (32*TM) x 128, 4 waves as 2 x 2, wave tile (16*TM) x 64; K-step = 2 blocks.
+//     bits); D = magic + isum reinterpreted as f32 IS 12582912 + isum exactly (|isum| < 2^22), so one
+//     packed v_pk_add_f32 replaces two v_cvt_f32_i32.  Epilogue = pk_add, pk_mul, pk_fma per 2 outputs.
+//   * the MFMA of tile t+1 is issued before the epilogue of tile t (software pipeline inside a wave,
+//     pinned with sched_barrier because hipcc otherwise re-serialises MFMA -> s_nop -> own epilogue).
+//   * a single wave issues a packed VALU op only every ~8-11 cycles; >= 4 waves per SIMD are needed to
+//     fill the pipe.  Hence small wave tiles (few accumulator VGPRs), several workgroup shapes
+//     (template WM x WN waves of TM x TN MFMA tiles) and a shape-driven choice among them (pick_config).
+//   * QW16 / QA16 make every LDS fill a linear 16-byte copy -> global_load_lds (no staging VGPRs) into a
+//     3-deep LDS ring with counted s_waitcnt vmcnt; per-lane source pointers are computed once and
+//     advanced by a constant per K-step.  Fragment reads are bank-conflict free by construction
+//     (q4_layout.h; SQ_LDS_BANK_CONFLICT = 0 in profiles/).
 //   * XCD-aware bijective tile order: the N-tiles that share a W row panel run on one XCD's L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,41 +33,47 @@ namespace fl {
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ const uint4 fl_zero_chunk[1] = {{0u, 0u, 0u, 0u}};  // source of out-of-range LDS fills
 
-constexpr int GM_KS = 2;  // quant blocks per K-step
+constexpr int GM_KS = 2;      // quant blocks per K-step
+constexpr int GM_NSTAGE = 3;  // LDS ring depth: fills run GM_NSTAGE-1 K-steps ahead of the MFMAs
 
-template <int TYPE, int TM>
+template <int TYPE, int WM, int WN, int TM, int TN>
 struct GemmCfg {
-    static constexpr int MG = 2 * TM;                        // row groups per workgroup tile
-    static constexpr int A_BYTES = MG * GM_KS * 256;         // packed nibbles
-    static constexpr int B_BYTES = 8 * GM_KS * 512;          // int8 activations
-    static constexpr int SW_BYTES = 1024;                    // d_w plane (MG*KS*64 <= 1024), padded to 1 KiB
-    static constexpr int SX_BYTES = 1024;                    // d_x plane (8*KS*64 = 1024)
+    static constexpr int NW = WM * WN;                        // waves per workgroup
+    static constexpr int MG = WM * TM;                        // W row groups (16 rows) per workgroup tile
+    static constexpr int NG = WN * TN;                        // activation column groups per workgroup tile
+    static constexpr int A_BYTES = MG * GM_KS * 256;          // packed nibbles
+    static constexpr int B_BYTES = NG * GM_KS * 512;          // int8 activations
+    static constexpr int A_PIECES = A_BYTES / 1024;           // 1-KiB global_load_lds pieces
+    static constexpr int B_PIECES = B_BYTES / 1024;
+    static constexpr int N_PLANES = TYPE == FL_TYPE_Q4_1 ? 4 : 2;   // dW, dX (, mW, sX): one piece each, padded
+    static constexpr int PIECES = A_PIECES + B_PIECES + N_PLANES;
+    static constexpr int LPW = (PIECES + NW - 1) / NW;        // pieces issued by EVERY wave per stage
     static constexpr int OFF_B = A_BYTES;
-    static constexpr int OFF_DW = OFF_B + B_BYTES;
-    static constexpr int OFF_DX = OFF_DW + SW_BYTES;
-    static constexpr int OFF_MW = OFF_DX + SX_BYTES;         // Q4_1 only
-    static constexpr int OFF_SX = OFF_MW + SW_BYTES;
-    static constexpr int STAGE = TYPE == FL_TYPE_Q4_1 ? OFF_SX + SX_BYTES : OFF_MW;
+    static constexpr int OFF_PL = OFF_B + B_BYTES;            // planes, 1 KiB apart: dW | dX | mW | sX
+    static constexpr int STAGE = OFF_PL + N_PLANES * 1024;
+    static constexpr int OFF_SINK = GM_NSTAGE * STAGE;        // 1 KiB sink for padding pieces
+    static constexpr int LDS_BYTES = OFF_SINK + 1024;
+    static_assert(A_BYTES % 1024 == 0 && B_BYTES % 1024 == 0, "tile must be made of whole 1-KiB pieces");
+    static_assert(MG * GM_KS * 64 <= 1024 && NG * GM_KS * 64 <= 1024, "scale plane must fit one piece");
 };
 
-template <int TYPE, int TM>
-__global__ __launch_bounds__(256, 2) void gemm_q4_mfma_kernel(
+template <int TYPE, int WM, int WN, int TM, int TN, int MINW>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_q4_mfma_kernel(
     const uint4 *__restrict__ qs, const float *__restrict__ dW, const float *__restrict__ mW,
     const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs, int N, int M,
     int MGT /* row groups total */, int NGT /* col groups total */, int KB, float *__restrict__ y, int ldy) {
-    using Cfg = GemmCfg<TYPE, TM>;
+    using Cfg = GemmCfg<TYPE, WM, WN, TM, TN>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int l15 = lane & 15, lg = lane >> 4;
 
     // ---- XCD-aware bijective remap of the tile id (cdna guide T1): block b runs on XCD b%8 ----
-    const int tiles_m = (MGT + Cfg::MG - 1) / Cfg::MG, tiles_n = (NGT + 7) >> 3;
+    const int tiles_m = (MGT + Cfg::MG - 1) / Cfg::MG, tiles_n = (NGT + Cfg::NG - 1) / Cfg::NG;
     int bid = blockIdx.x;
     {
         const int nwg = tiles_m * tiles_n;
@@ -68,109 +81,131 @@ __global__ __launch_bounds__(256, 2) void gemm_q4_mfma_kernel(
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
     }
     const int tn = bid % tiles_n, tm = bid / tiles_n;
-    const int mg0 = tm * Cfg::MG, ng0 = tn * 8;
+    const int mg0 = tm * Cfg::MG, ng0 = tn * Cfg::NG;
 
-    // ---- LDS fill: every wave issues its share of 1-KiB global_load_lds pieces ----
-    //   A : MG*KS*16 chunks of 16 B  (TM=4: 256 = 4 pieces, TM=2: 128 = 2 pieces)
-    //   B : 8*KS*32 = 512 chunks = 8 pieces;  scale planes: 1 piece each (padded)
-    auto fill = [&](int st, int kb0) {
-        unsigned char *base = smem + st * Cfg::STAGE;
-        const glb_void *zsrc = (glb_void *)fl_zero_chunk;
-        // A pieces: piece p covers chunks [64p, 64p+64): group gi = c / (KS*16), e = c % (KS*16)
-        constexpr int A_PIECES = Cfg::A_BYTES / 1024;
-        for (int p = wave; p < A_PIECES; p += 4) {
-            const int c = p * 64 + lane;
-            const int gi = c / (GM_KS * 16), e = c % (GM_KS * 16);
-            const int g = mg0 + gi, b = kb0 + e / 16;
-            const glb_void *src = (g < MGT && b < KB) ? (glb_void *)(qs + ((int64_t)g * KB + kb0) * 16 + e) : zsrc;
-            __builtin_amdgcn_global_load_lds(src, (lds_void *)(base + p * 1024), 16, 0, 0);
-        }
-        // B pieces: one piece per column group (KS*512 = 1024 B)
-        for (int p = wave * 2; p < wave * 2 + 2; ++p) {
-            const int g = ng0 + p, b = kb0 + lane / 32;
-            const glb_void *src = (g < NGT && b < KB)
-                                      ? (glb_void *)(xq + (((int64_t)g * KB + kb0) * 16) * 32 + lane * 16)
-                                      : zsrc;
-            __builtin_amdgcn_global_load_lds(src, (lds_void *)(base + Cfg::OFF_B + p * 1024), 16, 0, 0);
-        }
-        // scale planes: chunk c: group gi = c / (KS*4), e = c % (KS*4): block e/4, 4 rows each
-        {
-            const int gi = lane / (GM_KS * 4), e = lane % (GM_KS * 4);
-            const int b = kb0 + e / 4;
-            if (wave == 0 || (TYPE == FL_TYPE_Q4_1 && wave == 2)) {
-                const int g = mg0 + gi;
-                const float *pl = wave == 0 ? dW : mW;
-                const glb_void *src =
-                    (gi < Cfg::MG && g < MGT && b < KB) ? (glb_void *)(pl + ((int64_t)g * KB + kb0) * 16 + e * 4) : zsrc;
-                __builtin_amdgcn_global_load_lds(src, (lds_void *)(base + (wave == 0 ? Cfg::OFF_DW : Cfg::OFF_MW)), 16, 0, 0);
-            } else if (wave == 1 || (TYPE == FL_TYPE_Q4_1 && wave == 3)) {
-                const int g = ng0 + gi;
-                const float *pl = wave == 1 ? xd : xs;
-                const glb_void *src =
-                    (g < NGT && b < KB) ? (glb_void *)(pl + ((int64_t)g * KB + kb0) * 16 + e * 4) : zsrc;
-                __builtin_amdgcn_global_load_lds(src, (lds_void *)(base + (wave == 1 ? Cfg::OFF_DX : Cfg::OFF_SX)), 16, 0, 0);
+    // ---- LDS fill plan.  Piece ids: [0, A_PIECES) A, then B, then the scale planes.  Wave w owns pieces
+    //      w, w+NW, ...; every wave issues exactly LPW global_load_lds per stage (missing ones go to a sink
+    //      from a zero chunk) so one counted s_waitcnt vmcnt(LPW * stages_in_flight) is valid for all waves.
+    //      The per-lane source pointer of each owned piece is computed ONCE; a K-step advances it by a constant.
+    const unsigned char *src[Cfg::LPW];
+    int step_bytes[Cfg::LPW], lds_off[Cfg::LPW], blk_of_lane[Cfg::LPW];
+    const unsigned char *const zsrc = reinterpret_cast<const unsigned char *>(fl_zero_chunk);
+#pragma unroll
+    for (int s = 0; s < Cfg::LPW; ++s) {
+        const int p = wave + s * Cfg::NW;
+        src[s] = zsrc;
+        step_bytes[s] = 0;
+        lds_off[s] = -1;
+        blk_of_lane[s] = 0;
+        if (p < Cfg::A_PIECES) {
+            const int c = p * 64 + lane, gi = c / (GM_KS * 16), e = c % (GM_KS * 16);
+            lds_off[s] = p * 1024;
+            blk_of_lane[s] = e / 16;
+            if (mg0 + gi < MGT) {
+                src[s] = reinterpret_cast<const unsigned char *>(qs + ((int64_t)(mg0 + gi) * KB) * 16 + e);
+                step_bytes[s] = GM_KS * 256;
             }
+        } else if (p < Cfg::A_PIECES + Cfg::B_PIECES) {
+            const int pb = p - Cfg::A_PIECES;
+            const int c = pb * 64 + lane, gi = c / (GM_KS * 32), e = c % (GM_KS * 32);
+            lds_off[s] = Cfg::OFF_B + pb * 1024;
+            blk_of_lane[s] = e / 32;
+            if (ng0 + gi < NGT) {
+                src[s] = reinterpret_cast<const unsigned char *>(xq) + ((int64_t)(ng0 + gi) * KB) * 512 + e * 16;
+                step_bytes[s] = GM_KS * 512;
+            }
+        } else if (p < Cfg::PIECES) {
+            const int pl = p - Cfg::A_PIECES - Cfg::B_PIECES;  // 0 dW, 1 dX, 2 mW, 3 sX
+            const int gi = lane / (GM_KS * 4), e = lane % (GM_KS * 4);
+            const bool wside = (pl & 1) == 0;
+            const float *plane = pl == 0 ? dW : pl == 1 ? xd : pl == 2 ? mW : xs;
+            const int g = (wside ? mg0 : ng0) + gi;
+            lds_off[s] = Cfg::OFF_PL + pl * 1024;
+            blk_of_lane[s] = e / 4;
+            if (wside ? (gi < Cfg::MG && g < MGT) : (gi < Cfg::NG && g < NGT)) {
+                src[s] = reinterpret_cast<const unsigned char *>(plane + ((int64_t)g * KB) * 16 + e * 4);
+                step_bytes[s] = GM_KS * 64;
+            }
+        }
+    }
+    auto fill = [&](int st, int kb0) {
+        // kb0 .. kb0+KS-1 are the blocks of this stage; blocks >= KB read the zero chunk (K tail / past the end)
+        const bool tail = kb0 + GM_KS > KB;
+#pragma unroll
+        for (int s = 0; s < Cfg::LPW; ++s) {
+            const unsigned char *p = src[s];
+            if (tail && kb0 + blk_of_lane[s] >= KB) p = zsrc;
+            unsigned char *dst = smem + (lds_off[s] >= 0 ? st * Cfg::STAGE + lds_off[s] : Cfg::OFF_SINK);
+            __builtin_amdgcn_global_load_lds((glb_void *)p, (lds_void *)dst, 16, 0, 0);
+            src[s] += step_bytes[s];
         }
     };
 
-    v4f acc[TM][4];
+    v4f acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
     const v4i magic = {0x4B400000, 0x4B400000, 0x4B400000, 0x4B400000};  // 12582912.0f = 1.5 * 2^23
     const int apos = qw16_pos(l15, lg);
+    // per-lane LDS byte offsets inside a stage (constant over the kernel)
+    const int a_off = ((wm * TM * GM_KS) * 16 + l15) * 16 + apos * 4;               // + (i*KS + b)*256
+    const int b_off = Cfg::OFF_B + ((wn * TN * GM_KS) * 16 + l15) * 32 + apos * 8;  // + (j*KS + b)*512
+    const int dw_off = Cfg::OFF_PL + ((wm * TM * GM_KS) * 16 + lg * 4) * 4;         // + (i*KS + b)*64
+    const int dx_off = Cfg::OFF_PL + 1024 + ((wn * TN * GM_KS) * 16 + l15) * 4;     // + (j*KS + b)*64
 
     const int nsteps = (KB + GM_KS - 1) / GM_KS;
-    fill(0, 0);
-    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < GM_NSTAGE - 1; ++st) fill(st, st * GM_KS);  // past-the-end fills are all-zero pieces
 
+    int cur = 0;
     for (int t = 0; t < nsteps; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nsteps) fill(cur ^ 1, (t + 1) * GM_KS);
-
+        // this wave's pieces of stage t have landed once at most (NSTAGE-2) later stages are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::LPW * (GM_NSTAGE - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();  // all waves' pieces landed; all waves are done reading stage t-1
+        {
+            int nxt = cur + GM_NSTAGE - 1;
+            nxt = nxt >= GM_NSTAGE ? nxt - GM_NSTAGE : nxt;
+            fill(nxt, (t + GM_NSTAGE - 1) * GM_KS);  // refills the buffer that was read in step t-1
+        }
         const unsigned char *base = smem + cur * Cfg::STAGE;
-        const uint32_t *sa = reinterpret_cast<const uint32_t *>(base);
-        const unsigned char *sb = base + Cfg::OFF_B;
-        const float *sdw = reinterpret_cast<const float *>(base + Cfg::OFF_DW);
-        const float *sdx = reinterpret_cast<const float *>(base + Cfg::OFF_DX);
-        const float *smw = reinterpret_cast<const float *>(base + Cfg::OFF_MW);
-        const float *ssx = reinterpret_cast<const float *>(base + Cfg::OFF_SX);
 
 #pragma unroll
         for (int b = 0; b < GM_KS; ++b) {
-            long afrag[TM], bfrag[4];
+            long afrag[TM], bfrag[TN];
             v4f dwv[TM], mwv[TM];
-            float dxv[4], sxv[4];
+            float dxv[TN], sxv[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int g = wm * TM + i;
-                const uint32_t v = sa[((g * GM_KS + b) * 16 + l15) * 4 + apos];
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(base + a_off + (i * GM_KS + b) * 256);
                 uint32_t lo, hi;
                 unpack_nibbles<TYPE>(v, lo, hi);
                 afrag[i] = (long)(((uint64_t)hi << 32) | lo);
-                dwv[i] = *reinterpret_cast<const v4f *>(sdw + (g * GM_KS + b) * 16 + lg * 4);
-                if (TYPE == FL_TYPE_Q4_1) mwv[i] = *reinterpret_cast<const v4f *>(smw + (g * GM_KS + b) * 16 + lg * 4);
+                dwv[i] = *reinterpret_cast<const v4f *>(base + dw_off + (i * GM_KS + b) * 64);
+                if (TYPE == FL_TYPE_Q4_1) mwv[i] = *reinterpret_cast<const v4f *>(base + dw_off + 2048 + (i * GM_KS + b) * 64);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int g = wn * 4 + j;
-                bfrag[j] = *reinterpret_cast<const long *>(sb + ((g * GM_KS + b) * 16 + l15) * 32 + apos * 8);
-                dxv[j] = sdx[(g * GM_KS + b) * 16 + l15];
-                if (TYPE == FL_TYPE_Q4_1) sxv[j] = ssx[(g * GM_KS + b) * 16 + l15];
+            for (int j = 0; j < TN; ++j) {
+                bfrag[j] = *reinterpret_cast<const long *>(base + b_off + (j * GM_KS + b) * 512);
+                dxv[j] = *reinterpret_cast<const float *>(base + dx_off + (j * GM_KS + b) * 64);
+                if (TYPE == FL_TYPE_Q4_1) sxv[j] = *reinterpret_cast<const float *>(base + dx_off + 2048 + (j * GM_KS + b) * 64);
             }
             // software pipeline inside one wave: MFMA(tile t+1) is issued, THEN the VALU scales tile t, so the
-            // 6 packed VALU ops run under the 16-cycle MFMA.  hipcc's scheduler otherwise re-serialises this
-            // (MFMA -> s_nop -> its own epilogue), hence the sched_barrier(0) pins between the two halves.
-            v4i r0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(afrag[0], bfrag[0], magic, 0, 0, 0);
+            // packed VALU ops run under the 16-cycle MFMA.  sched_barrier(0) pins the two halves.
+#ifdef FL_ABL_NOMFMA   // timing experiment only: the epilogue runs on garbage, no MFMA is issued
+#define FL_MFMA(a, b, c) ({ v4i r_; asm volatile("; no mfma" : "=v"(r_) : "v"(a), "v"(b), "v"(c)); r_; })
+#else
+#define FL_MFMA(a, b, c) __builtin_amdgcn_mfma_i32_16x16x32_i8(a, b, c, 0, 0, 0)
+#endif
+            v4i r0 = FL_MFMA(afrag[0], bfrag[0], magic);
             v4i r1;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tt = 0; tt < TM * 4; ++tt) {
-                const int i = tt >> 2, j = tt & 3;
-                if (tt + 1 < TM * 4) {
-                    const v4i rn = __builtin_amdgcn_mfma_i32_16x16x32_i8(afrag[(tt + 1) >> 2], bfrag[(tt + 1) & 3], magic, 0, 0, 0);
+            for (int tt = 0; tt < TM * TN; ++tt) {
+                const int i = tt / TN, j = tt % TN;
+                if (tt + 1 < TM * TN) {
+                    const v4i rn = FL_MFMA(afrag[(tt + 1) / TN], bfrag[(tt + 1) % TN], magic);
                     if (tt & 1) r0 = rn; else r1 = rn;
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -184,16 +219,17 @@ __global__ __launch_bounds__(256, 2) void gemm_q4_mfma_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();  // hipcc drains the global_load_lds of the next stage here (vmcnt(0))
+        cur = cur + 1 == GM_NSTAGE ? 0 : cur + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the (zero) tail fills before the wave ends
 
     // ---- store: lane holds rows m = 16*g + 4*lg + {0..3} of column n = 16*h + l15 -> one 16-byte store
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row0 = (mg0 + wm * TM + i) * 16 + lg * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = (ng0 + wn * 4 + j) * 16 + l15;
+        for (int j = 0; j < TN; ++j) {
+            const int n = (ng0 + wn * TN + j) * 16 + l15;
             if (n < N && row0 < M) {
                 float *p = y + (int64_t)n * ldy + row0;
                 if (row0 + 3 < M) {
@@ -206,25 +242,62 @@ __global__ __launch_bounds__(256, 2) void gemm_q4_mfma_kernel(
     }
 }
 
-template <int TYPE, int TM>
+// ------------------------------------------------------------------------------------------------
+// configurations and the shape-driven choice
+// ------------------------------------------------------------------------------------------------
+//                      WM WN TM TN  minwaves/SIMD          tile      waves
+#define FL_GEMM_CONFIGS(X)                                                   \
+    X(0, 2, 2, 4, 4, 2) /* 128x128   4 waves of 64x64                    */ \
+    X(1, 2, 2, 2, 4, 4) /*  64x128   4 waves of 32x64                    */ \
+    X(2, 4, 2, 2, 4, 2) /* 128x128   8 waves of 32x64                    */ \
+    X(3, 4, 2, 1, 4, 2) /*  64x128   8 waves of 16x64                    */ \
+    X(4, 4, 4, 1, 2, 1) /*  64x128  16 waves of 16x32                    */ \
+    X(5, 4, 4, 2, 2, 1) /* 128x128  16 waves of 32x32                    */
+
+int g_gemm_force_cfg = -1;  // debug / autotune hook: >= 0 forces one configuration
+
+template <int TYPE, int WM, int WN, int TM, int TN, int MINW>
 static hipError_t launch_gemm(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st) {
-    using Cfg = GemmCfg<TYPE, TM>;
+    using Cfg = GemmCfg<TYPE, WM, WN, TM, TN>;
     const int MGT = W.M16 / 16, NGT = fl_roundup(N, 16) / 16;
-    const int tiles = ((MGT + Cfg::MG - 1) / Cfg::MG) * ((NGT + 7) / 8);
-    const size_t lds = 2 * Cfg::STAGE;
-    hipLaunchKernelGGL((gemm_q4_mfma_kernel<TYPE, TM>), dim3(tiles), dim3(256), lds, st,
-                       reinterpret_cast<const uint4 *>(W.qs), W.d, W.m, xq.q, xq.d, xq.s, N, W.M, MGT, NGT, W.KB, y, ldy);
+    const int tiles = ((MGT + Cfg::MG - 1) / Cfg::MG) * ((NGT + Cfg::NG - 1) / Cfg::NG);
+    auto kern = gemm_q4_mfma_kernel<TYPE, WM, WN, TM, TN, MINW>;
+    static bool attr_set = false;
+    if (!attr_set && Cfg::LDS_BYTES > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), Cfg::LDS_BYTES, st, reinterpret_cast<const uint4 *>(W.qs), W.d,
+                       W.m, xq.q, xq.d, xq.s, N, W.M, MGT, NGT, W.KB, y, ldy);
     return hipGetLastError();
+}
+
+// Choose the workgroup shape from the problem shape.  The quantity that matters (measured) is
+// waves per SIMD actually doing epilogue VALU work: tiles are cheap to shrink (QW16/QA16 keep the fills
+// linear), idle SIMDs are not.
+static int pick_config(int MGT, int NGT) {
+    if (g_gemm_force_cfg >= 0) return g_gemm_force_cfg;
+    const int64_t tiles16 = (int64_t)MGT * NGT;      // 16x16 output tiles
+    const double per_simd = (double)tiles16 / 1024;  // MI355X: 256 CUs x 4 SIMDs
+    // thresholds from scripts/sweep_cfg.py on MI355X at N=512 (profiles/r01_gemm_cfg_sweep.txt)
+    if (per_simd >= 48) return 2;                    // plenty of work: 128x128 tiles, 8 waves of 32x64
+    if (per_simd >= 12) return 1;                    // 64x128 tiles, 4 waves of 32x64, 4 workgroups per CU
+    return 4;                                        // small outputs: 64x128 tiles, 16 waves of 16x32
 }
 
 hipError_t gemm_q4_mfma(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st) {
     if ((ldy & 3) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return hipErrorInvalidValue;
     const int MGT = W.M16 / 16, NGT = fl_roundup(N, 16) / 16;
-    // 128-row tiles unless that leaves CUs idle: then 64-row tiles double the workgroup count
-    const bool small = ((MGT + 7) / 8) * ((NGT + 7) / 8) < 384;
-    if (W.type == FL_TYPE_Q4_0)
-        return small ? launch_gemm<FL_TYPE_Q4_0, 2>(W, xq, N, y, ldy, st) : launch_gemm<FL_TYPE_Q4_0, 4>(W, xq, N, y, ldy, st);
-    return small ? launch_gemm<FL_TYPE_Q4_1, 2>(W, xq, N, y, ldy, st) : launch_gemm<FL_TYPE_Q4_1, 4>(W, xq, N, y, ldy, st);
+    const int cfg = pick_config(MGT, NGT);
+#define X(ID, WM, WN, TM, TN, MINW)                                                                         \
+    if (cfg == ID)                                                                                          \
+        return W.type == FL_TYPE_Q4_0 ? launch_gemm<FL_TYPE_Q4_0, WM, WN, TM, TN, MINW>(W, xq, N, y, ldy, st) \
+                                      : launch_gemm<FL_TYPE_Q4_1, WM, WN, TM, TN, MINW>(W, xq, N, y, ldy, st);
+    FL_GEMM_CONFIGS(X)
+#undef X
+    return hipErrorInvalidValue;
 }
 
 }  // namespace fl

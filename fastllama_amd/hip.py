@@ -75,6 +75,7 @@ _PROTOS = {
     "fl_mul_mat_q_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "fl_debug_mul_mat_q": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "fl_debug_qact_layout": (C.c_int, [C.c_void_p]),
+    "fl_debug_set": (C.c_int, [C.c_int, C.c_int]),
     "fl_quantize_q8_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 

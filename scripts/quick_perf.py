@@ -8,8 +8,10 @@ import torch
 from fastllama_amd import hip, ops
 
 Ns = [int(a) for a in sys.argv[1:]] or [1, 512]
+ABL = int(os.environ.get("FL_ABL", "0"))
 L = hip.load()
 hip.require_device(0)
+L.fl_debug_set(0, int(os.environ.get('FL_CFG', '-1')))
 shapes = [(4096, 4096), (11008, 4096), (4096, 11008), (32000, 4096)]
 for qt in (2, 3):
     for (M, K) in shapes:
