@@ -1,0 +1,376 @@
+// eval_kernels.hip -- the non-matmul ops of Model::eval (/root/reference/lib/llama.cpp:301-465) as gfx950
+// kernels, so that an eval is device-resident end to end.  Each kernel fuses the
+// reference ops that sit between two quantized matmuls and reproduces their numerics:
+//
+//   rmsnorm_quant   rms_norm (f64 sum of squares, eps 1e-6)    lib/ggml.c:7378-7430
+//                   * norm weight (ggml_mul)                    lib/llama.cpp:312-318
+//                   -> quantize_row_q8_0 of the result          lib/ggml.c:1299 (the INIT phase of the next mul_mat)
+//   rope_kv         rope mode 0 on Q and K                      lib/ggml.c:8609-8682 (fma pattern of the gcc build)
+//                   K -> k cache, V -> transposed v cache       lib/llama.cpp:336-347
+//   gemm_f32_abt    KQ = K*Q, KQV = V*softmax (f32 mul_mat)     lib/ggml.c:7482, lib/llama.cpp:364,389
+//                   (+ ggml_scale by 1/sqrt(head_dim))          lib/llama.cpp:367-371
+//   softmax_rows    diag_mask_inf + soft_max with the fp16 exp TABLE and an f64 sum   lib/ggml.c:8466,8521-8580
+//   silu_mul_quant  silu through the fp16 TABLE, * w3 branch, -> Q8_0                  lib/ggml.c:3207-3215
+//
+// The fp16 tables (exp, silu) and the rope sin/cos table are computed on the HOST with the same libm the
+// reference uses (ggml_init, lib/ggml.c:3676-3693) and uploaded once, so table entries are bit-identical.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include "eval_kernels.h"
+#include "q4_device.h"
+
+namespace fl {
+
+// ------------------------------------------------------------------------------------------------
+// shared: quantize one 8-element group (4 adjacent lanes = one Q8_0 block) and store it
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void quantize_store_group(const float v[8], int n, int kg, int KB, int layout,
+                                                     int8_t *__restrict__ q, float *__restrict__ d,
+                                                     float *__restrict__ s) {
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    const float dd = __fdiv_rn(amax, 127.0f);
+    const float id = amax != 0.0f ? __fdiv_rn(127.0f, amax) : 0.0f;
+    int qi[8], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        qi[i] = (int)rintf(__fmul_rn(v[i], id));
+        sum += qi[i];
+    }
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    auto pk = [](int a, int b, int c, int e) -> uint32_t {
+        return (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(c & 0xFF) << 16) |
+               ((uint32_t)(e & 0xFF) << 24);
+    };
+    const uint2 w = make_uint2(pk(qi[0], qi[2], qi[4], qi[6]), pk(qi[1], qi[3], qi[5], qi[7]));
+    const int b = kg >> 2, g = kg & 3;
+    if (layout == 16) {
+        const int grp = n >> 4, c = n & 15;
+        const int64_t cb = ((int64_t)grp * KB + b) * 16 + c;
+        *reinterpret_cast<uint2 *>(q + cb * 32 + qw16_pos(c, g) * 8) = w;
+        if (g == 0) {
+            d[cb] = dd;
+            s[cb] = __fmul_rn(dd, (float)sum);
+        }
+    } else {
+        const int64_t vb = (int64_t)n * KB + b;
+        *reinterpret_cast<uint2 *>(q + vb * 32 + g * 8) = w;
+        if (g == 0) {
+            d[vb] = dd;
+            s[vb] = __fmul_rn(dd, (float)sum);
+        }
+    }
+}
+
+__device__ __forceinline__ double block_sum_f64(double v, double *sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < nw; ++i) t += sh[i];
+    __syncthreads();
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rms_norm * weight  (-> optional f32 copy)  -> Q8_0 in QA16 / QA1
+//   one workgroup per activation row; rows >= N (padding of QA16) produce all-zero blocks.
+// ------------------------------------------------------------------------------------------------
+constexpr int RN_MAXIT = 4;  // 256 threads * 8 elements * 4 = E <= 8192
+
+__global__ __launch_bounds__(256) void rmsnorm_quant_kernel(const float *__restrict__ x, int ldx,
+                                                            const float *__restrict__ w, int N, int E,
+                                                            float *__restrict__ y_f32, int ldy, int layout,
+                                                            int8_t *__restrict__ q, float *__restrict__ d,
+                                                            float *__restrict__ s) {
+    __shared__ double sh[4];
+    const int n = blockIdx.x;
+    const int gpr = E >> 3, KB = E >> 5;
+    float v[RN_MAXIT][8];
+    double sum = 0.0;
+#pragma unroll
+    for (int it = 0; it < RN_MAXIT; ++it) {
+        const int kg = threadIdx.x + it * 256;
+        if (kg < gpr && n < N) {
+            const float4 a = *reinterpret_cast<const float4 *>(x + (int64_t)n * ldx + kg * 8);
+            const float4 c = *reinterpret_cast<const float4 *>(x + (int64_t)n * ldx + kg * 8 + 4);
+            v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
+            v[it][4] = c.x; v[it][5] = c.y; v[it][6] = c.z; v[it][7] = c.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[it][i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sum += (double)__fmul_rn(v[it][i], v[it][i]);  // (ggml_float)(x*x)
+    }
+    sum = block_sum_f64(sum, sh);
+    const float mean = (float)(sum / (double)E);
+    const float scale = __fdiv_rn(1.0f, sqrtf(mean + 1e-6f));
+#pragma unroll
+    for (int it = 0; it < RN_MAXIT; ++it) {
+        const int kg = threadIdx.x + it * 256;
+        if (kg >= gpr) continue;   // whole quads leave together (gpr is a multiple of 4)
+        float o[8];
+        const float4 wa = *reinterpret_cast<const float4 *>(w + kg * 8);
+        const float4 wc = *reinterpret_cast<const float4 *>(w + kg * 8 + 4);
+        const float ww[8] = {wa.x, wa.y, wa.z, wa.w, wc.x, wc.y, wc.z, wc.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = __fmul_rn(ww[i], __fmul_rn(v[it][i], scale));  // w * (x*scale)
+        if (y_f32 && n < N) {
+            float4 *yp = reinterpret_cast<float4 *>(y_f32 + (int64_t)n * ldy + kg * 8);
+            yp[0] = make_float4(o[0], o[1], o[2], o[3]);
+            yp[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        if (q) quantize_store_group(o, n, kg, KB, layout, q, d, s);
+    }
+}
+
+hipError_t rmsnorm_quant(const float *x, int ldx, const float *w, int N, int E, float *y_f32, int ldy,
+                         const fl_qact *out, int layout, hipStream_t st) {
+    if (E % 32 != 0 || E > 256 * 8 * RN_MAXIT) return hipErrorInvalidValue;
+    const int rows = (out && layout == 16) ? fl_roundup(N, 16) : N;
+    hipLaunchKernelGGL(rmsnorm_quant_kernel, dim3(rows), dim3(256), 0, st, x, ldx, w, N, E, y_f32, ldy, layout,
+                       out ? out->q : nullptr, out ? out->d : nullptr, out ? out->s : nullptr);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// silu(w1 x) * (w3 x) -> Q8_0.   h13: N rows of [w1 x (F) | w3 x (F)]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void silu_mul_quant_kernel(const float *__restrict__ h13, int ld, int N, int NP,
+                                                             int F, const uint16_t *__restrict__ silu_tab,
+                                                             int layout, int8_t *__restrict__ q,
+                                                             float *__restrict__ d, float *__restrict__ s) {
+    const int gpr = F >> 3, KB = F >> 5;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)NP * gpr;
+    const bool live = gid < total;
+    const int n = live ? (int)(gid / gpr) : 0, kg = live ? (int)(gid % gpr) : 0;
+    float o[8];
+    if (live && n < N) {
+        const float *pa = h13 + (int64_t)n * ld + kg * 8;
+        const float4 a0 = *reinterpret_cast<const float4 *>(pa), a1 = *reinterpret_cast<const float4 *>(pa + 4);
+        const float4 b0 = *reinterpret_cast<const float4 *>(pa + F), b1 = *reinterpret_cast<const float4 *>(pa + F + 4);
+        const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint16_t hx = __half_as_ushort(__float2half_rn(a[i]));                 // GGML_FP32_TO_FP16
+            const float sl = __half2float(__ushort_as_half(silu_tab[hx]));              // table_silu_f16
+            o[i] = __fmul_rn(sl, b[i]);                                                 // ggml_mul(silu, tmp)
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = 0.f;
+    }
+    // all 4 lanes of a quad are live or dead together (gpr % 4 == 0); shuffles inside need full quads
+    if (live) quantize_store_group(o, n, kg, KB, layout, q, d, s);
+}
+
+hipError_t silu_mul_quant(const float *h13, int ld, int N, int F, const uint16_t *silu_tab, const fl_qact *out,
+                          int layout, hipStream_t st) {
+    const int NP = layout == 16 ? fl_roundup(N, 16) : N;
+    const int64_t total = (int64_t)NP * (F >> 3);
+    hipLaunchKernelGGL(silu_mul_quant_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st, h13, ld, N, NP, F,
+                       silu_tab, layout, out->q, out->d, out->s);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// rope (mode 0, interleaved pairs) on Q (in place) and K (-> k cache), V -> transposed v cache
+//   qkv : N rows of [q (E) | k (E) | v (E)]        rope_tab : [n_ctx][D/2] float2 {cos, sin}
+//   kc  : [n_ctx][E]   (row p = position)           vc : [E][n_ctx]
+// The reference's gcc build computes  d0 = fma(x0, cos, -(x1*sin)),  d1 = fma(x0, sin, x1*cos).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_kv_kernel(float *__restrict__ qkv, int ld, int N, int E, int D,
+                                                      int n_past, int n_ctx, const float2 *__restrict__ rope_tab,
+                                                      float *__restrict__ kc, float *__restrict__ vc) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (n, pair)
+    const int ppr = E >> 1;
+    if (gid >= (int64_t)N * ppr) return;
+    const int n = (int)(gid / ppr), pr = (int)(gid % ppr);
+    const int e0 = pr * 2, i = (e0 % D) >> 1, pos = n_past + n;
+    const float2 cs = rope_tab[(int64_t)pos * (D >> 1) + i];
+    float *row = qkv + (int64_t)n * ld;
+    {
+        const float2 x = *reinterpret_cast<const float2 *>(row + e0);
+        float2 o;
+        o.x = __fmaf_rn(x.x, cs.x, -__fmul_rn(x.y, cs.y));
+        o.y = __fmaf_rn(x.x, cs.y, __fmul_rn(x.y, cs.x));
+        *reinterpret_cast<float2 *>(row + e0) = o;
+    }
+    {
+        const float2 x = *reinterpret_cast<const float2 *>(row + E + e0);
+        float2 o;
+        o.x = __fmaf_rn(x.x, cs.x, -__fmul_rn(x.y, cs.y));
+        o.y = __fmaf_rn(x.x, cs.y, __fmul_rn(x.y, cs.x));
+        *reinterpret_cast<float2 *>(kc + (int64_t)pos * E + e0) = o;
+    }
+    if (N < 16) {  // decode-sized: scatter the two V elements directly
+        const float2 v = *reinterpret_cast<const float2 *>(row + 2 * E + e0);
+        vc[(int64_t)e0 * n_ctx + pos] = v.x;
+        vc[(int64_t)(e0 + 1) * n_ctx + pos] = v.y;
+    }
+}
+
+// prefill: V [N][E] (inside qkv) -> vc[E][n_ctx] at columns n_past.. via a 32x32 LDS transpose
+__global__ __launch_bounds__(256) void v_transpose_kernel(const float *__restrict__ qkv, int ld, int N, int E,
+                                                          int n_past, int n_ctx, float *__restrict__ vc) {
+    __shared__ float tile[32][33];
+    const int e0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + ty + r * 8;
+        tile[ty + r * 8][tx] = n < N ? qkv[(int64_t)n * ld + 2 * E + e0 + tx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e = e0 + ty + r * 8, n = n0 + tx;
+        if (n < N) vc[(int64_t)e * n_ctx + n_past + n] = tile[tx][ty + r * 8];
+    }
+}
+
+hipError_t rope_kv(float *qkv, int ld, int N, int E, int D, int n_past, int n_ctx, const float *rope_tab, float *kc,
+                   float *vc, hipStream_t st) {
+    const int64_t total = (int64_t)N * (E >> 1);
+    hipLaunchKernelGGL(rope_kv_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st, qkv, ld, N, E, D, n_past,
+                       n_ctx, reinterpret_cast<const float2 *>(rope_tab), kc, vc);
+    if (N >= 16)
+        hipLaunchKernelGGL(v_transpose_kernel, dim3(E / 32, (N + 31) / 32), dim3(256), 0, st, qkv, ld, N, E, n_past,
+                           n_ctx, vc);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// batched f32 GEMM  C[z][m][n] = alpha * sum_k A[z][m][k] * B[z][n][k]   (both operands k-contiguous)
+// on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, same numerics as a scalar loop).
+//   KQ  : A = Q rows, B = k-cache rows, K = head_dim, alpha = 1/sqrt(head_dim) applied after the dot
+//   KQV : A = softmax rows, B = transposed v-cache rows, K = n_past + N
+// causal != 0: row m only needs n <= n_past + m (scores) resp. k <= n_past + m (KQV): tiles that are
+// entirely masked are skipped (the softmax kernel never reads them, and wrote zeros where KQV reads).
+// One wave per 32x32 output tile, 4 tiles (2x2) per 256-thread workgroup; operands come straight from
+// L1/L2 (Q/K/V tiles of one head are a few hundred KiB).
+// ------------------------------------------------------------------------------------------------
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void gemm_f32_abt_kernel(const float *__restrict__ A, int lda, int64_t sAz,
+                                                           const float *__restrict__ B, int ldb, int64_t sBz,
+                                                           float *__restrict__ C, int ldc, int64_t sCz, int M, int Nn,
+                                                           int K, float alpha, int causal_mode, int n_past) {
+    const int z = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * 64 + (wave >> 1) * 32, n0 = blockIdx.x * 64 + (wave & 1) * 32;
+    if (m0 >= M || n0 >= Nn) return;
+    int kend = K;
+    if (causal_mode == 1 && n0 > n_past + m0 + 31) return;             // scores: whole tile is masked
+    if (causal_mode == 2) kend = min(K, n_past + m0 + 32);            // KQV: probabilities beyond are zero
+    const int r = lane & 31, kk = lane >> 5;
+    const float *pa = A + z * sAz + (int64_t)min(m0 + r, M - 1) * lda + kk;
+    const float *pb = B + z * sBz + (int64_t)min(n0 + r, Nn - 1) * ldb + kk;
+    v16f acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    int k = 0;
+    for (; k + 8 <= kend; k += 8) {
+        const float a0 = pa[k], a1 = pa[k + 2], a2 = pa[k + 4], a3 = pa[k + 6];
+        const float b0 = pb[k], b1 = pb[k + 2], b2 = pb[k + 4], b3 = pb[k + 6];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc, 0, 0, 0);
+    }
+    for (; k < kend; k += 2) {
+        const float a = (k + kk < kend) ? pa[k] : 0.f;
+        const float b = (k + kk < kend) ? pb[k] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float *pc = C + z * sCz;
+    const int col = n0 + r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * kk;
+        if (row < M && col < Nn) pc[(int64_t)row * ldc + col] = __fmul_rn(acc[i], alpha);
+    }
+}
+
+hipError_t gemm_f32_abt(const float *A, int lda, int64_t sAz, const float *B, int ldb, int64_t sBz, float *C, int ldc,
+                        int64_t sCz, int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past,
+                        hipStream_t st) {
+    const dim3 grid((Nn + 63) / 64, (M + 63) / 64, batch);
+    hipLaunchKernelGGL(gemm_f32_abt_kernel, grid, dim3(256), 0, st, A, lda, sAz, B, ldb, sBz, C, ldc, sCz, M, Nn, K, alpha,
+                       causal_mode, n_past);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// diag_mask_inf + soft_max over one score row [0, P):  valid length L = n_past + n + 1
+//   max over the row; val = fp16->f32(exp_tab[fp32->fp16(s - max)]); sum in f64 (exact: fp16 terms);
+//   p = val * (float)(1.0 / sum); masked entries become 0.          lib/ggml.c:8558-8580
+// one wave per row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float *__restrict__ S, int ld, int64_t sz, int N, int P,
+                                                           int n_past, const uint16_t *__restrict__ exp_tab,
+                                                           int rows_total) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows_total) return;
+    const int lane = threadIdx.x & 63;
+    const int z = row / N, n = row % N;
+    float *p = S + z * sz + (int64_t)n * ld;
+    const int L = min(P, n_past + n + 1);
+    float mx = -INFINITY;
+    for (int i = lane; i < L; i += 64) mx = fmaxf(mx, p[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    double sum = 0.0;
+    for (int i = lane; i < L; i += 64) {
+        const float x = p[i];
+        float val = 0.f;
+        if (x != -INFINITY) {
+            const uint16_t h = __half_as_ushort(__float2half_rn(x - mx));
+            val = __half2float(__ushort_as_half(exp_tab[h]));
+        }
+        sum += (double)val;
+        p[i] = val;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = (float)(1.0 / sum);
+    for (int i = lane; i < P; i += 64) p[i] = i < L ? __fmul_rn(p[i], inv) : 0.f;
+}
+
+hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab,
+                        hipStream_t st) {
+    const int rows = N * batch;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, S, ld, sz, N, P, n_past, exp_tab, rows);
+    return hipGetLastError();
+}
+
+// out[n][e] = a[n][e] + b[n][e]   (ggml_add)
+__global__ void add_rows_kernel(const float *__restrict__ a, int lda, const float *__restrict__ b, int ldb,
+                                float *__restrict__ o, int ldo, int N, int E) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int e4 = E >> 2;
+    if (gid >= (int64_t)N * e4) return;
+    const int n = (int)(gid / e4), e = (int)(gid % e4) * 4;
+    const float4 x = *reinterpret_cast<const float4 *>(a + (int64_t)n * lda + e);
+    const float4 y = *reinterpret_cast<const float4 *>(b + (int64_t)n * ldb + e);
+    *reinterpret_cast<float4 *>(o + (int64_t)n * ldo + e) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+}
+
+hipError_t add_rows(const float *a, int lda, const float *b, int ldb, float *o, int ldo, int N, int E, hipStream_t st) {
+    const int64_t total = (int64_t)N * (E >> 2);
+    hipLaunchKernelGGL(add_rows_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st, a, lda, b, ldb, o, ldo, N, E);
+    return hipGetLastError();
+}
+
+}  // namespace fl

@@ -64,7 +64,8 @@ template <int TYPE, int WM, int WN, int TM, int TN, int MINW>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_q4_mfma_kernel(
     const uint4 *__restrict__ qs, const float *__restrict__ dW, const float *__restrict__ mW,
     const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs, int N, int M,
-    int MGT /* row groups total */, int NGT /* col groups total */, int KB, float *__restrict__ y, int ldy) {
+    int MGT /* row groups total */, int NGT /* col groups total */, int KB, float *__restrict__ y, int ldy,
+    const float *__restrict__ resid, int ldr) {
     using Cfg = GemmCfg<TYPE, WM, WN, TM, TN>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -232,10 +233,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_q4_mfma_kernel(
             const int n = (ng0 + wn * TN + j) * 16 + l15;
             if (n < N && row0 < M) {
                 float *p = y + (int64_t)n * ldy + row0;
+                const float *pr = resid ? resid + (int64_t)n * ldr + row0 : nullptr;
                 if (row0 + 3 < M) {
-                    *reinterpret_cast<v4f *>(p) = acc[i][j];
+                    v4f o = acc[i][j];
+                    if (pr) o += *reinterpret_cast<const v4f *>(pr);   // ggml_add(cur, inp) fused into the store
+                    *reinterpret_cast<v4f *>(p) = o;
                 } else {
-                    for (int r = 0; r < 4 && row0 + r < M; ++r) p[r] = acc[i][j][r];
+                    for (int r = 0; r < 4 && row0 + r < M; ++r) p[r] = acc[i][j][r] + (pr ? pr[r] : 0.f);
                 }
             }
         }
@@ -257,7 +261,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_q4_mfma_kernel(
 int g_gemm_force_cfg = -1;  // debug / autotune hook: >= 0 forces one configuration
 
 template <int TYPE, int WM, int WN, int TM, int TN, int MINW>
-static hipError_t launch_gemm(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st) {
+static hipError_t launch_gemm(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
+                              const float *resid, int ldr) {
     using Cfg = GemmCfg<TYPE, WM, WN, TM, TN>;
     const int MGT = W.M16 / 16, NGT = fl_roundup(N, 16) / 16;
     const int tiles = ((MGT + Cfg::MG - 1) / Cfg::MG) * ((NGT + Cfg::NG - 1) / Cfg::NG);
@@ -270,7 +275,7 @@ static hipError_t launch_gemm(const fl_qtensor &W, const fl_qact &xq, int N, flo
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), Cfg::LDS_BYTES, st, reinterpret_cast<const uint4 *>(W.qs), W.d,
-                       W.m, xq.q, xq.d, xq.s, N, W.M, MGT, NGT, W.KB, y, ldy);
+                       W.m, xq.q, xq.d, xq.s, N, W.M, MGT, NGT, W.KB, y, ldy, resid, ldr);
     return hipGetLastError();
 }
 
@@ -287,14 +292,16 @@ static int pick_config(int MGT, int NGT) {
     return 4;                                        // small outputs: 64x128 tiles, 16 waves of 16x32
 }
 
-hipError_t gemm_q4_mfma(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st) {
+hipError_t gemm_q4_mfma(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
+                        const float *resid, int ldr) {
+    if (resid && ((ldr & 3) != 0 || (reinterpret_cast<uintptr_t>(resid) & 15) != 0)) return hipErrorInvalidValue;
     if ((ldy & 3) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return hipErrorInvalidValue;
     const int MGT = W.M16 / 16, NGT = fl_roundup(N, 16) / 16;
     const int cfg = pick_config(MGT, NGT);
 #define X(ID, WM, WN, TM, TN, MINW)                                                                         \
     if (cfg == ID)                                                                                          \
-        return W.type == FL_TYPE_Q4_0 ? launch_gemm<FL_TYPE_Q4_0, WM, WN, TM, TN, MINW>(W, xq, N, y, ldy, st) \
-                                      : launch_gemm<FL_TYPE_Q4_1, WM, WN, TM, TN, MINW>(W, xq, N, y, ldy, st);
+        return W.type == FL_TYPE_Q4_0 ? launch_gemm<FL_TYPE_Q4_0, WM, WN, TM, TN, MINW>(W, xq, N, y, ldy, st, resid, ldr) \
+                                      : launch_gemm<FL_TYPE_Q4_1, WM, WN, TM, TN, MINW>(W, xq, N, y, ldy, st, resid, ldr);
     FL_GEMM_CONFIGS(X)
 #undef X
     return hipErrorInvalidValue;

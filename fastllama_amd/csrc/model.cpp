@@ -1,0 +1,482 @@
+// model.cpp -- device-resident replacement of fastllama::Model (weights, KV cache, eval).
+//
+// Replaces, for the GPU path (all file:line into /root/reference):
+//   Model::load  tensor placement        lib/llama.cpp:223-258   -> fl_model_set_tensor / fl_model_finalize
+//   KVCacheBuffer (f32 K and V)          lib/llama.cpp:24-51     -> k/v caches in HBM (V stored transposed, as the
+//                                                                   reference's own view at lib/llama.cpp:341-343)
+//   Model::eval                          lib/llama.cpp:272-499   -> fl_model_eval: one stream of kernels, no host
+//                                                                   round trip between ops, logits copied out once
+//   ggml_graph_compute dispatch          lib/ggml.c:10811        -> the fixed kernel sequence below
+//
+// wq|wk|wv and w1|w3 are stacked row-wise into single QW16 tensors at load: rows of a mul_mat are
+// independent dots (lib/ggml.c:8140-8163), so one GEMM over the stacked matrix is bit-identical to three
+// (two) separate ones and shares the Q8_0 activation quantization, which the reference repeats per matmul.
+//
+// Tensor parallelism (tp_size > 1) follows the split the reference's loader already knows for the original
+// multi-part checkpoints (include/tensor/utils.hpp:93-112): wq/wk/wv/w1/w3 by rows (whole heads per rank),
+// wo/w2 by columns (K blocks), so each layer needs two all-reduces of the [N, n_embd] partial sums.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fastllama_hip.h"
+#include "comm.h"
+#include "eval_kernels.h"
+#include "q4_kernels.h"
+#include "runtime.h"
+
+using namespace fl;
+
+namespace {
+
+struct StagedFuse {            // device AoS staging of a row-stacked tensor (wq|wk|wv or w1|w3)
+    void *aos = nullptr;
+    int parts_needed = 0, parts_have = 0;
+    int rows_per_part = 0, K = 0;
+};
+
+struct Layer {
+    float *attn_norm = nullptr, *ffn_norm = nullptr;
+    fl_qtensor *wqkv = nullptr, *wo = nullptr, *w13 = nullptr, *w2 = nullptr;
+    StagedFuse s_qkv, s_13;
+};
+
+}  // namespace
+
+struct fl_model {
+    fl_model_params hp{};
+    int E = 0, H = 0, D = 0, F = 0, V = 0, L = 0, n_ctx = 0, B = 0, qtype = 0;
+    int G = 1, rank = 0;        // tensor parallel
+    int El = 0, Hl = 0, Fl = 0; // local (per rank) widths
+    fl_qtensor *tok_emb = nullptr, *output = nullptr;
+    float *norm_w = nullptr;
+    std::vector<Layer> layers;
+    float *kc = nullptr, *vc = nullptr;            // [L][n_ctx][El], [L][El][n_ctx]
+    uint16_t *exp_tab = nullptr, *silu_tab = nullptr;
+    float *rope_tab = nullptr;                      // [n_ctx][D/2][2]
+    // work buffers
+    int *tok_dev = nullptr;
+    float *x = nullptr, *x2 = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *ao = nullptr, *h13 = nullptr,
+          *part = nullptr, *logits = nullptr;
+    fl_qact qE{}, qEl{}, qF{};                      // K = E, K = E/G (input of wo), K = F/G (input of w2)
+    hipStream_t stream = nullptr;
+    fl_comm *comm = nullptr;
+    bool finalized = false;
+    size_t dev_bytes = 0;
+};
+
+#define M_HIP(call)                                        \
+    do {                                                   \
+        hipError_t e_ = (call);                            \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);  \
+    } while (0)
+
+static int dev_alloc(fl_model *m, void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(model)");
+    m->dev_bytes += bytes;
+    return FL_OK;
+}
+
+static int qact_alloc(fl_model *m, fl_qact *a, int maxN, int K) {
+    memset(a, 0, sizeof *a);
+    int rc = dev_alloc(m, (void **)&a->q, qact_bytes_q(maxN, K));
+    if (rc == FL_OK) rc = dev_alloc(m, (void **)&a->d, qact_bytes_scale(maxN, K));
+    if (rc == FL_OK) rc = dev_alloc(m, (void **)&a->s, qact_bytes_scale(maxN, K));
+    a->KB = K / FL_QK;
+    return rc;
+}
+
+static uint16_t f32_to_f16_bits(float f) {  // round-to-nearest-even, as _cvtss_sh(x, 0) (GGML_FP32_TO_FP16 with F16C)
+    _Float16 h = (_Float16)f;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+static float f16_bits_to_f32(uint16_t u) {
+    _Float16 h;
+    memcpy(&h, &u, 2);
+    return (float)h;
+}
+
+extern "C" {
+
+fl_model *fl_model_create(const fl_model_params *p) {
+    if (ensure_device() != FL_OK) return nullptr;
+    if (!p || p->n_embd <= 0 || p->n_head <= 0 || p->n_layer <= 0 || p->n_ff <= 0 || p->n_vocab <= 0 || p->n_ctx <= 0 ||
+        p->max_batch <= 0 || (p->qtype != FL_TYPE_Q4_0 && p->qtype != FL_TYPE_Q4_1)) {
+        set_error(FL_EINVAL, "fl_model_create: bad hyper-parameters");
+        return nullptr;
+    }
+    const int G = p->tp_size > 0 ? p->tp_size : 1;
+    if (p->n_embd % p->n_head || (p->n_embd / p->n_head) % 2 || p->n_embd % 64 || p->n_ff % 64 || p->n_head % G ||
+        (p->n_embd / G) % 32 || (p->n_ff / G) % 32 || p->tp_rank < 0 || p->tp_rank >= G) {
+        set_error(FL_EINVAL, "fl_model_create: n_embd/n_ff must be multiples of 64 (ggml.c:2372) and divisible by tp_size");
+        return nullptr;
+    }
+    fl_model *m = new fl_model();
+    m->hp = *p;
+    m->E = p->n_embd; m->H = p->n_head; m->D = m->E / m->H; m->F = p->n_ff; m->V = p->n_vocab; m->L = p->n_layer;
+    m->n_ctx = p->n_ctx; m->B = p->max_batch; m->qtype = p->qtype;
+    m->G = G; m->rank = p->tp_rank;
+    m->El = m->E / G; m->Hl = m->H / G; m->Fl = m->F / G;
+    m->layers.resize(m->L);
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error(FL_EHIP, "hipStreamCreate failed");
+        delete m;
+        return nullptr;
+    }
+    return m;
+}
+
+static int upload_f32(fl_model *m, float **dst, const void *host, size_t n) {
+    int rc = dev_alloc(m, (void **)dst, n * 4);
+    if (rc != FL_OK) return rc;
+    M_HIP(hipMemcpy(*dst, host, n * 4, hipMemcpyHostToDevice));
+    return FL_OK;
+}
+
+// copy `rows` x blocks [kb0, kb1) of a host AoS tensor (row length KB_full blocks) to a dense device AoS buffer
+static int stage_rows(const void *host, int bs, int KB_full, int row0, int rows, int kb0, int kb1, void *dst_dev) {
+    const size_t src_pitch = (size_t)KB_full * bs, width = (size_t)(kb1 - kb0) * bs;
+    const char *src = (const char *)host + (size_t)row0 * src_pitch + (size_t)kb0 * bs;
+    M_HIP(hipMemcpy2D(dst_dev, width, src, src_pitch, width, rows, hipMemcpyHostToDevice));
+    return FL_OK;
+}
+
+static int make_qtensor(fl_model *m, fl_qtensor **out, const void *aos_dev, int M, int K) {
+    *out = fl_qtensor_from_device(m->qtype, aos_dev, M, K, nullptr);
+    if (!*out) return FL_EHIP;
+    m->dev_bytes += fl_qtensor_device_bytes(*out);
+    return FL_OK;
+}
+
+static int stage_part(fl_model *m, StagedFuse &sf, fl_qtensor **out, int nparts, int part, const void *host, int bs,
+                      int KB_full, int row0, int rows, int K) {
+    if (!sf.aos) {
+        sf.parts_needed = nparts;
+        sf.rows_per_part = rows;
+        sf.K = K;
+        M_HIP(hipMalloc(&sf.aos, (size_t)nparts * rows * (K / FL_QK) * bs));
+    }
+    void *dst = (char *)sf.aos + (size_t)part * rows * (K / FL_QK) * bs;
+    int rc = stage_rows(host, bs, KB_full, row0, rows, 0, K / FL_QK, dst);
+    if (rc != FL_OK) return rc;
+    if (++sf.parts_have == sf.parts_needed) {
+        rc = make_qtensor(m, out, sf.aos, nparts * rows, K);
+        (void)hipFree(sf.aos);
+        sf.aos = nullptr;
+    }
+    return rc;
+}
+
+int fl_model_set_tensor(fl_model *m, const char *name, int type, const void *host, int ne0, int ne1) {
+    if (!m || !name || !host) return set_error(FL_EINVAL, "fl_model_set_tensor: null argument");
+    if (m->finalized) return set_error(FL_EINVAL, "model already finalized");
+    const int E = m->E, F = m->F, V = m->V, G = m->G, r = m->rank;
+    const int bs = m->qtype == FL_TYPE_Q4_0 ? 20 : 24;
+    auto want_q = [&](int k, int rows) -> int {
+        if (type != m->qtype) return set_error(FL_EINVAL, "%s: type %d, model is type %d", name, type, m->qtype);
+        if (ne0 != k || ne1 != rows) return set_error(FL_EINVAL, "%s: shape [%d,%d], expected [%d,%d]", name, ne0, ne1, k, rows);
+        return FL_OK;
+    };
+    auto want_f = [&](int k) -> int {
+        if (type != 0) return set_error(FL_EINVAL, "%s: norm vectors must be f32", name);
+        if (ne0 != k || (ne1 != 1 && ne1 != 0)) return set_error(FL_EINVAL, "%s: bad norm shape", name);
+        return FL_OK;
+    };
+    int rc;
+    std::string nm(name);
+    if (nm == "tok_embeddings.weight" || nm == "output.weight") {
+        if ((rc = want_q(E, V)) != FL_OK) return rc;
+        fl_qtensor **dst = nm[0] == 't' ? &m->tok_emb : &m->output;
+        *dst = fl_qtensor_upload(m->qtype, host, V, E, nullptr);
+        if (!*dst) return FL_EHIP;
+        m->dev_bytes += fl_qtensor_device_bytes(*dst);
+        return FL_OK;
+    }
+    if (nm == "norm.weight") {
+        if ((rc = want_f(E)) != FL_OK) return rc;
+        return upload_f32(m, &m->norm_w, host, E);
+    }
+    int il = -1, off = 0;
+    if (sscanf(name, "layers.%d.%n", &il, &off) != 1 || il < 0 || il >= m->L || off == 0)
+        return set_error(FL_EINVAL, "unknown tensor name '%s'", name);
+    Layer &ly = m->layers[il];
+    const std::string sub(name + off);
+    if (sub == "attention_norm.weight") { if ((rc = want_f(E)) != FL_OK) return rc; return upload_f32(m, &ly.attn_norm, host, E); }
+    if (sub == "ffn_norm.weight") { if ((rc = want_f(E)) != FL_OK) return rc; return upload_f32(m, &ly.ffn_norm, host, E); }
+    if (sub == "attention.wq.weight" || sub == "attention.wk.weight" || sub == "attention.wv.weight") {
+        if ((rc = want_q(E, E)) != FL_OK) return rc;
+        const int part = sub[11] == 'q' ? 0 : sub[11] == 'k' ? 1 : 2;
+        return stage_part(m, ly.s_qkv, &ly.wqkv, 3, part, host, bs, E / FL_QK, r * m->El, m->El, E);   // rows of rank r
+    }
+    if (sub == "feed_forward.w1.weight" || sub == "feed_forward.w3.weight") {
+        if ((rc = want_q(E, F)) != FL_OK) return rc;
+        const int part = sub[14] == '1' ? 0 : 1;
+        return stage_part(m, ly.s_13, &ly.w13, 2, part, host, bs, E / FL_QK, r * m->Fl, m->Fl, E);
+    }
+    if (sub == "attention.wo.weight" || sub == "feed_forward.w2.weight") {
+        const bool is_wo = sub[0] == 'a';
+        const int K = is_wo ? E : F, Kl = K / G;
+        if ((rc = want_q(K, E)) != FL_OK) return rc;
+        void *tmp = nullptr;
+        M_HIP(hipMalloc(&tmp, (size_t)E * (Kl / FL_QK) * bs));
+        rc = stage_rows(host, bs, K / FL_QK, 0, E, r * (Kl / FL_QK), (r + 1) * (Kl / FL_QK), tmp);   // K blocks of rank r
+        if (rc == FL_OK) rc = make_qtensor(m, is_wo ? &ly.wo : &ly.w2, tmp, E, Kl);
+        (void)hipFree(tmp);
+        return rc;
+    }
+    return set_error(FL_EINVAL, "unknown tensor name '%s'", name);
+}
+
+int fl_model_finalize(fl_model *m) {
+    if (!m) return set_error(FL_EINVAL, "null model");
+    if (m->finalized) return FL_OK;
+    if (!m->tok_emb || !m->output || !m->norm_w) return set_error(FL_EINVAL, "model is missing tok_embeddings/norm/output");
+    for (int l = 0; l < m->L; ++l) {
+        const Layer &ly = m->layers[l];
+        if (!ly.attn_norm || !ly.ffn_norm || !ly.wqkv || !ly.wo || !ly.w13 || !ly.w2)
+            return set_error(FL_EINVAL, "layer %d is missing tensors", l);
+    }
+    int rc;
+    const int E = m->E, El = m->El, Fl = m->Fl, B = m->B, V = m->V, n_ctx = m->n_ctx, D = m->D;
+    const size_t kv_elems = (size_t)m->L * n_ctx * El;
+    if ((rc = dev_alloc(m, (void **)&m->kc, kv_elems * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&m->vc, kv_elems * 4)) != FL_OK) return rc;
+    M_HIP(hipMemset(m->kc, 0, kv_elems * 4));
+    M_HIP(hipMemset(m->vc, 0, kv_elems * 4));
+    // fp16 tables, host libm -- lib/ggml.c:3676-3693
+    {
+        std::vector<uint16_t> te(1 << 16), ts(1 << 16);
+        for (int i = 0; i < (1 << 16); ++i) {
+            const float f = f16_bits_to_f32((uint16_t)i);
+            te[i] = f32_to_f16_bits(expf(f));
+            ts[i] = f32_to_f16_bits(f / (1.0f + expf(-f)));   // ggml_silu_f32, lib/ggml.c:3196-3198
+        }
+        if ((rc = dev_alloc(m, (void **)&m->exp_tab, 2 << 16)) != FL_OK) return rc;
+        if ((rc = dev_alloc(m, (void **)&m->silu_tab, 2 << 16)) != FL_OK) return rc;
+        M_HIP(hipMemcpy(m->exp_tab, te.data(), 2 << 16, hipMemcpyHostToDevice));
+        M_HIP(hipMemcpy(m->silu_tab, ts.data(), 2 << 16, hipMemcpyHostToDevice));
+    }
+    // rope table: theta = p, then theta *= theta_scale per pair -- lib/ggml.c:8655-8667
+    {
+        std::vector<float> rt((size_t)n_ctx * (D / 2) * 2);
+        const float theta_scale = powf(10000.0f, -2.0f / (float)D);
+        for (int p = 0; p < n_ctx; ++p) {
+            float theta = (float)p;
+            for (int i = 0; i < D / 2; ++i) {
+                float sn, cs;
+                sincosf(theta, &sn, &cs);   // the reference's gcc build calls sincosf (merged cosf/sinf)
+                rt[((size_t)p * (D / 2) + i) * 2 + 0] = cs;
+                rt[((size_t)p * (D / 2) + i) * 2 + 1] = sn;
+                theta *= theta_scale;
+            }
+        }
+        if ((rc = dev_alloc(m, (void **)&m->rope_tab, rt.size() * 4)) != FL_OK) return rc;
+        M_HIP(hipMemcpy(m->rope_tab, rt.data(), rt.size() * 4, hipMemcpyHostToDevice));
+    }
+    if ((rc = dev_alloc(m, (void **)&m->tok_dev, (size_t)B * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&m->x, (size_t)B * E * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&m->x2, (size_t)B * E * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&m->xn, (size_t)B * E * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&m->part, (size_t)B * E * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&m->qkv, (size_t)B * 3 * El * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&m->att, (size_t)m->Hl * B * n_ctx * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&m->ao, (size_t)B * El * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&m->h13, (size_t)B * 2 * Fl * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&m->logits, (size_t)B * V * 4)) != FL_OK) return rc;
+    if ((rc = qact_alloc(m, &m->qE, B, E)) != FL_OK) return rc;
+    if ((rc = qact_alloc(m, &m->qEl, B, El)) != FL_OK) return rc;
+    if ((rc = qact_alloc(m, &m->qF, B, Fl)) != FL_OK) return rc;
+    M_HIP(hipDeviceSynchronize());
+    m->finalized = true;
+    return FL_OK;
+}
+
+int fl_model_set_comm(fl_model *m, fl_comm *c) {
+    if (!m) return set_error(FL_EINVAL, "null model");
+    if (m->G > 1 && !c) return set_error(FL_EINVAL, "tensor-parallel model needs a communicator");
+    m->comm = c;
+    return FL_OK;
+}
+
+static hipError_t mm(fl_model *m, const fl_qtensor *W, const fl_qact &a, int N, float *y, int ldy, const float *resid,
+                     int ldr) {
+    if (N <= 8) return gemv_q4(*W, a, N, y, ldy, m->stream, resid, ldr);
+    return gemm_q4_mfma(*W, a, N, y, ldy, m->stream, resid, ldr);
+}
+
+static int allreduce_if_tp(fl_model *m, float *buf, size_t count) {
+    if (m->G == 1) return FL_OK;
+    if (!m->comm) return set_error(FL_EINVAL, "tensor-parallel eval without a communicator");
+    return fl_comm_allreduce_sum_f32(m->comm, buf, count, m->stream);
+}
+
+int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *logits_host, int all_logits,
+                  float *embeddings_host) {
+    if (!m || !tokens) return set_error(FL_EINVAL, "fl_model_eval: null argument");
+    if (!m->finalized) return set_error(FL_EINVAL, "fl_model_eval: model not finalized");
+    if (N <= 0 || N > m->B) return set_error(FL_EINVAL, "N=%d exceeds max_batch=%d", N, m->B);
+    if (n_past < 0 || n_past + N > m->n_ctx) return set_error(FL_EINVAL, "n_past+N=%d exceeds n_ctx=%d", n_past + N, m->n_ctx);
+    const int E = m->E, El = m->El, Fl = m->Fl, D = m->D, Hl = m->Hl, V = m->V, n_ctx = m->n_ctx;
+    const int layout = N <= 8 ? 1 : 16;
+    const int P = n_past + N;
+    hipStream_t st = m->stream;
+    const bool tp = m->G > 1;
+
+    M_HIP(hipMemcpyAsync(m->tok_dev, tokens, (size_t)N * 4, hipMemcpyHostToDevice, st));
+    M_HIP(get_rows_qw16(*m->tok_emb, m->tok_dev, N, m->x, E, st));                       // inpL = get_rows  llama.cpp:304
+    float *inp = m->x, *mid = m->x2;
+    for (int l = 0; l < m->L; ++l) {
+        const Layer &ly = m->layers[l];
+        float *kc = m->kc + (size_t)l * n_ctx * El, *vc = m->vc + (size_t)l * n_ctx * El;
+        // norm + attention_norm*cur -> Q8_0                                                        llama.cpp:311-319
+        M_HIP(rmsnorm_quant(inp, E, ly.attn_norm, N, E, nullptr, 0, &m->qE, layout, st));
+        M_HIP(mm(m, ly.wqkv, m->qE, N, m->qkv, 3 * El, nullptr, 0));                               // wq, wk, wv  :328-334
+        M_HIP(rope_kv(m->qkv, 3 * El, N, El, D, n_past, n_ctx, m->rope_tab, kc, vc, st));          // rope, store :328-347
+        // KQ, scale, mask, soft_max                                                                :364-379
+        M_HIP(gemm_f32_abt(m->qkv, 3 * El, D, kc, El, D, m->att, n_ctx, (int64_t)N * n_ctx, N, P, D, Hl,
+                           1.0f / sqrtf((float)E / (float)m->H), 1, n_past, st));
+        M_HIP(softmax_rows(m->att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, Hl, m->exp_tab, st));
+        // KQV, merged back to [N, n_embd]                                                          :389-398
+        M_HIP(gemm_f32_abt(m->att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, m->ao, El, D, N, D, P, Hl,
+                           1.0f, 2, n_past, st));
+        // wo projection + residual                                                                 :401-407
+        M_HIP((layout == 16 ? quantize_q8_qa16 : quantize_q8_qa1)(m->ao, El, N, El, m->qEl, st));
+        if (!tp) {
+            M_HIP(mm(m, ly.wo, m->qEl, N, mid, E, inp, E));
+        } else {
+            M_HIP(mm(m, ly.wo, m->qEl, N, m->part, E, nullptr, 0));
+            int rc = allreduce_if_tp(m, m->part, (size_t)N * E);
+            if (rc != FL_OK) return rc;
+            M_HIP(add_rows(m->part, E, inp, E, mid, E, N, E, st));
+        }
+        // feed-forward                                                                             :412-436
+        M_HIP(rmsnorm_quant(mid, E, ly.ffn_norm, N, E, nullptr, 0, &m->qE, layout, st));
+        M_HIP(mm(m, ly.w13, m->qE, N, m->h13, 2 * Fl, nullptr, 0));
+        M_HIP(silu_mul_quant(m->h13, 2 * Fl, N, Fl, m->silu_tab, &m->qF, layout, st));
+        if (!tp) {
+            M_HIP(mm(m, ly.w2, m->qF, N, inp, E, mid, E));                                        // + inpFF :441
+        } else {
+            M_HIP(mm(m, ly.w2, m->qF, N, m->part, E, nullptr, 0));
+            int rc = allreduce_if_tp(m, m->part, (size_t)N * E);
+            if (rc != FL_OK) return rc;
+            M_HIP(add_rows(m->part, E, mid, E, inp, E, N, E, st));
+        }
+    }
+    // final norm (kept in f32 for the embeddings) + lm head                                        :452-465
+    M_HIP(rmsnorm_quant(inp, E, m->norm_w, N, E, m->xn, E, &m->qE, layout, st));
+    M_HIP(mm(m, m->output, m->qE, N, m->logits, V, nullptr, 0));
+    if (logits_host) {
+        if (all_logits) M_HIP(hipMemcpyAsync(logits_host, m->logits, (size_t)N * V * 4, hipMemcpyDeviceToHost, st));
+        else M_HIP(hipMemcpyAsync(logits_host, m->logits + (size_t)(N - 1) * V, (size_t)V * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (embeddings_host)
+        M_HIP(hipMemcpyAsync(embeddings_host, m->xn + (size_t)(N - 1) * E, (size_t)E * 4, hipMemcpyDeviceToHost, st));
+    M_HIP(hipStreamSynchronize(st));
+    return FL_OK;
+}
+
+const float *fl_model_logits_dev(const fl_model *m) { return m ? m->logits : nullptr; }
+void *fl_model_stream(const fl_model *m) { return m ? (void *)m->stream : nullptr; }
+size_t fl_model_device_bytes(const fl_model *m) { return m ? m->dev_bytes : 0; }
+
+/* KV cache <-> host in the REFERENCE's layout (K: [layer][n_ctx][n_embd], V: [layer][n_embd][n_ctx], f32;
+ * KVCacheBuffer::save_state dumps both raw, lib/llama.cpp:57-78).  Only for tp_size == 1. */
+int fl_model_kv_read(const fl_model *m, float *k_host, float *v_host) {
+    if (!m || !m->finalized || m->G != 1) return set_error(FL_EINVAL, "kv_read: need a finalized single-GPU model");
+    const size_t n = (size_t)m->L * m->n_ctx * m->E * 4;
+    M_HIP(hipMemcpy(k_host, m->kc, n, hipMemcpyDeviceToHost));
+    M_HIP(hipMemcpy(v_host, m->vc, n, hipMemcpyDeviceToHost));
+    return FL_OK;
+}
+int fl_model_kv_write(fl_model *m, const float *k_host, const float *v_host) {
+    if (!m || !m->finalized || m->G != 1) return set_error(FL_EINVAL, "kv_write: need a finalized single-GPU model");
+    const size_t n = (size_t)m->L * m->n_ctx * m->E * 4;
+    M_HIP(hipMemcpy(m->kc, k_host, n, hipMemcpyHostToDevice));
+    M_HIP(hipMemcpy(m->vc, v_host, n, hipMemcpyHostToDevice));
+    return FL_OK;
+}
+
+void fl_model_free(fl_model *m) {
+    if (!m) return;
+    (void)hipDeviceSynchronize();
+    auto fr = [](void *p) { if (p) (void)hipFree(p); };
+    fl_qtensor_free(m->tok_emb);
+    fl_qtensor_free(m->output);
+    fr(m->norm_w);
+    for (auto &ly : m->layers) {
+        fr(ly.attn_norm); fr(ly.ffn_norm);
+        fl_qtensor_free(ly.wqkv); fl_qtensor_free(ly.wo); fl_qtensor_free(ly.w13); fl_qtensor_free(ly.w2);
+        fr(ly.s_qkv.aos); fr(ly.s_13.aos);
+    }
+    fr(m->kc); fr(m->vc); fr(m->exp_tab); fr(m->silu_tab); fr(m->rope_tab); fr(m->tok_dev);
+    fr(m->x); fr(m->x2); fr(m->xn); fr(m->part); fr(m->qkv); fr(m->att); fr(m->ao); fr(m->h13); fr(m->logits);
+    for (fl_qact *a : {&m->qE, &m->qEl, &m->qF}) { fr(a->q); fr(a->d); fr(a->s); }
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+}  // extern "C"
+
+/* ------------------------------------------------------------------------------------------------
+ * test hooks: the individual eval kernels on caller-provided device buffers (per-op parity tests)
+ * ---------------------------------------------------------------------------------------------- */
+extern "C" {
+
+int fl_debug_tables(uint16_t *exp_host, uint16_t *silu_host) {   /* the two 65536-entry fp16 tables, as built for a model */
+    for (int i = 0; i < (1 << 16); ++i) {
+        const float f = f16_bits_to_f32((uint16_t)i);
+        if (exp_host) exp_host[i] = f32_to_f16_bits(expf(f));
+        if (silu_host) silu_host[i] = f32_to_f16_bits(f / (1.0f + expf(-f)));
+    }
+    return FL_OK;
+}
+
+int fl_debug_rope_table(float *out_host, int n_ctx, int D) {     /* [n_ctx][D/2][2] {cos, sin} */
+    const float theta_scale = powf(10000.0f, -2.0f / (float)D);
+    for (int p = 0; p < n_ctx; ++p) {
+        float theta = (float)p;
+        for (int i = 0; i < D / 2; ++i) {
+            float sn, cs;
+            sincosf(theta, &sn, &cs);
+            out_host[((size_t)p * (D / 2) + i) * 2 + 0] = cs;
+            out_host[((size_t)p * (D / 2) + i) * 2 + 1] = sn;
+            theta *= theta_scale;
+        }
+    }
+    return FL_OK;
+}
+
+int fl_debug_rmsnorm_quant(const float *x, int ldx, const float *w, int N, int E, float *y_f32, int ldy, fl_qact *out,
+                           int layout, void *stream) {
+    M_HIP(rmsnorm_quant(x, ldx, w, N, E, y_f32, ldy, out, layout, (hipStream_t)stream));
+    return FL_OK;
+}
+int fl_debug_silu_mul_quant(const float *h13, int ld, int N, int F, const uint16_t *silu_tab_dev, fl_qact *out, int layout,
+                            void *stream) {
+    M_HIP(silu_mul_quant(h13, ld, N, F, silu_tab_dev, out, layout, (hipStream_t)stream));
+    return FL_OK;
+}
+int fl_debug_rope_kv(float *qkv, int ld, int N, int E, int D, int n_past, int n_ctx, const float *rope_tab_dev, float *kc,
+                     float *vc, void *stream) {
+    M_HIP(rope_kv(qkv, ld, N, E, D, n_past, n_ctx, rope_tab_dev, kc, vc, (hipStream_t)stream));
+    return FL_OK;
+}
+int fl_debug_gemm_f32_abt(const float *A, int lda, long sAz, const float *B, int ldb, long sBz, float *Cc, int ldc, long sCz,
+                          int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past, void *stream) {
+    M_HIP(gemm_f32_abt(A, lda, sAz, B, ldb, sBz, Cc, ldc, sCz, M, Nn, K, batch, alpha, causal_mode, n_past, (hipStream_t)stream));
+    return FL_OK;
+}
+int fl_debug_softmax_rows(float *S, int ld, long sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab_dev,
+                          void *stream) {
+    M_HIP(softmax_rows(S, ld, sz, N, P, n_past, batch, exp_tab_dev, (hipStream_t)stream));
+    return FL_OK;
+}
+
+}  // extern "C"

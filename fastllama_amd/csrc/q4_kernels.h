@@ -31,8 +31,11 @@ hipError_t vec_dot_aos(int type, int n, float *s_dev, const void *x_aos, const v
 
 // ---- a9: mul_mat_q_f32 compute phase on QW16 x QA* ----
 // y: N rows of M floats, row stride ldy.
-hipError_t gemv_q4(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st);
-hipError_t gemm_q4_mfma(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st);
+// resid (optional): y = mul_mat + resid, the ggml_add that follows wo / w2 (lib/llama.cpp:407,441), fused into the store
+hipError_t gemv_q4(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
+                   const float *resid = nullptr, int ldr = 0);
+hipError_t gemm_q4_mfma(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
+                        const float *resid = nullptr, int ldr = 0);
 hipError_t gemm_q4_naive(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st);
 
 size_t qact_bytes_q(int N, int K);      // bytes of the q plane for N columns (padded to 16)

@@ -442,7 +442,8 @@ __global__ __launch_bounds__(256) void gemv_q4_kernel(const uint4 *__restrict__ 
                                                       const float *__restrict__ mW,
                                                       const int8_t *__restrict__ xq, const float *__restrict__ xd,
                                                       const float *__restrict__ xs, int N, int M, int KB,
-                                                      float *__restrict__ y, int ldy) {
+                                                      float *__restrict__ y, int ldy,
+                                                      const float *__restrict__ resid, int ldr) {
     const int grp = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, bq = lane >> 4;
@@ -505,18 +506,22 @@ __global__ __launch_bounds__(256) void gemv_q4_kernel(const uint4 *__restrict__ 
     if (threadIdx.x < 16 * NC) {
         const int c = threadIdx.x >> 4, rr = threadIdx.x & 15;
         const int row = grp * 16 + rr;
-        if (c < N && row < M)
-            y[(int64_t)c * ldy + row] = (part[0][c][rr] + part[1][c][rr]) + (part[2][c][rr] + part[3][c][rr]);
+        if (c < N && row < M) {
+            float v = (part[0][c][rr] + part[1][c][rr]) + (part[2][c][rr] + part[3][c][rr]);
+            if (resid) v += resid[(int64_t)c * ldr + row];
+            y[(int64_t)c * ldy + row] = v;
+        }
     }
 }
 
 template <int TYPE>
-static hipError_t launch_gemv(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st) {
+static hipError_t launch_gemv(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
+                              const float *resid, int ldr) {
     const dim3 grid(W.M16 / 16), block(256);
     const uint4 *qs = reinterpret_cast<const uint4 *>(W.qs);
 #define FL_GEMV(NC)                                                                                         \
     hipLaunchKernelGGL((gemv_q4_kernel<TYPE, NC>), grid, block, 0, st, qs, W.d, W.m, xq.q, xq.d, xq.s, N, W.M, \
-                       W.KB, y, ldy)
+                       W.KB, y, ldy, resid, ldr)
     if (N == 1) FL_GEMV(1);
     else if (N == 2) FL_GEMV(2);
     else if (N <= 4) FL_GEMV(4);
@@ -525,10 +530,11 @@ static hipError_t launch_gemv(const fl_qtensor &W, const fl_qact &xq, int N, flo
     return hipGetLastError();
 }
 
-hipError_t gemv_q4(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st) {
+hipError_t gemv_q4(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
+                   const float *resid, int ldr) {
     if (N < 1 || N > 8) return hipErrorInvalidValue;
-    return W.type == FL_TYPE_Q4_0 ? launch_gemv<FL_TYPE_Q4_0>(W, xq, N, y, ldy, st)
-                                  : launch_gemv<FL_TYPE_Q4_1>(W, xq, N, y, ldy, st);
+    return W.type == FL_TYPE_Q4_0 ? launch_gemv<FL_TYPE_Q4_0>(W, xq, N, y, ldy, st, resid, ldr)
+                                  : launch_gemv<FL_TYPE_Q4_1>(W, xq, N, y, ldy, st, resid, ldr);
 }
 
 // ------------------------------------------------------------------------------------------------

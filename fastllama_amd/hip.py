@@ -35,6 +35,12 @@ class QuantizeFns(C.Structure):
                 ("vec_dot_q", _DOT)]
 
 
+class ModelParams(C.Structure):
+    """fl_model_params"""
+    _fields_ = [(n, C.c_int) for n in ("n_vocab", "n_embd", "n_head", "n_layer", "n_ff", "n_ctx", "qtype",
+                                       "max_batch", "tp_rank", "tp_size")]
+
+
 _PROTOS = {
     # name: (restype, [argtypes])
     "fl_device_count": (C.c_int, []),
@@ -73,6 +79,34 @@ _PROTOS = {
     "fl_qact_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "fl_mul_mat_q": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "fl_mul_mat_q_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "fl_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "fl_comm_create": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
+    "fl_comm_allreduce_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "fl_comm_rank": (C.c_int, [C.c_void_p]),
+    "fl_comm_size": (C.c_int, [C.c_void_p]),
+    "fl_comm_destroy": (None, [C.c_void_p]),
+    "fl_model_create": (C.c_void_p, [C.POINTER(ModelParams)]),
+    "fl_model_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    "fl_model_finalize": (C.c_int, [C.c_void_p]),
+    "fl_model_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fl_model_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "fl_model_logits_dev": (C.c_void_p, [C.c_void_p]),
+    "fl_model_stream": (C.c_void_p, [C.c_void_p]),
+    "fl_model_device_bytes": (C.c_size_t, [C.c_void_p]),
+    "fl_model_kv_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fl_model_kv_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fl_model_free": (None, [C.c_void_p]),
+    "fl_debug_tables": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fl_debug_rope_table": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "fl_debug_rmsnorm_quant": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_int, C.c_void_p]),
+    "fl_debug_silu_mul_quant": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "fl_debug_rope_kv": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    "fl_debug_gemm_f32_abt": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_int,
+                                        C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "fl_debug_softmax_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_void_p]),
     "fl_debug_mul_mat_q": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "fl_debug_qact_layout": (C.c_int, [C.c_void_p]),
     "fl_debug_set": (C.c_int, [C.c_int, C.c_int]),

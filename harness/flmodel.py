@@ -1,0 +1,55 @@
+"""Build an fl_model (include/fastllama_hip.h, "the model") straight from in-memory tensors (harness)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from fastllama_amd import hip
+from . import ggjt
+
+
+class FlModel:
+    def __init__(self, cfg: dict, qtype: int, tensors: dict, n_ctx: int, max_batch: int, tp_rank=0, tp_size=1,
+                 device: int = 0):
+        L = self.L = hip.load()
+        hip.require_device(device)
+        self.cfg, self.qtype = cfg, qtype
+        E = cfg["n_embd"]
+        self.V = cfg["n_vocab"]
+        self.E = E
+        p = hip.ModelParams(cfg["n_vocab"], E, cfg["n_head"], cfg["n_layer"], ggjt.n_ff_of(E, cfg["n_mult"]), n_ctx, qtype,
+                            max_batch, tp_rank, tp_size)
+        h = L.fl_model_create(C.byref(p))
+        if not h:
+            raise hip.FastLlamaHipError("fl_model_create: " + L.fl_last_error().decode())
+        self.h = C.c_void_p(h)
+        for name, (gtype, shape, data) in tensors.items():
+            a = np.ascontiguousarray(data)
+            hip.check(L.fl_model_set_tensor(self.h, name.encode(), gtype, a.ctypes.data_as(C.c_void_p), shape[0],
+                                            shape[1] if len(shape) > 1 else 1), "fl_model_set_tensor " + name)
+        hip.check(L.fl_model_finalize(self.h), "fl_model_finalize")
+
+    def set_comm(self, comm):
+        hip.check(self.L.fl_model_set_comm(self.h, comm), "fl_model_set_comm")
+
+    def eval(self, tokens, n_past=0, all_logits=False, embeddings=False):
+        toks = np.ascontiguousarray(tokens, dtype=np.int32)
+        N = toks.size
+        lg = np.empty((N if all_logits else 1, self.V), dtype=np.float32)
+        emb = np.empty(self.E, dtype=np.float32) if embeddings else None
+        hip.check(self.L.fl_model_eval(self.h, toks.ctypes.data_as(C.c_void_p), N, n_past, lg.ctypes.data_as(C.c_void_p),
+                                       1 if all_logits else 0, emb.ctypes.data_as(C.c_void_p) if embeddings else None),
+                  "fl_model_eval")
+        return (lg, emb) if embeddings else lg
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.L.fl_model_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -128,6 +128,63 @@ int fl_mul_mat_q(const fl_qtensor *W, const fl_qact *a, float *y_dev, int ldy, v
  * grow-on-demand workspace (do not call while a hipGraph capture is active). */
 int fl_mul_mat_q_f32(const fl_qtensor *W, const float *x_dev, int ldx, float *y_dev, int ldy, int N, void *stream);
 
+
+/* ---------------------------------------------------------------- collectives (RCCL over xGMI) -- */
+/* New for SURVEY.md section 8(e): the reference is single-process.  One process per GPU; rank 0 creates
+ * the id, the host program distributes its FL_COMM_ID_BYTES bytes to the other ranks. */
+#define FL_COMM_ID_BYTES 128
+typedef struct fl_comm fl_comm;
+int fl_comm_unique_id(void *id_out /* FL_COMM_ID_BYTES */);
+fl_comm *fl_comm_create(const void *id_bytes, int rank, int world); /* on the CURRENT device (fl_init) */
+int fl_comm_allreduce_sum_f32(fl_comm *c, float *buf_dev, size_t count, void *stream);
+int fl_comm_rank(const fl_comm *c);
+int fl_comm_size(const fl_comm *c);
+void fl_comm_destroy(fl_comm *c);
+
+/* ---------------------------------------------------------------- the model -------------------- */
+/* Device-resident replacement of fastllama::Model for the eval path.
+ * replaces: Model::load tensor placement lib/llama.cpp:223-258, KVCacheBuffer lib/llama.cpp:24-51,
+ *           Model::eval lib/llama.cpp:272-499 (and with it the ggml_graph_compute dispatch, lib/ggml.c:10811). */
+typedef struct fl_model fl_model;
+typedef struct {
+    int n_vocab, n_embd, n_head, n_layer, n_ff; /* hparams, lib/llama.cpp:118-129 (n_ff already derived) */
+    int n_ctx;                                  /* KV-cache positions                                    */
+    int qtype;                                  /* FL_TYPE_Q4_0 | FL_TYPE_Q4_1 of all 2-D tensors         */
+    int max_batch;                              /* largest N of one eval (n_batch)                        */
+    int tp_rank, tp_size;                       /* tensor parallel shard of this process (0, 1 = none)    */
+} fl_model_params;
+fl_model *fl_model_create(const fl_model_params *p);
+/* Feed one tensor with the name/shape/bytes it has in a GGML/GGMF/GGJT llama file (lib/llama.cpp:223-246):
+ * type 0 = f32 (norm vectors), qtype for every 2-D weight; ne0 = row length K, ne1 = rows.  The FULL tensor is
+ * passed on every rank; the tensor-parallel slice is taken here. */
+int fl_model_set_tensor(fl_model *m, const char *name, int type, const void *data_host, int ne0, int ne1);
+int fl_model_finalize(fl_model *m); /* checks completeness, allocates KV cache, tables, work buffers */
+int fl_model_set_comm(fl_model *m, fl_comm *c);
+/* Model::eval: N tokens at positions n_past..n_past+N-1.  logits_host receives n_vocab floats (last token) or
+ * N*n_vocab (all_logits != 0, `should_put_all_logits`); embeddings_host (optional) n_embd floats of the last token. */
+int fl_model_eval(fl_model *m, const int32_t *tokens_host, int N, int n_past, float *logits_host, int all_logits,
+                  float *embeddings_host);
+const float *fl_model_logits_dev(const fl_model *m);
+void *fl_model_stream(const fl_model *m);
+size_t fl_model_device_bytes(const fl_model *m);
+int fl_model_kv_read(const fl_model *m, float *k_host, float *v_host);
+int fl_model_kv_write(fl_model *m, const float *k_host, const float *v_host);
+void fl_model_free(fl_model *m);
+
+/* test hooks: the individual non-matmul eval kernels (fastllama_amd/csrc/eval_kernels.hip) and their tables */
+int fl_debug_tables(uint16_t *exp_host, uint16_t *silu_host);
+int fl_debug_rope_table(float *out_host, int n_ctx, int D);
+int fl_debug_rmsnorm_quant(const float *x_dev, int ldx, const float *w_dev, int N, int E, float *y_f32_dev, int ldy,
+                           fl_qact *out, int layout, void *stream);
+int fl_debug_silu_mul_quant(const float *h13_dev, int ld, int N, int F, const uint16_t *silu_tab_dev, fl_qact *out,
+                            int layout, void *stream);
+int fl_debug_rope_kv(float *qkv_dev, int ld, int N, int E, int D, int n_past, int n_ctx, const float *rope_tab_dev,
+                     float *kc_dev, float *vc_dev, void *stream);
+int fl_debug_gemm_f32_abt(const float *A, int lda, long sAz, const float *B, int ldb, long sBz, float *C, int ldc, long sCz,
+                          int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past, void *stream);
+int fl_debug_softmax_rows(float *S_dev, int ld, long sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab_dev,
+                          void *stream);
+
 /* test hooks: force one kernel family regardless of N (N must suit the layout of `a`) */
 int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a, float *y_dev, int ldy, int which /*0 naive,1 mfma,2 gemv*/,
                        void *stream);

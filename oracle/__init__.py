@@ -63,6 +63,9 @@ class Port:
         L.orc_mul_mat_q_f32.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_mul_mat_q_f32.restype = C.c_int
+        L.orc_mul_mat_q_f32_ex.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_mul_mat_q_f32_ex.restype = C.c_int
         L.orc_quantize_q4.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.orc_quantize_q4.restype = None
 
@@ -99,16 +102,17 @@ class Port:
         fn(K, _ptr(s), _ptr(np.ascontiguousarray(wrow)), _ptr(np.ascontiguousarray(xq)))
         return s[0]
 
-    def mul_mat_q(self, qtype: int, wq: np.ndarray, x: np.ndarray, n_threads: int = 0) -> np.ndarray:
-        """y[N, M] = mul_mat_q_f32(W[M, K] (AoS blocks), x[N, K])."""
+    def mul_mat_q(self, qtype: int, wq: np.ndarray, x: np.ndarray, n_threads: int = 0, strict: bool = True) -> np.ndarray:
+        """y[N, M] = mul_mat_q_f32(W[M, K] (AoS blocks), x[N, K]).  strict=False waives the reference's
+        even-block-count assert (tensor-parallel K shards)."""
         x = np.ascontiguousarray(x, dtype=np.float32)
         wq = np.ascontiguousarray(wq, dtype=np.uint8)
         N, K = x.shape
         M = wq.shape[0]
         assert wq.shape[1] == K // QK * BLOCK_BYTES[qtype]
         y = np.empty((N, M), dtype=np.float32)
-        rc = self.lib.orc_mul_mat_q_f32(qtype, _ptr(wq), _ptr(x), _ptr(y), M, K, N,
-                                        n_threads or (os.cpu_count() or 1))
+        rc = self.lib.orc_mul_mat_q_f32_ex(qtype, _ptr(wq), _ptr(x), _ptr(y), M, K, N,
+                                           n_threads or (os.cpu_count() or 1), 1 if strict else 0)
         if rc != 0:
             raise ValueError("orc_mul_mat_q_f32 rejected the arguments (K must be a multiple of 64)")
         return y

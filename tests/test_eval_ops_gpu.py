@@ -1,0 +1,145 @@
+"""GPU: each non-matmul eval kernel (fastllama_amd/csrc/eval_kernels.hip) against the numpy restatement of the
+reference op (oracle/llama_eval.py, itself pinned to the reference), at toy width and at LLaMA-7B width.
+Integer outputs (Q8_0 quants) and table-driven values must be bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import llama_eval as le
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from fastllama_amd import hip, ops
+    hip.require_device(0)
+    return torch, hip, ops, hip.load(), oracle.Port()
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_fp16_tables_and_rope_table_bitexact(env):
+    torch, hip, ops, L, port = env
+    e = np.empty(1 << 16, np.uint16)
+    s = np.empty(1 << 16, np.uint16)
+    L.fl_debug_tables(e.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p))
+    exp_tab, silu_tab = le.tables()
+    ok = ~np.isnan(exp_tab)
+    assert np.array_equal(e.view(np.float16).astype(np.float32)[ok], exp_tab[ok])
+    ok = ~np.isnan(silu_tab)
+    assert np.array_equal(s.view(np.float16).astype(np.float32)[ok], silu_tab[ok])
+    for D in (32, 128):
+        rt = np.empty((64, D // 2, 2), np.float32)
+        L.fl_debug_rope_table(rt.ctypes.data_as(C.c_void_p), 64, D)
+        x = np.zeros((64, D), np.float32)
+        x[:, 0::2] = 1.0                                  # rope of (1, 0) pairs = (cos, sin)
+        r = np.stack([le.rope(x[p:p + 1], p, 1)[0] for p in range(64)])
+        assert np.array_equal(rt[:, :, 0], r[:, 0::2]) and np.array_equal(rt[:, :, 1], r[:, 1::2])
+
+
+@pytest.mark.parametrize("N,E", [(1, 256), (5, 256), (40, 256), (3, 4096), (96, 4096), (20, 8192)])
+def test_rmsnorm_quant_bitexact(env, N, E):
+    torch, hip, ops, L, port = env
+    rng = np.random.default_rng(E + N)
+    x = (rng.standard_normal((N, E)) * rng.uniform(0.01, 3.0, (N, 1))).astype(np.float32)
+    w = (1 + 0.1 * rng.standard_normal(E)).astype(np.float32)
+    want = le.rms_norm_mul(x, w)
+    xd, wd = dev(torch, x), dev(torch, w)
+    y = torch.empty((N, E), device="cuda")
+    for layout in (1, 16):
+        if layout == 1 and N > 8:
+            continue
+        a = ops.QAct(N, E)
+        hip.check(L.fl_debug_rmsnorm_quant(xd.data_ptr(), E, wd.data_ptr(), N, E, y.data_ptr(), E, a.handle, layout, None))
+        hip.check(L.fl_quantize_q8_layout(a.handle, y.data_ptr(), E, N, E, layout, None))   # sets N/layout bookkeeping
+        a.N, a.K = N, E
+        hip.check(L.fl_debug_rmsnorm_quant(xd.data_ptr(), E, wd.data_ptr(), N, E, y.data_ptr(), E, a.handle, layout, None))
+        assert np.array_equal(y.cpu().numpy().view(np.uint32), want.view(np.uint32)), (N, E, layout)
+        q8 = a.export().cpu().numpy()
+        assert np.array_equal(q8, np.stack([port.quantize_row_q8_0(r) for r in want]))
+
+
+@pytest.mark.parametrize("N,F", [(2, 704), (33, 704), (96, 11008)])
+def test_silu_mul_quant_bitexact(env, N, F):
+    torch, hip, ops, L, port = env
+    rng = np.random.default_rng(F)
+    h = (rng.standard_normal((N, 2 * F)) * 2).astype(np.float32)
+    want = (le.silu(h[:, :F]) * h[:, F:]).astype(np.float32)
+    s = np.empty(1 << 16, np.uint16)
+    L.fl_debug_tables(None, s.ctypes.data_as(C.c_void_p))
+    sd, hd = dev(torch, s.view(np.int16)), dev(torch, h)
+    layout = 1 if N <= 8 else 16
+    a = ops.QAct(N, F)
+    hip.check(L.fl_quantize_q8_layout(a.handle, hd.data_ptr(), 2 * F, N, F, layout, None))
+    a.N, a.K = N, F
+    hip.check(L.fl_debug_silu_mul_quant(hd.data_ptr(), 2 * F, N, F, sd.data_ptr(), a.handle, layout, None))
+    assert np.array_equal(a.export().cpu().numpy(), np.stack([port.quantize_row_q8_0(r) for r in want]))
+
+
+@pytest.mark.parametrize("N,E,D,n_past", [(1, 128, 32, 7), (20, 256, 32, 5), (64, 4096, 128, 30)])
+def test_rope_kv_bitexact(env, N, E, D, n_past):
+    torch, hip, ops, L, port = env
+    n_ctx = 128
+    rng = np.random.default_rng(N * E)
+    qkv = rng.standard_normal((N, 3 * E)).astype(np.float32)
+    rt = np.empty((n_ctx, D // 2, 2), np.float32)
+    L.fl_debug_rope_table(rt.ctypes.data_as(C.c_void_p), n_ctx, D)
+    qd, rd = dev(torch, qkv), dev(torch, rt)
+    kc = torch.zeros((n_ctx, E), device="cuda")
+    vc = torch.zeros((E, n_ctx), device="cuda")
+    hip.check(L.fl_debug_rope_kv(qd.data_ptr(), 3 * E, N, E, D, n_past, n_ctx, rd.data_ptr(), kc.data_ptr(), vc.data_ptr(), None))
+    H = E // D
+    want_q = le.rope(qkv[:, :E], n_past, H)
+    want_k = le.rope(qkv[:, E:2 * E], n_past, H)
+    out = qd.cpu().numpy()
+    assert np.array_equal(out[:, :E].view(np.uint32), want_q.view(np.uint32))
+    assert np.array_equal(kc.cpu().numpy()[n_past:n_past + N].view(np.uint32), want_k.view(np.uint32))
+    assert np.array_equal(vc.cpu().numpy()[:, n_past:n_past + N], qkv[:, 2 * E:].T)
+    assert not kc.cpu().numpy()[:n_past].any() and not vc.cpu().numpy()[:, n_past + N:].any()
+
+
+@pytest.mark.parametrize("N,P0,D,H", [(1, 17, 32, 4), (20, 0, 32, 8), (96, 0, 128, 32), (40, 23, 128, 4)])
+def test_attention_scores_softmax_kqv(env, N, P0, D, H):
+    """KQ -> scale -> mask -> soft_max (fp16 table, f64 sum) -> KQV against numpy; softmax given identical
+    scores must be bit-exact, the two f32 GEMMs agree to f32 round-off (MFMA k-order chain vs BLAS)."""
+    torch, hip, ops, L, port = env
+    n_ctx, E, P = 128, H * D, P0 + N
+    rng = np.random.default_rng(N + D + H)
+    q = rng.standard_normal((N, E)).astype(np.float32)
+    kc = np.zeros((n_ctx, E), np.float32)
+    vc = np.zeros((E, n_ctx), np.float32)
+    kc[:P] = rng.standard_normal((P, E))
+    vc[:, :P] = rng.standard_normal((E, P))
+    e = np.empty(1 << 16, np.uint16)
+    L.fl_debug_tables(e.ctypes.data_as(C.c_void_p), None)
+    ed = dev(torch, e.view(np.int16))
+    qd, kd, vd = dev(torch, q), dev(torch, kc), dev(torch, vc)
+    att = torch.full((H, N, n_ctx), 7.0, device="cuda")       # stale garbage must never leak into results
+    scale = np.float32(1.0) / np.sqrt(np.float32(D))
+    hip.check(L.fl_debug_gemm_f32_abt(qd.data_ptr(), E, D, kd.data_ptr(), E, D, att.data_ptr(), n_ctx, N * n_ctx, N, P, D, H,
+                                      float(scale), 1, P0, None))
+    s_gpu = att.cpu().numpy()[:, :, :P].copy()
+    mask = np.arange(P)[None, :] > (P0 + np.arange(N))[:, None]
+    for h in range(H):
+        want = ((q[:, h * D:(h + 1) * D] @ kc[:P, h * D:(h + 1) * D].T).astype(np.float32) * scale).astype(np.float32)
+        got = s_gpu[h]
+        assert np.max(np.abs(got - want)[~mask]) <= 1e-5 * np.max(np.abs(want))
+    hip.check(L.fl_debug_softmax_rows(att.data_ptr(), n_ctx, N * n_ctx, N, P, P0, H, ed.data_ptr(), None))
+    p_gpu = att.cpu().numpy()[:, :, :P]
+    for h in range(H):
+        s = s_gpu[h].copy()
+        s[mask] = -np.inf
+        assert np.array_equal(p_gpu[h].view(np.uint32), le.soft_max_rows(s).view(np.uint32))   # bit-exact softmax
+    ao = torch.zeros((N, E), device="cuda")
+    hip.check(L.fl_debug_gemm_f32_abt(att.data_ptr(), n_ctx, N * n_ctx, vd.data_ptr(), n_ctx, D * n_ctx, ao.data_ptr(), E, D,
+                                      N, D, P, H, 1.0, 2, P0, None))
+    got = ao.cpu().numpy()
+    for h in range(H):
+        want = (p_gpu[h] @ vc[h * D:(h + 1) * D, :P].T).astype(np.float32)
+        assert np.max(np.abs(got[:, h * D:(h + 1) * D] - want)) <= 1e-5 * np.max(np.abs(want))
