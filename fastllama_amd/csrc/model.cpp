@@ -136,7 +136,7 @@ fl_model *fl_model_create(const fl_model_params *p) {
 static int upload_f32(fl_model *m, float **dst, const void *host, size_t n) {
     int rc = dev_alloc(m, (void **)dst, n * 4);
     if (rc != FL_OK) return rc;
-    M_HIP(hipMemcpy(*dst, host, n * 4, hipMemcpyHostToDevice));
+    M_HIP(hipMemcpy(*dst, host, n * 4, hipMemcpyDefault));   // host or device source
     return FL_OK;
 }
 
@@ -144,7 +144,7 @@ static int upload_f32(fl_model *m, float **dst, const void *host, size_t n) {
 static int stage_rows(const void *host, int bs, int KB_full, int row0, int rows, int kb0, int kb1, void *dst_dev) {
     const size_t src_pitch = (size_t)KB_full * bs, width = (size_t)(kb1 - kb0) * bs;
     const char *src = (const char *)host + (size_t)row0 * src_pitch + (size_t)kb0 * bs;
-    M_HIP(hipMemcpy2D(dst_dev, width, src, src_pitch, width, rows, hipMemcpyHostToDevice));
+    M_HIP(hipMemcpy2D(dst_dev, width, src, src_pitch, width, rows, hipMemcpyDefault));   // host or device source
     return FL_OK;
 }
 
@@ -194,10 +194,12 @@ int fl_model_set_tensor(fl_model *m, const char *name, int type, const void *hos
     if (nm == "tok_embeddings.weight" || nm == "output.weight") {
         if ((rc = want_q(E, V)) != FL_OK) return rc;
         fl_qtensor **dst = nm[0] == 't' ? &m->tok_emb : &m->output;
-        *dst = fl_qtensor_upload(m->qtype, host, V, E, nullptr);
-        if (!*dst) return FL_EHIP;
-        m->dev_bytes += fl_qtensor_device_bytes(*dst);
-        return FL_OK;
+        void *tmp = nullptr;
+        M_HIP(hipMalloc(&tmp, (size_t)V * (E / FL_QK) * bs));
+        rc = stage_rows(host, bs, E / FL_QK, 0, V, 0, E / FL_QK, tmp);
+        if (rc == FL_OK) rc = make_qtensor(m, dst, tmp, V, E);
+        (void)hipFree(tmp);
+        return rc;
     }
     if (nm == "norm.weight") {
         if ((rc = want_f(E)) != FL_OK) return rc;

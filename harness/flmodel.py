@@ -24,14 +24,24 @@ class FlModel:
         if not h:
             raise hip.FastLlamaHipError("fl_model_create: " + L.fl_last_error().decode())
         self.h = C.c_void_p(h)
-        for name, (gtype, shape, data) in tensors.items():
-            a = np.ascontiguousarray(data)
-            hip.check(L.fl_model_set_tensor(self.h, name.encode(), gtype, a.ctypes.data_as(C.c_void_p), shape[0],
+        for name, (gtype, shape, data) in (tensors.items() if hasattr(tensors, "items") else tensors):
+            if hasattr(data, "data_ptr"):                       # torch tensor (host or device memory)
+                ptr = C.c_void_p(data.data_ptr())
+            else:
+                data = np.ascontiguousarray(data)
+                ptr = data.ctypes.data_as(C.c_void_p)
+            hip.check(L.fl_model_set_tensor(self.h, name.encode(), gtype, ptr, shape[0],
                                             shape[1] if len(shape) > 1 else 1), "fl_model_set_tensor " + name)
+            del data
         hip.check(L.fl_model_finalize(self.h), "fl_model_finalize")
 
     def set_comm(self, comm):
         hip.check(self.L.fl_model_set_comm(self.h, comm), "fl_model_set_comm")
+
+    def eval_nocopy(self, toks_i32: np.ndarray, n_past: int):
+        """eval without copying logits back (they stay in HBM: fl_model_logits_dev) -- the bench's timed call."""
+        hip.check(self.L.fl_model_eval(self.h, toks_i32.ctypes.data_as(C.c_void_p), toks_i32.size, n_past, None, 0, None),
+                  "fl_model_eval")
 
     def eval(self, tokens, n_past=0, all_logits=False, embeddings=False):
         toks = np.ascontiguousarray(tokens, dtype=np.int32)

@@ -81,3 +81,20 @@ def synth_q4(M: int, K: int, qtype: int, seed: int, device="cuda", scale: float 
         w = torch.randn((r1 - r0, K), generator=g, device=device, dtype=torch.float32) * scale
         out[r0:r1] = quantize_q4_torch(w, qtype)
     return out
+
+
+def synth_model_tensors(cfg, qtype, seed=1234, device="cuda"):
+    """Generator of (name, (gtype, shape, device tensor)) for a whole LLaMA-shaped model, in GGJT tensor order.
+    2-D weights ~ N(0, 0.02^2) quantized on the GPU (SURVEY.md 8d recipe); norm vectors 1 + 0.1 N(0,1)."""
+    from . import ggjt
+    E, L, V = cfg["n_embd"], cfg["n_layer"], cfg["n_vocab"]
+    F = cfg["n_ff"]
+    g = torch.Generator(device=device)
+    for t, (name, shape) in enumerate(ggjt.tensor_specs(V, E, L, F)):
+        if len(shape) == 1:
+            g.manual_seed(seed + t)
+            v = 1.0 + 0.1 * torch.randn(shape[0], generator=g, device=device, dtype=torch.float32)
+            yield name, (0, shape, v)
+        else:
+            K, M = shape
+            yield name, (qtype, shape, synth_q4(M, K, qtype, seed + t, device=device))

@@ -156,8 +156,8 @@ typedef struct {
 fl_model *fl_model_create(const fl_model_params *p);
 /* Feed one tensor with the name/shape/bytes it has in a GGML/GGMF/GGJT llama file (lib/llama.cpp:223-246):
  * type 0 = f32 (norm vectors), qtype for every 2-D weight; ne0 = row length K, ne1 = rows.  The FULL tensor is
- * passed on every rank; the tensor-parallel slice is taken here. */
-int fl_model_set_tensor(fl_model *m, const char *name, int type, const void *data_host, int ne0, int ne1);
+ * passed on every rank; the tensor-parallel slice is taken here.  `data` may be a host OR a device pointer. */
+int fl_model_set_tensor(fl_model *m, const char *name, int type, const void *data, int ne0, int ne1);
 int fl_model_finalize(fl_model *m); /* checks completeness, allocates KV cache, tables, work buffers */
 int fl_model_set_comm(fl_model *m, fl_comm *c);
 /* Model::eval: N tokens at positions n_past..n_past+N-1.  logits_host receives n_vocab floats (last token) or
