@@ -274,23 +274,40 @@ __global__ __launch_bounds__(256) void gemm_f32_abt_kernel(const float *__restri
     if (causal_mode == 1 && n0 > n_past + m0 + 31) return;             // scores: whole tile is masked
     if (causal_mode == 2) kend = min(K, n_past + m0 + 32);            // KQV: probabilities beyond are zero
     const int r = lane & 31, kk = lane >> 5;
-    const float *pa = A + z * sAz + (int64_t)min(m0 + r, M - 1) * lda + kk;
-    const float *pb = B + z * sBz + (int64_t)min(n0 + r, Nn - 1) * ldb + kk;
+    const float *pa = A + z * sAz + (int64_t)min(m0 + r, M - 1) * lda;
+    const float *pb = B + z * sBz + (int64_t)min(n0 + r, Nn - 1) * ldb;
     v16f acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // main loop, 8 k per step: lane (r, kk) loads ONE float4 = k {8j+4kk .. 8j+4kk+3}; MFMA step s pairs
+    // k = 8j+s (lanes kk=0) with k = 8j+4+s (lanes kk=1).  A and B use the same pairing, so the sum over k is
+    // complete; only the f32 order of the additions differs from a scalar loop.
     int k = 0;
-    for (; k + 8 <= kend; k += 8) {
-        const float a0 = pa[k], a1 = pa[k + 2], a2 = pa[k + 4], a3 = pa[k + 6];
-        const float b0 = pb[k], b1 = pb[k + 2], b2 = pb[k + 4], b3 = pb[k + 6];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc, 0, 0, 0);
+    for (; k + 16 <= kend; k += 16) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(pa + k + 4 * kk);
+        const float4 b0 = *reinterpret_cast<const float4 *>(pb + k + 4 * kk);
+        const float4 a1 = *reinterpret_cast<const float4 *>(pa + k + 8 + 4 * kk);
+        const float4 b1 = *reinterpret_cast<const float4 *>(pb + k + 8 + 4 * kk);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc, 0, 0, 0);
     }
-    for (; k < kend; k += 2) {
-        const float a = (k + kk < kend) ? pa[k] : 0.f;
-        const float b = (k + kk < kend) ? pb[k] : 0.f;
+    for (; k + 8 <= kend; k += 8) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(pa + k + 4 * kk);
+        const float4 b0 = *reinterpret_cast<const float4 *>(pb + k + 4 * kk);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc, 0, 0, 0);
+    }
+    for (; k < kend; k += 2) {   // tail: plain (k, k+1) pairing
+        const float a = (k + kk < kend) ? pa[k + kk] : 0.f;
+        const float b = (k + kk < kend) ? pb[k + kk] : 0.f;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
     // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)

@@ -67,6 +67,12 @@ struct fl_model {
     fl_comm *comm = nullptr;
     bool finalized = false;
     size_t dev_bytes = 0;
+    // live per-kernel timing of the quantized matmuls (bench.py roofline leg)
+    bool profile = false;
+    std::vector<hipEvent_t> ev;   // pairs
+    size_t ev_used = 0;
+    double prof_mm_ms = 0.0;
+    long prof_mm_launches = 0;
 };
 
 #define M_HIP(call)                                        \
@@ -107,7 +113,7 @@ extern "C" {
 
 fl_model *fl_model_create(const fl_model_params *p) {
     if (ensure_device() != FL_OK) return nullptr;
-    if (!p || p->n_embd <= 0 || p->n_head <= 0 || p->n_layer <= 0 || p->n_ff <= 0 || p->n_vocab <= 0 || p->n_ctx <= 0 ||
+    if (!p || p->n_embd <= 0 || p->n_head <= 0 || p->n_layer <= 0 || p->n_ff <= 0 || p->n_vocab <= 0 || p->n_ctx <= 0 || p->n_ctx % 4 != 0 ||
         p->max_batch <= 0 || (p->qtype != FL_TYPE_Q4_0 && p->qtype != FL_TYPE_Q4_1)) {
         set_error(FL_EINVAL, "fl_model_create: bad hyper-parameters");
         return nullptr;
@@ -309,8 +315,23 @@ int fl_model_set_comm(fl_model *m, fl_comm *c) {
 
 static hipError_t mm(fl_model *m, const fl_qtensor *W, const fl_qact &a, int N, float *y, int ldy, const float *resid,
                      int ldr) {
-    if (N <= 8) return gemv_q4(*W, a, N, y, ldy, m->stream, resid, ldr);
-    return gemm_q4_mfma(*W, a, N, y, ldy, m->stream, resid, ldr);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (m->profile) {
+        if (m->ev_used + 2 > m->ev.size()) {
+            for (int i = 0; i < 2; ++i) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) return hipErrorOutOfMemory;
+                m->ev.push_back(e);
+            }
+        }
+        e0 = m->ev[m->ev_used++];
+        e1 = m->ev[m->ev_used++];
+        (void)hipEventRecord(e0, m->stream);
+    }
+    const hipError_t r = N <= 8 ? gemv_q4(*W, a, N, y, ldy, m->stream, resid, ldr)
+                                : gemm_q4_mfma(*W, a, N, y, ldy, m->stream, resid, ldr);
+    if (m->profile) (void)hipEventRecord(e1, m->stream);
+    return r;
 }
 
 static int allreduce_if_tp(fl_model *m, float *buf, size_t count) {
@@ -381,6 +402,24 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
     if (embeddings_host)
         M_HIP(hipMemcpyAsync(embeddings_host, m->xn + (size_t)(N - 1) * E, (size_t)E * 4, hipMemcpyDeviceToHost, st));
     M_HIP(hipStreamSynchronize(st));
+    if (m->profile) {
+        for (size_t i = 0; i + 1 < m->ev_used; i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, m->ev[i], m->ev[i + 1]) == hipSuccess) m->prof_mm_ms += ms;
+            m->prof_mm_launches++;
+        }
+        m->ev_used = 0;
+    }
+    return FL_OK;
+}
+
+/* bench hook: time every quantized-matmul launch of the following evals with HIP events on the eval stream */
+int fl_model_profile(fl_model *m, int enable, double *mm_ms_total, long *mm_launches) {
+    if (!m) return set_error(FL_EINVAL, "null model");
+    if (mm_ms_total) *mm_ms_total = m->prof_mm_ms;
+    if (mm_launches) *mm_launches = m->prof_mm_launches;
+    m->profile = enable != 0;
+    if (enable == 1) { m->prof_mm_ms = 0.0; m->prof_mm_launches = 0; }
     return FL_OK;
 }
 
@@ -420,6 +459,7 @@ void fl_model_free(fl_model *m) {
     fr(m->kc); fr(m->vc); fr(m->exp_tab); fr(m->silu_tab); fr(m->rope_tab); fr(m->tok_dev);
     fr(m->x); fr(m->x2); fr(m->xn); fr(m->part); fr(m->qkv); fr(m->att); fr(m->ao); fr(m->h13); fr(m->logits);
     for (fl_qact *a : {&m->qE, &m->qEl, &m->qF}) { fr(a->q); fr(a->d); fr(a->s); }
+    for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }

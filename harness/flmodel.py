@@ -18,7 +18,8 @@ class FlModel:
         E = cfg["n_embd"]
         self.V = cfg["n_vocab"]
         self.E = E
-        p = hip.ModelParams(cfg["n_vocab"], E, cfg["n_head"], cfg["n_layer"], ggjt.n_ff_of(E, cfg["n_mult"]), n_ctx, qtype,
+        p = hip.ModelParams(cfg["n_vocab"], E, cfg["n_head"], cfg["n_layer"],
+                            cfg["n_ff"] if "n_ff" in cfg else ggjt.n_ff_of(E, cfg["n_mult"]), n_ctx, qtype,
                             max_batch, tp_rank, tp_size)
         h = L.fl_model_create(C.byref(p))
         if not h:
@@ -42,6 +43,11 @@ class FlModel:
         """eval without copying logits back (they stay in HBM: fl_model_logits_dev) -- the bench's timed call."""
         hip.check(self.L.fl_model_eval(self.h, toks_i32.ctypes.data_as(C.c_void_p), toks_i32.size, n_past, None, 0, None),
                   "fl_model_eval")
+
+    def profile(self, enable: int):
+        ms, n = C.c_double(), C.c_long()
+        hip.check(self.L.fl_model_profile(self.h, enable, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def eval(self, tokens, n_past=0, all_logits=False, embeddings=False):
         toks = np.ascontiguousarray(tokens, dtype=np.int32)

@@ -164,6 +164,9 @@ int fl_model_set_comm(fl_model *m, fl_comm *c);
  * N*n_vocab (all_logits != 0, `should_put_all_logits`); embeddings_host (optional) n_embd floats of the last token. */
 int fl_model_eval(fl_model *m, const int32_t *tokens_host, int N, int n_past, float *logits_host, int all_logits,
                   float *embeddings_host);
+/* enable: 1 = reset + start timing every quantized-matmul launch (HIP events on the eval stream), 0 = stop; the
+ * accumulated totals so far are returned through the two pointers (either may be NULL). */
+int fl_model_profile(fl_model *m, int enable, double *mm_ms_total, long *mm_launches);
 const float *fl_model_logits_dev(const fl_model *m);
 void *fl_model_stream(const fl_model *m);
 size_t fl_model_device_bytes(const fl_model *m);
