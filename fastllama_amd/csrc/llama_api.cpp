@@ -1,0 +1,683 @@
+// llama_api.cpp -- the PRIMARY drop-in boundary: the 17 `llama_*` symbols of the reference's C-ABI
+// (/root/reference/interfaces/c/fastllama.h:64-218 + llama_handle_signal, interfaces/c/main.cpp:229),
+// re-implemented on top of the device-resident model (fl_model, model.cpp).
+//
+// Host-side pieces written here (C++, as in the reference), each mirroring the behaviour of:
+//   model file reader (GGML / GGMF v1 / GGJT v1)   include/file_loader.hpp:94-250      -> load_model_file
+//   vocabulary + SentencePiece-style tokenizer     include/tokenizer.hpp:71-176        -> tokenize
+//   sampler (repeat penalty, top-k, top-p, temp)   lib/bridge.cpp:13-108               -> sample_top_p_top_k
+//   streaming token buffer with stop words         include/token_buffer.hpp            -> TokenBuffer
+//   session: ingest / generate / perplexity / state lib/bridge.cpp:110-559             -> Session
+// Model::eval itself (lib/llama.cpp:272-499) is fl_model_eval on the GPU.  There is no CPU evaluation path:
+// if no gfx950 device is present llama_load_model fails and says so.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <queue>
+#include <random>
+#include <sstream>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/fastllama.h"
+#include "../../include/fastllama_hip.h"
+
+namespace {
+
+using token_t = int32_t;
+constexpr token_t TOKEN_BOS = 1, TOKEN_EOS = 2;   // include/bridge.hpp:18-19
+
+// ------------------------------------------------------------------------------------------------ logger
+struct Log {
+    llama_logger cb{};
+    void emit(LLAMA_LOGGER_FUNC f, const char *fn, const std::string &msg) const {
+        if (f) f(fn, (int)strlen(fn), msg.data(), (int)msg.size());
+    }
+    void info(const char *fn, const std::string &m) const { emit(cb.log, fn, m); }
+    void err(const char *fn, const std::string &m) const { emit(cb.log_err, fn, m); }
+    void warn(const char *fn, const std::string &m) const { emit(cb.log_warn, fn, m); }
+    void reset() const { if (cb.reset) cb.reset(); }
+    void progress(progress_type_tag t, size_t done, size_t total) const { if (cb.progress) cb.progress(t, done, total); }
+};
+
+void def_log_info(const char *fn, int fl, const char *m, int ml) { printf("\x1b[32;1m[Info]:\x1b[0m Func('%.*s') %.*s", fl, fn, ml, m); fflush(stdout); }
+void def_log_err(const char *fn, int fl, const char *m, int ml) { fprintf(stderr, "\x1b[31;1m[Error]:\x1b[0m Func('%.*s') %.*s", fl, fn, ml, m); fflush(stderr); }
+void def_log_warn(const char *fn, int fl, const char *m, int ml) { printf("\x1b[93;1m[Warn]:\x1b[0m Func('%.*s') %.*s", fl, fn, ml, m); fflush(stdout); }
+void def_log_reset() { printf("\x1b[0m"); fflush(stdout); }
+void def_log_progress(progress_type_tag, size_t, size_t) {}
+
+// ------------------------------------------------------------------------------------------------ vocabulary
+struct Vocab {
+    std::vector<std::string> tok;
+    std::vector<float> score;
+    std::unordered_map<std::string, token_t> to_id;
+    std::string_view token(token_t id) const {
+        return (size_t)id < tok.size() ? std::string_view(tok[(size_t)id]) : std::string_view{};
+    }
+};
+
+// SentencePiece-style greedy bigram merging by vocabulary score (include/tokenizer.hpp:71-176): split into UTF-8
+// characters, repeatedly merge the adjacent pair whose concatenation is the highest-scoring vocabulary entry
+// (ties: leftmost), emit ids, bytes of unknown pieces fall back to id = byte + 3.
+size_t utf8_len(char c) {
+    static const size_t lut[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 3, 4};
+    return lut[(uint8_t)c >> 4];
+}
+
+std::vector<token_t> tokenize(const Vocab &v, std::string_view text, bool bos) {
+    std::vector<token_t> out;
+    if (text.empty()) return out;
+    if (bos) out.push_back(TOKEN_BOS);
+    struct Sym { size_t pos, len; int prev, next; };
+    struct Bigram { int left, right; float score; size_t size; };
+    struct Cmp { bool operator()(const Bigram &l, const Bigram &r) const { return l.score < r.score || (l.score == r.score && l.left > r.left); } };
+    std::vector<Sym> syms;
+    for (size_t off = 0; off < text.size();) {
+        const size_t n = std::min(text.size() - off, utf8_len(text[off]));
+        Sym s{off, n, (int)syms.size() - 1, -1};
+        off += n;
+        s.next = off == text.size() ? -1 : (int)syms.size() + 1;
+        syms.push_back(s);
+    }
+    std::priority_queue<Bigram, std::vector<Bigram>, Cmp> q;
+    auto try_add = [&](int l, int r) {
+        if (l == -1 || r == -1) return;
+        const std::string piece(text.substr(syms[l].pos, syms[l].len + syms[r].len));
+        auto it = v.to_id.find(piece);
+        if (it == v.to_id.end() || (size_t)it->second >= v.tok.size()) return;
+        q.push(Bigram{l, r, v.score[(size_t)it->second], piece.size()});
+    };
+    for (size_t i = 1; i < syms.size(); ++i) try_add((int)i - 1, (int)i);
+    while (!q.empty()) {
+        const Bigram b = q.top();
+        q.pop();
+        Sym &L = syms[b.left], &R = syms[b.right];
+        if (L.len == 0 || R.len == 0 || L.len + R.len != b.size) continue;
+        L.len += R.len;
+        L.next = R.next;
+        if (R.next >= 0) syms[R.next].prev = b.left;
+        R.len = 0;
+        try_add(L.prev, b.left);
+        try_add(b.left, L.next);
+    }
+    for (int i = 0; i != -1; i = syms[i].next) {
+        const std::string piece(text.substr(syms[i].pos, syms[i].len));
+        auto it = v.to_id.find(piece);
+        if (it != v.to_id.end()) out.push_back(it->second);
+        else for (char c : piece) out.push_back((token_t)((uint8_t)c) + 3);
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------ sampler
+// lib/bridge.cpp:24-108.  temp <= 0: argmax.  Otherwise logits/temp with the CTRL repetition penalty on the last-n
+// tokens, top-k (partial sort), softmax in double over exp(float), top-p cut, std::discrete_distribution on mt19937.
+token_t sample_top_p_top_k(const float *logits, int n_vocab, const std::deque<token_t> &last_n, double repeat_penalty,
+                           int top_k, double top_p, double temp, std::mt19937 &rng) {
+    if (temp <= 0.0) return (token_t)(std::max_element(logits, logits + n_vocab) - logits);
+    std::vector<std::pair<double, token_t>> lid((size_t)n_vocab);
+    const std::unordered_set<token_t> recent(last_n.begin(), last_n.end());
+    const double scale = 1.0 / temp, inv_pen = 1.0 / repeat_penalty;
+    for (int i = 0; i < n_vocab; ++i) {
+        const double sl = (double)logits[i] * scale;
+        lid[(size_t)i] = {recent.count(i) ? sl * (logits[i] < 0.0f ? repeat_penalty : inv_pen) : sl, i};
+    }
+    const int k = top_k > 0 ? std::min(top_k, n_vocab) : n_vocab;
+    std::partial_sort(lid.begin(), lid.begin() + k, lid.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+    lid.resize((size_t)k);
+    const double maxl = lid[0].first;
+    std::vector<double> probs(lid.size());
+    double sum = 0.0;
+    for (size_t i = 0; i < lid.size(); ++i) {
+        probs[i] = (double)std::exp((float)(lid[i].first - maxl));
+        sum += probs[i];
+    }
+    for (double &p : probs) p /= sum;
+    if (top_p < 1.0) {
+        double cum = 0.0;
+        for (size_t i = 0; i < probs.size(); ++i) {
+            cum += probs[i];
+            if (cum >= top_p) {
+                probs.resize(i + 1);
+                lid.resize(i + 1);
+                break;
+            }
+        }
+    }
+    std::discrete_distribution<> dist(probs.begin(), probs.end());
+    return lid[(size_t)dist(rng)].second;
+}
+
+// ------------------------------------------------------------------------------------------------ token buffer
+// include/token_buffer.hpp: holds back as many tokens as the longest stop word has, so a stop word can be cut out
+// before it is streamed; incomplete UTF-8 tails wait for their continuation bytes.
+struct TokenBufferState {
+    std::string left_out;
+    std::string unicode_backlog;
+};
+
+struct TokenBuffer {
+    const Vocab &vocab;
+    size_t max_size;
+    std::function<void(const std::string &)> fn;
+    std::deque<token_t> buf;
+    std::string backlog;
+
+    void fix_utf8(std::string &s) {
+        if (s.empty()) return;
+        if (!backlog.empty()) { s = backlog + s; backlog.clear(); }
+        size_t last = 0, ulen = 0;
+        for (size_t i = 0; i < s.size();) { ulen = utf8_len(s[i]); last = i; i += ulen; }
+        if (last + ulen > s.size()) { backlog = s.substr(last); s.resize(last); }
+    }
+    void flush_one() {
+        if (buf.empty()) return;
+        std::string t(vocab.token(buf.front()));
+        buf.pop_front();
+        fix_utf8(t);
+        if (!t.empty()) fn(t);
+    }
+    void add(token_t id) {
+        if (max_size <= buf.size()) flush_one();
+        buf.push_back(id);
+    }
+    // -> (found, text before the stop word, text after it)
+    bool find_stop(const std::vector<std::string> &stops, std::string &before, std::string &after) const {
+        if (stops.empty()) return false;
+        std::string s = backlog;
+        for (token_t id : buf) s += vocab.token(id);
+        for (const auto &w : stops) {
+            const size_t p = s.find(w);
+            if (p != std::string::npos) { before = s.substr(0, p); after = s.substr(p + w.size()); return true; }
+        }
+        return false;
+    }
+    void restore(TokenBufferState &st) {
+        if (!st.left_out.empty()) {
+            fix_utf8(st.left_out);
+            if (!st.left_out.empty()) fn(st.left_out);
+            st.left_out.clear();
+        }
+        backlog = st.unicode_backlog;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ model file
+struct MappedFile {
+    const uint8_t *p = nullptr;
+    size_t n = 0;
+    int fd = -1;
+    bool open(const char *path) {
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0) return false;
+        n = (size_t)st.st_size;
+        void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) return false;
+        p = (const uint8_t *)m;
+        return true;
+    }
+    ~MappedFile() {
+        if (p) munmap((void *)p, n);
+        if (fd >= 0) close(fd);
+    }
+};
+
+struct Reader {
+    const uint8_t *p;
+    size_t n, off = 0;
+    bool ok = true;
+    template <class T> T get() {
+        T v{};
+        if (off + sizeof(T) > n) { ok = false; return v; }
+        memcpy(&v, p + off, sizeof(T));
+        off += sizeof(T);
+        return v;
+    }
+    std::string str(size_t len) {
+        if (off + len > n) { ok = false; return {}; }
+        std::string s((const char *)p + off, len);
+        off += len;
+        return s;
+    }
+};
+
+struct HParams { int32_t n_vocab = 0, n_embd = 0, n_mult = 0, n_head = 0, n_layer = 0, n_rot = 0, ftype = 0; };
+
+// ------------------------------------------------------------------------------------------------ session
+struct Session {
+    llama_model_context_args args{};
+    Log log;
+    HParams hp;
+    Vocab vocab;
+    fl_model *model = nullptr;
+    int max_batch = 0;
+    int n_past = 0, seed = 0, keep = 0;
+    size_t mem_per_token = 0;
+    std::mt19937 rng;
+    std::vector<token_t> embd;
+    std::deque<token_t> last_n;      // RingBuffer<token_id_t>, include/ring_buffer.hpp:26-40
+    size_t last_n_cap = 64;
+    std::vector<float> logits, embeddings;
+    std::vector<token_t> system_prompt;
+    TokenBufferState tb_state;
+    bool all_logits = false;
+
+    ~Session() { if (model) fl_model_free(model); }
+
+    void push_last(token_t t) {
+        if (last_n.size() >= last_n_cap) last_n.pop_front();
+        last_n.push_back(t);
+    }
+
+    bool load(const char *path) {
+        MappedFile f;
+        if (!f.open(path)) { log.err("Model::load", std::string("unable to open '") + path + "'\n"); return false; }
+        Reader r{f.p, f.n};
+        const uint32_t magic = r.get<uint32_t>();
+        int version = 0;                                             // 0 GGML, 1 GGMF v1, 2 GGJT v1
+        if (magic == 0x67676d6c) version = 0;
+        else if (magic == 0x67676d66 || magic == 0x67676a74) {
+            const uint32_t fv = r.get<uint32_t>();
+            if (fv != 1) { log.err("read_magic_number", "unsupported file version\n"); return false; }
+            version = magic == 0x67676d66 ? 1 : 2;
+        } else { log.err("read_magic_number", std::string("invalid model file '") + path + "' (bad magic)\n"); return false; }
+        hp.n_vocab = r.get<int32_t>(); hp.n_embd = r.get<int32_t>(); hp.n_mult = r.get<int32_t>(); hp.n_head = r.get<int32_t>();
+        hp.n_layer = r.get<int32_t>(); hp.n_rot = r.get<int32_t>(); hp.ftype = r.get<int32_t>();
+        if (!r.ok || hp.n_vocab <= 0 || hp.n_embd <= 0 || hp.n_head <= 0 || hp.n_layer <= 0 || hp.n_mult <= 0) {
+            log.err("read_hyperparams", "failed to read hyper parameters\n");
+            return false;
+        }
+        if (hp.ftype != FL_TYPE_Q4_0 && hp.ftype != FL_TYPE_Q4_1) {
+            log.err("Model::load", "this build evaluates Q4_0 / Q4_1 models on the GPU (file ftype " + std::to_string(hp.ftype) + ")\n");
+            return false;
+        }
+        vocab.tok.resize((size_t)hp.n_vocab);
+        vocab.score.assign((size_t)hp.n_vocab, 0.f);
+        for (int i = 0; i < hp.n_vocab; ++i) {
+            const uint32_t len = r.get<uint32_t>();
+            vocab.tok[(size_t)i] = r.str(len);
+            if (version >= 1) vocab.score[(size_t)i] = r.get<float>();
+            if (!r.ok) { log.err("read_vocab", "failed to read vocab\n"); return false; }
+            vocab.to_id[vocab.tok[(size_t)i]] = i;
+        }
+        const int n_ff = ((2 * (4 * hp.n_embd) / 3 + hp.n_mult - 1) / hp.n_mult) * hp.n_mult;   // lib/llama.cpp:129
+        max_batch = std::min(args.n_ctx, std::max(args.n_batch, args.n_keep + (int)args.last_n_tokens + args.n_batch));
+        fl_model_params mp{};
+        mp.n_vocab = hp.n_vocab; mp.n_embd = hp.n_embd; mp.n_head = hp.n_head; mp.n_layer = hp.n_layer; mp.n_ff = n_ff;
+        mp.n_ctx = args.n_ctx; mp.qtype = hp.ftype; mp.max_batch = max_batch; mp.tp_rank = 0; mp.tp_size = 1;
+        if (fl_init(0) != FL_OK) { log.err("Model::load", std::string(fl_last_error()) + "\n"); return false; }
+        model = fl_model_create(&mp);
+        if (!model) { log.err("Model::load", std::string(fl_last_error()) + "\n"); return false; }
+        log.info("Model::load", "n_vocab=" + std::to_string(hp.n_vocab) + " n_embd=" + std::to_string(hp.n_embd) + " n_head=" +
+                                    std::to_string(hp.n_head) + " n_layer=" + std::to_string(hp.n_layer) + " n_ff=" + std::to_string(n_ff) + "\n");
+        size_t done = 0;
+        while (r.ok && r.off < r.n) {
+            const uint32_t n_dims = r.get<uint32_t>(), name_len = r.get<uint32_t>(), type = r.get<uint32_t>();
+            if (!r.ok) break;
+            if (n_dims < 1 || n_dims > 2) { log.err("read_tensor_metadata", "tensor has a bad number of dimensions\n"); return false; }
+            uint32_t ne[2] = {1, 1};
+            for (uint32_t d = 0; d < n_dims; ++d) ne[d] = r.get<uint32_t>();
+            const std::string name = r.str(name_len);
+            if (version >= 2) r.off += (size_t)(-(int64_t)r.off & 31);
+            size_t bytes;
+            const size_t nel = (size_t)ne[0] * ne[1];
+            if (type == 0) bytes = nel * 4;
+            else if (type == 1) bytes = nel * 2;
+            else if (type == FL_TYPE_Q4_0) bytes = nel / 32 * 20;
+            else if (type == FL_TYPE_Q4_1) bytes = nel / 32 * 24;
+            else { log.err("read_tensor_metadata", "unrecognized tensor type\n"); return false; }
+            if (!r.ok || r.off + bytes > r.n) { log.err("read_tensor_metadata", "truncated tensor '" + name + "'\n"); return false; }
+            if (fl_model_set_tensor(model, name.c_str(), (int)type, r.p + r.off, (int)ne[0], (int)ne[1]) != FL_OK) {
+                log.err("Model::load", std::string(fl_last_error()) + "\n");
+                return false;
+            }
+            r.off += bytes;
+            log.progress(PROGRESS_TAG_LOAD, ++done, (size_t)(3 + 9 * hp.n_layer));
+        }
+        if (fl_model_finalize(model) != FL_OK) { log.err("Model::load", std::string(fl_last_error()) + "\n"); return false; }
+        log.info("Model::load", "model resident in HBM: " + std::to_string(fl_model_device_bytes(model) >> 20) + " MiB\n");
+        return true;
+    }
+
+    // Model::eval(n_past, tokens, logits, ...) -- lib/llama.cpp:272; batches larger than max_batch are split
+    bool eval(int past, const std::vector<token_t> &toks) {
+        const int V = hp.n_vocab, N = (int)toks.size();
+        if (N == 0) return true;
+        logits.resize((size_t)V * (all_logits ? N : 1));
+        if (args.embedding_eval_enabled) embeddings.resize((size_t)hp.n_embd);
+        for (int i = 0; i < N; i += max_batch) {
+            const int n = std::min(max_batch, N - i);
+            float *dst = all_logits ? logits.data() + (size_t)i * V : logits.data();
+            if (fl_model_eval(model, toks.data() + i, n, past + i, dst, all_logits ? 1 : 0,
+                              args.embedding_eval_enabled ? embeddings.data() : nullptr) != FL_OK) {
+                log.err("Model::eval", std::string(fl_last_error()) + "\n");
+                return false;
+            }
+        }
+        if (mem_per_token == 0) mem_per_token = 1;
+        return true;
+    }
+
+    // lib/bridge.cpp:161-180
+    bool recycle_if_exceeds_context() {
+        const size_t len = embd.size();
+        if (len == 0 || (int)len + n_past <= args.n_ctx) return false;
+        const size_t last_len = last_n.size();
+        const size_t remaining = (size_t)(n_past - std::min(keep, n_past));
+        const size_t begin_pos = last_len - std::min(remaining >> 1, last_len);
+        n_past = keep;
+        if (begin_pos < system_prompt.size()) {
+            embd.insert(embd.begin(), system_prompt.begin(), system_prompt.end());
+            return true;
+        }
+        embd.insert(embd.begin(), last_n.end() - (std::ptrdiff_t)begin_pos, last_n.end());
+        embd.insert(embd.begin(), system_prompt.begin(), system_prompt.end());
+        return true;
+    }
+
+    // lib/bridge.cpp:186-238: the block staged last is evaluated by the NEXT ingest()/generate() call
+    bool ingest(std::string prompt, bool is_system) {
+        log.reset();
+        prompt.insert(0, 1, ' ');
+        const std::vector<token_t> in = tokenize(vocab, prompt, true);
+        const int max_in = args.n_ctx - 4;
+        if ((int)in.size() > max_in) {
+            log.err("ingest", "prompt size(='" + std::to_string(in.size()) + "') exceeds maximum allowed size('" + std::to_string(max_in) + "')");
+            return false;
+        }
+        if (is_system) {
+            if (keep < (int)in.size()) {
+                log.err("ingest", "system prompt size(='" + std::to_string(in.size()) + "') exceeds 'n_keep'(='" + std::to_string(keep) + "')");
+                return false;
+            }
+            system_prompt = in;
+        }
+        const size_t nb = (size_t)args.n_batch;
+        for (size_t i = 0; i < in.size(); i += nb) {
+            log.progress(PROGRESS_TAG_INGEST, i, in.size());
+            const size_t block = std::min(nb, in.size() - i);
+            recycle_if_exceeds_context();
+            if (!embd.empty() && !eval(n_past, embd)) return false;
+            n_past += (int)embd.size();
+            embd.assign(in.begin() + (std::ptrdiff_t)i, in.begin() + (std::ptrdiff_t)(i + block));
+            for (size_t j = 0; j < block; ++j) push_last(in[i + j]);
+        }
+        log.progress(PROGRESS_TAG_INGEST, in.size(), in.size());
+        last_n.clear();
+        return true;
+    }
+
+    // lib/bridge.cpp:240-312
+    bool generate(const std::function<void(const std::string &)> &fn, size_t num_tokens, float top_k, float top_p, float temp,
+                  float repeat_penalty, const std::vector<std::string> &stops) {
+        log.reset();
+        size_t max_buf = 0;
+        for (const auto &w : stops) max_buf = std::max(max_buf, tokenize(vocab, w, false).size());
+        TokenBuffer tb{vocab, max_buf, fn, {}, {}};
+        tb.restore(tb_state);
+        for (size_t i = 0; i < num_tokens; ++i) {
+            std::string before, after;
+            if (tb.find_stop(stops, before, after)) {
+                fn(before);
+                tb_state.unicode_backlog = tb.backlog;
+                tb_state.left_out = after;
+                return true;
+            }
+            recycle_if_exceeds_context();
+            if (!embd.empty() && !eval(n_past, embd)) return false;
+            n_past += (int)embd.size();
+            embd.clear();
+            const float *last = logits.data() + logits.size() - (size_t)hp.n_vocab;
+            const token_t id = sample_top_p_top_k(last, hp.n_vocab, last_n, (double)repeat_penalty, (int)top_k, (double)top_p,
+                                                  (double)temp, rng);
+            if (id == TOKEN_EOS) break;
+            push_last(id);
+            tb.add(id);
+            embd.push_back(id);
+        }
+        while (!tb.buf.empty()) tb.flush_one();
+        return true;
+    }
+
+    // lib/bridge.cpp:331-422
+    float perplexity(std::string_view prompt) {
+        const bool old = all_logits;
+        all_logits = true;
+        const std::vector<token_t> toks = tokenize(vocab, prompt, true);
+        const size_t bs = (size_t)args.n_batch, V = (size_t)hp.n_vocab;
+        const size_t blocks = toks.size() / bs + (toks.size() % bs != 0);
+        log.info("perplexity", "calculating perplexity over " + std::to_string(blocks) + " chunk(s)\n");
+        double nll = 0.0, res = 0.0;
+        size_t count = 0, idx = 1;
+        std::vector<float> probs;
+        for (size_t i = 0; i < toks.size(); i += bs, ++idx) {
+            const size_t block = std::min(bs, toks.size() - i);
+            const std::vector<token_t> in(toks.begin() + (std::ptrdiff_t)i, toks.begin() + (std::ptrdiff_t)(i + block));
+            if (!eval(0, in)) { all_logits = old; return -1.f; }
+            for (size_t j = block >> 1; j + 1 < block; ++j) {
+                const float *l = logits.data() + j * V;
+                const float mx = *std::max_element(l, l + V);
+                probs.resize(V);
+                float sum = 0.f;
+                for (size_t k = 0; k < V; ++k) { probs[k] = std::exp(l[k] - mx); sum += probs[k]; }
+                const float p = probs[(size_t)toks[i + j + 1]] / sum;
+                nll += (double)(-std::log(p));
+                ++count;
+            }
+            res = std::exp(nll / (double)count);
+            char line[96];
+            snprintf(line, sizeof line, "[%zu/%zu]: %.4f\n", idx, blocks, res);
+            log.info("perplexity", line);
+        }
+        all_logits = old;
+        return (float)res;
+    }
+
+    // session state file: byte-compatible with the reference's (lib/bridge.cpp:424-525 + KV dump lib/llama.cpp:57-78)
+    bool save_state(const char *path) {
+        FILE *f = fopen(path, "wb");
+        if (!f) { log.err("save_state", "unable to open the file saving the model state"); return false; }
+        auto W = [&](const void *p, size_t n) { return fwrite(p, 1, n, f) == n; };
+        bool ok = W(&n_past, sizeof n_past);
+        std::stringstream ss;
+        ss << rng;
+        const std::string rs = ss.str();
+        size_t n = rs.size();
+        ok = ok && W(&n, sizeof n) && W(rs.data(), n) && W(&mem_per_token, sizeof mem_per_token);
+        n = embd.size();
+        ok = ok && W(&n, sizeof n) && W(embd.data(), n * sizeof(token_t));
+        n = last_n.size();
+        ok = ok && W(&n, sizeof n);
+        for (token_t t : last_n) ok = ok && W(&t, sizeof t);
+        n = logits.size();
+        ok = ok && W(&n, sizeof n) && W(logits.data(), n * sizeof(float));
+        n = system_prompt.size();
+        ok = ok && W(&n, sizeof n) && W(system_prompt.data(), n * sizeof(token_t));
+        const int32_t memory_type = 0;   // GGML_TYPE_F32, include/llama.hpp:111
+        ok = ok && W(&memory_type, sizeof memory_type);
+        const size_t kv = (size_t)hp.n_layer * args.n_ctx * hp.n_embd;
+        std::vector<float> k(kv), v(kv);
+        ok = ok && fl_model_kv_read(model, k.data(), v.data()) == FL_OK && W(k.data(), kv * 4) && W(v.data(), kv * 4);
+        fclose(f);
+        if (!ok) log.err("save_state", "failed to write the model state\n");
+        return ok;
+    }
+
+    bool load_state(const char *path) {
+        FILE *f = fopen(path, "rb");
+        if (!f) { log.err("load_state", "unable to open the file loading the model state"); return false; }
+        auto R = [&](void *p, size_t n) { return fread(p, 1, n, f) == n; };
+        bool ok = R(&n_past, sizeof n_past);
+        size_t n = 0;
+        ok = ok && R(&n, sizeof n);
+        std::string rs(ok ? n : 0, '\0');
+        ok = ok && R(rs.data(), n);
+        if (ok) { std::stringstream ss; ss << rs; ss >> rng; }
+        ok = ok && R(&mem_per_token, sizeof mem_per_token) && R(&n, sizeof n);
+        if (ok) { embd.resize(n); ok = R(embd.data(), n * sizeof(token_t)); }
+        ok = ok && R(&n, sizeof n);
+        if (ok) { last_n.clear(); for (size_t i = 0; i < n && ok; ++i) { token_t t; ok = R(&t, sizeof t); if (ok) push_last(t); } }
+        ok = ok && R(&n, sizeof n);
+        if (ok) { logits.resize(n); ok = R(logits.data(), n * sizeof(float)); }
+        ok = ok && R(&n, sizeof n);
+        if (ok) { system_prompt.resize(n); ok = R(system_prompt.data(), n * sizeof(token_t)); }
+        int32_t memory_type = 0;
+        ok = ok && R(&memory_type, sizeof memory_type) && memory_type == 0;
+        const size_t kv = (size_t)hp.n_layer * args.n_ctx * hp.n_embd;
+        std::vector<float> k(ok ? kv : 0), v(ok ? kv : 0);
+        ok = ok && R(k.data(), kv * 4) && R(v.data(), kv * 4) && fl_model_kv_write(model, k.data(), v.data()) == FL_OK;
+        fclose(f);
+        if (!ok) log.err("load_state", "failed to read the model state (was it saved with the same model and n_ctx?)\n");
+        return ok;
+    }
+
+    bool reset() {
+        log.info("reset", "resetting the model...\n");
+        n_past = 0;
+        last_n.clear();
+        logits.clear();
+        system_prompt.clear();
+        embd.clear();
+        rng = std::mt19937((uint32_t)seed);
+        log.info("reset", "reset completed.\n");
+        return true;
+    }
+};
+
+}  // namespace
+
+struct llama_model_context {
+    llama_model_context_args args{};
+    std::unique_ptr<Session> inner;
+    std::vector<std::string> stop_words;
+};
+
+static bool valid(const llama_model_context *c) {
+    if (!c) { fprintf(stderr, "model context is not initalized. Please use `llama_create_context` to create a context.\n"); return false; }
+    if (!c->inner) { fprintf(stderr, "model is not loaded. Please use `llama_load_model` to load a model.\n"); return false; }
+    return true;
+}
+
+extern "C" {
+
+struct llama_model_context_args llama_create_default_context_args(void) {
+    llama_model_context_args a{};                       // FastLlama::Params defaults, include/bridge.hpp:21-36
+    a.embedding_eval_enabled = false;
+    a.should_get_all_logits = false;
+    a.use_mmap = false;
+    a.use_mlock = false;
+    a.load_parallel = false;
+    a.seed = 0;
+    a.n_keep = 64;
+    a.n_ctx = 512;
+    a.n_threads = 1;
+    a.n_batch = 16;
+    a.n_load_parallel_blocks = 1;
+    a.last_n_tokens = 64;
+    a.allocate_extra_mem = 0;
+    a.logger = {def_log_info, def_log_err, def_log_warn, def_log_reset, def_log_progress};
+    return a;
+}
+
+struct llama_model_context *llama_create_context(struct llama_model_context_args args) {
+    auto *c = new (std::nothrow) llama_model_context();
+    if (c) c->args = args;
+    return c;
+}
+
+bool llama_load_model(struct llama_model_context *c, char const *filepath) {
+    if (!c) { fprintf(stderr, "model context is not initalized. Please use `llama_create_context` to create a context.\n"); return false; }
+    if (c->inner) { fprintf(stderr, "model is already loaded.\n"); return false; }
+    if (!filepath) return false;
+    auto s = std::make_unique<Session>();
+    s->args = c->args;
+    s->log.cb = c->args.logger;
+    s->seed = c->args.seed;
+    s->keep = c->args.n_keep;
+    s->rng = std::mt19937((uint32_t)c->args.seed);
+    s->last_n_cap = c->args.last_n_tokens;
+    s->last_n.assign(c->args.last_n_tokens, 0);      // RingBuffer(size) starts with `size` zero tokens, ring_buffer.hpp:26-29
+    s->all_logits = c->args.should_get_all_logits;
+    if (c->args.n_ctx <= 8 || c->args.n_batch <= 0) { s->log.err("FastLlama::Params::build", "bad n_ctx / n_batch\n"); return false; }
+    if (c->args.n_ctx % 4 != 0) s->args.n_ctx = c->args.n_ctx = (c->args.n_ctx + 3) / 4 * 4;
+    if (!s->load(filepath)) {
+        s->log.err("FastLlama::Params::build", "Unable to load model\n");
+        return false;
+    }
+    c->inner = std::move(s);
+    return true;
+}
+
+bool llama_set_stop_words(struct llama_model_context *c, char const **words, size_t len) {
+    if (!c) { fprintf(stderr, "model context is not initalized. Please use `llama_create_context` to create a context.\n"); return false; }
+    c->stop_words.assign(len, std::string());
+    for (size_t i = 0; i < len; ++i) c->stop_words[i] = words[i] ? words[i] : "";
+    return true;
+}
+
+bool llama_ingest(struct llama_model_context *c, char const *prompt) { return valid(c) && prompt && c->inner->ingest(prompt, false); }
+bool llama_ingest_system_prompt(struct llama_model_context *c, char const *prompt) { return valid(c) && prompt && c->inner->ingest(prompt, true); }
+
+bool llama_generate(struct llama_model_context *c, LLAMA_STREAM_FUNC stream_fn, size_t number_of_tokens, float top_k, float top_p,
+                    float temp, float repeat_penalty) {
+    if (!valid(c)) return false;
+    return c->inner->generate([stream_fn](const std::string &s) { if (stream_fn) stream_fn(s.data(), (int)s.size()); },
+                              number_of_tokens, top_k, top_p, temp, repeat_penalty, c->stop_words);
+}
+
+float llama_perplexity(struct llama_model_context *c, char const *prompt) {
+    if (!valid(c) || !prompt) return -1.f;
+    return c->inner->perplexity(prompt);
+}
+
+struct llama_array_view_f llama_get_embeddings(struct llama_model_context const *c) {
+    if (!valid(c)) return {nullptr, 0};
+    if (!c->inner->args.embedding_eval_enabled)
+        c->inner->log.warn("get_embeddings", "Please set the flag `embeddings_eval_enable` to true before getting the embeddings.\n");
+    return {c->inner->embeddings.data(), c->inner->embeddings.size()};
+}
+
+struct llama_array_view_f llama_get_logits(struct llama_model_context const *c) {
+    if (!valid(c)) return {nullptr, 0};
+    return {c->inner->logits.data(), c->inner->logits.size()};
+}
+
+bool llama_save_state(struct llama_model_context *c, char const *path) { return valid(c) && path && c->inner->save_state(path); }
+bool llama_load_state(struct llama_model_context *c, char const *path) { return valid(c) && path && c->inner->load_state(path); }
+
+bool llama_attach_lora(struct llama_model_context *c, char const *) {
+    if (!valid(c)) return false;
+    c->inner->log.err("attach_lora", "LoRA adapters on device-resident Q4 weights are not implemented yet (SURVEY.md 8 f-3)\n");
+    return false;
+}
+bool llama_detach_lora(struct llama_model_context *c) {
+    if (!valid(c)) return false;
+    c->inner->log.err("detach_lora", "no LoRA adapter is attached\n");
+    return false;
+}
+
+bool llama_reset_model(struct llama_model_context *c) { return valid(c) && c->inner->reset(); }
+void llama_free_context(struct llama_model_context *c) { delete c; }
+
+void llama_handle_signal(int) {
+    printf("Quitting the app...");
+    exit(0);
+}
+
+}  // extern "C"

@@ -34,6 +34,31 @@ def test_kernel_abi_symbols_exported(lib):
     assert not missing, missing
 
 
+def test_primary_llama_abi_symbols_exported(lib):
+    """include/fastllama.h = the reference's interfaces/c/fastllama.h: all 17 llama_* symbols are exported."""
+    names = _declared("fastllama.h", "llama_")
+    names = {n for n in names if n not in ("llama_model_context", "llama_model_context_args", "llama_logger",
+                                           "llama_array_view_f")}
+    assert len(names) == 17, sorted(names)
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_llama_context_args_layout_matches_reference_python_binding(lib):
+    """sizeof/offsets of llama_model_context_args as ctypes lays it out (fastllama.py:132-151 does the same)."""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, ROOT)
+    from harness import llama_capi
+    assert C.sizeof(llama_capi.Logger) == 5 * C.sizeof(C.c_void_p)
+    a = llama_capi.ContextArgs
+    assert a.seed.offset == 8 and a.n_load_parallel_blocks.offset == 28 and a.last_n_tokens.offset == 32
+    assert a.logger.offset == 48 and C.sizeof(a) == 88
+    lib.llama_create_default_context_args.restype = a
+    d = lib.llama_create_default_context_args()
+    assert (d.n_ctx, d.n_batch, d.n_keep, d.n_threads, d.last_n_tokens) == (512, 16, 64, 1, 64)   # bridge.hpp:21-36
+
+
 def test_python_binding_covers_header():
     from fastllama_amd import hip
     names = _declared("fastllama_hip.h", "fl_")

@@ -1,0 +1,151 @@
+"""GPU: the PRIMARY boundary.  The same ctypes driver (harness/llama_capi.py, a mirror of the reference's
+interfaces/python/fastllama.py struct layouts) runs the reference (oracle/_ref/pyfastllama.so) and
+libfastllama_hip.so on the same synthetic GGJT file: perplexity, logits, embeddings, ingest + greedy generate
+(token stream), stop words, reset, save/load state (files are byte-compatible both ways)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from harness import ggjt, llama_capi
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OURS = os.path.join(ROOT, "fastllama_amd", "libfastllama_hip.so")
+TEXT = "The quick brown fox jumps over the lazy dog; 0123456789 times!?"
+
+
+@pytest.fixture(scope="module")
+def libs():
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not shipped")
+    return llama_capi.LlamaLib(os.path.join(oracle.REF_DIR, "pyfastllama.so")), llama_capi.LlamaLib(OURS)
+
+
+@pytest.fixture(scope="module")
+def model_file(tmp_path_factory):
+    port = oracle.Port()
+    cfg, qtype = ggjt.TINY, ggjt.Q4_0
+    tensors = ggjt.synth_tensors(cfg, qtype, port.quantize_q4, seed=77)
+    path = str(tmp_path_factory.mktemp("api") / "tiny.bin")
+    ggjt.write_ggjt(path, cfg, qtype, tensors)
+    return path, cfg
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a.astype(np.float64) - b)) / np.max(np.abs(b)))
+
+
+def test_all_17_symbols_exported(libs):
+    ours = libs[1].lib
+    for n in ("llama_create_default_context_args llama_create_context llama_load_model llama_set_stop_words "
+              "llama_ingest_system_prompt llama_ingest llama_generate llama_perplexity llama_get_embeddings "
+              "llama_get_logits llama_save_state llama_load_state llama_attach_lora llama_detach_lora "
+              "llama_reset_model llama_free_context llama_handle_signal").split():
+        assert hasattr(ours, n), n
+
+
+def test_default_args_match_reference(libs):
+    a, b = libs[0].lib.llama_create_default_context_args(), libs[1].lib.llama_create_default_context_args()
+    for f in ("embedding_eval_enabled should_get_all_logits use_mmap use_mlock load_parallel seed n_keep n_ctx n_threads "
+              "n_batch n_load_parallel_blocks last_n_tokens allocate_extra_mem").split():
+        assert getattr(a, f) == getattr(b, f), f
+
+
+def test_perplexity_logits_embeddings(libs, model_file):
+    path, cfg = model_file
+    out = []
+    for lib in libs:
+        s = llama_capi.Session(lib, path, n_ctx=128, n_batch=32, all_logits=True, embeddings=True)
+        ppl = s.perplexity(TEXT)                       # 64 tokens -> two n_batch blocks, each eval at n_past = 0
+        out.append((ppl, s.logits().reshape(-1, cfg["n_vocab"]), s.embeddings()))
+        s.close()
+    (p0, l0, e0), (p1, l1, e1) = out
+    assert l0.shape == l1.shape == (32, cfg["n_vocab"])      # logits of the LAST block, all positions
+    assert rel(l1[0], l0[0]) <= 1e-5 and rel(l1, l0) <= 5e-2
+    assert abs(p1 - p0) / p0 <= 3e-2
+    assert e0.shape == e1.shape == (cfg["n_embd"],) and rel(e1, e0) <= 5e-2
+
+
+def test_ingest_then_greedy_generate_streams_same_tokens(libs, model_file):
+    path, cfg = model_file
+    res = []
+    for lib in libs:
+        s = llama_capi.Session(lib, path, n_ctx=96, n_batch=8)
+        assert s.ingest("Once upon a time", system=True) is True
+        assert s.ingest(" there was a GPU")
+        ok, text = s.generate(12, temp=0.0)
+        assert ok
+        res.append((text, s.logits()))
+        s.close()
+    assert res[0][1].shape == res[1][1].shape == (cfg["n_vocab"],)
+    # greedy streams agree token for token unless a rounding flip hits a near-tie; require a long common prefix
+    a, b = res[0][0], res[1][0]
+    common = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b)))
+    assert common >= 6, (a, b)
+
+
+def test_sampling_is_seeded_and_reset_restores_it(libs, model_file):
+    path, cfg = model_file
+    ours = libs[1]
+    s = llama_capi.Session(ours, path, n_ctx=64, n_batch=16, seed=123)
+    assert s.ingest("hello")
+    ok, t1 = s.generate(8, top_k=40, top_p=0.9, temp=0.8, repeat_penalty=1.1)
+    assert ok and s.reset()
+    assert s.ingest("hello")
+    ok, t2 = s.generate(8, top_k=40, top_p=0.9, temp=0.8, repeat_penalty=1.1)
+    assert ok and t1 == t2                              # reset() re-seeds the mt19937 (lib/bridge.cpp:546)
+    s.close()
+
+
+def test_stop_words_cut_the_stream(libs, model_file):
+    path, cfg = model_file
+    ours = libs[1]
+    s = llama_capi.Session(ours, path, n_ctx=64, n_batch=16)
+    assert s.ingest("abc")
+    ok, full = s.generate(10, temp=0.0)
+    assert ok and len(full) >= 4
+    stop = full[2:4].decode("latin1")
+    s.reset()
+    assert s.ingest("abc")
+    ok, cut = s.generate(10, temp=0.0, stop_words=[stop])
+    assert ok and cut == full[:2]
+    s.close()
+
+
+def test_state_files_are_interchangeable_with_the_reference(libs, model_file, tmp_path):
+    path, cfg = model_file
+    ref, ours = libs
+    a = llama_capi.Session(ref, path, n_ctx=64, n_batch=8)
+    assert a.ingest("state of the art")
+    ok, _ = a.generate(3, temp=0.0)
+    st = str(tmp_path / "ref.state")
+    assert a.save_state(st)
+    ok, cont_ref = a.generate(5, temp=0.0)
+    b = llama_capi.Session(ours, path, n_ctx=64, n_batch=8)
+    assert b.load_state(st)                              # a file written by the reference
+    st2 = str(tmp_path / "ours.state")
+    assert b.save_state(st2)
+    assert open(st2, "rb").read() == open(st, "rb").read()   # load -> save reproduces the reference's file byte for byte
+    ok, cont_ours = b.generate(5, temp=0.0)
+    assert ok and cont_ours[:2] == cont_ref[:2]
+    c = llama_capi.Session(ref, path, n_ctx=64, n_batch=8)
+    assert c.load_state(st2)                             # and the reference reads ours
+    a.close(); b.close(); c.close()
+
+
+def test_error_paths(libs, tmp_path):
+    ours = libs[1]
+    L = ours.lib
+    args = L.llama_create_default_context_args()
+    ctx = L.llama_create_context(args)
+    assert ctx
+    assert L.llama_perplexity(ctx, b"x") == -1.0         # model not loaded
+    assert not L.llama_ingest(ctx, b"x")
+    assert L.llama_get_logits(ctx).size == 0
+    assert not L.llama_load_model(ctx, os.fsencode(str(tmp_path / "missing.bin")))
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(b"notamodel" * 10)
+    assert not L.llama_load_model(ctx, os.fsencode(str(bad)))
+    L.llama_free_context(ctx)
