@@ -14,13 +14,14 @@ hipError_t silu_mul_quant(const float *h13, int ld, int N, int F, const uint16_t
                           int layout, hipStream_t st);
 // rope on q (in place) and k (-> kc rows n_past..), v -> vc columns n_past..
 hipError_t rope_kv(float *qkv, int ld, int N, int E, int D, int n_past, int n_ctx, const float *rope_tab, float *kc,
-                   float *vc, hipStream_t st);
-// C[z] = alpha * A[z] * B[z]^T on the exact-f32 MFMA; causal_mode 0 none, 1 scores, 2 KQV
+                   float *vc, hipStream_t st, const int *dyn_past = nullptr);
+// C[z] = alpha * A[z] * B[z]^T on the exact-f32 MFMA; causal_mode 0 none, 1 scores, 2 KQV.
+// dyn_past (decode hipGraph): n_past is read from device memory, so one captured graph serves every position.
 hipError_t gemm_f32_abt(const float *A, int lda, int64_t sAz, const float *B, int ldb, int64_t sBz, float *C, int ldc,
                         int64_t sCz, int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past,
-                        hipStream_t st);
+                        hipStream_t st, const int *dyn_past = nullptr, int nn_max = 0);
 hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab,
-                        hipStream_t st);
+                        hipStream_t st, const int *dyn_past = nullptr);
 hipError_t add_rows(const float *a, int lda, const float *b, int ldb, float *o, int ldo, int N, int E, hipStream_t st);
 
 }  // namespace fl

@@ -191,7 +191,9 @@ hipError_t silu_mul_quant(const float *h13, int ld, int N, int F, const uint16_t
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rope_kv_kernel(float *__restrict__ qkv, int ld, int N, int E, int D,
                                                       int n_past, int n_ctx, const float2 *__restrict__ rope_tab,
-                                                      float *__restrict__ kc, float *__restrict__ vc) {
+                                                      float *__restrict__ kc, float *__restrict__ vc,
+                                                      const int *__restrict__ dyn_past) {
+    if (dyn_past) n_past = *dyn_past;   // decode graph: the position lives in device memory
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (n, pair)
     const int ppr = E >> 1;
     if (gid >= (int64_t)N * ppr) return;
@@ -240,10 +242,10 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const float *__restric
 }
 
 hipError_t rope_kv(float *qkv, int ld, int N, int E, int D, int n_past, int n_ctx, const float *rope_tab, float *kc,
-                   float *vc, hipStream_t st) {
+                   float *vc, hipStream_t st, const int *dyn_past) {
     const int64_t total = (int64_t)N * (E >> 1);
     hipLaunchKernelGGL(rope_kv_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st, qkv, ld, N, E, D, n_past,
-                       n_ctx, reinterpret_cast<const float2 *>(rope_tab), kc, vc);
+                       n_ctx, reinterpret_cast<const float2 *>(rope_tab), kc, vc, dyn_past);
     if (N >= 16)
         hipLaunchKernelGGL(v_transpose_kernel, dim3(E / 32, (N + 31) / 32), dim3(256), 0, st, qkv, ld, N, E, n_past,
                            n_ctx, vc);
@@ -265,7 +267,13 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void gemm_f32_abt_kernel(const float *__restrict__ A, int lda, int64_t sAz,
                                                            const float *__restrict__ B, int ldb, int64_t sBz,
                                                            float *__restrict__ C, int ldc, int64_t sCz, int M, int Nn,
-                                                           int K, float alpha, int causal_mode, int n_past) {
+                                                           int K, float alpha, int causal_mode, int n_past,
+                                                           const int *__restrict__ dyn_past) {
+    if (dyn_past) {                      // decode graph: P = n_past + M is read from device memory
+        n_past = *dyn_past;
+        if (causal_mode == 1) Nn = n_past + M;
+        if (causal_mode == 2) K = n_past + M;
+    }
     const int z = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m0 = blockIdx.y * 64 + (wave >> 1) * 32, n0 = blockIdx.x * 64 + (wave & 1) * 32;
@@ -322,10 +330,11 @@ __global__ __launch_bounds__(256) void gemm_f32_abt_kernel(const float *__restri
 
 hipError_t gemm_f32_abt(const float *A, int lda, int64_t sAz, const float *B, int ldb, int64_t sBz, float *C, int ldc,
                         int64_t sCz, int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past,
-                        hipStream_t st) {
-    const dim3 grid((Nn + 63) / 64, (M + 63) / 64, batch);
+                        hipStream_t st, const int *dyn_past, int nn_max) {
+    // with dyn_past the grid is sized for the largest possible Nn (scores: n_ctx columns); surplus tiles exit at once
+    const dim3 grid(((dyn_past && causal_mode == 1 ? nn_max : Nn) + 63) / 64, (M + 63) / 64, batch);
     hipLaunchKernelGGL(gemm_f32_abt_kernel, grid, dim3(256), 0, st, A, lda, sAz, B, ldb, sBz, C, ldc, sCz, M, Nn, K, alpha,
-                       causal_mode, n_past);
+                       causal_mode, n_past, dyn_past);
     return hipGetLastError();
 }
 
@@ -337,7 +346,11 @@ hipError_t gemm_f32_abt(const float *A, int lda, int64_t sAz, const float *B, in
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float *__restrict__ S, int ld, int64_t sz, int N, int P,
                                                            int n_past, const uint16_t *__restrict__ exp_tab,
-                                                           int rows_total) {
+                                                           int rows_total, const int *__restrict__ dyn_past) {
+    if (dyn_past) {
+        n_past = *dyn_past;
+        P = n_past + N;
+    }
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows_total) return;
     const int lane = threadIdx.x & 63;
@@ -366,9 +379,10 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float *__restrict__ S
 }
 
 hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab,
-                        hipStream_t st) {
+                        hipStream_t st, const int *dyn_past) {
     const int rows = N * batch;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, S, ld, sz, N, P, n_past, exp_tab, rows);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, S, ld, sz, N, P, n_past, exp_tab, rows,
+                       dyn_past);
     return hipGetLastError();
 }
 

@@ -67,6 +67,11 @@ struct fl_model {
     fl_comm *comm = nullptr;
     bool finalized = false;
     size_t dev_bytes = 0;
+    // decode hipGraph
+    bool graph_enabled = true;
+    hipGraphExec_t graph_exec = nullptr;
+    int *npast_dev = nullptr;
+    int32_t *pinned = nullptr;   // [token, n_past] staging in pinned host memory
     // live per-kernel timing of the quantized matmuls (bench.py roofline leg)
     bool profile = false;
     std::vector<hipEvent_t> ev;   // pairs
@@ -289,6 +294,8 @@ int fl_model_finalize(fl_model *m) {
         M_HIP(hipMemcpy(m->rope_tab, rt.data(), rt.size() * 4, hipMemcpyHostToDevice));
     }
     if ((rc = dev_alloc(m, (void **)&m->tok_dev, (size_t)B * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&m->npast_dev, 16)) != FL_OK) return rc;
+    M_HIP(hipHostMalloc((void **)&m->pinned, 16, hipHostMallocDefault));
     if ((rc = dev_alloc(m, (void **)&m->x, (size_t)B * E * 4)) != FL_OK) return rc;
     if ((rc = dev_alloc(m, (void **)&m->x2, (size_t)B * E * 4)) != FL_OK) return rc;
     if ((rc = dev_alloc(m, (void **)&m->xn, (size_t)B * E * 4)) != FL_OK) return rc;
@@ -340,19 +347,14 @@ static int allreduce_if_tp(fl_model *m, float *buf, size_t count) {
     return fl_comm_allreduce_sum_f32(m->comm, buf, count, m->stream);
 }
 
-int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *logits_host, int all_logits,
-                  float *embeddings_host) {
-    if (!m || !tokens) return set_error(FL_EINVAL, "fl_model_eval: null argument");
-    if (!m->finalized) return set_error(FL_EINVAL, "fl_model_eval: model not finalized");
-    if (N <= 0 || N > m->B) return set_error(FL_EINVAL, "N=%d exceeds max_batch=%d", N, m->B);
-    if (n_past < 0 || n_past + N > m->n_ctx) return set_error(FL_EINVAL, "n_past+N=%d exceeds n_ctx=%d", n_past + N, m->n_ctx);
+// The fixed kernel sequence of one eval (what ggml_graph_compute walks node by node in the reference).  `dyn` != null:
+// positions are read from device memory (m->npast_dev) instead of the n_past argument -- the decode hipGraph.
+static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn) {
     const int E = m->E, El = m->El, Fl = m->Fl, D = m->D, Hl = m->Hl, V = m->V, n_ctx = m->n_ctx;
     const int layout = N <= 8 ? 1 : 16;
     const int P = n_past + N;
     hipStream_t st = m->stream;
     const bool tp = m->G > 1;
-
-    M_HIP(hipMemcpyAsync(m->tok_dev, tokens, (size_t)N * 4, hipMemcpyHostToDevice, st));
     M_HIP(get_rows_qw16(*m->tok_emb, m->tok_dev, N, m->x, E, st));                       // inpL = get_rows  llama.cpp:304
     float *inp = m->x, *mid = m->x2;
     for (int l = 0; l < m->L; ++l) {
@@ -361,14 +363,14 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
         // norm + attention_norm*cur -> Q8_0                                                        llama.cpp:311-319
         M_HIP(rmsnorm_quant(inp, E, ly.attn_norm, N, E, nullptr, 0, &m->qE, layout, st));
         M_HIP(mm(m, ly.wqkv, m->qE, N, m->qkv, 3 * El, nullptr, 0));                               // wq, wk, wv  :328-334
-        M_HIP(rope_kv(m->qkv, 3 * El, N, El, D, n_past, n_ctx, m->rope_tab, kc, vc, st));          // rope, store :328-347
+        M_HIP(rope_kv(m->qkv, 3 * El, N, El, D, n_past, n_ctx, m->rope_tab, kc, vc, st, dyn));     // rope, store :328-347
         // KQ, scale, mask, soft_max                                                                :364-379
         M_HIP(gemm_f32_abt(m->qkv, 3 * El, D, kc, El, D, m->att, n_ctx, (int64_t)N * n_ctx, N, P, D, Hl,
-                           1.0f / sqrtf((float)E / (float)m->H), 1, n_past, st));
-        M_HIP(softmax_rows(m->att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, Hl, m->exp_tab, st));
+                           1.0f / sqrtf((float)E / (float)m->H), 1, n_past, st, dyn, n_ctx));
+        M_HIP(softmax_rows(m->att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, Hl, m->exp_tab, st, dyn));
         // KQV, merged back to [N, n_embd]                                                          :389-398
         M_HIP(gemm_f32_abt(m->att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, m->ao, El, D, N, D, P, Hl,
-                           1.0f, 2, n_past, st));
+                           1.0f, 2, n_past, st, dyn, n_ctx));
         // wo projection + residual                                                                 :401-407
         M_HIP((layout == 16 ? quantize_q8_qa16 : quantize_q8_qa1)(m->ao, El, N, El, m->qEl, st));
         if (!tp) {
@@ -395,6 +397,42 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
     // final norm (kept in f32 for the embeddings) + lm head                                        :452-465
     M_HIP(rmsnorm_quant(inp, E, m->norm_w, N, E, m->xn, E, &m->qE, layout, st));
     M_HIP(mm(m, m->output, m->qE, N, m->logits, V, nullptr, 0));
+    return FL_OK;
+}
+
+int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *logits_host, int all_logits,
+                  float *embeddings_host) {
+    if (!m || !tokens) return set_error(FL_EINVAL, "fl_model_eval: null argument");
+    if (!m->finalized) return set_error(FL_EINVAL, "fl_model_eval: model not finalized");
+    if (N <= 0 || N > m->B) return set_error(FL_EINVAL, "N=%d exceeds max_batch=%d", N, m->B);
+    if (n_past < 0 || n_past + N > m->n_ctx) return set_error(FL_EINVAL, "n_past+N=%d exceeds n_ctx=%d", n_past + N, m->n_ctx);
+    const int E = m->E, V = m->V;
+    hipStream_t st = m->stream;
+
+    // Decode (N = 1) is launch-bound (~450 short kernels per token): the whole sequence is captured ONCE into a
+    // hipGraph whose kernels read the position from device memory, and replayed per token.
+    const bool use_graph = N == 1 && m->G == 1 && m->graph_enabled && !m->profile;
+    if (use_graph) {
+        m->pinned[0] = tokens[0];
+        m->pinned[1] = n_past;
+        M_HIP(hipMemcpyAsync(m->tok_dev, &m->pinned[0], 4, hipMemcpyHostToDevice, st));
+        M_HIP(hipMemcpyAsync(m->npast_dev, &m->pinned[1], 4, hipMemcpyHostToDevice, st));
+        if (!m->graph_exec) {
+            hipGraph_t g = nullptr;
+            M_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const int rc = run_eval_kernels(m, 1, 0, m->npast_dev);
+            const hipError_t e = hipStreamEndCapture(st, &g);
+            if (rc != FL_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
+            M_HIP(hipGraphInstantiate(&m->graph_exec, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+        }
+        M_HIP(hipGraphLaunch(m->graph_exec, st));
+    } else {
+        M_HIP(hipMemcpyAsync(m->tok_dev, tokens, (size_t)N * 4, hipMemcpyHostToDevice, st));
+        const int rc = run_eval_kernels(m, N, n_past, nullptr);
+        if (rc != FL_OK) return rc;
+    }
     if (logits_host) {
         if (all_logits) M_HIP(hipMemcpyAsync(logits_host, m->logits, (size_t)N * V * 4, hipMemcpyDeviceToHost, st));
         else M_HIP(hipMemcpyAsync(logits_host, m->logits + (size_t)(N - 1) * V, (size_t)V * 4, hipMemcpyDeviceToHost, st));
@@ -410,6 +448,13 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
         }
         m->ev_used = 0;
     }
+    return FL_OK;
+}
+
+/* 1 (default): decode evals replay a captured hipGraph; 0: plain launches (debugging / A-B timing) */
+int fl_model_set_graph(fl_model *m, int enable) {
+    if (!m) return set_error(FL_EINVAL, "null model");
+    m->graph_enabled = enable != 0;
     return FL_OK;
 }
 
@@ -460,6 +505,9 @@ void fl_model_free(fl_model *m) {
     fr(m->x); fr(m->x2); fr(m->xn); fr(m->part); fr(m->qkv); fr(m->att); fr(m->ao); fr(m->h13); fr(m->logits);
     for (fl_qact *a : {&m->qE, &m->qEl, &m->qF}) { fr(a->q); fr(a->d); fr(a->s); }
     for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
+    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    if (m->pinned) (void)hipHostFree(m->pinned);
+    fr(m->npast_dev);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }

@@ -437,8 +437,8 @@ hipError_t vec_dot_aos(int type, int n, float *s, const void *x, const void *y, 
 // lanes {r, r+16, r+32, r+48} and the four waves are summed.
 // Per lane and block: 12 VALU unpack + NC*(8 v_dot4 + cvt + mul + fma).
 // ------------------------------------------------------------------------------------------------
-template <int TYPE, int NC>
-__global__ __launch_bounds__(256) void gemv_q4_kernel(const uint4 *__restrict__ qs, const float *__restrict__ dW,
+template <int TYPE, int NC, int NWAVES>
+__global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__restrict__ qs, const float *__restrict__ dW,
                                                       const float *__restrict__ mW,
                                                       const int8_t *__restrict__ xq, const float *__restrict__ xd,
                                                       const float *__restrict__ xs, int N, int M, int KB,
@@ -455,14 +455,15 @@ __global__ __launch_bounds__(256) void gemv_q4_kernel(const uint4 *__restrict__ 
     const int nquads = (KB + 3) >> 2;
     const int64_t gbase = (int64_t)grp * KB;
     constexpr int U = NC <= 2 ? 4 : 2;  // block-quads in flight per wave
-    for (int q0 = wave * U; q0 < nquads; q0 += 4 * U) {
+    // block-quad q is owned by wave q % NWAVES: every wave streams, whatever K is
+    for (int q0 = wave; q0 < nquads; q0 += NWAVES * U) {
         uint4 w[U];
         float dw[U], mw[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int b = (q0 + u) * 4 + bq;
-            ok[u] = (q0 + u) < nquads && b < KB;
+            const int b = (q0 + u * NWAVES) * 4 + bq;
+            ok[u] = (q0 + u * NWAVES) < nquads && b < KB;
             const int64_t idx = (gbase + (ok[u] ? b : 0)) * 16 + r;
             w[u] = qs[idx];
             dw[u] = dW[idx];
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(256) void gemv_q4_kernel(const uint4 *__restrict__ 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!ok[u]) continue;
-            const int b = (q0 + u) * 4 + bq;
+            const int b = (q0 + u * NWAVES) * 4 + bq;
             uint32_t lo[4], hi[4];
             unpack_nibbles<TYPE>(w[u].x, lo[0], hi[0]);
             unpack_nibbles<TYPE>(w[u].y, lo[1], hi[1]);
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(256) void gemv_q4_kernel(const uint4 *__restrict__ 
             }
         }
     }
-    __shared__ float part[4][NC][16];
+    __shared__ float part[NWAVES][NC][16];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         float v = acc[c];
@@ -507,7 +508,14 @@ __global__ __launch_bounds__(256) void gemv_q4_kernel(const uint4 *__restrict__ 
         const int c = threadIdx.x >> 4, rr = threadIdx.x & 15;
         const int row = grp * 16 + rr;
         if (c < N && row < M) {
-            float v = (part[0][c][rr] + part[1][c][rr]) + (part[2][c][rr] + part[3][c][rr]);
+            float t[NWAVES];
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) t[w] = part[w][c][rr];
+#pragma unroll
+            for (int st = 1; st < NWAVES; st <<= 1)       // fixed pairwise tree: deterministic
+#pragma unroll
+                for (int w = 0; w + st < NWAVES; w += 2 * st) t[w] += t[w + st];
+            float v = t[0];
             if (resid) v += resid[(int64_t)c * ldr + row];
             y[(int64_t)c * ldy + row] = v;
         }
@@ -517,15 +525,26 @@ __global__ __launch_bounds__(256) void gemv_q4_kernel(const uint4 *__restrict__ 
 template <int TYPE>
 static hipError_t launch_gemv(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                               const float *resid, int ldr) {
-    const dim3 grid(W.M16 / 16), block(256);
+    const dim3 grid(W.M16 / 16);
     const uint4 *qs = reinterpret_cast<const uint4 *>(W.qs);
-#define FL_GEMV(NC)                                                                                         \
-    hipLaunchKernelGGL((gemv_q4_kernel<TYPE, NC>), grid, block, 0, st, qs, W.d, W.m, xq.q, xq.d, xq.s, N, W.M, \
-                       W.KB, y, ldy, resid, ldr)
-    if (N == 1) FL_GEMV(1);
-    else if (N == 2) FL_GEMV(2);
-    else if (N <= 4) FL_GEMV(4);
-    else FL_GEMV(8);
+    // HBM-bound: what matters is bytes in flight per CU.  One workgroup streams one 16-row group; small M gets
+    // more waves per group (each takes every NWAVES-th block-quad) so that >= ~16 waves per CU are loading.
+    const int groups = W.M16 / 16;
+    const int nw = groups >= 1024 ? 4 : groups >= 512 ? 8 : 16;
+#define FL_GEMV(NC, NW)                                                                                              \
+    hipLaunchKernelGGL((gemv_q4_kernel<TYPE, NC, NW>), grid, dim3(64 * NW), 0, st, qs, W.d, W.m, xq.q, xq.d, xq.s, N, \
+                       W.M, W.KB, y, ldy, resid, ldr)
+#define FL_GEMV_NW(NC)                       \
+    do {                                     \
+        if (nw == 4) FL_GEMV(NC, 4);         \
+        else if (nw == 8) FL_GEMV(NC, 8);    \
+        else FL_GEMV(NC, 16);                \
+    } while (0)
+    if (N == 1) FL_GEMV_NW(1);
+    else if (N == 2) FL_GEMV_NW(2);
+    else if (N <= 4) FL_GEMV_NW(4);
+    else FL_GEMV_NW(8);
+#undef FL_GEMV_NW
 #undef FL_GEMV
     return hipGetLastError();
 }

@@ -167,6 +167,8 @@ int fl_model_eval(fl_model *m, const int32_t *tokens_host, int N, int n_past, fl
 /* enable: 1 = reset + start timing every quantized-matmul launch (HIP events on the eval stream), 0 = stop; the
  * accumulated totals so far are returned through the two pointers (either may be NULL). */
 int fl_model_profile(fl_model *m, int enable, double *mm_ms_total, long *mm_launches);
+/* decode (N = 1) evals replay a captured hipGraph by default; 0 switches to plain launches */
+int fl_model_set_graph(fl_model *m, int enable);
 const float *fl_model_logits_dev(const fl_model *m);
 void *fl_model_stream(const fl_model *m);
 size_t fl_model_device_bytes(const fl_model *m);

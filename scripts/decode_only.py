@@ -1,0 +1,22 @@
+"""Decode-only run for profiling: python scripts/decode_only.py [steps] [graph 0/1]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from fastllama_amd import hip
+from harness import synth
+from harness.flmodel import FlModel
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+graph = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+cfg = dict(synth.MODELS["7B"])
+m = FlModel(cfg, 2, synth.synth_model_tensors(cfg, 2), n_ctx=1024, max_batch=512)
+hip.load().fl_model_set_graph(m.h, graph)
+toks = np.random.default_rng(0).integers(3, 259, 512).astype(np.int32)
+m.eval_nocopy(toks, 0)
+t1 = toks[:1].copy()
+for i in range(3):
+    m.eval_nocopy(t1, 128 + i)
+t0 = time.perf_counter()
+for i in range(steps):
+    m.eval_nocopy(t1, 131 + i)
+dt = (time.perf_counter() - t0) / steps
+print(f"decode {dt*1e3:.3f} ms/token  {1/dt:.1f} tok/s (graph={graph})")
