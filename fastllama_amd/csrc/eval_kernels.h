@@ -22,6 +22,10 @@ hipError_t gemm_f32_abt(const float *A, int lda, int64_t sAz, const float *B, in
                         hipStream_t st, const int *dyn_past = nullptr, int nn_max = 0);
 hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab,
                         hipStream_t st, const int *dyn_past = nullptr);
+// decode (N = 1): rope + KV store + KQ + soft_max + KQV + Q8_0 of the result, one workgroup per head
+hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab, float *kc,
+                            float *vc, const uint16_t *exp_tab, float scale, const fl_qact *out, hipStream_t st,
+                            const int *dyn_past = nullptr);
 hipError_t add_rows(const float *a, int lda, const float *b, int ldb, float *o, int ldo, int N, int E, hipStream_t st);
 
 }  // namespace fl

@@ -386,6 +386,120 @@ hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// decode attention (N = 1), one workgroup per head: rope(q, k) -> KV store -> KQ*scale -> soft_max (fp16 table,
+// f64 sum) -> KQV -> quantize_row_q8_0 of the head's 128 outputs straight into the QA1 workspace of the wo matmul.
+// Replaces five launches (rope_kv, 2 x gemm_f32_abt, softmax_rows, quantize_q8) of the generic path; same op
+// semantics, f32 dots in plain k order.  The position is read from device memory when dyn_past != null.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decode_attention_kernel(const float *__restrict__ qkv, int E, int D, int n_past,
+                                                               int n_ctx, const float2 *__restrict__ rope_tab,
+                                                               float *__restrict__ kc, float *__restrict__ vc,
+                                                               const uint16_t *__restrict__ exp_tab, float scale,
+                                                               int8_t *__restrict__ oq, float *__restrict__ od,
+                                                               float *__restrict__ os, const int *__restrict__ dyn_past) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    if (dyn_past) n_past = *dyn_past;
+    const int h = blockIdx.x, tid = threadIdx.x, pos = n_past, P = n_past + 1;
+    float *qs = reinterpret_cast<float *>(dsm);          // [D] roped q
+    float *ks = qs + D;                                   // [D] roped k (position pos)
+    float *vs = ks + D;                                   // [D] v (position pos)
+    float *out = vs + D;                                  // [D]
+    float *sc = out + D;                                  // [n_ctx] scores / probabilities
+    double *red = reinterpret_cast<double *>(sc + n_ctx); // [8] reduction scratch
+    const float *q = qkv + h * D, *k = qkv + E + h * D, *v = qkv + 2 * E + h * D;
+    if (tid < D / 2) {
+        const float2 cs = rope_tab[(int64_t)pos * (D >> 1) + tid];
+        const float2 xq = *reinterpret_cast<const float2 *>(q + 2 * tid), xk = *reinterpret_cast<const float2 *>(k + 2 * tid);
+        qs[2 * tid] = __fmaf_rn(xq.x, cs.x, -__fmul_rn(xq.y, cs.y));
+        qs[2 * tid + 1] = __fmaf_rn(xq.x, cs.y, __fmul_rn(xq.y, cs.x));
+        const float k0 = __fmaf_rn(xk.x, cs.x, -__fmul_rn(xk.y, cs.y)), k1 = __fmaf_rn(xk.x, cs.y, __fmul_rn(xk.y, cs.x));
+        ks[2 * tid] = k0;
+        ks[2 * tid + 1] = k1;
+        *reinterpret_cast<float2 *>(kc + (int64_t)pos * E + h * D + 2 * tid) = make_float2(k0, k1);
+    } else if (tid < D / 2 + D) {
+        const int d = tid - D / 2;
+        const float vv = v[d];
+        vs[d] = vv;
+        vc[(int64_t)(h * D + d) * n_ctx + pos] = vv;
+    }
+    __syncthreads();
+    // scores
+    float mx = -INFINITY;
+    for (int p = tid; p < P; p += 256) {
+        const float *kr = p == pos ? ks : kc + (int64_t)p * E + h * D;
+        float a = 0.f;
+        for (int d = 0; d < D; d += 4) {
+            const float4 kv4 = *reinterpret_cast<const float4 *>(kr + d);
+            a = __fmaf_rn(qs[d], kv4.x, a);
+            a = __fmaf_rn(qs[d + 1], kv4.y, a);
+            a = __fmaf_rn(qs[d + 2], kv4.z, a);
+            a = __fmaf_rn(qs[d + 3], kv4.w, a);
+        }
+        a = __fmul_rn(a, scale);
+        sc[p] = a;
+        mx = fmaxf(mx, a);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float *redf = reinterpret_cast<float *>(red);
+    if ((tid & 63) == 0) redf[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    __syncthreads();
+    double sum = 0.0;
+    for (int p = tid; p < P; p += 256) {
+        const uint16_t hb = __half_as_ushort(__float2half_rn(sc[p] - mx));
+        const float val = __half2float(__ushort_as_half(exp_tab[hb]));
+        sum += (double)val;
+        sc[p] = val;
+    }
+    sum = block_sum_f64(sum, red);
+    const float inv = (float)(1.0 / sum);
+    for (int p = tid; p < P; p += 256) sc[p] = __fmul_rn(sc[p], inv);
+    __syncthreads();
+    // KQV: 2 threads per output d, each over half of the positions (contiguous in the transposed V cache)
+    {
+        const int d = tid >> 1, half = tid & 1;
+        float a = 0.f;
+        if (d < D) {
+            const float *vr = vc + (int64_t)(h * D + d) * n_ctx;
+            const int mid = ((P - 1) / 2 + 3) & ~3;            // split on a float4 boundary; position pos handled apart
+            const int p0 = half ? mid : 0, p1 = half ? P - 1 : min(mid, P - 1);
+            int p = p0;
+            for (; p + 4 <= p1; p += 4) {
+                const float4 v4 = *reinterpret_cast<const float4 *>(vr + p);
+                a = __fmaf_rn(sc[p], v4.x, a);
+                a = __fmaf_rn(sc[p + 1], v4.y, a);
+                a = __fmaf_rn(sc[p + 2], v4.z, a);
+                a = __fmaf_rn(sc[p + 3], v4.w, a);
+            }
+            for (; p < p1; ++p) a = __fmaf_rn(sc[p], vr[p], a);
+            if (half) a = __fmaf_rn(sc[pos], vs[d], a);         // the fresh V value never round-trips through HBM
+        }
+        a += __shfl_xor(a, 1);
+        if (d < D && half == 0) out[d] = a;
+    }
+    __syncthreads();
+    // Q8_0 of the head's outputs: D/8 groups, 4 adjacent lanes per block
+    if (tid < D / 8) {
+        float o8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o8[i] = out[tid * 8 + i];
+        quantize_store_group(o8, 0, (h * D >> 3) + tid, E >> 5, 1, oq, od, os);
+    }
+}
+
+hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab, float *kc,
+                            float *vc, const uint16_t *exp_tab, float scale, const fl_qact *out, hipStream_t st,
+                            const int *dyn_past) {
+    if (D % 8 != 0 || D / 2 + D > 256 || D * 2 > 256) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(4 * D + n_ctx) * 4 + 64;
+    hipLaunchKernelGGL(decode_attention_kernel, dim3(H), dim3(256), lds, st, qkv, E, D, n_past, n_ctx,
+                       reinterpret_cast<const float2 *>(rope_tab), kc, vc, exp_tab, scale, out->q, out->d, out->s, dyn_past);
+    return hipGetLastError();
+}
+
 // out[n][e] = a[n][e] + b[n][e]   (ggml_add)
 __global__ void add_rows_kernel(const float *__restrict__ a, int lda, const float *__restrict__ b, int ldb,
                                 float *__restrict__ o, int ldo, int N, int E) {

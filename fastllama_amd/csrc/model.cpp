@@ -69,6 +69,7 @@ struct fl_model {
     size_t dev_bytes = 0;
     // decode hipGraph
     bool graph_enabled = true;
+    bool fuse_decode = true;     // N == 1: norm-in-GEMV + one attention kernel per layer
     hipGraphExec_t graph_exec = nullptr;
     int *npast_dev = nullptr;
     int32_t *pinned = nullptr;   // [token, n_past] staging in pinned host memory
@@ -341,6 +342,23 @@ static hipError_t mm(fl_model *m, const fl_qtensor *W, const fl_qact &a, int N, 
     return r;
 }
 
+// decode: y = W . Q8_0(norm_w * rms_norm(x)) in one launch (timed like mm() when profiling)
+static hipError_t mm_norm(fl_model *m, const fl_qtensor *W, const float *x, const float *norm_w, float *ynorm, float *y) {
+    hipEvent_t e1 = nullptr;
+    if (m->profile) {
+        while (m->ev_used + 2 > m->ev.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return hipErrorOutOfMemory;
+            m->ev.push_back(e);
+        }
+        (void)hipEventRecord(m->ev[m->ev_used++], m->stream);
+        e1 = m->ev[m->ev_used++];
+    }
+    const hipError_t r = gemv_q4_norm(*W, x, norm_w, ynorm, y, m->stream);
+    if (m->profile) (void)hipEventRecord(e1, m->stream);
+    return r;
+}
+
 static int allreduce_if_tp(fl_model *m, float *buf, size_t count) {
     if (m->G == 1) return FL_OK;
     if (!m->comm) return set_error(FL_EINVAL, "tensor-parallel eval without a communicator");
@@ -355,24 +373,32 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn) {
     const int P = n_past + N;
     hipStream_t st = m->stream;
     const bool tp = m->G > 1;
+    const bool fused = N == 1 && D <= 128 && D % 8 == 0 && E <= 8192 && m->fuse_decode;   // single-token kernels
     M_HIP(get_rows_qw16(*m->tok_emb, m->tok_dev, N, m->x, E, st));                       // inpL = get_rows  llama.cpp:304
     float *inp = m->x, *mid = m->x2;
     for (int l = 0; l < m->L; ++l) {
         const Layer &ly = m->layers[l];
         float *kc = m->kc + (size_t)l * n_ctx * El, *vc = m->vc + (size_t)l * n_ctx * El;
-        // norm + attention_norm*cur -> Q8_0                                                        llama.cpp:311-319
-        M_HIP(rmsnorm_quant(inp, E, ly.attn_norm, N, E, nullptr, 0, &m->qE, layout, st));
-        M_HIP(mm(m, ly.wqkv, m->qE, N, m->qkv, 3 * El, nullptr, 0));                               // wq, wk, wv  :328-334
-        M_HIP(rope_kv(m->qkv, 3 * El, N, El, D, n_past, n_ctx, m->rope_tab, kc, vc, st, dyn));     // rope, store :328-347
-        // KQ, scale, mask, soft_max                                                                :364-379
-        M_HIP(gemm_f32_abt(m->qkv, 3 * El, D, kc, El, D, m->att, n_ctx, (int64_t)N * n_ctx, N, P, D, Hl,
-                           1.0f / sqrtf((float)E / (float)m->H), 1, n_past, st, dyn, n_ctx));
-        M_HIP(softmax_rows(m->att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, Hl, m->exp_tab, st, dyn));
-        // KQV, merged back to [N, n_embd]                                                          :389-398
-        M_HIP(gemm_f32_abt(m->att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, m->ao, El, D, N, D, P, Hl,
-                           1.0f, 2, n_past, st, dyn, n_ctx));
+        if (fused) {
+            // decode: norm folded into the matmul, attention in one launch per layer (rope .. KQV .. Q8_0)
+            M_HIP(mm_norm(m, ly.wqkv, inp, ly.attn_norm, nullptr, m->qkv));
+            M_HIP(decode_attention(m->qkv, El, D, Hl, n_past, n_ctx, m->rope_tab, kc, vc, m->exp_tab,
+                                   1.0f / sqrtf((float)E / (float)m->H), &m->qEl, st, dyn));
+        } else {
+            // norm + attention_norm*cur -> Q8_0                                                        llama.cpp:311-319
+            M_HIP(rmsnorm_quant(inp, E, ly.attn_norm, N, E, nullptr, 0, &m->qE, layout, st));
+            M_HIP(mm(m, ly.wqkv, m->qE, N, m->qkv, 3 * El, nullptr, 0));                               // wq, wk, wv  :328-334
+            M_HIP(rope_kv(m->qkv, 3 * El, N, El, D, n_past, n_ctx, m->rope_tab, kc, vc, st, dyn));     // rope, store :328-347
+            // KQ, scale, mask, soft_max                                                                :364-379
+            M_HIP(gemm_f32_abt(m->qkv, 3 * El, D, kc, El, D, m->att, n_ctx, (int64_t)N * n_ctx, N, P, D, Hl,
+                               1.0f / sqrtf((float)E / (float)m->H), 1, n_past, st, dyn, n_ctx));
+            M_HIP(softmax_rows(m->att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, Hl, m->exp_tab, st, dyn));
+            // KQV, merged back to [N, n_embd]                                                          :389-398
+            M_HIP(gemm_f32_abt(m->att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, m->ao, El, D, N, D, P, Hl,
+                               1.0f, 2, n_past, st, dyn, n_ctx));
+            M_HIP((layout == 16 ? quantize_q8_qa16 : quantize_q8_qa1)(m->ao, El, N, El, m->qEl, st));
+        }
         // wo projection + residual                                                                 :401-407
-        M_HIP((layout == 16 ? quantize_q8_qa16 : quantize_q8_qa1)(m->ao, El, N, El, m->qEl, st));
         if (!tp) {
             M_HIP(mm(m, ly.wo, m->qEl, N, mid, E, inp, E));
         } else {
@@ -382,8 +408,12 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn) {
             M_HIP(add_rows(m->part, E, inp, E, mid, E, N, E, st));
         }
         // feed-forward                                                                             :412-436
-        M_HIP(rmsnorm_quant(mid, E, ly.ffn_norm, N, E, nullptr, 0, &m->qE, layout, st));
-        M_HIP(mm(m, ly.w13, m->qE, N, m->h13, 2 * Fl, nullptr, 0));
+        if (fused) {
+            M_HIP(mm_norm(m, ly.w13, mid, ly.ffn_norm, nullptr, m->h13));
+        } else {
+            M_HIP(rmsnorm_quant(mid, E, ly.ffn_norm, N, E, nullptr, 0, &m->qE, layout, st));
+            M_HIP(mm(m, ly.w13, m->qE, N, m->h13, 2 * Fl, nullptr, 0));
+        }
         M_HIP(silu_mul_quant(m->h13, 2 * Fl, N, Fl, m->silu_tab, &m->qF, layout, st));
         if (!tp) {
             M_HIP(mm(m, ly.w2, m->qF, N, inp, E, mid, E));                                        // + inpFF :441
@@ -395,8 +425,12 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn) {
         }
     }
     // final norm (kept in f32 for the embeddings) + lm head                                        :452-465
-    M_HIP(rmsnorm_quant(inp, E, m->norm_w, N, E, m->xn, E, &m->qE, layout, st));
-    M_HIP(mm(m, m->output, m->qE, N, m->logits, V, nullptr, 0));
+    if (fused) {
+        M_HIP(mm_norm(m, m->output, inp, m->norm_w, m->xn, m->logits));
+    } else {
+        M_HIP(rmsnorm_quant(inp, E, m->norm_w, N, E, m->xn, E, &m->qE, layout, st));
+        M_HIP(mm(m, m->output, m->qE, N, m->logits, V, nullptr, 0));
+    }
     return FL_OK;
 }
 
@@ -451,10 +485,17 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
     return FL_OK;
 }
 
-/* 1 (default): decode evals replay a captured hipGraph; 0: plain launches (debugging / A-B timing) */
-int fl_model_set_graph(fl_model *m, int enable) {
+/* bit 0 (default 1): decode evals replay a captured hipGraph, else plain launches; bit 1 (default 0): decode uses the
+ * generic per-op kernels instead of the fused single-token ones (debugging / A-B timing) */
+int fl_model_set_graph(fl_model *m, int mode) {
     if (!m) return set_error(FL_EINVAL, "null model");
-    m->graph_enabled = enable != 0;
+    m->graph_enabled = (mode & 1) != 0;
+    const bool fuse = (mode & 2) == 0;
+    if (fuse != m->fuse_decode && m->graph_exec) {
+        (void)hipGraphExecDestroy(m->graph_exec);
+        m->graph_exec = nullptr;
+    }
+    m->fuse_decode = fuse;
     return FL_OK;
 }
 
@@ -546,6 +587,15 @@ int fl_debug_rope_table(float *out_host, int n_ctx, int D) {     /* [n_ctx][D/2]
 int fl_debug_rmsnorm_quant(const float *x, int ldx, const float *w, int N, int E, float *y_f32, int ldy, fl_qact *out,
                            int layout, void *stream) {
     M_HIP(rmsnorm_quant(x, ldx, w, N, E, y_f32, ldy, out, layout, (hipStream_t)stream));
+    return FL_OK;
+}
+int fl_debug_gemv_norm(const fl_qtensor *W, const float *x, const float *norm_w, float *ynorm, float *y, void *stream) {
+    M_HIP(gemv_q4_norm(*W, x, norm_w, ynorm, y, (hipStream_t)stream));
+    return FL_OK;
+}
+int fl_debug_decode_attention(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab_dev,
+                              float *kc, float *vc, const uint16_t *exp_tab_dev, float scale, fl_qact *out, void *stream) {
+    M_HIP(decode_attention(qkv, E, D, H, n_past, n_ctx, rope_tab_dev, kc, vc, exp_tab_dev, scale, out, (hipStream_t)stream));
     return FL_OK;
 }
 int fl_debug_silu_mul_quant(const float *h13, int ld, int N, int F, const uint16_t *silu_tab_dev, fl_qact *out, int layout,

@@ -437,13 +437,20 @@ hipError_t vec_dot_aos(int type, int n, float *s, const void *x, const void *y, 
 // lanes {r, r+16, r+32, r+48} and the four waves are summed.
 // Per lane and block: 12 VALU unpack + NC*(8 v_dot4 + cvt + mul + fma).
 // ------------------------------------------------------------------------------------------------
-template <int TYPE, int NC, int NWAVES>
+// PRO = 1 (decode, NC = 1): the activation arrives as f32 and the kernel first does rms_norm * weight -> Q8_0 into LDS
+// (the arithmetic of rmsnorm_quant_kernel, same thread/group assignment so the f64 sum order is identical), AFTER its
+// first weight loads are in flight.  Saves one launch + one HBM round trip per matmul; every workgroup redoes the
+// 16 KB norm, which is L2 traffic only.
+template <int TYPE, int NC, int NWAVES, int PRO>
 __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__restrict__ qs, const float *__restrict__ dW,
                                                       const float *__restrict__ mW,
                                                       const int8_t *__restrict__ xq, const float *__restrict__ xd,
                                                       const float *__restrict__ xs, int N, int M, int KB,
                                                       float *__restrict__ y, int ldy,
-                                                      const float *__restrict__ resid, int ldr) {
+                                                      const float *__restrict__ resid, int ldr,
+                                                      const float *__restrict__ xf, const float *__restrict__ nw,
+                                                      float *__restrict__ ynorm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     const int grp = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, bq = lane >> 4;
@@ -455,11 +462,10 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
     const int nquads = (KB + 3) >> 2;
     const int64_t gbase = (int64_t)grp * KB;
     constexpr int U = NC <= 2 ? 4 : 2;  // block-quads in flight per wave
-    // block-quad q is owned by wave q % NWAVES: every wave streams, whatever K is
-    for (int q0 = wave; q0 < nquads; q0 += NWAVES * U) {
-        uint4 w[U];
-        float dw[U], mw[U];
-        bool ok[U];
+    uint4 w[U];
+    float dw[U], mw[U];
+    bool ok[U];
+    auto load = [&](int q0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int b = (q0 + u * NWAVES) * 4 + bq;
@@ -469,6 +475,93 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
             dw[u] = dW[idx];
             mw[u] = TYPE == FL_TYPE_Q4_1 ? mW[idx] : 0.f;
         }
+    };
+    // block-quad q is owned by wave q % NWAVES: every wave streams, whatever K is
+    int q0 = wave;
+    if (q0 < nquads) load(q0);
+
+    int8_t *lq = reinterpret_cast<int8_t *>(gsm);             // [KB][32]
+    float *ld_ = reinterpret_cast<float *>(gsm + (size_t)KB * 32);  // [KB] d
+    float *ls_ = ld_ + KB;                                    // [KB] s
+    if constexpr (PRO) {
+        __shared__ double sh[4];
+        const int E = KB * 32, gpr = E >> 3;
+        constexpr int MAXIT = 4;
+        float v[MAXIT][8];
+        double sum = 0.0;
+        if (threadIdx.x < 256) {
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int kg = threadIdx.x + it * 256;
+                if (kg < gpr) {
+                    const float4 a = *reinterpret_cast<const float4 *>(xf + kg * 8);
+                    const float4 c = *reinterpret_cast<const float4 *>(xf + kg * 8 + 4);
+                    v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
+                    v[it][4] = c.x; v[it][5] = c.y; v[it][6] = c.z; v[it][7] = c.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[it][i] = 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sum += (double)__fmul_rn(v[it][i], v[it][i]);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            if (lane == 0) sh[wave] = sum;
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            double t = 0.0;
+            for (int i = 0; i < 4; ++i) t += sh[i];
+            const float mean = (float)(t / (double)E);
+            const float scale = __fdiv_rn(1.0f, sqrtf(mean + 1e-6f));
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int kg = threadIdx.x + it * 256;
+                if (kg >= gpr) continue;   // whole quads leave together
+                float o[8];
+                const float4 wa = *reinterpret_cast<const float4 *>(nw + kg * 8);
+                const float4 wc = *reinterpret_cast<const float4 *>(nw + kg * 8 + 4);
+                const float ww[8] = {wa.x, wa.y, wa.z, wa.w, wc.x, wc.y, wc.z, wc.w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = __fmul_rn(ww[i], __fmul_rn(v[it][i], scale));
+                if (ynorm && grp == 0) {
+                    float4 *yp = reinterpret_cast<float4 *>(ynorm + kg * 8);
+                    yp[0] = make_float4(o[0], o[1], o[2], o[3]);
+                    yp[1] = make_float4(o[4], o[5], o[6], o[7]);
+                }
+                // quantize_row_q8_0 of the group (4 adjacent lanes = one block), into LDS in QA1 order
+                float amax = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(o[i]));
+                amax = fmaxf(amax, __shfl_xor(amax, 1));
+                amax = fmaxf(amax, __shfl_xor(amax, 2));
+                const float dd = __fdiv_rn(amax, 127.0f);
+                const float id = amax != 0.0f ? __fdiv_rn(127.0f, amax) : 0.0f;
+                int qi[8], isum = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    qi[i] = (int)rintf(__fmul_rn(o[i], id));
+                    isum += qi[i];
+                }
+                isum += __shfl_xor(isum, 1);
+                isum += __shfl_xor(isum, 2);
+                auto pk = [](int a, int b, int c, int e) -> uint32_t {
+                    return (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(c & 0xFF) << 16) |
+                           ((uint32_t)(e & 0xFF) << 24);
+                };
+                *reinterpret_cast<uint2 *>(lq + kg * 8) =
+                    make_uint2(pk(qi[0], qi[2], qi[4], qi[6]), pk(qi[1], qi[3], qi[5], qi[7]));
+                if ((kg & 3) == 0) {
+                    ld_[kg >> 2] = dd;
+                    ls_[kg >> 2] = __fmul_rn(dd, (float)isum);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    while (q0 < nquads) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!ok[u]) continue;
@@ -481,19 +574,31 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int n = c < N ? c : 0;
-                const int8_t *xb = xq + ((int64_t)n * KB + b) * 32;
-                const uint4 xa = *reinterpret_cast<const uint4 *>(xb + xswap);
-                const uint4 xc = *reinterpret_cast<const uint4 *>(xb + (16 - xswap));
+                uint4 xa, xc;
+                float dx, sx;
+                if constexpr (PRO) {
+                    xa = *reinterpret_cast<const uint4 *>(lq + b * 32 + xswap);
+                    xc = *reinterpret_cast<const uint4 *>(lq + b * 32 + (16 - xswap));
+                    dx = ld_[b];
+                    sx = ls_[b];
+                } else {
+                    const int8_t *xb = xq + ((int64_t)n * KB + b) * 32;
+                    xa = *reinterpret_cast<const uint4 *>(xb + xswap);
+                    xc = *reinterpret_cast<const uint4 *>(xb + (16 - xswap));
+                    dx = xd[(int64_t)n * KB + b];
+                    sx = TYPE == FL_TYPE_Q4_1 ? xs[(int64_t)n * KB + b] : 0.f;
+                }
                 int isum = 0;
                 isum = dot8(lo[0], hi[0], xa.x, xa.y, isum);
                 isum = dot8(lo[1], hi[1], xa.z, xa.w, isum);
                 isum = dot8(lo[2], hi[2], xc.x, xc.y, isum);
                 isum = dot8(lo[3], hi[3], xc.z, xc.w, isum);
-                const float dx = xd[(int64_t)n * KB + b];
                 acc[c] = __fmaf_rn(__fmul_rn(dw[u], dx), (float)isum, acc[c]);
-                if (TYPE == FL_TYPE_Q4_1) acc[c] = __fmaf_rn(mw[u], xs[(int64_t)n * KB + b], acc[c]);
+                if (TYPE == FL_TYPE_Q4_1) acc[c] = __fmaf_rn(mw[u], sx, acc[c]);
             }
         }
+        q0 += NWAVES * U;
+        if (q0 < nquads) load(q0);
     }
     __shared__ float part[NWAVES][NC][16];
 #pragma unroll
@@ -522,6 +627,8 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
     }
 }
 
+static inline int gemv_waves(int groups) { return groups >= 1024 ? 4 : groups >= 512 ? 8 : 16; }
+
 template <int TYPE>
 static hipError_t launch_gemv(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                               const float *resid, int ldr) {
@@ -529,11 +636,10 @@ static hipError_t launch_gemv(const fl_qtensor &W, const fl_qact &xq, int N, flo
     const uint4 *qs = reinterpret_cast<const uint4 *>(W.qs);
     // HBM-bound: what matters is bytes in flight per CU.  One workgroup streams one 16-row group; small M gets
     // more waves per group (each takes every NWAVES-th block-quad) so that >= ~16 waves per CU are loading.
-    const int groups = W.M16 / 16;
-    const int nw = groups >= 1024 ? 4 : groups >= 512 ? 8 : 16;
-#define FL_GEMV(NC, NW)                                                                                              \
-    hipLaunchKernelGGL((gemv_q4_kernel<TYPE, NC, NW>), grid, dim3(64 * NW), 0, st, qs, W.d, W.m, xq.q, xq.d, xq.s, N, \
-                       W.M, W.KB, y, ldy, resid, ldr)
+    const int nw = gemv_waves(W.M16 / 16);
+#define FL_GEMV(NC, NW)                                                                                                  \
+    hipLaunchKernelGGL((gemv_q4_kernel<TYPE, NC, NW, 0>), grid, dim3(64 * NW), 0, st, qs, W.d, W.m, xq.q, xq.d, xq.s, N, \
+                       W.M, W.KB, y, ldy, resid, ldr, nullptr, nullptr, nullptr)
 #define FL_GEMV_NW(NC)                       \
     do {                                     \
         if (nw == 4) FL_GEMV(NC, 4);         \
@@ -547,6 +653,30 @@ static hipError_t launch_gemv(const fl_qtensor &W, const fl_qact &xq, int N, flo
 #undef FL_GEMV_NW
 #undef FL_GEMV
     return hipGetLastError();
+}
+
+template <int TYPE>
+static hipError_t launch_gemv_norm(const fl_qtensor &W, const float *x, const float *norm_w, float *ynorm, float *y,
+                                   hipStream_t st) {
+    const dim3 grid(W.M16 / 16);
+    const uint4 *qs = reinterpret_cast<const uint4 *>(W.qs);
+    const int nw = gemv_waves(W.M16 / 16);
+    const size_t lds = (size_t)W.KB * 40;
+#define FL_GEMV(NW)                                                                                                    \
+    hipLaunchKernelGGL((gemv_q4_kernel<TYPE, 1, NW, 1>), grid, dim3(64 * NW), lds, st, qs, W.d, W.m, nullptr, nullptr, \
+                       nullptr, 1, W.M, W.KB, y, 0, nullptr, 0, x, norm_w, ynorm)
+    if (nw == 4) FL_GEMV(4);
+    else if (nw == 8) FL_GEMV(8);
+    else FL_GEMV(16);
+#undef FL_GEMV
+    return hipGetLastError();
+}
+
+// y[M] = W . Q8_0(norm_w * rms_norm(x))   -- decode: rms_norm + mul + quantize_row_q8_0 + mul_mat in one launch
+hipError_t gemv_q4_norm(const fl_qtensor &W, const float *x, const float *norm_w, float *ynorm, float *y, hipStream_t st) {
+    if (W.K % 32 != 0 || W.K > 8192) return hipErrorInvalidValue;
+    return W.type == FL_TYPE_Q4_0 ? launch_gemv_norm<FL_TYPE_Q4_0>(W, x, norm_w, ynorm, y, st)
+                                  : launch_gemv_norm<FL_TYPE_Q4_1>(W, x, norm_w, ynorm, y, st);
 }
 
 hipError_t gemv_q4(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,

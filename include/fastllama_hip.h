@@ -168,7 +168,7 @@ int fl_model_eval(fl_model *m, const int32_t *tokens_host, int N, int n_past, fl
  * accumulated totals so far are returned through the two pointers (either may be NULL). */
 int fl_model_profile(fl_model *m, int enable, double *mm_ms_total, long *mm_launches);
 /* decode (N = 1) evals replay a captured hipGraph by default; 0 switches to plain launches */
-int fl_model_set_graph(fl_model *m, int enable);
+int fl_model_set_graph(fl_model *m, int mode); /* bit0: hipGraph replay for decode (default on); bit1: generic per-op decode kernels */
 const float *fl_model_logits_dev(const fl_model *m);
 void *fl_model_stream(const fl_model *m);
 size_t fl_model_device_bytes(const fl_model *m);
@@ -181,6 +181,10 @@ int fl_debug_tables(uint16_t *exp_host, uint16_t *silu_host);
 int fl_debug_rope_table(float *out_host, int n_ctx, int D);
 int fl_debug_rmsnorm_quant(const float *x_dev, int ldx, const float *w_dev, int N, int E, float *y_f32_dev, int ldy,
                            fl_qact *out, int layout, void *stream);
+int fl_debug_gemv_norm(const fl_qtensor *W, const float *x_dev, const float *norm_w_dev, float *ynorm_dev, float *y_dev,
+                       void *stream);  /* y = W . Q8_0(norm_w * rms_norm(x)), one launch (decode) */
+int fl_debug_decode_attention(const float *qkv_dev, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab_dev,
+                              float *kc, float *vc, const uint16_t *exp_tab_dev, float scale, fl_qact *out, void *stream);
 int fl_debug_silu_mul_quant(const float *h13_dev, int ld, int N, int F, const uint16_t *silu_tab_dev, fl_qact *out,
                             int layout, void *stream);
 int fl_debug_rope_kv(float *qkv_dev, int ld, int N, int E, int D, int n_past, int n_ctx, const float *rope_tab_dev,

@@ -143,3 +143,82 @@ def test_attention_scores_softmax_kqv(env, N, P0, D, H):
     for h in range(H):
         want = (p_gpu[h] @ vc[h * D:(h + 1) * D, :P].T).astype(np.float32)
         assert np.max(np.abs(got[:, h * D:(h + 1) * D] - want)) <= 1e-5 * np.max(np.abs(want))
+
+
+@pytest.mark.parametrize("qtype", [2, 3])
+@pytest.mark.parametrize("M,K", [(48, 64), (300, 256), (12288, 4096), (32000, 4096), (4096, 4096), (1024, 8192)])
+def test_gemv_norm_fused_equals_unfused(env, qtype, M, K):
+    """decode: rms_norm*w -> Q8_0 -> mul_mat in ONE launch must equal the three-kernel sequence bit for bit, and the
+    Q8_0 it builds in LDS is the oracle's quantize_row_q8_0 of the oracle's norm (checked through the unfused path)."""
+    torch, hip, ops, L, port = env
+    rng = np.random.default_rng(M + K + qtype)
+    wq = port.quantize_q4(qtype, (rng.standard_normal((M, K)) * 0.05).astype(np.float32))
+    W = ops.QTensor(qtype, wq, M, K)
+    x = (rng.standard_normal((1, K)) * 1.7).astype(np.float32)
+    nw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    xd, nd = dev(torch, x), dev(torch, nw)
+    a = ops.QAct(1, K)
+    yn0 = torch.empty((1, K), device="cuda")
+    hip.check(L.fl_quantize_q8_layout(a.handle, xd.data_ptr(), K, 1, K, 1, None))
+    a.N, a.K = 1, K
+    hip.check(L.fl_debug_rmsnorm_quant(xd.data_ptr(), K, nd.data_ptr(), 1, K, yn0.data_ptr(), K, a.handle, 1, None))
+    y0 = torch.empty(M, device="cuda")
+    hip.check(L.fl_debug_mul_mat_q(W.handle, a.handle, y0.data_ptr(), M, 2, None))
+    y1 = torch.full((M,), 3.0, device="cuda")
+    yn1 = torch.zeros((1, K), device="cuda")
+    hip.check(L.fl_debug_gemv_norm(W.handle, xd.data_ptr(), nd.data_ptr(), yn1.data_ptr(), y1.data_ptr(), None))
+    assert np.array_equal(y1.cpu().numpy().view(np.uint32), y0.cpu().numpy().view(np.uint32))
+    assert np.array_equal(yn1.cpu().numpy().view(np.uint32), yn0.cpu().numpy().view(np.uint32))
+    want = port.mul_mat_q(qtype, wq, le.rms_norm_mul(x, nw))[0]
+    assert np.max(np.abs(y1.cpu().numpy() - want)) <= 2e-5 * np.max(np.abs(want))
+
+
+@pytest.mark.parametrize("D,H,n_past", [(32, 4, 0), (32, 4, 9), (128, 32, 0), (128, 32, 1), (128, 32, 130), (128, 8, 511),
+                                        (64, 5, 37)])
+def test_decode_attention_fused(env, D, H, n_past):
+    """single-token attention in one launch: rope + KV store bit-exact, probabilities/outputs against numpy
+    (oracle/llama_eval.py ops), Q8_0 output equal to quantize_row_q8_0 of the kernel's own f32 result semantics."""
+    torch, hip, ops, L, port = env
+    n_ctx, E, P = 512, H * D, n_past + 1
+    rng = np.random.default_rng(D + H + n_past)
+    qkv = rng.standard_normal((1, 3 * E)).astype(np.float32)
+    kc = np.zeros((n_ctx, E), np.float32)
+    vc = np.zeros((E, n_ctx), np.float32)
+    kc[:n_past] = rng.standard_normal((n_past, E))
+    vc[:, :n_past] = rng.standard_normal((E, n_past))
+    e = np.empty(1 << 16, np.uint16)
+    L.fl_debug_tables(e.ctypes.data_as(C.c_void_p), None)
+    rt = np.empty((n_ctx, D // 2, 2), np.float32)
+    L.fl_debug_rope_table(rt.ctypes.data_as(C.c_void_p), n_ctx, D)
+    ed, rd, qd, kd, vd = dev(torch, e.view(np.int16)), dev(torch, rt), dev(torch, qkv), dev(torch, kc), dev(torch, vc)
+    a = ops.QAct(1, E)
+    hip.check(L.fl_quantize_q8_layout(a.handle, qd.data_ptr(), 3 * E, 1, E, 1, None))
+    a.N, a.K = 1, E
+    scale = np.float32(1.0) / np.sqrt(np.float32(D))
+    hip.check(L.fl_debug_decode_attention(qd.data_ptr(), E, D, H, n_past, n_ctx, rd.data_ptr(), kd.data_ptr(), vd.data_ptr(),
+                                          ed.data_ptr(), float(scale), a.handle, None))
+    q_r = le.rope(qkv[:, :E], n_past, H)
+    k_r = le.rope(qkv[:, E:2 * E], n_past, H)
+    kc2, vc2 = kd.cpu().numpy(), vd.cpu().numpy()
+    assert np.array_equal(kc2[n_past].view(np.uint32), k_r[0].view(np.uint32))
+    assert np.array_equal(vc2[:, n_past], qkv[0, 2 * E:])
+    assert np.array_equal(kc2[:n_past], kc[:n_past]) and np.array_equal(vc2[:, :n_past], vc[:, :n_past])
+    assert not kc2[P:].any() and not vc2[:, P:].any()
+    assert np.array_equal(qd.cpu().numpy(), qkv)                       # inputs untouched
+    want = np.empty((1, E), np.float32)
+    for h in range(H):
+        sl = slice(h * D, (h + 1) * D)
+        s = ((q_r[:, sl] @ kc2[:P, sl].T).astype(np.float32) * scale).astype(np.float32)
+        p = le.soft_max_rows(s)
+        want[:, sl] = (p @ vc2[sl, :P].T).astype(np.float32)
+    q8 = a.export().cpu().numpy()[0].reshape(-1, 40)                   # block_q8_0: d, s, 32 x int8
+    d = q8[:, :4].copy().view(np.float32)[:, 0]
+    qs = q8[:, 8:].view(np.int8).astype(np.float32)
+    got = (qs * d[:, None]).reshape(-1)
+    wq8 = port.quantize_row_q8_0(want[0]).reshape(-1, 40)
+    wd = wq8[:, :4].copy().view(np.float32)[:, 0]
+    assert np.max(np.abs(d - wd)) <= 1e-5 * np.max(np.abs(wd))
+    assert np.max(np.abs(got - want[0])) <= np.max(wd) * 1.01          # within one quantization step everywhere
+    assert np.mean(q8[:, 8:].view(np.int8) == wq8[:, 8:].view(np.int8)) > 0.98   # only round-off flips of f32 dots
+    s_field = q8[:, 4:8].copy().view(np.float32)[:, 0]
+    assert np.array_equal(s_field, (d * qs.reshape(-1, 32).sum(1).astype(np.float32)).astype(np.float32))
