@@ -392,21 +392,55 @@ hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, 
 // Replaces five launches (rope_kv, 2 x gemm_f32_abt, softmax_rows, quantize_q8) of the generic path; same op
 // semantics, f32 dots in plain k order.  The position is read from device memory when dyn_past != null.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void decode_attention_kernel(const float *__restrict__ qkv, int E, int D, int n_past,
-                                                               int n_ctx, const float2 *__restrict__ rope_tab,
-                                                               float *__restrict__ kc, float *__restrict__ vc,
-                                                               const uint16_t *__restrict__ exp_tab, float scale,
-                                                               int8_t *__restrict__ oq, float *__restrict__ od,
-                                                               float *__restrict__ os, const int *__restrict__ dyn_past) {
+//
+// 512 threads.  K.q: 8 lanes share one cached position (each 16 B x D/32 pieces of the row, coalesced 128 B), 64
+// positions per pass; KQV: 8 lanes share one row of the transposed V cache (32 positions per 128 B piece), 64 rows
+// per pass.  The first 256 positions of both caches are requested before anything else is computed, so the two HBM
+// round trips overlap the rope / soft_max latency chains.
+constexpr int DA_T = 512, DA_KPRE = 4, DA_VPRE = 8;
+
+__global__ __launch_bounds__(DA_T) void decode_attention_kernel(const float *__restrict__ qkv, int E, int D, int n_past,
+                                                                int n_ctx, const float2 *__restrict__ rope_tab,
+                                                                float *__restrict__ kc, float *__restrict__ vc,
+                                                                const uint16_t *__restrict__ exp_tab, float scale,
+                                                                int8_t *__restrict__ oq, float *__restrict__ od,
+                                                                float *__restrict__ os, const int *__restrict__ dyn_past) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     if (dyn_past) n_past = *dyn_past;
     const int h = blockIdx.x, tid = threadIdx.x, pos = n_past, P = n_past + 1;
-    float *qs = reinterpret_cast<float *>(dsm);          // [D] roped q
-    float *ks = qs + D;                                   // [D] roped k (position pos)
-    float *vs = ks + D;                                   // [D] v (position pos)
-    float *out = vs + D;                                  // [D]
-    float *sc = out + D;                                  // [n_ctx] scores / probabilities
-    double *red = reinterpret_cast<double *>(sc + n_ctx); // [8] reduction scratch
+    float *qs = reinterpret_cast<float *>(dsm);           // [D] roped q
+    float *ks = qs + D;                                    // [D] roped k (position pos)
+    float *vs = ks + D;                                    // [D] v (position pos)
+    float *out = vs + D;                                   // [D]
+    float *sc = out + D;                                   // [n_ctx + 4] scores / probabilities
+    double *red = reinterpret_cast<double *>(sc + n_ctx + 4);  // [8] reduction scratch
+    float *redf = reinterpret_cast<float *>(red + 8);      // [8]
+    const int l8 = tid & 7, r64 = tid >> 3;
+    const int J = D >> 5;                                  // float4 pieces per lane and K row (<= 4)
+    const float *kbase = kc + h * D + l8 * 4;
+    const int nvr = (D + 63) >> 6;                         // row passes of the V phase (<= 2)
+    const int nchunk = (P + 31) >> 5;                      // 32-position pieces
+
+    // ---- requests first: K rows [0, 256) and V pieces [0, 256) of this head ----
+    float4 kreg[DA_KPRE][4];
+#pragma unroll
+    for (int u = 0; u < DA_KPRE; ++u) {
+        const int p = u * 64 + r64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < J && p < pos) kreg[u][j] = *reinterpret_cast<const float4 *>(kbase + (int64_t)p * E + j * 32);
+    }
+    float4 vreg[2][DA_VPRE];
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp) {
+        const int d = rp * 64 + r64;
+#pragma unroll
+        for (int c = 0; c < DA_VPRE; ++c)
+            if (rp < nvr && d < D && c < nchunk && c * 32 + l8 * 4 < P)
+                vreg[rp][c] = *reinterpret_cast<const float4 *>(vc + (int64_t)(h * D + d) * n_ctx + c * 32 + l8 * 4);
+    }
+
+    // ---- rope(q), rope(k) -> LDS + K cache; v -> LDS + V cache ----
     const float *q = qkv + h * D, *k = qkv + E + h * D, *v = qkv + 2 * E + h * D;
     if (tid < D / 2) {
         const float2 cs = rope_tab[(int64_t)pos * (D >> 1) + tid];
@@ -417,38 +451,62 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const float *__re
         ks[2 * tid] = k0;
         ks[2 * tid + 1] = k1;
         *reinterpret_cast<float2 *>(kc + (int64_t)pos * E + h * D + 2 * tid) = make_float2(k0, k1);
-    } else if (tid < D / 2 + D) {
-        const int d = tid - D / 2;
+    } else if (tid >= 64 && tid < 64 + D) {
+        const int d = tid - 64;
         const float vv = v[d];
         vs[d] = vv;
         vc[(int64_t)(h * D + d) * n_ctx + pos] = vv;
     }
+    if (tid < 4) sc[P + tid] = 0.f;                        // tail of the last float4 of probabilities
     __syncthreads();
-    // scores
+
+    // ---- scores ----
+    float4 q4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < J) q4[j] = *reinterpret_cast<const float4 *>(qs + l8 * 4 + j * 32);
     float mx = -INFINITY;
-    for (int p = tid; p < P; p += 256) {
-        const float *kr = p == pos ? ks : kc + (int64_t)p * E + h * D;
+    auto kq = [&](int p, const float4 *kr) {
         float a = 0.f;
-        for (int d = 0; d < D; d += 4) {
-            const float4 kv4 = *reinterpret_cast<const float4 *>(kr + d);
-            a = __fmaf_rn(qs[d], kv4.x, a);
-            a = __fmaf_rn(qs[d + 1], kv4.y, a);
-            a = __fmaf_rn(qs[d + 2], kv4.z, a);
-            a = __fmaf_rn(qs[d + 3], kv4.w, a);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j >= J) break;
+            const float4 k4 = p == pos ? *reinterpret_cast<const float4 *>(ks + l8 * 4 + j * 32) : kr[j];
+            a = __fmaf_rn(q4[j].x, k4.x, a);
+            a = __fmaf_rn(q4[j].y, k4.y, a);
+            a = __fmaf_rn(q4[j].z, k4.z, a);
+            a = __fmaf_rn(q4[j].w, k4.w, a);
         }
+        a += __shfl_xor(a, 1);
+        a += __shfl_xor(a, 2);
+        a += __shfl_xor(a, 4);
         a = __fmul_rn(a, scale);
-        sc[p] = a;
+        if (l8 == 0) sc[p] = a;
         mx = fmaxf(mx, a);
+    };
+#pragma unroll
+    for (int u = 0; u < DA_KPRE; ++u) {
+        const int p = u * 64 + r64;
+        if (p < P) kq(p, kreg[u]);
+    }
+    for (int p = DA_KPRE * 64 + r64; p < P; p += 64) {     // long contexts: the rest, pass by pass
+        float4 kr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < J && p < pos) kr[j] = *reinterpret_cast<const float4 *>(kbase + (int64_t)p * E + j * 32);
+        kq(p, kr);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    float *redf = reinterpret_cast<float *>(red);
     if ((tid & 63) == 0) redf[tid >> 6] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
-    __syncthreads();
+    mx = redf[0];
+#pragma unroll
+    for (int i = 1; i < DA_T / 64; ++i) mx = fmaxf(mx, redf[i]);
+
+    // ---- soft_max: fp16 exp table, f64 sum (ggml_compute_forward_soft_max_f32) ----
     double sum = 0.0;
-    for (int p = tid; p < P; p += 256) {
+    for (int p = tid; p < P; p += DA_T) {
         const uint16_t hb = __half_as_ushort(__float2half_rn(sc[p] - mx));
         const float val = __half2float(__ushort_as_half(exp_tab[hb]));
         sum += (double)val;
@@ -456,32 +514,46 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const float *__re
     }
     sum = block_sum_f64(sum, red);
     const float inv = (float)(1.0 / sum);
-    for (int p = tid; p < P; p += 256) sc[p] = __fmul_rn(sc[p], inv);
+    for (int p = tid; p < P; p += DA_T) sc[p] = __fmul_rn(sc[p], inv);
     __syncthreads();
-    // KQV: 2 threads per output d, each over half of the positions (contiguous in the transposed V cache)
-    {
-        const int d = tid >> 1, half = tid & 1;
+
+    // ---- KQV ----
+    auto pv = [&](float a, int d, int c, float4 v4) -> float {
+        const int p0 = c * 32 + l8 * 4;
+        if (p0 + 3 >= pos) {                               // piece holding the fresh position (and what lies beyond)
+            const float fresh = vs[d];
+            v4.x = p0 == pos ? fresh : p0 > pos ? 0.f : v4.x;
+            v4.y = p0 + 1 == pos ? fresh : p0 + 1 > pos ? 0.f : v4.y;
+            v4.z = p0 + 2 == pos ? fresh : p0 + 2 > pos ? 0.f : v4.z;
+            v4.w = p0 + 3 == pos ? fresh : p0 + 3 > pos ? 0.f : v4.w;
+        }
+        const float4 p4 = *reinterpret_cast<const float4 *>(sc + p0);
+        a = __fmaf_rn(p4.x, v4.x, a);
+        a = __fmaf_rn(p4.y, v4.y, a);
+        a = __fmaf_rn(p4.z, v4.z, a);
+        a = __fmaf_rn(p4.w, v4.w, a);
+        return a;
+    };
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp) {
+        if (rp >= nvr) break;
+        const int d = rp * 64 + r64;
         float a = 0.f;
         if (d < D) {
-            const float *vr = vc + (int64_t)(h * D + d) * n_ctx;
-            const int mid = ((P - 1) / 2 + 3) & ~3;            // split on a float4 boundary; position pos handled apart
-            const int p0 = half ? mid : 0, p1 = half ? P - 1 : min(mid, P - 1);
-            int p = p0;
-            for (; p + 4 <= p1; p += 4) {
-                const float4 v4 = *reinterpret_cast<const float4 *>(vr + p);
-                a = __fmaf_rn(sc[p], v4.x, a);
-                a = __fmaf_rn(sc[p + 1], v4.y, a);
-                a = __fmaf_rn(sc[p + 2], v4.z, a);
-                a = __fmaf_rn(sc[p + 3], v4.w, a);
-            }
-            for (; p < p1; ++p) a = __fmaf_rn(sc[p], vr[p], a);
-            if (half) a = __fmaf_rn(sc[pos], vs[d], a);         // the fresh V value never round-trips through HBM
+#pragma unroll
+            for (int c = 0; c < DA_VPRE; ++c)
+                if (c < nchunk && c * 32 + l8 * 4 < P) a = pv(a, d, c, vreg[rp][c]);
+            for (int c = DA_VPRE; c < nchunk; ++c)
+                if (c * 32 + l8 * 4 < P)
+                    a = pv(a, d, c, *reinterpret_cast<const float4 *>(vc + (int64_t)(h * D + d) * n_ctx + c * 32 + l8 * 4));
         }
         a += __shfl_xor(a, 1);
-        if (d < D && half == 0) out[d] = a;
+        a += __shfl_xor(a, 2);
+        a += __shfl_xor(a, 4);
+        if (d < D && l8 == 0) out[d] = a;
     }
     __syncthreads();
-    // Q8_0 of the head's outputs: D/8 groups, 4 adjacent lanes per block
+    // ---- Q8_0 of the head's outputs: D/8 groups, 4 adjacent lanes per block ----
     if (tid < D / 8) {
         float o8[8];
 #pragma unroll
@@ -493,9 +565,9 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const float *__re
 hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab, float *kc,
                             float *vc, const uint16_t *exp_tab, float scale, const fl_qact *out, hipStream_t st,
                             const int *dyn_past) {
-    if (D % 8 != 0 || D / 2 + D > 256 || D * 2 > 256) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(4 * D + n_ctx) * 4 + 64;
-    hipLaunchKernelGGL(decode_attention_kernel, dim3(H), dim3(256), lds, st, qkv, E, D, n_past, n_ctx,
+    if (D % 32 != 0 || D > 128 || n_ctx % 4 != 0 || E % 4 != 0) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(4 * D + n_ctx + 4) * 4 + 8 * 8 + 8 * 4;
+    hipLaunchKernelGGL(decode_attention_kernel, dim3(H), dim3(DA_T), lds, st, qkv, E, D, n_past, n_ctx,
                        reinterpret_cast<const float2 *>(rope_tab), kc, vc, exp_tab, scale, out->q, out->d, out->s, dyn_past);
     return hipGetLastError();
 }

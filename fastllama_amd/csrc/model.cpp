@@ -321,41 +321,50 @@ int fl_model_set_comm(fl_model *m, fl_comm *c) {
     return FL_OK;
 }
 
+// bench hook: bracket one quantized-matmul launch with HIP events on the eval stream
+static hipError_t prof_begin(fl_model *m, hipEvent_t *e1) {
+    *e1 = nullptr;
+    if (!m->profile) return hipSuccess;
+    while (m->ev_used + 2 > m->ev.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return hipErrorOutOfMemory;
+        m->ev.push_back(e);
+    }
+    (void)hipEventRecord(m->ev[m->ev_used++], m->stream);
+    *e1 = m->ev[m->ev_used++];
+    return hipSuccess;
+}
+static inline void prof_end(fl_model *m, hipEvent_t e1) {
+    if (e1) (void)hipEventRecord(e1, m->stream);
+}
+
 static hipError_t mm(fl_model *m, const fl_qtensor *W, const fl_qact &a, int N, float *y, int ldy, const float *resid,
                      int ldr) {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (m->profile) {
-        if (m->ev_used + 2 > m->ev.size()) {
-            for (int i = 0; i < 2; ++i) {
-                hipEvent_t e;
-                if (hipEventCreate(&e) != hipSuccess) return hipErrorOutOfMemory;
-                m->ev.push_back(e);
-            }
-        }
-        e0 = m->ev[m->ev_used++];
-        e1 = m->ev[m->ev_used++];
-        (void)hipEventRecord(e0, m->stream);
-    }
-    const hipError_t r = N <= 8 ? gemv_q4(*W, a, N, y, ldy, m->stream, resid, ldr)
-                                : gemm_q4_mfma(*W, a, N, y, ldy, m->stream, resid, ldr);
-    if (m->profile) (void)hipEventRecord(e1, m->stream);
+    hipEvent_t e1;
+    hipError_t r = prof_begin(m, &e1);
+    if (r != hipSuccess) return r;
+    r = N <= 8 ? gemv_q4(*W, a, N, y, ldy, m->stream, resid, ldr) : gemm_q4_mfma(*W, a, N, y, ldy, m->stream, resid, ldr);
+    prof_end(m, e1);
     return r;
 }
 
-// decode: y = W . Q8_0(norm_w * rms_norm(x)) in one launch (timed like mm() when profiling)
+// decode: y = W . Q8_0(norm_w * rms_norm(x)) in one launch
 static hipError_t mm_norm(fl_model *m, const fl_qtensor *W, const float *x, const float *norm_w, float *ynorm, float *y) {
-    hipEvent_t e1 = nullptr;
-    if (m->profile) {
-        while (m->ev_used + 2 > m->ev.size()) {
-            hipEvent_t e;
-            if (hipEventCreate(&e) != hipSuccess) return hipErrorOutOfMemory;
-            m->ev.push_back(e);
-        }
-        (void)hipEventRecord(m->ev[m->ev_used++], m->stream);
-        e1 = m->ev[m->ev_used++];
-    }
-    const hipError_t r = gemv_q4_norm(*W, x, norm_w, ynorm, y, m->stream);
-    if (m->profile) (void)hipEventRecord(e1, m->stream);
+    hipEvent_t e1;
+    hipError_t r = prof_begin(m, &e1);
+    if (r != hipSuccess) return r;
+    r = gemv_q4_norm(*W, x, norm_w, ynorm, y, m->stream);
+    prof_end(m, e1);
+    return r;
+}
+
+// decode: y = W . Q8_0(silu(h13[:F]) * h13[F:]) (+ resid) in one launch
+static hipError_t mm_silu(fl_model *m, const fl_qtensor *W, const float *h13, float *y, const float *resid) {
+    hipEvent_t e1;
+    hipError_t r = prof_begin(m, &e1);
+    if (r != hipSuccess) return r;
+    r = gemv_q4_silu(*W, h13, m->silu_tab, y, resid, m->stream);
+    prof_end(m, e1);
     return r;
 }
 
@@ -373,7 +382,7 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn) {
     const int P = n_past + N;
     hipStream_t st = m->stream;
     const bool tp = m->G > 1;
-    const bool fused = N == 1 && D <= 128 && D % 8 == 0 && E <= 8192 && m->fuse_decode;   // single-token kernels
+    const bool fused = N == 1 && D <= 128 && D % 32 == 0 && E <= 8192 && Fl <= 32768 && m->fuse_decode;   // single-token kernels
     M_HIP(get_rows_qw16(*m->tok_emb, m->tok_dev, N, m->x, E, st));                       // inpL = get_rows  llama.cpp:304
     float *inp = m->x, *mid = m->x2;
     for (int l = 0; l < m->L; ++l) {
@@ -414,11 +423,13 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn) {
             M_HIP(rmsnorm_quant(mid, E, ly.ffn_norm, N, E, nullptr, 0, &m->qE, layout, st));
             M_HIP(mm(m, ly.w13, m->qE, N, m->h13, 2 * Fl, nullptr, 0));
         }
-        M_HIP(silu_mul_quant(m->h13, 2 * Fl, N, Fl, m->silu_tab, &m->qF, layout, st));
+        if (!fused) M_HIP(silu_mul_quant(m->h13, 2 * Fl, N, Fl, m->silu_tab, &m->qF, layout, st));
         if (!tp) {
-            M_HIP(mm(m, ly.w2, m->qF, N, inp, E, mid, E));                                        // + inpFF :441
+            if (fused) M_HIP(mm_silu(m, ly.w2, m->h13, inp, mid));
+            else M_HIP(mm(m, ly.w2, m->qF, N, inp, E, mid, E));                                   // + inpFF :441
         } else {
-            M_HIP(mm(m, ly.w2, m->qF, N, m->part, E, nullptr, 0));
+            if (fused) M_HIP(mm_silu(m, ly.w2, m->h13, m->part, nullptr));
+            else M_HIP(mm(m, ly.w2, m->qF, N, m->part, E, nullptr, 0));
             int rc = allreduce_if_tp(m, m->part, (size_t)N * E);
             if (rc != FL_OK) return rc;
             M_HIP(add_rows(m->part, E, mid, E, inp, E, N, E, st));
@@ -591,6 +602,11 @@ int fl_debug_rmsnorm_quant(const float *x, int ldx, const float *w, int N, int E
 }
 int fl_debug_gemv_norm(const fl_qtensor *W, const float *x, const float *norm_w, float *ynorm, float *y, void *stream) {
     M_HIP(gemv_q4_norm(*W, x, norm_w, ynorm, y, (hipStream_t)stream));
+    return FL_OK;
+}
+int fl_debug_gemv_silu(const fl_qtensor *W, const float *h13, const uint16_t *silu_tab, float *y, const float *resid,
+                       void *stream) {
+    M_HIP(gemv_q4_silu(*W, h13, silu_tab, y, resid, (hipStream_t)stream));
     return FL_OK;
 }
 int fl_debug_decode_attention(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab_dev,

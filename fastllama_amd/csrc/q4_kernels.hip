@@ -12,6 +12,7 @@
 // bit-identical to the reference; the only freedom taken is the ORDER in which the per-block f32
 // terms d_w*d_x*isum are added (the reference itself adds them in 8 interleaved partial sums).
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 #include "q4_kernels.h"
 #include "q4_device.h"
@@ -437,18 +438,49 @@ hipError_t vec_dot_aos(int type, int n, float *s, const void *x, const void *y, 
 // lanes {r, r+16, r+32, r+48} and the four waves are summed.
 // Per lane and block: 12 VALU unpack + NC*(8 v_dot4 + cvt + mul + fma).
 // ------------------------------------------------------------------------------------------------
-// PRO = 1 (decode, NC = 1): the activation arrives as f32 and the kernel first does rms_norm * weight -> Q8_0 into LDS
-// (the arithmetic of rmsnorm_quant_kernel, same thread/group assignment so the f64 sum order is identical), AFTER its
-// first weight loads are in flight.  Saves one launch + one HBM round trip per matmul; every workgroup redoes the
-// 16 KB norm, which is L2 traffic only.
-template <int TYPE, int NC, int NWAVES, int PRO>
+// quantize_row_q8_0 of one 8-element group (4 adjacent lanes = one block) into an LDS copy of the QA1 layout
+__device__ __forceinline__ void quantize_group_lds(const float o[8], int kg, int8_t *lq, float *ld_, float *ls_) {
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(o[i]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    const float dd = __fdiv_rn(amax, 127.0f);
+    const float id = amax != 0.0f ? __fdiv_rn(127.0f, amax) : 0.0f;
+    int qi[8], isum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        qi[i] = (int)rintf(__fmul_rn(o[i], id));
+        isum += qi[i];
+    }
+    isum += __shfl_xor(isum, 1);
+    isum += __shfl_xor(isum, 2);
+    auto pk = [](int a, int b, int c, int e) -> uint32_t {
+        return (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(c & 0xFF) << 16) |
+               ((uint32_t)(e & 0xFF) << 24);
+    };
+    *reinterpret_cast<uint2 *>(lq + kg * 8) = make_uint2(pk(qi[0], qi[2], qi[4], qi[6]), pk(qi[1], qi[3], qi[5], qi[7]));
+    if ((kg & 3) == 0) {
+        ld_[kg >> 2] = dd;
+        ls_[kg >> 2] = __fmul_rn(dd, (float)isum);
+    }
+}
+
+// Decode prologues (NC = 1): the activation arrives as f32 and the kernel builds its Q8_0 form in LDS itself, AFTER
+// its weight loads are in flight -- one launch and one HBM round trip less per matmul; every workgroup redoes the
+// small prologue from L2.
+//   PRO = 1: rms_norm * weight -> Q8_0 (arithmetic and f64 sum order of rmsnorm_quant_kernel: first 256 threads)
+//   PRO = 2: silu(w1 x) * (w3 x) -> Q8_0 (silu_mul_quant_kernel; xf = [w1 x (K) | w3 x (K)], aux = fp16 silu table)
+// U = block-quads in flight per wave; the launcher picks U so that NWAVES * U covers the row when it can, i.e. all of
+// a workgroup's weight bytes are requested before anything waits.
+template <int TYPE, int NC, int NWAVES, int PRO, int U>
 __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__restrict__ qs, const float *__restrict__ dW,
                                                       const float *__restrict__ mW,
                                                       const int8_t *__restrict__ xq, const float *__restrict__ xd,
                                                       const float *__restrict__ xs, int N, int M, int KB,
                                                       float *__restrict__ y, int ldy,
                                                       const float *__restrict__ resid, int ldr,
-                                                      const float *__restrict__ xf, const float *__restrict__ nw,
+                                                      const float *__restrict__ xf, const void *__restrict__ aux,
                                                       float *__restrict__ ynorm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     const int grp = blockIdx.x;
@@ -461,7 +493,6 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
 
     const int nquads = (KB + 3) >> 2;
     const int64_t gbase = (int64_t)grp * KB;
-    constexpr int U = NC <= 2 ? 4 : 2;  // block-quads in flight per wave
     uint4 w[U];
     float dw[U], mw[U];
     bool ok[U];
@@ -480,11 +511,12 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
     int q0 = wave;
     if (q0 < nquads) load(q0);
 
-    int8_t *lq = reinterpret_cast<int8_t *>(gsm);             // [KB][32]
+    int8_t *lq = reinterpret_cast<int8_t *>(gsm);                   // [KB][32]
     float *ld_ = reinterpret_cast<float *>(gsm + (size_t)KB * 32);  // [KB] d
-    float *ls_ = ld_ + KB;                                    // [KB] s
-    if constexpr (PRO) {
+    float *ls_ = ld_ + KB;                                          // [KB] s
+    if constexpr (PRO == 1) {
         __shared__ double sh[4];
+        const float *nw = static_cast<const float *>(aux);
         const int E = KB * 32, gpr = E >> 3;
         constexpr int MAXIT = 4;
         float v[MAXIT][8];
@@ -530,33 +562,27 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
                     yp[0] = make_float4(o[0], o[1], o[2], o[3]);
                     yp[1] = make_float4(o[4], o[5], o[6], o[7]);
                 }
-                // quantize_row_q8_0 of the group (4 adjacent lanes = one block), into LDS in QA1 order
-                float amax = 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(o[i]));
-                amax = fmaxf(amax, __shfl_xor(amax, 1));
-                amax = fmaxf(amax, __shfl_xor(amax, 2));
-                const float dd = __fdiv_rn(amax, 127.0f);
-                const float id = amax != 0.0f ? __fdiv_rn(127.0f, amax) : 0.0f;
-                int qi[8], isum = 0;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    qi[i] = (int)rintf(__fmul_rn(o[i], id));
-                    isum += qi[i];
-                }
-                isum += __shfl_xor(isum, 1);
-                isum += __shfl_xor(isum, 2);
-                auto pk = [](int a, int b, int c, int e) -> uint32_t {
-                    return (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(c & 0xFF) << 16) |
-                           ((uint32_t)(e & 0xFF) << 24);
-                };
-                *reinterpret_cast<uint2 *>(lq + kg * 8) =
-                    make_uint2(pk(qi[0], qi[2], qi[4], qi[6]), pk(qi[1], qi[3], qi[5], qi[7]));
-                if ((kg & 3) == 0) {
-                    ld_[kg >> 2] = dd;
-                    ls_[kg >> 2] = __fmul_rn(dd, (float)isum);
-                }
+                quantize_group_lds(o, kg, lq, ld_, ls_);
             }
+        }
+        __syncthreads();
+    } else if constexpr (PRO == 2) {
+        const uint16_t *silu_tab = static_cast<const uint16_t *>(aux);
+        const int F = KB * 32, gpr = F >> 3;
+        for (int kg = threadIdx.x; kg < gpr; kg += 64 * NWAVES) {   // gpr % 4 == 0: quads stay together
+            const float *pa = xf + kg * 8;
+            const float4 a0 = *reinterpret_cast<const float4 *>(pa), a1 = *reinterpret_cast<const float4 *>(pa + 4);
+            const float4 b0 = *reinterpret_cast<const float4 *>(pa + F), b1 = *reinterpret_cast<const float4 *>(pa + F + 4);
+            const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint16_t hx = __half_as_ushort(__float2half_rn(a[i]));
+                const float sl = __half2float(__ushort_as_half(silu_tab[hx]));
+                o[i] = __fmul_rn(sl, b[i]);
+            }
+            quantize_group_lds(o, kg, lq, ld_, ls_);
         }
         __syncthreads();
     }
@@ -576,7 +602,7 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
                 const int n = c < N ? c : 0;
                 uint4 xa, xc;
                 float dx, sx;
-                if constexpr (PRO) {
+                if constexpr (PRO != 0) {
                     xa = *reinterpret_cast<const uint4 *>(lq + b * 32 + xswap);
                     xc = *reinterpret_cast<const uint4 *>(lq + b * 32 + (16 - xswap));
                     dx = ld_[b];
@@ -629,45 +655,57 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
 
 static inline int gemv_waves(int groups) { return groups >= 1024 ? 4 : groups >= 512 ? 8 : 16; }
 
-template <int TYPE>
-static hipError_t launch_gemv(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
-                              const float *resid, int ldr) {
+// single-token launches: (NWAVES by M, U by K) so that one pass covers the row when NWAVES * 8 >= K/128
+template <int TYPE, int PRO>
+static hipError_t launch_gemv1(const fl_qtensor &W, const fl_qact *xq, float *y, hipStream_t st, const float *resid,
+                               const float *xf, const void *aux, float *ynorm) {
     const dim3 grid(W.M16 / 16);
     const uint4 *qs = reinterpret_cast<const uint4 *>(W.qs);
-    // HBM-bound: what matters is bytes in flight per CU.  One workgroup streams one 16-row group; small M gets
-    // more waves per group (each takes every NWAVES-th block-quad) so that >= ~16 waves per CU are loading.
     const int nw = gemv_waves(W.M16 / 16);
-#define FL_GEMV(NC, NW)                                                                                                  \
-    hipLaunchKernelGGL((gemv_q4_kernel<TYPE, NC, NW, 0>), grid, dim3(64 * NW), 0, st, qs, W.d, W.m, xq.q, xq.d, xq.s, N, \
-                       W.M, W.KB, y, ldy, resid, ldr, nullptr, nullptr, nullptr)
-#define FL_GEMV_NW(NC)                       \
-    do {                                     \
-        if (nw == 4) FL_GEMV(NC, 4);         \
-        else if (nw == 8) FL_GEMV(NC, 8);    \
-        else FL_GEMV(NC, 16);                \
+    const int nquads = (W.KB + 3) / 4, per_wave = (nquads + nw - 1) / nw;
+    const int u = per_wave <= 2 ? 2 : per_wave <= 4 ? 4 : per_wave <= 6 ? 6 : 8;
+    const size_t lds = PRO ? (size_t)W.KB * 40 : 0;
+#define FL_GEMV(NW, UU)                                                                                              \
+    hipLaunchKernelGGL((gemv_q4_kernel<TYPE, 1, NW, PRO, UU>), grid, dim3(64 * NW), lds, st, qs, W.d, W.m,           \
+                       xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, 1, W.M, W.KB, y, 0, resid, 0, \
+                       xf, aux, ynorm)
+#define FL_GEMV_U(NW)                   \
+    do {                                \
+        if (u == 2) FL_GEMV(NW, 2);     \
+        else if (u == 4) FL_GEMV(NW, 4);\
+        else if (u == 6) FL_GEMV(NW, 6);\
+        else FL_GEMV(NW, 8);            \
     } while (0)
-    if (N == 1) FL_GEMV_NW(1);
-    else if (N == 2) FL_GEMV_NW(2);
-    else if (N <= 4) FL_GEMV_NW(4);
-    else FL_GEMV_NW(8);
-#undef FL_GEMV_NW
+    if (nw == 4) FL_GEMV_U(4);
+    else if (nw == 8) FL_GEMV_U(8);
+    else FL_GEMV_U(16);
+#undef FL_GEMV_U
 #undef FL_GEMV
     return hipGetLastError();
 }
 
 template <int TYPE>
-static hipError_t launch_gemv_norm(const fl_qtensor &W, const float *x, const float *norm_w, float *ynorm, float *y,
-                                   hipStream_t st) {
+static hipError_t launch_gemv(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
+                              const float *resid, int ldr) {
+    if (N == 1) return launch_gemv1<TYPE, 0>(W, &xq, y, st, resid, nullptr, nullptr, nullptr);
     const dim3 grid(W.M16 / 16);
     const uint4 *qs = reinterpret_cast<const uint4 *>(W.qs);
+    // HBM-bound: what matters is bytes in flight per CU.  One workgroup streams one 16-row group; small M gets
+    // more waves per group (each takes every NWAVES-th block-quad) so that >= ~16 waves per CU are loading.
     const int nw = gemv_waves(W.M16 / 16);
-    const size_t lds = (size_t)W.KB * 40;
-#define FL_GEMV(NW)                                                                                                    \
-    hipLaunchKernelGGL((gemv_q4_kernel<TYPE, 1, NW, 1>), grid, dim3(64 * NW), lds, st, qs, W.d, W.m, nullptr, nullptr, \
-                       nullptr, 1, W.M, W.KB, y, 0, nullptr, 0, x, norm_w, ynorm)
-    if (nw == 4) FL_GEMV(4);
-    else if (nw == 8) FL_GEMV(8);
-    else FL_GEMV(16);
+#define FL_GEMV(NC, NW, UU)                                                                                             \
+    hipLaunchKernelGGL((gemv_q4_kernel<TYPE, NC, NW, 0, UU>), grid, dim3(64 * NW), 0, st, qs, W.d, W.m, xq.q, xq.d, xq.s, \
+                       N, W.M, W.KB, y, ldy, resid, ldr, nullptr, nullptr, nullptr)
+#define FL_GEMV_NW(NC, UU)                       \
+    do {                                         \
+        if (nw == 4) FL_GEMV(NC, 4, UU);         \
+        else if (nw == 8) FL_GEMV(NC, 8, UU);    \
+        else FL_GEMV(NC, 16, UU);                \
+    } while (0)
+    if (N == 2) FL_GEMV_NW(2, 4);
+    else if (N <= 4) FL_GEMV_NW(4, 2);
+    else FL_GEMV_NW(8, 2);
+#undef FL_GEMV_NW
 #undef FL_GEMV
     return hipGetLastError();
 }
@@ -675,8 +713,16 @@ static hipError_t launch_gemv_norm(const fl_qtensor &W, const float *x, const fl
 // y[M] = W . Q8_0(norm_w * rms_norm(x))   -- decode: rms_norm + mul + quantize_row_q8_0 + mul_mat in one launch
 hipError_t gemv_q4_norm(const fl_qtensor &W, const float *x, const float *norm_w, float *ynorm, float *y, hipStream_t st) {
     if (W.K % 32 != 0 || W.K > 8192) return hipErrorInvalidValue;
-    return W.type == FL_TYPE_Q4_0 ? launch_gemv_norm<FL_TYPE_Q4_0>(W, x, norm_w, ynorm, y, st)
-                                  : launch_gemv_norm<FL_TYPE_Q4_1>(W, x, norm_w, ynorm, y, st);
+    return W.type == FL_TYPE_Q4_0 ? launch_gemv1<FL_TYPE_Q4_0, 1>(W, nullptr, y, st, nullptr, x, norm_w, ynorm)
+                                  : launch_gemv1<FL_TYPE_Q4_1, 1>(W, nullptr, y, st, nullptr, x, norm_w, ynorm);
+}
+
+// y[M] = W . Q8_0(silu(h13[0:K]) * h13[K:2K]) (+ resid)   -- decode feed-forward down projection in one launch
+hipError_t gemv_q4_silu(const fl_qtensor &W, const float *h13, const uint16_t *silu_tab, float *y, const float *resid,
+                        hipStream_t st) {
+    if (W.K % 32 != 0 || W.K > 32768) return hipErrorInvalidValue;
+    return W.type == FL_TYPE_Q4_0 ? launch_gemv1<FL_TYPE_Q4_0, 2>(W, nullptr, y, st, resid, h13, silu_tab, nullptr)
+                                  : launch_gemv1<FL_TYPE_Q4_1, 2>(W, nullptr, y, st, resid, h13, silu_tab, nullptr);
 }
 
 hipError_t gemv_q4(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,

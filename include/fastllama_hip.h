@@ -183,6 +183,8 @@ int fl_debug_rmsnorm_quant(const float *x_dev, int ldx, const float *w_dev, int 
                            fl_qact *out, int layout, void *stream);
 int fl_debug_gemv_norm(const fl_qtensor *W, const float *x_dev, const float *norm_w_dev, float *ynorm_dev, float *y_dev,
                        void *stream);  /* y = W . Q8_0(norm_w * rms_norm(x)), one launch (decode) */
+int fl_debug_gemv_silu(const fl_qtensor *W, const float *h13_dev, const uint16_t *silu_tab_dev, float *y_dev,
+                       const float *resid_dev, void *stream); /* y = W . Q8_0(silu(h13[:K]) * h13[K:]) + resid, one launch */
 int fl_debug_decode_attention(const float *qkv_dev, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab_dev,
                               float *kc, float *vc, const uint16_t *exp_tab_dev, float scale, fl_qact *out, void *stream);
 int fl_debug_silu_mul_quant(const float *h13_dev, int ld, int N, int F, const uint16_t *silu_tab_dev, fl_qact *out,

@@ -222,3 +222,31 @@ def test_decode_attention_fused(env, D, H, n_past):
     assert np.mean(q8[:, 8:].view(np.int8) == wq8[:, 8:].view(np.int8)) > 0.98   # only round-off flips of f32 dots
     s_field = q8[:, 4:8].copy().view(np.float32)[:, 0]
     assert np.array_equal(s_field, (d * qs.reshape(-1, 32).sum(1).astype(np.float32)).astype(np.float32))
+
+
+@pytest.mark.parametrize("qtype", [2, 3])
+@pytest.mark.parametrize("M,F", [(48, 64), (256, 704), (4096, 11008), (5120, 13824)])
+def test_gemv_silu_fused_equals_unfused(env, qtype, M, F):
+    """decode: silu(w1 x)*(w3 x) -> Q8_0 -> mul_mat (+ residual) in ONE launch == silu_mul_quant + gemv, bit for bit."""
+    torch, hip, ops, L, port = env
+    rng = np.random.default_rng(M + F + qtype)
+    wq = port.quantize_q4(qtype, (rng.standard_normal((M, F)) * 0.05).astype(np.float32))
+    W = ops.QTensor(qtype, wq, M, F)
+    h = (rng.standard_normal((1, 2 * F)) * 2).astype(np.float32)
+    res = rng.standard_normal(M).astype(np.float32)
+    s = np.empty(1 << 16, np.uint16)
+    L.fl_debug_tables(None, s.ctypes.data_as(C.c_void_p))
+    sd, hd, rd = dev(torch, s.view(np.int16)), dev(torch, h), dev(torch, res)
+    a = ops.QAct(1, F)
+    hip.check(L.fl_quantize_q8_layout(a.handle, hd.data_ptr(), 2 * F, 1, F, 1, None))
+    a.N, a.K = 1, F
+    hip.check(L.fl_debug_silu_mul_quant(hd.data_ptr(), 2 * F, 1, F, sd.data_ptr(), a.handle, 1, None))
+    y0 = torch.empty(M, device="cuda")
+    hip.check(L.fl_debug_mul_mat_q(W.handle, a.handle, y0.data_ptr(), M, 2, None))
+    y1 = torch.full((M,), 3.0, device="cuda")
+    hip.check(L.fl_debug_gemv_silu(W.handle, hd.data_ptr(), sd.data_ptr(), y1.data_ptr(), None, None))
+    assert np.array_equal(y1.cpu().numpy().view(np.uint32), y0.cpu().numpy().view(np.uint32))
+    hip.check(L.fl_debug_gemv_silu(W.handle, hd.data_ptr(), sd.data_ptr(), y1.data_ptr(), rd.data_ptr(), None))
+    assert np.array_equal(y1.cpu().numpy(), y0.cpu().numpy() + res)
+    want = port.mul_mat_q(qtype, wq, (le.silu(h[:, :F]) * h[:, F:]).astype(np.float32))[0]
+    assert np.max(np.abs(y0.cpu().numpy() - want)) <= 2e-5 * np.max(np.abs(want))
