@@ -6,19 +6,27 @@
 //
 // One MFMA K-step is exactly one 32-element quant block: v_mfma_i32_16x16x32_i8 (A = 16 W rows,
 // B = 16 activation columns) produces the 16x16 block dots exactly.  The per-block scale product cannot
-// be folded into integer operands, so the f32 scale-accumulate is a VALU epilogue of 1/32 of the MACs.
-// Measured on MI355X (profiles/): that epilogue, not the MFMA, bounds the kernel -- 12 f32 lane-ops
-// (6 packed VALU instructions, ~4 cycles each) per 16-cycle MFMA -- so the design is built around
-// keeping the VALU pipe of every SIMD saturated:
+// be folded into integer operands, so every 16x16x32 tile needs a scale-accumulate of its 256 block sums.
+// What that costs on gfx950 was measured first (scripts/ubench/coexec*.hip, profiles/r01_gemm_ablation.txt):
 //
+//   * on one SIMD the i8 MFMA (16 cycles) and the VALU barely overlap: ~2 scalar VALU ops hide under one MFMA,
+//     every further one costs its full ~2 cycles.  A v_pk_*_f32 does not co-issue with an executing MFMA at all
+//     and has no throughput edge over two scalar ops -> the kernel is compiled without packed-f32 selection.
+//   * floor for this instruction mix = MFMA + 8 scalar ops (4 magic subtracts + 4 FMAs) + the scale product
+//     ~= 18.5 ns per tile per SIMD (~900 TOP/s chip-wide); the loop below runs at ~70 % of that.
+//
+// Design points:
 //   * int -> float without v_cvt: the MFMA's C input is the constant 0x4B400000 (= 1.5*2^23 as f32
-//     bits); D = magic + isum reinterpreted as f32 IS 12582912 + isum exactly (|isum| < 2^22), so one
-//     packed v_pk_add_f32 replaces two v_cvt_f32_i32.  Epilogue = pk_add, pk_mul, pk_fma per 2 outputs.
+//     bits); D = magic + isum reinterpreted as f32 IS 12582912 + isum exactly (|isum| < 2^22).
+//   * d_w x d_x for FOUR tiles comes from one v_mfma_f32_16x16x1 (4-block outer product, C = 0): its D layout is
+//     the i8 MFMA's D layout, so acc = fma(float(isum), P, acc) needs no shuffles.  For Q4_1 the m_w x s_x term is
+//     the same instruction accumulating into its own registers (no VALU at all).
 //   * the MFMA of tile t+1 is issued before the epilogue of tile t (software pipeline inside a wave,
 //     pinned with sched_barrier because hipcc otherwise re-serialises MFMA -> s_nop -> own epilogue).
-//   * a single wave issues a packed VALU op only every ~8-11 cycles; >= 4 waves per SIMD are needed to
-//     fill the pipe.  Hence small wave tiles (few accumulator VGPRs), several workgroup shapes
-//     (template WM x WN waves of TM x TN MFMA tiles) and a shape-driven choice among them (pick_config).
+//   * block-granular operand pipeline: while block b is on the MFMA/VALU pipes, the LDS reads of block b+1 are in
+//     flight, and the stage barrier + global_load_lds issue sit in the middle of a K-step under MFMAs in flight.
+//   * several workgroup shapes (template WM x WN waves of TM x TN MFMA tiles) and a shape-driven choice among
+//     them (pick_config): small outputs need many small wave tiles to occupy all 1024 SIMDs.
 //   * QW16 / QA16 make every LDS fill a linear 16-byte copy -> global_load_lds (no staging VGPRs) into a
 //     3-deep LDS ring with counted s_waitcnt vmcnt; per-lane source pointers are computed once and
 //     advanced by a constant per K-step.  Fragment reads are bank-conflict free by construction
@@ -36,8 +44,15 @@ typedef const __attribute__((address_space(1))) void glb_void;
 
 __device__ const uint4 fl_zero_chunk[1] = {{0u, 0u, 0u, 0u}};  // source of out-of-range LDS fills
 
+#ifndef FL_ABL
+#define FL_ABL 0
+#endif
+
 constexpr int GM_KS = 2;      // quant blocks per K-step
-constexpr int GM_NSTAGE = 3;  // LDS ring depth: fills run GM_NSTAGE-1 K-steps ahead of the MFMAs
+#ifndef FL_NSTAGE
+#define FL_NSTAGE 3
+#endif
+constexpr int GM_NSTAGE = FL_NSTAGE;  // LDS ring depth: fills run GM_NSTAGE-1 K-steps ahead of the MFMAs
 
 template <int TYPE, int WM, int WN, int TM, int TN>
 struct GemmCfg {
@@ -60,8 +75,13 @@ struct GemmCfg {
     static_assert(MG * GM_KS * 64 <= 1024 && NG * GM_KS * 64 <= 1024, "scale plane must fit one piece");
 };
 
+// gfx950: a v_pk_*_f32 cannot issue while an MFMA is executing (scripts/ubench/coexec.hip: 8 x (mfma + 1 v_pk_fma) takes
+// 96 ns against 57 ns for 8 x (mfma + 2 v_fma)), and packed f32 has no throughput edge over two scalar ops here.
+// The whole kernel is therefore compiled without packed-f32 instruction selection.
+#define FL_NOPK __attribute__((target("no-packed-fp32-ops")))
+
 template <int TYPE, int WM, int WN, int TM, int TN, int MINW>
-__global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_q4_mfma_kernel(
+__global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ? 3 : MINW) FL_NOPK void gemm_q4_mfma_kernel(
     const uint4 *__restrict__ qs, const float *__restrict__ dW, const float *__restrict__ mW,
     const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs, int N, int M,
     int MGT /* row groups total */, int NGT /* col groups total */, int KB, float *__restrict__ y, int ldy,
@@ -129,7 +149,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_q4_mfma_kernel(
             }
         }
     }
-    auto fill = [&](int st, int kb0) {
+    auto fill = [&](int st, int kb0) FL_NOPK __attribute__((always_inline)) {
         // kb0 .. kb0+KS-1 are the blocks of this stage; blocks >= KB read the zero chunk (K tail / past the end)
         const bool tail = kb0 + GM_KS > KB;
 #pragma unroll
@@ -142,85 +162,161 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_q4_mfma_kernel(
         }
     };
 
-    v4f acc[TM][TN];
+    // Accumulators live in groups of four 16x16 tiles (v16f = the D operand of one 4-block f32 MFMA).  Tiles of one
+    // K-step are numbered flat = b*TT + i*TN + j; group u = flat/4 shares one "scale MFMA", lane group k = flat%4.
+    // TT = 2 (one 16x32 wave tile): the group is {b even, b odd} x {j0, j1} -- even/odd blocks accumulate apart.
+    constexpr int TT = TM * TN;
+    static_assert(TT == 2 || TT % 4 == 0, "wave tile must be 2 or a multiple of 4 MFMA tiles");
+    static_assert(TN == 2 || TN == 4, "TN must be 2 or 4");
+    static_assert(TT != 2 || GM_KS % 2 == 0, "16x32 wave tiles pair up two quant blocks");
+    constexpr int G = TT == 2 ? 1 : TT / 4;            // accumulator groups
+    v16f acc[G], msacc[G];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < 16; ++e) acc[g][e] = 0.f, msacc[g][e] = 0.f;
 
     const v4i magic = {0x4B400000, 0x4B400000, 0x4B400000, 0x4B400000};  // 12582912.0f = 1.5 * 2^23
+    v4f negmagic = {-12582912.0f, -12582912.0f, -12582912.0f, -12582912.0f};
+    asm volatile("" : "+v"(negmagic));   // keep it in VGPRs: with an SGPR operand hipcc splits half of the packed adds
     const int apos = qw16_pos(l15, lg);
     // per-lane LDS byte offsets inside a stage (constant over the kernel)
     const int a_off = ((wm * TM * GM_KS) * 16 + l15) * 16 + apos * 4;               // + (i*KS + b)*256
     const int b_off = Cfg::OFF_B + ((wn * TN * GM_KS) * 16 + l15) * 32 + apos * 8;  // + (j*KS + b)*512
-    const int dw_off = Cfg::OFF_PL + ((wm * TM * GM_KS) * 16 + lg * 4) * 4;         // + (i*KS + b)*64
-    const int dx_off = Cfg::OFF_PL + 1024 + ((wn * TN * GM_KS) * 16 + l15) * 4;     // + (j*KS + b)*64
+    // scale operands of the 4-block outer-product MFMA: lane group lg = k supplies rows (A: d_w) / columns (B: d_x)
+    // of tile flat = 4u + k.  Offset = lane part (below) + compile-time part of u.
+    int ki, kj, kb;                                                                  // (i, j, b) contribution of k
+    if constexpr (TT == 2) { ki = 0; kj = lg & 1; kb = lg >> 1; }
+    else if constexpr (TN == 4) { ki = 0; kj = lg; kb = 0; }
+    else { ki = lg >> 1; kj = lg & 1; kb = 0; }
+    const int sa_off = Cfg::OFF_PL + (((wm * TM + ki) * GM_KS + kb) * 16 + l15) * 4;          // d_w (m_w: +2048)
+    const int sb_off = Cfg::OFF_PL + 1024 + (((wn * TN + kj) * GM_KS + kb) * 16 + l15) * 4;   // d_x (s_x: +2048)
 
-    const int nsteps = (KB + GM_KS - 1) / GM_KS;
+    // ---- block-granular software pipeline (GM_KS = 2 blocks per stage) --------------------------------------------
+    //   registers hold the operands of two quant blocks: the one the MFMAs are consuming and the one whose LDS reads are
+    //   in flight.  Step t:   read(t, b1) | tiles of (t, b0) | wait + barrier + fill(stage t+3) + read(t+1, b0) | tiles of (t, b1)
+    //   so LDS latency, the barrier and the fill issue all sit under a full block of MFMA/VALU work of the same wave.
+    static_assert(GM_KS == 2 && GM_NSTAGE >= 3, "pipeline below is written for 2 blocks per stage, >= 3 stages");
+    constexpr int UB = TT == 2 ? 1 : TT / 4;           // scale MFMAs per block (TT == 2: one per STEP, read with block 0)
+    struct Ops {
+        uint32_t araw[TM];                             // packed nibbles as read from LDS (unpacked right before use)
+        long bq[TN];
+        float sa[UB], sb[UB], ma[UB], mb[UB];
+    };
+    auto read_ops = [&](Ops &o, const unsigned char *base, int b) FL_NOPK __attribute__((always_inline)) {
 #pragma unroll
-    for (int st = 0; st < GM_NSTAGE - 1; ++st) fill(st, st * GM_KS);  // past-the-end fills are all-zero pieces
-
-    int cur = 0;
-    for (int t = 0; t < nsteps; ++t) {
-        // this wave's pieces of stage t have landed once at most (NSTAGE-2) later stages are outstanding
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::LPW * (GM_NSTAGE - 2)) : "memory");
-        __builtin_amdgcn_s_barrier();  // all waves' pieces landed; all waves are done reading stage t-1
-        {
-            int nxt = cur + GM_NSTAGE - 1;
-            nxt = nxt >= GM_NSTAGE ? nxt - GM_NSTAGE : nxt;
-            fill(nxt, (t + GM_NSTAGE - 1) * GM_KS);  // refills the buffer that was read in step t-1
+        for (int i = 0; i < TM; ++i) o.araw[i] = *reinterpret_cast<const uint32_t *>(base + a_off + (i * GM_KS + b) * 256);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) o.bq[j] = *reinterpret_cast<const long *>(base + b_off + (j * GM_KS + b) * 512);
+        if (TT == 2 && b != 0) return;
+#pragma unroll
+        for (int ub = 0; ub < UB; ++ub) {
+            int cu_i;                                  // compile-time part of i for group ub (lane part is in sa_off)
+            if constexpr (TT == 2) cu_i = 0;
+            else if constexpr (TN == 4) cu_i = ub;
+            else cu_i = ub * 2;
+            const int oa = (cu_i * GM_KS + b) * 64, ob = b * 64;
+            o.sa[ub] = *reinterpret_cast<const float *>(base + sa_off + oa);
+            o.sb[ub] = *reinterpret_cast<const float *>(base + sb_off + ob);
+            if (TYPE == FL_TYPE_Q4_1) {
+                o.ma[ub] = *reinterpret_cast<const float *>(base + sa_off + 2048 + oa);
+                o.mb[ub] = *reinterpret_cast<const float *>(base + sb_off + 2048 + ob);
+            }
         }
-        const unsigned char *base = smem + cur * Cfg::STAGE;
-
-#pragma unroll
-        for (int b = 0; b < GM_KS; ++b) {
-            long afrag[TM], bfrag[TN];
-            v4f dwv[TM], mwv[TM];
-            float dxv[TN], sxv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const uint32_t v = *reinterpret_cast<const uint32_t *>(base + a_off + (i * GM_KS + b) * 256);
-                uint32_t lo, hi;
-                unpack_nibbles<TYPE>(v, lo, hi);
-                afrag[i] = (long)(((uint64_t)hi << 32) | lo);
-                dwv[i] = *reinterpret_cast<const v4f *>(base + dw_off + (i * GM_KS + b) * 64);
-                if (TYPE == FL_TYPE_Q4_1) mwv[i] = *reinterpret_cast<const v4f *>(base + dw_off + 2048 + (i * GM_KS + b) * 64);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bfrag[j] = *reinterpret_cast<const long *>(base + b_off + (j * GM_KS + b) * 512);
-                dxv[j] = *reinterpret_cast<const float *>(base + dx_off + (j * GM_KS + b) * 64);
-                if (TYPE == FL_TYPE_Q4_1) sxv[j] = *reinterpret_cast<const float *>(base + dx_off + 2048 + (j * GM_KS + b) * 64);
-            }
-            // software pipeline inside one wave: MFMA(tile t+1) is issued, THEN the VALU scales tile t, so the
-            // packed VALU ops run under the 16-cycle MFMA.  sched_barrier(0) pins the two halves.
+    };
 #ifdef FL_ABL_NOMFMA   // timing experiment only: the epilogue runs on garbage, no MFMA is issued
 #define FL_MFMA(a, b, c) ({ v4i r_; asm volatile("; no mfma" : "=v"(r_) : "v"(a), "v"(b), "v"(c)); r_; })
 #else
 #define FL_MFMA(a, b, c) __builtin_amdgcn_mfma_i32_16x16x32_i8(a, b, c, 0, 0, 0)
 #endif
-            v4i r0 = FL_MFMA(afrag[0], bfrag[0], magic);
-            v4i r1;
-            __builtin_amdgcn_sched_barrier(0);
+    const int nsteps = (KB + GM_KS - 1) / GM_KS;
 #pragma unroll
-            for (int tt = 0; tt < TM * TN; ++tt) {
-                const int i = tt / TN, j = tt % TN;
-                if (tt + 1 < TM * TN) {
-                    const v4i rn = FL_MFMA(afrag[(tt + 1) / TN], bfrag[(tt + 1) % TN], magic);
-                    if (tt & 1) r0 = rn; else r1 = rn;
+    for (int st = 0; st < GM_NSTAGE - 1; ++st) fill(st, st * GM_KS);   // past-the-end fills are all-zero pieces
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::LPW * (GM_NSTAGE - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();                      // stage 0 has landed for every wave
+    fill(GM_NSTAGE - 1, (GM_NSTAGE - 1) * GM_KS);
+    Ops ops[2];
+    read_ops(ops[0], smem, 0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    constexpr int NT = GM_KS * TT;                     // tiles per K-step
+    const v16f zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int cur = 0;
+    for (int t = 0; t < nsteps; ++t) {
+        const unsigned char *base = smem + cur * Cfg::STAGE;
+        int nxt = cur + 1 == GM_NSTAGE ? 0 : cur + 1;
+        long afrag[GM_KS][TM];
+        // MFMA stream of the step: P(0) T(0) T(1) | E(0) T(2) | E(1) T(3) | E(2) P(1) T(4) | ...  (E = VALU scale-accumulate)
+        // The d_w x d_x outer products of four tiles come from ONE v_mfma_f32_16x16x1 (4 blocks): 8 passes of the matrix
+        // pipe instead of four VALU multiplies per tile.
+        auto unpack_block = [&](int b) FL_NOPK __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                uint32_t lo, hi;
+                unpack_nibbles<TYPE>(ops[b].araw[i], lo, hi);
+                afrag[b][i] = (long)(((uint64_t)hi << 32) | lo);
+            }
+        };
+        auto tile_mfma = [&](int flat) FL_NOPK __attribute__((always_inline)) -> v4i {
+            int b, i, j;
+            if constexpr (TT == 2) { b = flat / 2; i = 0; j = flat % 2; }
+            else { b = flat / TT; i = (flat % TT) / TN; j = flat % TN; }
+            return FL_MFMA(afrag[b][i], ops[b].bq[j], magic);
+        };
+        auto scale_mfma = [&](int u, v16f &P) FL_NOPK __attribute__((always_inline)) {   // group u of the step
+            const int b = TT == 2 ? 0 : u / UB, ub = TT == 2 ? 0 : u % UB;
+            P = __builtin_amdgcn_mfma_f32_16x16x1f32(ops[b].sa[ub], ops[b].sb[ub], zero16, 0, 0, 0);
+            if (TYPE == FL_TYPE_Q4_1)
+                msacc[u % G] = __builtin_amdgcn_mfma_f32_16x16x1f32(ops[b].ma[ub], ops[b].mb[ub], msacc[u % G], 0, 0, 0);
+        };
+        v16f P0, P1 = zero16;
+        unpack_block(0);
+        scale_mfma(0, P0);
+        v4i r0 = tile_mfma(0), r1 = magic;
+        __builtin_amdgcn_sched_barrier(0);
+        // block 1's LDS reads go out only now: hipcc waits with lgkmcnt(0) before the first use of block 0's operands
+        // (the counter state is unknown across the back edge), and that wait must not cover these reads.
+#if !(FL_ABL & 2)
+        read_ops(ops[1], base, 1);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            if (tt + 1 < NT) {
+                if ((tt + 1) % TT == 0) unpack_block((tt + 1) / TT);            // first tile of the next block
+                if ((tt + 1) % 4 == 0) {
+                    if (((tt + 1) / 4) & 1) scale_mfma((tt + 1) / 4, P1); else scale_mfma((tt + 1) / 4, P0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                const v4f f = __builtin_bit_cast(v4f, (tt & 1) ? r1 : r0) - 12582912.0f;  // exact: float(isum)
-                const v4f p = dwv[i] * dxv[j];                                             // d_w*d_x (ggml.c:2452)
-                acc[i][j] = __builtin_elementwise_fma(f, p, acc[i][j]);                    // fma(d, isum, acc) (:2478)
-                if (TYPE == FL_TYPE_Q4_1) {
-                    const v4f sv = {sxv[j], sxv[j], sxv[j], sxv[j]};
-                    acc[i][j] = __builtin_elementwise_fma(mwv[i], sv, acc[i][j]);          // summs += m*s (:2651)
-                }
+                const v4i rn = tile_mfma(tt + 1);
+                if (tt & 1) r0 = rn; else r1 = rn;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int u = tt / 4, k = tt % 4, g = u % G;
+            const v4f f = __builtin_bit_cast(v4f, (tt & 1) ? r1 : r0) + negmagic;   // exact: float(isum)
+            const v16f &P = (u & 1) ? P1 : P0;
+            const v4f p = {P[4 * k], P[4 * k + 1], P[4 * k + 2], P[4 * k + 3]};        // d_w*d_x (ggml.c:2452)
+            v4f a = {acc[g][4 * k], acc[g][4 * k + 1], acc[g][4 * k + 2], acc[g][4 * k + 3]};
+            a = __builtin_elementwise_fma(f, p, a);                                     // fma(d, isum, acc) (:2478)
+            acc[g][4 * k] = a[0]; acc[g][4 * k + 1] = a[1]; acc[g][4 * k + 2] = a[2]; acc[g][4 * k + 3] = a[3];
+            __builtin_amdgcn_sched_barrier(0);
+            if (tt == TT - 1) {
+                // every MFMA of block 0 has been issued: its operand registers are free.  Stage t+1 must have landed
+                // (this wave's pieces: vmcnt; everyone's: barrier); everyone has also finished reading stage t.
+#if !(FL_ABL & 1)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::LPW * (GM_NSTAGE - 2)) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !(FL_ABL & 4)
+                __builtin_amdgcn_s_barrier();
+#endif
+                fill(cur, (t + GM_NSTAGE) * GM_KS);    // stage t+NSTAGE into the buffer stage t occupied
+#endif
+#if !(FL_ABL & 2)
+                read_ops(ops[0], smem + nxt * Cfg::STAGE, 0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        cur = cur + 1 == GM_NSTAGE ? 0 : cur + 1;
+        cur = nxt;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the (zero) tail fills before the wave ends
 
@@ -231,15 +327,29 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_q4_mfma_kernel(
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = (ng0 + wn * TN + j) * 16 + l15;
+            v4f o;
+            if constexpr (TT == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = acc[0][4 * j + e] + acc[0][8 + 4 * j + e];          // even + odd quant blocks
+                    if (TYPE == FL_TYPE_Q4_1) o[e] += msacc[0][4 * j + e] + msacc[0][8 + 4 * j + e];
+                }
+            } else {
+                const int flat = i * TN + j, g = flat / 4, k = flat % 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = acc[g][4 * k + e];
+                    if (TYPE == FL_TYPE_Q4_1) o[e] += msacc[g][4 * k + e];   // + sum_b m_w*s_x (ggml.c:2651)
+                }
+            }
             if (n < N && row0 < M) {
                 float *p = y + (int64_t)n * ldy + row0;
                 const float *pr = resid ? resid + (int64_t)n * ldr + row0 : nullptr;
                 if (row0 + 3 < M) {
-                    v4f o = acc[i][j];
                     if (pr) o += *reinterpret_cast<const v4f *>(pr);   // ggml_add(cur, inp) fused into the store
                     *reinterpret_cast<v4f *>(p) = o;
                 } else {
-                    for (int r = 0; r < 4 && row0 + r < M; ++r) p[r] = acc[i][j][r] + (pr ? pr[r] : 0.f);
+                    for (int r = 0; r < 4 && row0 + r < M; ++r) p[r] = o[r] + (pr ? pr[r] : 0.f);
                 }
             }
         }
@@ -287,7 +397,7 @@ static int pick_config(int MGT, int NGT) {
     const int64_t tiles16 = (int64_t)MGT * NGT;      // 16x16 output tiles
     const double per_simd = (double)tiles16 / 1024;  // MI355X: 256 CUs x 4 SIMDs
     // thresholds from scripts/sweep_cfg.py on MI355X at N=512 (profiles/r01_gemm_cfg_sweep.txt)
-    if (per_simd >= 48) return 2;                    // plenty of work: 128x128 tiles, 8 waves of 32x64
+    if (per_simd >= 40) return 2;                    // plenty of work: 128x128 tiles, 8 waves of 32x64
     if (per_simd >= 12) return 1;                    // 64x128 tiles, 4 waves of 32x64, 4 workgroups per CU
     return 4;                                        // small outputs: 64x128 tiles, 16 waves of 16x32
 }

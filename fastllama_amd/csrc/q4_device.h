@@ -8,6 +8,7 @@ namespace fl {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int qw16_pos(int r, int g) { return g ^ (((r >> 3) & 1) << 1); }
 

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libfastllama_hip.so")
+# FASTLLAMA_HIP_LIB: development override (kernel ablation builds); the default is the in-tree library
+LIB_PATH = os.environ.get("FASTLLAMA_HIP_LIB") or os.path.join(PKG_DIR, "libfastllama_hip.so")
 
 FL_OK, FL_EINVAL, FL_EHIP, FL_ENOMEM, FL_ENODEV = 0, -1, -2, -3, -4
 Q4_0, Q4_1 = 2, 3
