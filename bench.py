@@ -184,6 +184,17 @@ def main():
     decode_ms = ddt / args.decode_steps * 1e3
 
     # ---------------- roofline of the dominant kernels: HIP events around every matmul launch -----
+    def pmc_traffic(kernel):
+        """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3 --pmc
+        FETCH_SIZE / WRITE_SIZE, gfx950 correction applied) -- valid for the default 7B Q4_0 n_batch=512 workload."""
+        try:
+            if args.model != "7B" or qtype != 2 or N != 512 or tp:
+                return None
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+        except Exception:
+            return None
+
     wk, wk1 = synth.algorithmic_work(cfg, N, qtype), synth.algorithmic_work(cfg, 1, qtype)
     shard = world if tp else 1
     model.profile(1)
@@ -194,12 +205,14 @@ def main():
     tops = wk["flops"] / shard * evals / (mm_ms * 1e-3) / 1e12
     roofline = {
         "kernel": "gemm_q4_mfma_kernel<Q4_%d,...>" % (qtype - 2), "bound": "mfma",
-        "achieved": tops, "peak": PEAK_I8_TOPS, "unit": "TOP/s", "frac": tops / PEAK_I8_TOPS, "traffic": None,
+        "achieved": tops, "peak": PEAK_I8_TOPS, "unit": "TOP/s", "frac": tops / PEAK_I8_TOPS,
+        "traffic": pmc_traffic("gemm_q4_mfma_kernel"),
         "launches_per_step": n_launch // evals, "avg_launch_us": mm_ms * 1e3 / max(1, n_launch),
         "algorithmic_flops_per_launch": wk["flops"] / shard / (n_launch / evals),
         "note": ("ALGORITHMIC 2*M*K*N of the 225 mul_mat_q_f32 (fused into %d launches) / event-timed launch durations; "
-                 "the exact per-32-block scaling forces the K=32 i8 MFMA (2.5 PTOP/s peak) and makes the f32 VALU "
-                 "epilogue the co-critical pipe (DESIGN.md)") % (n_launch // evals),
+                 "the exact per-32-block scaling forces the K=32 i8 MFMA (2.5 PTOP/s peak) plus 8 scalar VALU ops per "
+                 "16x16x32 tile that do not overlap the MFMA on gfx950 -> measured instruction-mix floor ~0.9 PTOP/s "
+                 "(DESIGN.md, scripts/ubench/coexec2.hip); traffic = HBM bytes per launch from profiles/r01_pmc_traffic.json") % (n_launch // evals),
     }
     model.profile(1)
     for i in range(8):
@@ -208,7 +221,8 @@ def main():
     gbs = wk1["bytes"] / shard * 8 / (mm1_ms * 1e-3) / 1e9
     roofline_decode = {
         "kernel": "gemv_q4_kernel<Q4_%d,1>" % (qtype - 2), "bound": "hbm",
-        "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+        "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+        "traffic": pmc_traffic("gemv_q4_kernel"),
         "launches_per_step": n1 // 8, "avg_launch_us": mm1_ms * 1e3 / max(1, n1),
         "algorithmic_bytes_per_launch": wk1["bytes"] / shard / (n1 / 8),
     }

@@ -6,7 +6,9 @@
 // ranks by the host program (bench.py / tests broadcast it with torch.distributed or a file).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "comm.h"
@@ -14,9 +16,24 @@
 
 using namespace fl;
 
+// Shards of ONE process on ONE device (fl_comm_create_local): the collective is a rendezvous of the shards' host
+// threads plus one device kernel that sums the partials in rank order.  It exists so that the tensor-parallel model
+// path can be run -- and tested -- with G logical shards on a single GPU, and for hosts that
+// drive several shards from one process.
+struct LocalGroup {
+    std::mutex mu;
+    std::condition_variable cv;
+    int world = 1, arrived = 0, refs = 0;
+    unsigned long gen = 0;
+    float *bufs[FL_COMM_MAX_LOCAL] = {nullptr};
+    size_t count = 0;
+    int status = FL_OK;
+};
+
 struct fl_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
+    LocalGroup *lg = nullptr;
 };
 
 static_assert(sizeof(ncclUniqueId) == FL_COMM_ID_BYTES, "ncclUniqueId size");
@@ -53,8 +70,52 @@ fl_comm *fl_comm_create(const void *id_bytes, int rank, int world) {
     return c;
 }
 
+int fl_comm_create_local(int world, fl_comm **out) {
+    if (ensure_device() != FL_OK) return FL_ENODEV;
+    if (!out || world < 1 || world > FL_COMM_MAX_LOCAL) return set_error(FL_EINVAL, "fl_comm_create_local: world must be 1..%d", FL_COMM_MAX_LOCAL);
+    LocalGroup *g = new (std::nothrow) LocalGroup();
+    if (!g) return set_error(FL_ENOMEM, "out of host memory");
+    g->world = world;
+    g->refs = world;
+    for (int r = 0; r < world; ++r) {
+        fl_comm *c = new (std::nothrow) fl_comm();
+        if (!c) return set_error(FL_ENOMEM, "out of host memory");
+        c->rank = r;
+        c->world = world;
+        c->lg = g;
+        out[r] = c;
+    }
+    return FL_OK;
+}
+
+static int local_allreduce(fl_comm *c, float *buf, size_t count, hipStream_t st) {
+    LocalGroup *g = c->lg;
+    hipError_t e = hipStreamSynchronize(st);                 // this shard's partial sum is complete
+    if (e != hipSuccess) return set_error(FL_EHIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
+    std::unique_lock<std::mutex> lk(g->mu);
+    const unsigned long my_gen = g->gen;
+    g->bufs[c->rank] = buf;
+    if (g->arrived == 0) g->count = count;
+    else if (g->count != count) g->status = FL_EINVAL;
+    if (++g->arrived == g->world) {
+        if (g->status == FL_OK) {
+            e = sum_buffers_inplace(g->bufs, g->world, count, st);   // every buffer <- sum over ranks, rank order
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) g->status = FL_EHIP;
+        }
+        g->arrived = 0;
+        ++g->gen;
+        g->cv.notify_all();
+    } else {
+        g->cv.wait(lk, [&] { return g->gen != my_gen; });
+    }
+    const int rc = g->status;
+    return rc == FL_OK ? FL_OK : set_error(rc, "local all-reduce failed (mismatched counts or a device error)");
+}
+
 int fl_comm_allreduce_sum_f32(fl_comm *c, float *buf_dev, size_t count, void *stream) {
     if (!c || !buf_dev) return set_error(FL_EINVAL, "fl_comm_allreduce: null argument");
+    if (c->lg) return local_allreduce(c, buf_dev, count, reinterpret_cast<hipStream_t>(stream));
     ncclResult_t r = ncclAllReduce(buf_dev, buf_dev, count, ncclFloat32, ncclSum, c->comm, reinterpret_cast<hipStream_t>(stream));
     if (r != ncclSuccess) return set_error(FL_EHIP, "ncclAllReduce: %s", ncclGetErrorString(r));
     return FL_OK;
@@ -66,6 +127,14 @@ int fl_comm_size(const fl_comm *c) { return c ? c->world : 0; }
 void fl_comm_destroy(fl_comm *c) {
     if (!c) return;
     if (c->comm) ncclCommDestroy(c->comm);
+    if (c->lg) {
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(c->lg->mu);
+            last = --c->lg->refs == 0;
+        }
+        if (last) delete c->lg;
+    }
     delete c;
 }
 

@@ -18,6 +18,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include "eval_kernels.h"
+#include "comm.h"
 #include "q4_device.h"
 
 namespace fl {
@@ -569,6 +570,24 @@ hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, i
     const size_t lds = (size_t)(4 * D + n_ctx + 4) * 4 + 8 * 8 + 8 * 4;
     hipLaunchKernelGGL(decode_attention_kernel, dim3(H), dim3(DA_T), lds, st, qkv, E, D, n_past, n_ctx,
                        reinterpret_cast<const float2 *>(rope_tab), kc, vc, exp_tab, scale, out->q, out->d, out->s, dyn_past);
+    return hipGetLastError();
+}
+
+// local (single-process) all-reduce of the tensor-parallel partial sums: rank-order sum written back to every shard
+struct SumBufs { float *p[FL_COMM_MAX_LOCAL]; };
+__global__ __launch_bounds__(256) void sum_buffers_kernel(SumBufs b, int world, size_t count) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        float s = b.p[0][i];
+        for (int r = 1; r < world; ++r) s += b.p[r][i];
+        for (int r = 0; r < world; ++r) b.p[r][i] = s;
+    }
+}
+hipError_t sum_buffers_inplace(float *const *bufs, int world, size_t count, hipStream_t st) {
+    if (world < 1 || world > FL_COMM_MAX_LOCAL) return hipErrorInvalidValue;
+    SumBufs b;
+    for (int r = 0; r < FL_COMM_MAX_LOCAL; ++r) b.p[r] = r < world ? bufs[r] : nullptr;
+    const int grid = (int)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
+    hipLaunchKernelGGL(sum_buffers_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, b, world, count);
     return hipGetLastError();
 }
 

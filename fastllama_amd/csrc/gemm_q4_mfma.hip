@@ -78,7 +78,11 @@ struct GemmCfg {
 // gfx950: a v_pk_*_f32 cannot issue while an MFMA is executing (scripts/ubench/coexec.hip: 8 x (mfma + 1 v_pk_fma) takes
 // 96 ns against 57 ns for 8 x (mfma + 2 v_fma)), and packed f32 has no throughput edge over two scalar ops here.
 // The whole kernel is therefore compiled without packed-f32 instruction selection.
+#if defined(__HIP_DEVICE_COMPILE__)
 #define FL_NOPK __attribute__((target("no-packed-fp32-ops")))
+#else
+#define FL_NOPK   /* the host pass only needs the launch stub */
+#endif
 
 template <int TYPE, int WM, int WN, int TM, int TN, int MINW>
 __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ? 3 : MINW) FL_NOPK void gemm_q4_mfma_kernel(

@@ -507,20 +507,14 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
             mw[u] = TYPE == FL_TYPE_Q4_1 ? mW[idx] : 0.f;
         }
     };
-    // block-quad q is owned by wave q % NWAVES: every wave streams, whatever K is
-    int q0 = wave;
-    if (q0 < nquads) load(q0);
-
-    int8_t *lq = reinterpret_cast<int8_t *>(gsm);                   // [KB][32]
-    float *ld_ = reinterpret_cast<float *>(gsm + (size_t)KB * 32);  // [KB] d
-    float *ls_ = ld_ + KB;                                          // [KB] s
+    // Vector-memory loads return in order: the small activation loads of the prologue are issued BEFORE the weight
+    // stream, or the prologue would sit behind all of it.
+    constexpr int MAXIT = 4;
+    float v[PRO == 1 ? MAXIT : 1][8];
+    float ww[PRO == 1 ? MAXIT : 1][8];
     if constexpr (PRO == 1) {
-        __shared__ double sh[4];
         const float *nw = static_cast<const float *>(aux);
-        const int E = KB * 32, gpr = E >> 3;
-        constexpr int MAXIT = 4;
-        float v[MAXIT][8];
-        double sum = 0.0;
+        const int gpr = KB * 4;
         if (threadIdx.x < 256) {
 #pragma unroll
             for (int it = 0; it < MAXIT; ++it) {
@@ -530,10 +524,62 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
                     const float4 c = *reinterpret_cast<const float4 *>(xf + kg * 8 + 4);
                     v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
                     v[it][4] = c.x; v[it][5] = c.y; v[it][6] = c.z; v[it][7] = c.w;
+                    const float4 wa = *reinterpret_cast<const float4 *>(nw + kg * 8);
+                    const float4 wc = *reinterpret_cast<const float4 *>(nw + kg * 8 + 4);
+                    ww[it][0] = wa.x; ww[it][1] = wa.y; ww[it][2] = wa.z; ww[it][3] = wa.w;
+                    ww[it][4] = wc.x; ww[it][5] = wc.y; ww[it][6] = wc.z; ww[it][7] = wc.w;
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[it][i] = 0.f;
+                    for (int i = 0; i < 8; ++i) v[it][i] = 0.f, ww[it][i] = 0.f;
                 }
+            }
+        }
+    }
+    constexpr int SIT = 2;                       // PRO == 2: group-iterations whose loads precede the weight stream
+    float sl_[PRO == 2 ? SIT : 1][8], sb_[PRO == 2 ? SIT : 1][8];
+    if constexpr (PRO == 2) {
+        const uint16_t *silu_tab = static_cast<const uint16_t *>(aux);
+        const int F = KB * 32, gpr = F >> 3;
+        float sa_[SIT][8];
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int kg = threadIdx.x + it * 64 * NWAVES;
+            if (kg < gpr) {
+                const float *pa = xf + kg * 8;
+                const float4 a0 = *reinterpret_cast<const float4 *>(pa), a1 = *reinterpret_cast<const float4 *>(pa + 4);
+                const float4 b0 = *reinterpret_cast<const float4 *>(pa + F), b1 = *reinterpret_cast<const float4 *>(pa + F + 4);
+                sa_[it][0] = a0.x; sa_[it][1] = a0.y; sa_[it][2] = a0.z; sa_[it][3] = a0.w;
+                sa_[it][4] = a1.x; sa_[it][5] = a1.y; sa_[it][6] = a1.z; sa_[it][7] = a1.w;
+                sb_[it][0] = b0.x; sb_[it][1] = b0.y; sb_[it][2] = b0.z; sb_[it][3] = b0.w;
+                sb_[it][4] = b1.x; sb_[it][5] = b1.y; sb_[it][6] = b1.z; sb_[it][7] = b1.w;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int kg = threadIdx.x + it * 64 * NWAVES;
+            if (kg < gpr) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {   // the table gathers go out now; their results are used after the weight loads
+                    const uint16_t hx = __half_as_ushort(__float2half_rn(sa_[it][i]));
+                    sl_[it][i] = __half2float(__ushort_as_half(silu_tab[hx]));
+                }
+            }
+        }
+    }
+    // block-quad q is owned by wave q % NWAVES: every wave streams, whatever K is
+    int q0 = wave;
+    if (q0 < nquads) load(q0);
+
+    int8_t *lq = reinterpret_cast<int8_t *>(gsm);                   // [KB][32]
+    float *ld_ = reinterpret_cast<float *>(gsm + (size_t)KB * 32);  // [KB] d
+    float *ls_ = ld_ + KB;                                          // [KB] s
+    if constexpr (PRO == 1) {
+        __shared__ double sh[4];
+        const int E = KB * 32, gpr = E >> 3;
+        double sum = 0.0;
+        if (threadIdx.x < 256) {
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) sum += (double)__fmul_rn(v[it][i], v[it][i]);
             }
@@ -552,11 +598,8 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
                 const int kg = threadIdx.x + it * 256;
                 if (kg >= gpr) continue;   // whole quads leave together
                 float o[8];
-                const float4 wa = *reinterpret_cast<const float4 *>(nw + kg * 8);
-                const float4 wc = *reinterpret_cast<const float4 *>(nw + kg * 8 + 4);
-                const float ww[8] = {wa.x, wa.y, wa.z, wa.w, wc.x, wc.y, wc.z, wc.w};
 #pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = __fmul_rn(ww[i], __fmul_rn(v[it][i], scale));
+                for (int i = 0; i < 8; ++i) o[i] = __fmul_rn(ww[it][i], __fmul_rn(v[it][i], scale));
                 if (ynorm && grp == 0) {
                     float4 *yp = reinterpret_cast<float4 *>(ynorm + kg * 8);
                     yp[0] = make_float4(o[0], o[1], o[2], o[3]);
@@ -569,7 +612,16 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
     } else if constexpr (PRO == 2) {
         const uint16_t *silu_tab = static_cast<const uint16_t *>(aux);
         const int F = KB * 32, gpr = F >> 3;
-        for (int kg = threadIdx.x; kg < gpr; kg += 64 * NWAVES) {   // gpr % 4 == 0: quads stay together
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int kg = threadIdx.x + it * 64 * NWAVES;
+            if (kg >= gpr) continue;                                   // gpr % 4 == 0: quads stay together
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = __fmul_rn(sl_[it][i], sb_[it][i]);
+            quantize_group_lds(o, kg, lq, ld_, ls_);
+        }
+        for (int kg = threadIdx.x + SIT * 64 * NWAVES; kg < gpr; kg += 64 * NWAVES) {   // very wide rows: the rest
             const float *pa = xf + kg * 8;
             const float4 a0 = *reinterpret_cast<const float4 *>(pa), a1 = *reinterpret_cast<const float4 *>(pa + 4);
             const float4 b0 = *reinterpret_cast<const float4 *>(pa + F), b1 = *reinterpret_cast<const float4 *>(pa + F + 4);

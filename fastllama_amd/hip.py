@@ -82,6 +82,7 @@ _PROTOS = {
     "fl_mul_mat_q_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "fl_comm_unique_id": (C.c_int, [C.c_void_p]),
     "fl_comm_create": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
+    "fl_comm_create_local": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "fl_comm_allreduce_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "fl_comm_rank": (C.c_int, [C.c_void_p]),
     "fl_comm_size": (C.c_int, [C.c_void_p]),

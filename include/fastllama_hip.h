@@ -136,6 +136,11 @@ int fl_mul_mat_q_f32(const fl_qtensor *W, const float *x_dev, int ldx, float *y_
 typedef struct fl_comm fl_comm;
 int fl_comm_unique_id(void *id_out /* FL_COMM_ID_BYTES */);
 fl_comm *fl_comm_create(const void *id_bytes, int rank, int world); /* on the CURRENT device (fl_init) */
+/* `world` shards driven by ONE process on the current device (one host thread per shard): out[r] is rank r's handle.
+ * The all-reduce is a host rendezvous + one device kernel (rank-order sum).  For single-GPU validation of the
+ * tensor-parallel path and for hosts that keep several shards in one process. */
+#define FL_COMM_MAX_LOCAL 8
+int fl_comm_create_local(int world, fl_comm **out /* [world] */);
 int fl_comm_allreduce_sum_f32(fl_comm *c, float *buf_dev, size_t count, void *stream);
 int fl_comm_rank(const fl_comm *c);
 int fl_comm_size(const fl_comm *c);

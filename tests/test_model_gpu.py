@@ -171,3 +171,72 @@ def test_llama7b_width_logits(tmp_path_factory, port, reflib):
         l = got[j].astype(np.float64)
         nll -= (l[toks[j + 1]] - l.max()) - np.log(np.exp(l - l.max()).sum())
     assert abs(np.exp(nll / (N - 1 - (N >> 1))) - ppl) / ppl < 5e-3
+
+
+def test_rccl_world_of_one_allreduce():
+    """the RCCL wrapper itself on the GPU box: id, communicator, in-place f32 sum over a world of one"""
+    import ctypes as C
+    import torch
+    from fastllama_amd import hip
+    L = hip.load()
+    hip.require_device(0)
+    idb = (C.c_ubyte * 128)()
+    hip.check(L.fl_comm_unique_id(idb), "fl_comm_unique_id")
+    c = L.fl_comm_create(idb, 0, 1)
+    assert c, L.fl_last_error().decode()
+    c = C.c_void_p(c)
+    assert L.fl_comm_rank(c) == 0 and L.fl_comm_size(c) == 1
+    x = torch.randn(4096 * 7, device="cuda")
+    want = x.clone()
+    hip.check(L.fl_comm_allreduce_sum_f32(c, x.data_ptr(), x.numel(), None), "allreduce")
+    torch.cuda.synchronize()
+    assert torch.equal(x, want)
+    L.fl_comm_destroy(c)
+
+
+@pytest.mark.parametrize("cfgname,G", [("SMALL", 2), ("TINY", 4)])
+@pytest.mark.parametrize("qtype", [ggjt.Q4_0, ggjt.Q4_1])
+def test_tensor_parallel_shards_on_one_gpu(tmp_path_factory, port, qtype, cfgname, G):
+    """the Megatron split (wq/wk/wv/w1/w3 by rows, wo/w2 by K blocks, partial sums all-reduced) run as G
+    logical shards on ONE device -- each shard its own fl_model and host thread, the collective being the
+    single-process group of fl_comm_create_local.  Checked against the unsharded model on the same GPU (the numpy
+    restatement of the same split is pinned to the reference on the CPU in tests/test_llama_eval_oracle.py)."""
+    import ctypes as C
+    import threading
+    from fastllama_amd import hip
+    from harness.flmodel import FlModel
+    L = hip.load()
+    cfg = getattr(ggjt, cfgname)
+    tensors, _ = build(tmp_path_factory, port, cfg, qtype, f"tp{cfgname}")
+    toks = ggjt.text_tokens(TEXT[:33])
+    full = FlModel(cfg, qtype, tensors, n_ctx=64, max_batch=64)
+    want = full.eval(toks, all_logits=True)
+    want_dec = full.eval([toks[3]], n_past=len(toks))
+    comms = (C.c_void_p * G)()
+    hip.check(L.fl_comm_create_local(G, comms), "fl_comm_create_local")
+    shards = []
+    for r in range(G):
+        m = FlModel(cfg, qtype, tensors, n_ctx=64, max_batch=64, tp_rank=r, tp_size=G)
+        m.set_comm(C.c_void_p(comms[r]))
+        shards.append(m)
+    got, got_dec, errs = [None] * G, [None] * G, []
+
+    def run(r):
+        try:
+            got[r] = shards[r].eval(toks, all_logits=True)
+            got_dec[r] = shards[r].eval([toks[3]], n_past=len(toks))
+        except Exception as e:           # a failing shard must not leave the others waiting forever
+            errs.append(e)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert not errs and all(not t.is_alive() for t in th), errs
+    for r in range(1, G):                # every shard holds the full logits (lm-head is replicated), identical bits
+        assert np.array_equal(got[r], got[0]) and np.array_equal(got_dec[r], got_dec[0])
+    check_logits(got[0], want.astype(np.float64), f"tp{G} prefill vs unsharded")
+    assert relerr(got_dec[0], want_dec) <= 5e-2
+    for m in shards:
+        m.free()
+    for r in range(G):
+        L.fl_comm_destroy(C.c_void_p(comms[r]))
