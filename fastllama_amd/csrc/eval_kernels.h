@@ -26,6 +26,9 @@ hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, 
 hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab, float *kc,
                             float *vc, const uint16_t *exp_tab, float scale, const fl_qact *out, hipStream_t st,
                             const int *dyn_past = nullptr);
+// LoRA merge on reference AoS blocks (lora_kernels.hip): rows [row0, row0+rows) <- quantize(dequantize + sign * BA)
+hipError_t lora_add_aos(int type, void *aos, int KB, int row0, int rows, const float *ba, int64_t ldba, const float *A,
+                        const float *B, int r, int ba_row0, int ba_col0, float sign, hipStream_t st);
 hipError_t add_rows(const float *a, int lda, const float *b, int ldb, float *o, int ldo, int N, int E, hipStream_t st);
 
 }  // namespace fl

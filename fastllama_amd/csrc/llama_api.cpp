@@ -23,6 +23,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <map>
 #include <memory>
 #include <queue>
 #include <random>
@@ -355,6 +356,117 @@ struct Session {
         return true;
     }
 
+    // ---- LoRA (lib/llama.cpp:697-944): "ggla" v1 file = { u8 use_cache_matrix, u32 r, u32 alpha } + tensors named
+    // <base>.loraA [r, ne0(base)] (pre-scaled by alpha/r, scripts/convert-lora-to-ggml.py:140-145) and <base>.loraB
+    // [r, ne1(base)], or <base>.lora [ne0, ne1] (the cached product).  Every pair is merged into the resident weights by
+    // fl_model_lora_apply (dequantize + add + re-quantize, the reference's add_q_f32).  use_mmap keeps the originals for
+    // an exact detach (:714-726, :868-874); otherwise detach re-applies the file with the sign flipped (:921-938).
+    std::string attached_lora;
+
+    bool apply_lora_file(const std::string &path, float sign, bool keep_backup, const char *fn, progress_type_tag tag) {
+        MappedFile f;
+        if (!f.open(path.c_str())) { log.err("FileLoader", "Failed to open file: '" + path + "'\n"); return false; }
+        Reader r{f.p, f.n};
+        const uint32_t magic = r.get<uint32_t>(), fv = r.get<uint32_t>();
+        if (!r.ok || magic != 0x67676c61 || fv != 1) { log.err("read_magic_number", "invalid model file " + path + " (bad magic)\n"); return false; }
+        const bool use_cache = r.get<uint8_t>() != 0;
+        const uint32_t rank = r.get<uint32_t>(), alpha = r.get<uint32_t>();
+        if (!r.ok) { log.err(fn, "truncated lora adapter header\n"); return false; }
+        if (sign > 0) {
+            char buf[32];
+            snprintf(buf, sizeof buf, "%.2f", rank ? (double)alpha / (double)rank : 0.0);
+            log.info(fn, "lora_params: \n");
+            log.info(fn, std::string("   Use cached matrix= ") + (use_cache ? "Yes" : "No") + "\n");
+            log.info(fn, "   Alpha            = " + std::to_string(alpha) + "\n");
+            log.info(fn, "   Rank             = " + std::to_string(rank) + "\n");
+            log.info(fn, std::string("   Scale            = ") + buf + "\n");
+        }
+        struct Half { const float *p = nullptr; uint32_t ne0 = 0, ne1 = 0; };
+        std::map<std::string, std::pair<Half, Half>> pending;           // base -> (A, B)
+        bool warned = false;
+        size_t done = 0;
+        while (r.ok && r.off < r.n) {
+            const uint32_t n_dims = r.get<uint32_t>(), name_len = r.get<uint32_t>(), type = r.get<uint32_t>();
+            if (!r.ok) break;
+            if (n_dims != 2) { log.err(fn, "lora adapter only supports matrices\n"); return false; }
+            const uint32_t ne0 = r.get<uint32_t>(), ne1 = r.get<uint32_t>();
+            const std::string name = r.str(name_len);
+            r.off += (size_t)(-(int64_t)r.off & 31);
+            const size_t nel = (size_t)ne0 * ne1, bytes = type == 0 ? nel * 4 : type == 1 ? nel * 2 : 0;
+            if (!r.ok || bytes == 0 || r.off + bytes > r.n) { log.err(fn, "bad or truncated tensor '" + name + "' in lora adapter\n"); return false; }
+            const float *data = reinterpret_cast<const float *>(r.p + r.off);
+            r.off += bytes;
+            const std::string suffix = ".lora";
+            const size_t pos = name.rfind(suffix);
+            const size_t want_pos = name.size() - suffix.size() - (use_cache ? 0 : 1);
+            if (pos == std::string::npos || pos != want_pos) { log.err(fn, "'" + name + "' is not a lora tensor\n"); return false; }
+            const std::string base = name.substr(0, pos);
+            int b0 = 0, b1 = 0;
+            if (fl_model_lora_shape(model, base.c_str(), &b0, &b1) != FL_OK) { log.err(fn, "unknown tensor '" + base + "' in lora adapter\n"); return false; }
+            if (type != 0) { log.err(fn, "currently, we support fp32 lora tensors only.\n"); return false; }
+            if (!warned) {
+                log.warn(fn, "using a lora adapter with a quantized model may result in poor quality, use a f16 or f32 base model\n");
+                warned = true;
+            }
+            int rc = FL_OK;
+            bool merged = false;
+            if (use_cache) {
+                if ((int)ne0 != b0 || (int)ne1 != b1) {
+                    log.err(fn, "incompatible tensor dimensions (" + std::to_string(b0) + " and " + std::to_string(ne1) + ") are you sure that this adapter is for this model?\n");
+                    return false;
+                }
+                rc = fl_model_lora_apply(model, base.c_str(), data, nullptr, nullptr, 0, sign, keep_backup ? 1 : 0);
+                merged = true;
+            } else {
+                auto &pr = pending[base];
+                Half &h = name.back() == 'A' ? pr.first : pr.second;
+                h.p = data; h.ne0 = ne0; h.ne1 = ne1;
+                if (pr.first.p && pr.second.p) {
+                    if ((int)pr.first.ne1 != b0 || (int)pr.second.ne1 != b1 || pr.first.ne0 != pr.second.ne0) {
+                        log.err(fn, "incompatible tensor dimensions (" + std::to_string(b0) + " and " + std::to_string(pr.first.ne1) + ") are you sure that this adapter is for this model?\n");
+                        return false;
+                    }
+                    rc = fl_model_lora_apply(model, base.c_str(), nullptr, pr.first.p, pr.second.p, (int)pr.first.ne0, sign, keep_backup ? 1 : 0);
+                    pending.erase(base);
+                    merged = true;
+                }
+            }
+            if (merged && rc != FL_OK) { log.err(fn, std::string(fl_last_error()) + "\n"); return false; }
+            done += nel;
+            log.progress(tag, done, f.n / 4);
+        }
+        if (!r.ok) { log.err(fn, "failed to load all tensors\n"); return false; }
+        return true;
+    }
+
+    bool attach_lora(const char *path) {
+        if (!attached_lora.empty()) {
+            log.err("attach_lora", "already attached LoRa model from '" + attached_lora + "'. Detach it first or reload the model.\n");
+            return false;
+        }
+        log.info("attach_lora", std::string("attaching LoRa model from '") + path + "'. Please wait ...\n");
+        if (!apply_lora_file(path, 1.0f, args.use_mmap, "attach_lora", PROGRESS_TAG_ATTACH_LORA_ADAPTER)) {
+            if (args.use_mmap) (void)fl_model_lora_restore(model);     // leave the model as it was
+            return false;
+        }
+        attached_lora = path;
+        return true;
+    }
+
+    bool detach_lora() {
+        if (attached_lora.empty()) { log.err("detach_lora", "no LoRa model attached.\n"); return false; }
+        log.info("detach_lora", "detaching LoRa model from '" + attached_lora + "'. Please wait ...\n");
+        bool ok;
+        if (args.use_mmap) {
+            ok = fl_model_lora_restore(model) == FL_OK;
+            if (!ok) log.err("detach_lora", std::string(fl_last_error()) + "\n");
+        } else {
+            ok = apply_lora_file(attached_lora, -1.0f, false, "detach_lora", PROGRESS_TAG_DETACH_LORA_ADAPTER);
+        }
+        if (ok || args.use_mmap) attached_lora.clear();
+        return ok;
+    }
+
     // Model::eval(n_past, tokens, logits, ...) -- lib/llama.cpp:272; batches larger than max_batch are split
     bool eval(int past, const std::vector<token_t> &toks) {
         const int V = hp.n_vocab, N = (int)toks.size();
@@ -661,16 +773,8 @@ struct llama_array_view_f llama_get_logits(struct llama_model_context const *c) 
 bool llama_save_state(struct llama_model_context *c, char const *path) { return valid(c) && path && c->inner->save_state(path); }
 bool llama_load_state(struct llama_model_context *c, char const *path) { return valid(c) && path && c->inner->load_state(path); }
 
-bool llama_attach_lora(struct llama_model_context *c, char const *) {
-    if (!valid(c)) return false;
-    c->inner->log.err("attach_lora", "LoRA adapters on device-resident Q4 weights are not implemented yet (SURVEY.md 8 f-3)\n");
-    return false;
-}
-bool llama_detach_lora(struct llama_model_context *c) {
-    if (!valid(c)) return false;
-    c->inner->log.err("detach_lora", "no LoRA adapter is attached\n");
-    return false;
-}
+bool llama_attach_lora(struct llama_model_context *c, char const *path) { return valid(c) && path && c->inner->attach_lora(path); }
+bool llama_detach_lora(struct llama_model_context *c) { return valid(c) && c->inner->detach_lora(); }
 
 bool llama_reset_model(struct llama_model_context *c) { return valid(c) && c->inner->reset(); }
 void llama_free_context(struct llama_model_context *c) { delete c; }

@@ -70,6 +70,9 @@ struct fl_model {
     // decode hipGraph
     bool graph_enabled = true;
     bool fuse_decode = true;     // N == 1: norm-in-GEMV + one attention kernel per layer
+    // LoRA: originals of the tensors an adapter touched (the reference's use_mmap path keeps them too, llama.cpp:868-874)
+    struct LoraBackup { fl_qtensor *t; void *qs, *d, *mm; };
+    std::vector<LoraBackup> lora_backups;
     hipGraphExec_t graph_exec = nullptr;
     int *npast_dev = nullptr;
     int32_t *pinned = nullptr;   // [token, n_past] staging in pinned host memory
@@ -541,6 +544,164 @@ int fl_model_kv_write(fl_model *m, const float *k_host, const float *v_host) {
     return FL_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// LoRA on resident weights (reference lib/llama.cpp:697-944)
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct TensorRef {
+    fl_qtensor *t = nullptr;
+    int row0 = 0, rows = 0;        // rows of the (possibly fused) device tensor that hold this base tensor's shard
+    int grow0 = 0, gcol0 = 0;      // where the shard sits in the FULL base tensor (tensor parallel): row / column offset
+    int Kfull = 0, Mfull = 0;      // full base tensor: ne0, ne1
+};
+}  // namespace
+
+static int locate_tensor(fl_model *m, const char *name, TensorRef *o) {
+    const int E = m->E, F = m->F, V = m->V, G = m->G, r = m->rank;
+    std::string nm(name);
+    if (nm == "tok_embeddings.weight" || nm == "output.weight") {
+        o->t = nm[0] == 't' ? m->tok_emb : m->output;
+        o->rows = V; o->Kfull = E; o->Mfull = V;
+        return FL_OK;
+    }
+    int il = -1, off = 0;
+    if (sscanf(name, "layers.%d.%n", &il, &off) != 1 || il < 0 || il >= m->L || off == 0)
+        return set_error(FL_EINVAL, "unknown tensor '%s'", name);
+    Layer &ly = m->layers[il];
+    const std::string sub(name + off);
+    if (sub == "attention.wq.weight" || sub == "attention.wk.weight" || sub == "attention.wv.weight") {
+        const int part = sub[11] == 'q' ? 0 : sub[11] == 'k' ? 1 : 2;
+        o->t = ly.wqkv; o->row0 = part * m->El; o->rows = m->El; o->grow0 = r * m->El; o->Kfull = E; o->Mfull = E;
+        return FL_OK;
+    }
+    if (sub == "feed_forward.w1.weight" || sub == "feed_forward.w3.weight") {
+        const int part = sub[14] == '1' ? 0 : 1;
+        o->t = ly.w13; o->row0 = part * m->Fl; o->rows = m->Fl; o->grow0 = r * m->Fl; o->Kfull = E; o->Mfull = F;
+        return FL_OK;
+    }
+    if (sub == "attention.wo.weight") {
+        o->t = ly.wo; o->rows = E; o->gcol0 = r * (E / G); o->Kfull = E; o->Mfull = E;
+        return FL_OK;
+    }
+    if (sub == "feed_forward.w2.weight") {
+        o->t = ly.w2; o->rows = E; o->gcol0 = r * (F / G); o->Kfull = F; o->Mfull = E;
+        return FL_OK;
+    }
+    return set_error(FL_EINVAL, "tensor '%s' is not a quantized matrix of the model", name);
+}
+
+static int dev_copy_f32(const float *src, size_t n, float **out) {
+    *out = nullptr;
+    if (!src) return FL_OK;
+    M_HIP(hipMalloc((void **)out, n * 4));
+    M_HIP(hipMemcpy(*out, src, n * 4, hipMemcpyDefault));       // host or device source
+    return FL_OK;
+}
+
+extern "C" int fl_model_lora_shape(fl_model *m, const char *base_name, int *ne0, int *ne1) {
+    if (!m || !base_name) return set_error(FL_EINVAL, "null argument");
+    TensorRef tr;
+    int rc = locate_tensor(m, base_name, &tr);
+    if (rc != FL_OK) return rc;
+    if (ne0) *ne0 = tr.Kfull;
+    if (ne1) *ne1 = tr.Mfull;
+    return FL_OK;
+}
+
+/* W_base <- quantize_row_q(dequantize_row_q(W_base) + sign * BA).  ba: [ne1][ne0] f32 (cached adapter), or a: [ne0][r],
+ * b: [ne1][r] (BA[m][k] = ggml_vec_dot_f32(r, a_k, b_m)); FULL tensors even under tensor parallelism (the shard is
+ * taken here); host or device pointers.  keep_backup != 0: the first touch of a tensor saves its current contents for
+ * fl_model_lora_restore (the reference's use_mmap behaviour). */
+extern "C" int fl_model_lora_apply(fl_model *m, const char *base_name, const float *ba, const float *a, const float *b, int r,
+                                   float sign, int keep_backup) {
+    if (!m || !base_name) return set_error(FL_EINVAL, "null argument");
+    if (!m->finalized) return set_error(FL_EINVAL, "model not finalized");
+    if (!ba && (!a || !b || r < 1)) return set_error(FL_EINVAL, "lora: need either BA or A, B and r >= 1");
+    TensorRef tr;
+    int rc = locate_tensor(m, base_name, &tr);
+    if (rc != FL_OK) return rc;
+    fl_qtensor *t = tr.t;
+    M_HIP(hipStreamSynchronize(m->stream));
+    const size_t nblk = (size_t)t->M16 * t->KB;
+    if (keep_backup) {
+        bool have = false;
+        for (auto &bk : m->lora_backups) have = have || bk.t == t;
+        if (!have) {
+            fl_model::LoraBackup bk{t, nullptr, nullptr, nullptr};
+            M_HIP(hipMalloc(&bk.qs, nblk * 16));
+            M_HIP(hipMalloc(&bk.d, nblk * 4));
+            M_HIP(hipMemcpy(bk.qs, t->qs, nblk * 16, hipMemcpyDeviceToDevice));
+            M_HIP(hipMemcpy(bk.d, t->d, nblk * 4, hipMemcpyDeviceToDevice));
+            if (t->m) {
+                M_HIP(hipMalloc(&bk.mm, nblk * 4));
+                M_HIP(hipMemcpy(bk.mm, t->m, nblk * 4, hipMemcpyDeviceToDevice));
+            }
+            m->lora_backups.push_back(bk);
+        }
+    }
+    const int bs = t->type == FL_TYPE_Q4_0 ? 20 : 24;
+    void *aos = nullptr;
+    float *dba = nullptr, *da = nullptr, *db = nullptr;
+    int *flag = nullptr;
+    int bad = 0;
+    auto cleanup = [&] { for (void *p : {aos, (void *)dba, (void *)da, (void *)db, (void *)flag}) if (p) (void)hipFree(p); };
+    hipError_t e = hipMalloc(&aos, (size_t)t->M * t->KB * bs);
+    if (e == hipSuccess) e = hipMalloc((void **)&flag, 4);
+    if (e != hipSuccess) { cleanup(); return hip_fail(e, "hipMalloc(lora staging)"); }
+    if (ba) rc = dev_copy_f32(ba, (size_t)tr.Mfull * tr.Kfull, &dba);
+    else {
+        rc = dev_copy_f32(a, (size_t)tr.Kfull * r, &da);
+        if (rc == FL_OK) rc = dev_copy_f32(b, (size_t)tr.Mfull * r, &db);
+    }
+    if (rc != FL_OK) { cleanup(); return rc; }
+    e = unpack_from_qw16(t->type, t->qs, t->d, t->m, t->M, t->K, aos, m->stream);
+    if (e == hipSuccess)
+        e = lora_add_aos(t->type, aos, t->KB, tr.row0, tr.rows, dba, tr.Kfull, da, db, r, tr.grow0, tr.gcol0, sign, m->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(flag, 0, 4, m->stream);
+    if (e == hipSuccess) e = repack_to_qw16(t->type, aos, t->M, t->K, t->qs, t->d, t->m, flag, m->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    cleanup();
+    if (e != hipSuccess) return hip_fail(e, "fl_model_lora_apply");
+    if (bad) return set_error(FL_EINVAL, "lora: a merged Q4_0 block scale fell below 2^-122");
+    return FL_OK;
+}
+
+/* put back every tensor saved by fl_model_lora_apply(keep_backup = 1) and drop the copies */
+extern "C" int fl_model_lora_restore(fl_model *m) {
+    if (!m) return set_error(FL_EINVAL, "null model");
+    M_HIP(hipStreamSynchronize(m->stream));
+    for (auto &bk : m->lora_backups) {
+        const size_t nblk = (size_t)bk.t->M16 * bk.t->KB;
+        M_HIP(hipMemcpy(bk.t->qs, bk.qs, nblk * 16, hipMemcpyDeviceToDevice));
+        M_HIP(hipMemcpy(bk.t->d, bk.d, nblk * 4, hipMemcpyDeviceToDevice));
+        if (bk.mm) M_HIP(hipMemcpy(bk.t->m, bk.mm, nblk * 4, hipMemcpyDeviceToDevice));
+        (void)hipFree(bk.qs); (void)hipFree(bk.d);
+        if (bk.mm) (void)hipFree(bk.mm);
+    }
+    m->lora_backups.clear();
+    return FL_OK;
+}
+
+/* this rank's rows of a base tensor as reference AoS blocks (tests, tooling): rows x (K_local/32) blocks */
+extern "C" int fl_model_tensor_download(fl_model *m, const char *base_name, void *aos_host) {
+    if (!m || !base_name || !aos_host) return set_error(FL_EINVAL, "null argument");
+    TensorRef tr;
+    int rc = locate_tensor(m, base_name, &tr);
+    if (rc != FL_OK) return rc;
+    const fl_qtensor *t = tr.t;
+    const int bs = t->type == FL_TYPE_Q4_0 ? 20 : 24;
+    void *aos = nullptr;
+    M_HIP(hipMalloc(&aos, (size_t)t->M * t->KB * bs));
+    hipError_t e = unpack_from_qw16(t->type, t->qs, t->d, t->m, t->M, t->K, aos, m->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(aos_host, (char *)aos + (size_t)tr.row0 * t->KB * bs, (size_t)tr.rows * t->KB * bs, hipMemcpyDeviceToHost, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    (void)hipFree(aos);
+    return e == hipSuccess ? FL_OK : hip_fail(e, "fl_model_tensor_download");
+}
+
 void fl_model_free(fl_model *m) {
     if (!m) return;
     (void)hipDeviceSynchronize();
@@ -556,6 +717,7 @@ void fl_model_free(fl_model *m) {
     fr(m->kc); fr(m->vc); fr(m->exp_tab); fr(m->silu_tab); fr(m->rope_tab); fr(m->tok_dev);
     fr(m->x); fr(m->x2); fr(m->xn); fr(m->part); fr(m->qkv); fr(m->att); fr(m->ao); fr(m->h13); fr(m->logits);
     for (fl_qact *a : {&m->qE, &m->qEl, &m->qF}) { fr(a->q); fr(a->d); fr(a->s); }
+    for (auto &bk : m->lora_backups) { fr(bk.qs); fr(bk.d); fr(bk.mm); }
     for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
     if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
     if (m->pinned) (void)hipHostFree(m->pinned);

@@ -88,6 +88,10 @@ _PROTOS = {
     "fl_comm_size": (C.c_int, [C.c_void_p]),
     "fl_comm_destroy": (None, [C.c_void_p]),
     "fl_model_create": (C.c_void_p, [C.POINTER(ModelParams)]),
+    "fl_model_lora_shape": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "fl_model_lora_apply": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int]),
+    "fl_model_lora_restore": (C.c_int, [C.c_void_p]),
+    "fl_model_tensor_download": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     "fl_model_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     "fl_model_finalize": (C.c_int, [C.c_void_p]),
     "fl_model_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -91,6 +91,28 @@ def write_ggjt(path: str, cfg: dict, qtype: int, tensors: dict):
             f.write(np.ascontiguousarray(data).tobytes())
 
 
+def write_lora(path: str, adapters: dict, r: int, alpha: int, cached: bool = False):
+    """'ggla' v1 adapter file as scripts/convert-lora-to-ggml.py writes it (header :52-55, tensors :57-72).
+    adapters: base tensor name -> (A [ne0(base), r] f32 ALREADY scaled by alpha/r, B [ne1(base), r] f32), or, with
+    cached=True, base -> BA [ne1(base), ne0(base)] f32 (already scaled)."""
+    def tensor(f, name, arr):
+        nb = name.encode()
+        f.write(struct.pack("<III", arr.ndim, len(nb), 0))
+        f.write(struct.pack("<%dI" % arr.ndim, *arr.shape[::-1]))
+        f.write(nb)
+        f.write(b"\0" * ((-f.tell()) & 31))
+        f.write(np.ascontiguousarray(arr, dtype=np.float32).tobytes())
+    with open(path, "wb") as f:
+        f.write(struct.pack("<II", 0x67676C61, 1))
+        f.write(struct.pack("<?II", cached, r, alpha))
+        for base, t in adapters.items():
+            if cached:
+                tensor(f, base + ".lora", t)
+            else:
+                tensor(f, base + ".loraA", t[0])
+                tensor(f, base + ".loraB", t[1])
+
+
 def text_tokens(text: str, bos: bool = True):
     return ([1] if bos else []) + [b + 3 for b in text.encode()]
 

@@ -61,12 +61,12 @@ class Session:
     """One llama_model_context (the reference's fastllama.Model, interfaces/python/fastllama.py:194-479)."""
 
     def __init__(self, lib: LlamaLib, path: str, n_ctx=512, n_batch=16, n_threads=4, all_logits=False,
-                 embeddings=False, seed=0, n_keep=200, last_n_tokens=64, quiet=True):
+                 embeddings=False, seed=0, n_keep=200, last_n_tokens=64, quiet=True, use_mmap=False):
         self.L = lib.lib
         args = self.L.llama_create_default_context_args()
         args.embedding_eval_enabled = embeddings
         args.should_get_all_logits = all_logits
-        args.use_mmap = False
+        args.use_mmap = use_mmap
         args.use_mlock = False
         args.load_parallel = False
         args.seed, args.n_keep, args.n_ctx, args.n_threads, args.n_batch = seed, n_keep, n_ctx, n_threads, n_batch
@@ -123,6 +123,8 @@ class Session:
     def save_state(self, path): return bool(self.L.llama_save_state(self.ctx, os.fsencode(path)))
     def load_state(self, path): return bool(self.L.llama_load_state(self.ctx, os.fsencode(path)))
     def reset(self): return bool(self.L.llama_reset_model(self.ctx))
+    def attach_lora(self, path): return bool(self.L.llama_attach_lora(self.ctx, os.fsencode(path)))
+    def detach_lora(self): return bool(self.L.llama_detach_lora(self.ctx))
 
     def close(self):
         if self.ctx:

@@ -174,6 +174,19 @@ int fl_model_eval(fl_model *m, const int32_t *tokens_host, int N, int n_past, fl
 int fl_model_profile(fl_model *m, int enable, double *mm_ms_total, long *mm_launches);
 /* decode (N = 1) evals replay a captured hipGraph by default; 0 switches to plain launches */
 int fl_model_set_graph(fl_model *m, int mode); /* bit0: hipGraph replay for decode (default on); bit1: generic per-op decode kernels */
+/* LoRA on the resident Q4 weights -- replaces Model::attach_lora / detach_lora (lib/llama.cpp:697-944) and its
+ * ggml_compute_forward_add_q_f32 (lib/ggml.c:6414-6520): W <- quantize_row_q(dequantize_row_q(W) + sign * BA), with the
+ * reference's SIMD quantizer arithmetic.  base_name is the base tensor ("layers.3.attention.wq.weight"); pass either
+ * ba [ne1][ne0] f32 (cached adapter) or a [ne0][r] + b [ne1][r] (BA[m][k] = ggml_vec_dot_f32(r, a_k, b_m)); host or
+ * device pointers, FULL tensors also under tensor parallelism.  keep_backup: save the tensor's current contents on its
+ * first touch so fl_model_lora_restore() can put the originals back (the reference's use_mmap detach, :714-726);
+ * without it detach is a second apply with sign = -1 (:933-938). */
+int fl_model_lora_shape(fl_model *m, const char *base_name, int *ne0, int *ne1);
+int fl_model_lora_apply(fl_model *m, const char *base_name, const float *ba, const float *a, const float *b, int r, float sign,
+                        int keep_backup);
+int fl_model_lora_restore(fl_model *m);
+/* this rank's rows of a base tensor as reference AoS blocks (block_q4_0 / block_q4_1), for tests and tooling */
+int fl_model_tensor_download(fl_model *m, const char *base_name, void *aos_host);
 const float *fl_model_logits_dev(const fl_model *m);
 void *fl_model_stream(const fl_model *m);
 size_t fl_model_device_bytes(const fl_model *m);

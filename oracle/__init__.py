@@ -68,6 +68,9 @@ class Port:
         L.orc_mul_mat_q_f32_ex.restype = C.c_int
         L.orc_quantize_q4.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.orc_quantize_q4.restype = None
+        L.orc_lora_add.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_float, C.c_void_p]
+        L.orc_lora_add.restype = C.c_int
 
     # ---- weights ----
     def quantize_q4(self, qtype: int, w: np.ndarray) -> np.ndarray:
@@ -87,6 +90,25 @@ class Port:
 
     def dequantize(self, qtype: int, wq: np.ndarray, K: int) -> np.ndarray:
         return np.stack([self.dequantize_row(qtype, r, K) for r in wq])
+
+
+    def lora_add(self, qtype: int, wq: np.ndarray, K: int, a=None, b=None, ba=None, sign: float = 1.0):
+        """LoRA merge on AoS Q4 rows (oracle/q4_oracle.c:orc_lora_add / oracle/ref_driver.c:ref_lora_add).
+        a: [K, r] f32, b: [M, r] f32 (uncached adapter) or ba: [M, K] f32 (cached).  Returns (new rows, BA)."""
+        out = np.ascontiguousarray(wq, dtype=np.uint8).copy()
+        M = out.shape[0]
+        if ba is not None:
+            ba = np.ascontiguousarray(ba, dtype=np.float32)
+            r, pa, pb, pba = 0, None, None, _ptr(ba)
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            b = np.ascontiguousarray(b, dtype=np.float32)
+            r, pa, pb, pba = a.shape[1], _ptr(a), _ptr(b), None
+        got = np.empty((M, K), dtype=np.float32)
+        rc = self.lib.orc_lora_add(qtype, _ptr(out), pa, pb, pba, r, M, K, float(sign), _ptr(got))
+        if rc != 0:
+            raise RuntimeError(f"lora_add failed rc={rc}")
+        return out, got
 
     # ---- activations ----
     def quantize_row_q8_0(self, x: np.ndarray) -> np.ndarray:
@@ -160,6 +182,9 @@ class Ref:
         L.ref_mm_read.restype = None
         L.ref_mm_close.argtypes = [C.c_void_p]
         L.ref_mm_close.restype = None
+        L.ref_lora_add.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_float, C.c_void_p, C.c_int]
+        L.ref_lora_add.restype = C.c_int
         self.fns = {t: L.ggml_internal_get_quantize_fn(t) for t in (Q4_0, Q4_1)}
 
     def quantize_q4(self, qtype: int, w: np.ndarray) -> np.ndarray:
@@ -180,6 +205,24 @@ class Ref:
         out = np.empty(K, dtype=np.float32)
         self.fns[qtype].dequantize_row_q(_ptr(row), _ptr(out), K)
         return out
+
+    def lora_add(self, qtype: int, wq: np.ndarray, K: int, a=None, b=None, ba=None, sign: float = 1.0):
+        """LoRA merge on AoS Q4 rows (oracle/q4_oracle.c:orc_lora_add / oracle/ref_driver.c:ref_lora_add).
+        a: [K, r] f32, b: [M, r] f32 (uncached adapter) or ba: [M, K] f32 (cached).  Returns (new rows, BA)."""
+        out = np.ascontiguousarray(wq, dtype=np.uint8).copy()
+        M = out.shape[0]
+        if ba is not None:
+            ba = np.ascontiguousarray(ba, dtype=np.float32)
+            r, pa, pb, pba = 0, None, None, _ptr(ba)
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            b = np.ascontiguousarray(b, dtype=np.float32)
+            r, pa, pb, pba = a.shape[1], _ptr(a), _ptr(b), None
+        got = np.empty((M, K), dtype=np.float32)
+        rc = self.lib.ref_lora_add(qtype, _ptr(out), pa, pb, pba, r, M, K, float(sign), _ptr(got), 4)
+        if rc != 0:
+            raise RuntimeError(f"lora_add failed rc={rc}")
+        return out, got
 
     def quantize_row_q8_0(self, x: np.ndarray, qtype: int = Q4_0) -> np.ndarray:
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -247,6 +247,93 @@ int orc_mul_mat_q_f32(int type, const void *W, const float *x, float *y, int M, 
     return orc_mul_mat_q_f32_ex(type, W, x, y, M, K, N, n_threads, 1);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * LoRA merge on quantized weights: restatement of what the reference executes on x86-64 (AVX2 build).
+ *   BA[m][k] = ggml_vec_dot_f32(r, A_k, B_m)            lib/ggml.c:2295-2330 (GGML_F32_STEP 32, 4 x 8 lanes,
+ *                                                       reduction :1921-1936, leftovers mul-then-add)
+ *   W_row    = quantize_row_q(dequantize_row_q(W_row) + sign * BA_row)      ggml_compute_forward_add_q_f32 :6414-6520
+ * with the SIMD quantizers quantize_row_q4_0 (:757-803: d = amax/7, id = 7/amax, round-half-even) and
+ * quantize_row_q4_1 (:965-1037: d = (max-min)/15, id = 1/d, round-half-even of (x-min)*id).
+ * ---------------------------------------------------------------------------------------- */
+float orc_vec_dot_f32(int n, const float *x, const float *y) {
+    float sum[4][8] = {{0}};
+    const int np = n & ~31;
+    for (int i = 0; i < np; i += 32)
+        for (int j = 0; j < 4; ++j)
+            for (int l = 0; l < 8; ++l) sum[j][l] = fmaf(x[i + 8 * j + l], y[i + 8 * j + l], sum[j][l]);
+    float t0[4];
+    for (int l = 0; l < 8; ++l) {
+        sum[0][l] = sum[0][l] + sum[1][l];
+        sum[2][l] = sum[2][l] + sum[3][l];
+        sum[0][l] = sum[0][l] + sum[2][l];
+    }
+    for (int l = 0; l < 4; ++l) t0[l] = sum[0][l] + sum[0][l + 4];
+    float sumf = (t0[0] + t0[1]) + (t0[2] + t0[3]);
+    for (int i = np; i < n; ++i) sumf += x[i] * y[i];   /* leftovers: product rounded, then added (gcc vectorises the
+                                                          multiply and keeps the adds in order -- no FMA here) */
+    return sumf;
+}
+
+void orc_quantize_row_q4_0_simd(const float *x, void *vy, int k) {
+    orc_block_q4_0 *y = (orc_block_q4_0 *)vy;
+    for (int b = 0; b < k / QK; ++b) {
+        float amax = 0.0f;
+        for (int l = 0; l < QK; ++l) amax = fmaxf(amax, fabsf(x[b * QK + l]));
+        const float d = amax / 7.0f;
+        const float id = amax != 0.0f ? 7.0f / amax : 0.0f;
+        y[b].d = d;
+        for (int l = 0; l < QK; l += 2) {
+            const int q0 = (int)rintf(x[b * QK + l] * id) + 8, q1 = (int)rintf(x[b * QK + l + 1] * id) + 8;
+            y[b].qs[l / 2] = (uint8_t)((q0 & 0xF) | ((q1 & 0xF) << 4));
+        }
+    }
+}
+
+void orc_quantize_row_q4_1_simd(const float *x, void *vy, int k) {
+    orc_block_q4_1 *y = (orc_block_q4_1 *)vy;
+    for (int b = 0; b < k / QK; ++b) {
+        float mn = x[b * QK], mx = x[b * QK];
+        for (int l = 1; l < QK; ++l) {
+            mn = fminf(mn, x[b * QK + l]);
+            mx = fmaxf(mx, x[b * QK + l]);
+        }
+        const float d = (mx - mn) / 15.0f;
+        const float id = d != 0.0f ? 1.0f / d : 0.0f;
+        y[b].d = d;
+        y[b].m = mn;
+        for (int l = 0; l < QK; l += 2) {
+            const int q0 = (int)rintf((x[b * QK + l] - mn) * id), q1 = (int)rintf((x[b * QK + l + 1] - mn) * id);
+            y[b].qs[l / 2] = (uint8_t)((q0 & 0xF) | ((q1 & 0xF) << 4));
+        }
+    }
+}
+
+/* W: M rows of K/32 AoS blocks, updated in place.  ba != NULL: cached adapter (M rows of K floats); else a: K rows of r
+ * floats, b: M rows of r floats.  ba_out (optional): the f32 BA that was added (before the sign). */
+int orc_lora_add(int type, void *W, const float *a, const float *b, const float *ba, int r, int M, int K, float sign,
+                 float *ba_out) {
+    if ((type != 2 && type != 3) || K % QK != 0) return -1;
+    const size_t bsz = type == 2 ? sizeof(orc_block_q4_0) : sizeof(orc_block_q4_1);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int m = 0; m < M; ++m) {
+        float *w = (float *)malloc((size_t)K * sizeof(float));
+        char *row = (char *)W + (size_t)m * (size_t)(K / QK) * bsz;
+        if (type == 2) orc_dequantize_row_q4_0(row, w, K);
+        else           orc_dequantize_row_q4_1(row, w, K);
+        for (int k = 0; k < K; ++k) {
+            const float v = ba ? ba[(size_t)m * K + k] : orc_vec_dot_f32(r, a + (size_t)k * r, b + (size_t)m * r);
+            if (ba_out) ba_out[(size_t)m * K + k] = v;
+            w[k] += sign == 1.0f ? v : v * sign;              /* ggml_scale by -1 is exact */
+        }
+        if (type == 2) orc_quantize_row_q4_0_simd(w, row, K);
+        else           orc_quantize_row_q4_1_simd(w, row, K);
+        free(w);
+    }
+    return 0;
+}
+
 /* Whole-matrix helpers used to build synthetic weights (row length k = K, lib/ggml.c:12122). */
 void orc_quantize_q4(int type, const float *src, void *dst, int64_t nelem, int K) {
     const size_t bsz = type == 2 ? sizeof(orc_block_q4_0) : sizeof(orc_block_q4_1);

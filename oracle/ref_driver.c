@@ -94,3 +94,43 @@ void ref_mm_close(void *vh) {
     ggml_free(h->ctx);
     free(h);
 }
+
+/* LoRA merge as the reference does it (lib/llama.cpp:872-878): BA = ggml_mul_mat(loraA[r,K], loraB[r,M]) (f32 x f32 ->
+ * ggml_compute_forward_mul_mat_f32 -> ggml_vec_dot_f32), then ggml_add_inplace(W_q4, BA) -> ggml_compute_forward_add_q_f32
+ * (lib/ggml.c:6414): dequantize_row_q, ggml_vec_acc_f32, quantize_row_q (the SIMD quantizer).
+ * a: K rows of r floats (NULL when ba is given), b: M rows of r floats, ba: optional M rows of K floats (cached adapter).
+ * W (M rows of K/32 AoS blocks) is updated in place; ba_out (optional, M*K floats) receives the BA that was added. */
+int ref_lora_add(int type, void *W, const float *a, const float *b, const float *ba, int r, int M, int K, float sign,
+                 float *ba_out, int n_threads) {
+    if (type != GGML_TYPE_Q4_0 && type != GGML_TYPE_Q4_1) return -1;
+    const size_t wbytes = (size_t)M * (size_t)(K / 32) * ggml_type_size((enum ggml_type)type);
+    const size_t need = wbytes + 3 * (size_t)M * K * 4 + (size_t)(M + K) * (r > 0 ? r : 1) * 4 + (size_t)n_threads * (K + 64) * 8 + (64u << 20);
+    struct ggml_init_params ip;
+    memset(&ip, 0, sizeof ip);
+    ip.mem_size = need;
+    struct ggml_context *ctx = ggml_init(ip);
+    if (!ctx) return -2;
+    struct ggml_tensor *tw = ggml_new_tensor_2d(ctx, (enum ggml_type)type, K, M);
+    memcpy(tw->data, W, wbytes);
+    struct ggml_tensor *tba;
+    if (ba) {
+        tba = ggml_new_tensor_2d(ctx, GGML_TYPE_F32, K, M);
+        memcpy(tba->data, ba, (size_t)M * K * 4);
+    } else {
+        struct ggml_tensor *ta = ggml_new_tensor_2d(ctx, GGML_TYPE_F32, r, K);
+        struct ggml_tensor *tb = ggml_new_tensor_2d(ctx, GGML_TYPE_F32, r, M);
+        memcpy(ta->data, a, (size_t)K * r * 4);
+        memcpy(tb->data, b, (size_t)M * r * 4);
+        tba = ggml_mul_mat(ctx, ta, tb);
+    }
+    struct ggml_tensor *delta = tba;
+    if (sign != 1.0f) delta = ggml_scale(ctx, tba, ggml_new_f32(ctx, sign));     /* detach: lib/llama.cpp:933-934 */
+    struct ggml_tensor *res = ggml_add_inplace(ctx, tw, delta);
+    struct ggml_cgraph gf = ggml_build_forward(res);
+    gf.n_threads = n_threads;
+    ggml_graph_compute(ctx, &gf);
+    memcpy(W, tw->data, wbytes);
+    if (ba_out) memcpy(ba_out, tba->data, (size_t)M * K * 4);
+    ggml_free(ctx);
+    return 0;
+}

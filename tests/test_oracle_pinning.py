@@ -95,3 +95,26 @@ def test_reference_result_independent_of_thread_count(ref, port):
     y1 = ref.mul_mat_q(oracle.Q4_0, wq, x, n_threads=1)
     y4 = ref.mul_mat_q(oracle.Q4_0, wq, x, n_threads=4)
     assert np.array_equal(bits(y1), bits(y4))
+
+
+@pytest.mark.parametrize("qtype", [2, 3])
+@pytest.mark.parametrize("r", [4, 16, 32, 72])
+def test_lora_merge_restatement_pinned_to_reference(port, ref, qtype, r):
+    """oracle orc_lora_add (vec_dot_f32 lane order, dequantize + add + SIMD quantizer) == the reference's own
+    ggml_mul_mat(loraA, loraB) -> ggml_add_inplace(W_q4, BA) graph, byte for byte; attach, detach (sign -1) and the
+    cached-matrix form."""
+    rng = np.random.default_rng(100 * qtype + r)
+    M, K = 48, 256
+    wq = port.quantize_q4(qtype, (rng.standard_normal((M, K)) * 0.05).astype(np.float32))
+    a = (rng.standard_normal((K, r)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal((M, r)) * 0.1).astype(np.float32)
+    w_ref, ba_ref = ref.lora_add(qtype, wq, K, a=a, b=b)
+    w_orc, ba_orc = port.lora_add(qtype, wq, K, a=a, b=b)
+    assert np.array_equal(ba_ref.view(np.uint32), ba_orc.view(np.uint32))
+    assert np.array_equal(w_ref, w_orc) and not np.array_equal(w_ref, wq)
+    w_ref2, _ = ref.lora_add(qtype, w_ref, K, a=a, b=b, sign=-1.0)            # detach without mmap: W - BA, requantized
+    w_orc2, _ = port.lora_add(qtype, w_orc, K, a=a, b=b, sign=-1.0)
+    assert np.array_equal(w_ref2, w_orc2)
+    w_ref3, _ = ref.lora_add(qtype, wq, K, ba=ba_ref)                         # cached adapter
+    w_orc3, _ = port.lora_add(qtype, wq, K, ba=ba_ref)
+    assert np.array_equal(w_ref3, w_orc3) and np.array_equal(w_ref3, w_ref)
