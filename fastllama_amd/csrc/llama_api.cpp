@@ -286,36 +286,96 @@ struct Session {
         last_n.push_back(t);
     }
 
-    bool load(const char *path) {
+    // One model file: header, vocab and the tensor directory (file_loader.hpp:37-252).
+    struct TensorEntry { std::string name; uint32_t type = 0, n_dims = 0, ne[2] = {1, 1}; size_t off = 0, bytes = 0; };
+    struct ModelFile {
         MappedFile f;
-        if (!f.open(path)) { log.err("Model::load", std::string("unable to open '") + path + "'\n"); return false; }
-        Reader r{f.p, f.n};
-        const uint32_t magic = r.get<uint32_t>();
+        HParams hp;
         int version = 0;                                             // 0 GGML, 1 GGMF v1, 2 GGJT v1
-        if (magic == 0x67676d6c) version = 0;
+        std::vector<TensorEntry> tensors;
+    };
+
+    bool parse_file(const std::string &path, ModelFile &mf, bool want_vocab) {
+        if (!mf.f.open(path.c_str())) { log.err("Model::load", "unable to open '" + path + "'\n"); return false; }
+        Reader r{mf.f.p, mf.f.n};
+        const uint32_t magic = r.get<uint32_t>();
+        if (magic == 0x67676d6c) mf.version = 0;
         else if (magic == 0x67676d66 || magic == 0x67676a74) {
             const uint32_t fv = r.get<uint32_t>();
             if (fv != 1) { log.err("read_magic_number", "unsupported file version\n"); return false; }
-            version = magic == 0x67676d66 ? 1 : 2;
-        } else { log.err("read_magic_number", std::string("invalid model file '") + path + "' (bad magic)\n"); return false; }
-        hp.n_vocab = r.get<int32_t>(); hp.n_embd = r.get<int32_t>(); hp.n_mult = r.get<int32_t>(); hp.n_head = r.get<int32_t>();
-        hp.n_layer = r.get<int32_t>(); hp.n_rot = r.get<int32_t>(); hp.ftype = r.get<int32_t>();
-        if (!r.ok || hp.n_vocab <= 0 || hp.n_embd <= 0 || hp.n_head <= 0 || hp.n_layer <= 0 || hp.n_mult <= 0) {
+            mf.version = magic == 0x67676d66 ? 1 : 2;
+        } else { log.err("read_magic_number", "invalid model file '" + path + "' (bad magic)\n"); return false; }
+        HParams &h = mf.hp;
+        h.n_vocab = r.get<int32_t>(); h.n_embd = r.get<int32_t>(); h.n_mult = r.get<int32_t>(); h.n_head = r.get<int32_t>();
+        h.n_layer = r.get<int32_t>(); h.n_rot = r.get<int32_t>(); h.ftype = r.get<int32_t>();
+        if (!r.ok || h.n_vocab <= 0 || h.n_embd <= 0 || h.n_head <= 0 || h.n_layer <= 0 || h.n_mult <= 0) {
             log.err("read_hyperparams", "failed to read hyper parameters\n");
             return false;
         }
+        if (want_vocab) {
+            vocab.tok.resize((size_t)h.n_vocab);
+            vocab.score.assign((size_t)h.n_vocab, 0.f);
+        }
+        for (int i = 0; i < h.n_vocab; ++i) {
+            const uint32_t len = r.get<uint32_t>();
+            std::string w = r.str(len);
+            const float sc = mf.version >= 1 ? r.get<float>() : 0.f;
+            if (!r.ok) { log.err("read_vocab", "failed to read vocab\n"); return false; }
+            if (want_vocab) {
+                vocab.score[(size_t)i] = sc;
+                vocab.to_id[w] = i;
+                vocab.tok[(size_t)i] = std::move(w);
+            }
+        }
+        while (r.ok && r.off < r.n) {
+            TensorEntry t;
+            t.n_dims = r.get<uint32_t>();
+            const uint32_t name_len = r.get<uint32_t>();
+            t.type = r.get<uint32_t>();
+            if (!r.ok) break;
+            if (t.n_dims < 1 || t.n_dims > 2) { log.err("read_tensor_metadata", "tensor has a bad number of dimensions\n"); return false; }
+            for (uint32_t d = 0; d < t.n_dims; ++d) t.ne[d] = r.get<uint32_t>();
+            t.name = r.str(name_len);
+            if (mf.version >= 2) r.off += (size_t)(-(int64_t)r.off & 31);
+            const size_t nel = (size_t)t.ne[0] * t.ne[1];
+            if (t.type == 0) t.bytes = nel * 4;
+            else if (t.type == 1) t.bytes = nel * 2;
+            else if (t.type == FL_TYPE_Q4_0) t.bytes = nel / 32 * 20;
+            else if (t.type == FL_TYPE_Q4_1) t.bytes = nel / 32 * 24;
+            else { log.err("read_tensor_metadata", "unrecognized tensor type\n"); return false; }
+            if (!r.ok || r.off + t.bytes > r.n) { log.err("read_tensor_metadata", "truncated tensor '" + t.name + "'\n"); return false; }
+            t.off = r.off;
+            r.off += t.bytes;
+            mf.tensors.push_back(std::move(t));
+        }
+        return true;
+    }
+
+    // Model::load (lib/llama.cpp:105-270) + ModelLoader (file_loader.hpp:377-644).  Multi-part checkpoints
+    // (<path>, <path>.1, ...; count = n_embd / ne0 of tok_embeddings in the first part, :443-453) are merged the way the
+    // loader's split table intends -- tok_embeddings / wo / w2 by columns (each row is the concatenation of the parts'
+    // rows), every other matrix by rows, vectors not split (tensor/utils.hpp:93-112) -- and go to HBM as one tensor.
+    bool load(const char *path) {
+        std::vector<std::unique_ptr<ModelFile>> files;
+        files.emplace_back(new ModelFile());
+        if (!parse_file(path, *files[0], true)) return false;
+        hp = files[0]->hp;
         if (hp.ftype != FL_TYPE_Q4_0 && hp.ftype != FL_TYPE_Q4_1) {
             log.err("Model::load", "this build evaluates Q4_0 / Q4_1 models on the GPU (file ftype " + std::to_string(hp.ftype) + ")\n");
             return false;
         }
-        vocab.tok.resize((size_t)hp.n_vocab);
-        vocab.score.assign((size_t)hp.n_vocab, 0.f);
-        for (int i = 0; i < hp.n_vocab; ++i) {
-            const uint32_t len = r.get<uint32_t>();
-            vocab.tok[(size_t)i] = r.str(len);
-            if (version >= 1) vocab.score[(size_t)i] = r.get<float>();
-            if (!r.ok) { log.err("read_vocab", "failed to read vocab\n"); return false; }
-            vocab.to_id[vocab.tok[(size_t)i]] = i;
+        size_t n_files = 1;
+        for (const TensorEntry &t : files[0]->tensors)
+            if (t.name == "tok_embeddings.weight" && t.ne[0] > 0) n_files = (size_t)hp.n_embd / t.ne[0];
+        if (n_files < 1) n_files = 1;
+        for (size_t i = 1; i < n_files; ++i) {
+            files.emplace_back(new ModelFile());
+            const std::string pi = std::string(path) + "." + std::to_string(i);
+            if (!parse_file(pi, *files[i], false)) return false;
+            if (memcmp(&files[i]->hp, &hp, sizeof hp) != 0) {
+                log.err("ModelLoader", "Hyper parameters mismatch between '" + pi + "' and '" + path + "'\n");
+                return false;
+            }
         }
         const int n_ff = ((2 * (4 * hp.n_embd) / 3 + hp.n_mult - 1) / hp.n_mult) * hp.n_mult;   // lib/llama.cpp:129
         max_batch = std::min(args.n_ctx, std::max(args.n_batch, args.n_keep + (int)args.last_n_tokens + args.n_batch));
@@ -326,29 +386,43 @@ struct Session {
         model = fl_model_create(&mp);
         if (!model) { log.err("Model::load", std::string(fl_last_error()) + "\n"); return false; }
         log.info("Model::load", "n_vocab=" + std::to_string(hp.n_vocab) + " n_embd=" + std::to_string(hp.n_embd) + " n_head=" +
-                                    std::to_string(hp.n_head) + " n_layer=" + std::to_string(hp.n_layer) + " n_ff=" + std::to_string(n_ff) + "\n");
+                                    std::to_string(hp.n_head) + " n_layer=" + std::to_string(hp.n_layer) + " n_ff=" + std::to_string(n_ff) +
+                                    (n_files > 1 ? " parts=" + std::to_string(n_files) : std::string()) + "\n");
         size_t done = 0;
-        while (r.ok && r.off < r.n) {
-            const uint32_t n_dims = r.get<uint32_t>(), name_len = r.get<uint32_t>(), type = r.get<uint32_t>();
-            if (!r.ok) break;
-            if (n_dims < 1 || n_dims > 2) { log.err("read_tensor_metadata", "tensor has a bad number of dimensions\n"); return false; }
-            uint32_t ne[2] = {1, 1};
-            for (uint32_t d = 0; d < n_dims; ++d) ne[d] = r.get<uint32_t>();
-            const std::string name = r.str(name_len);
-            if (version >= 2) r.off += (size_t)(-(int64_t)r.off & 31);
-            size_t bytes;
-            const size_t nel = (size_t)ne[0] * ne[1];
-            if (type == 0) bytes = nel * 4;
-            else if (type == 1) bytes = nel * 2;
-            else if (type == FL_TYPE_Q4_0) bytes = nel / 32 * 20;
-            else if (type == FL_TYPE_Q4_1) bytes = nel / 32 * 24;
-            else { log.err("read_tensor_metadata", "unrecognized tensor type\n"); return false; }
-            if (!r.ok || r.off + bytes > r.n) { log.err("read_tensor_metadata", "truncated tensor '" + name + "'\n"); return false; }
-            if (fl_model_set_tensor(model, name.c_str(), (int)type, r.p + r.off, (int)ne[0], (int)ne[1]) != FL_OK) {
+        std::vector<uint8_t> merged;
+        for (const TensorEntry &t0 : files[0]->tensors) {
+            const uint8_t *data = files[0]->f.p + t0.off;
+            uint32_t ne0 = t0.ne[0], ne1 = t0.ne[1];
+            if (n_files > 1 && t0.n_dims == 2) {
+                std::vector<const TensorEntry *> sh{&t0};
+                for (size_t i = 1; i < n_files; ++i) {
+                    const TensorEntry *found = nullptr;
+                    for (const TensorEntry &t : files[i]->tensors) if (t.name == t0.name) found = &t;
+                    if (!found || found->type != t0.type || found->ne[0] != t0.ne[0] || found->ne[1] != t0.ne[1] || found->bytes != t0.bytes) {
+                        log.err("ModelLoader", "inconsistent tensor shards for '" + t0.name + "'\n");
+                        return false;
+                    }
+                    sh.push_back(found);
+                }
+                const bool by_cols = t0.name.rfind("tok_embeddings.", 0) == 0 || t0.name.find(".attention.wo.weight") != std::string::npos ||
+                                     t0.name.find(".feed_forward.w2.weight") != std::string::npos;
+                merged.resize(t0.bytes * n_files);
+                if (by_cols) {
+                    const size_t row_bytes = t0.bytes / t0.ne[1];
+                    for (uint32_t rrow = 0; rrow < t0.ne[1]; ++rrow)
+                        for (size_t i = 0; i < n_files; ++i)
+                            memcpy(merged.data() + ((size_t)rrow * n_files + i) * row_bytes, files[i]->f.p + sh[i]->off + (size_t)rrow * row_bytes, row_bytes);
+                    ne0 = t0.ne[0] * (uint32_t)n_files;
+                } else {
+                    for (size_t i = 0; i < n_files; ++i) memcpy(merged.data() + i * t0.bytes, files[i]->f.p + sh[i]->off, t0.bytes);
+                    ne1 = t0.ne[1] * (uint32_t)n_files;
+                }
+                data = merged.data();
+            }
+            if (fl_model_set_tensor(model, t0.name.c_str(), (int)t0.type, data, (int)ne0, (int)ne1) != FL_OK) {
                 log.err("Model::load", std::string(fl_last_error()) + "\n");
                 return false;
             }
-            r.off += bytes;
             log.progress(PROGRESS_TAG_LOAD, ++done, (size_t)(3 + 9 * hp.n_layer));
         }
         if (fl_model_finalize(model) != FL_OK) { log.err("Model::load", std::string(fl_last_error()) + "\n"); return false; }

@@ -91,6 +91,27 @@ def write_ggjt(path: str, cfg: dict, qtype: int, tensors: dict):
             f.write(np.ascontiguousarray(data).tobytes())
 
 
+def write_ggjt_parts(path: str, cfg: dict, qtype: int, tensors: dict, n_parts: int):
+    """The same model as `n_parts` files <path>, <path>.1, ... the way the original multi-part LLaMA checkpoints were
+    converted: tok_embeddings / wo / w2 split along ne0 (columns), every other matrix along ne1 (rows), vectors whole in
+    every part (the split table of the reference's loader, include/tensor/utils.hpp:93-112)."""
+    for part in range(n_parts):
+        sub = {}
+        for name, (gtype, shape, data) in tensors.items():
+            if len(shape) == 1:
+                sub[name] = (gtype, shape, data)
+                continue
+            K, M = shape
+            arr = np.ascontiguousarray(data).reshape(M, -1)
+            if name.startswith("tok_embeddings.") or ".attention.wo.weight" in name or ".feed_forward.w2.weight" in name:
+                w = arr.shape[1] // n_parts
+                sub[name] = (gtype, (K // n_parts, M), arr[:, part * w:(part + 1) * w])
+            else:
+                rows = M // n_parts
+                sub[name] = (gtype, (K, rows), arr[part * rows:(part + 1) * rows])
+        write_ggjt(path if part == 0 else f"{path}.{part}", cfg, qtype, sub)
+
+
 def write_lora(path: str, adapters: dict, r: int, alpha: int, cached: bool = False):
     """'ggla' v1 adapter file as scripts/convert-lora-to-ggml.py writes it (header :52-55, tensors :57-72).
     adapters: base tensor name -> (A [ne0(base), r] f32 ALREADY scaled by alpha/r, B [ne1(base), r] f32), or, with

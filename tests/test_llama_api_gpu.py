@@ -149,3 +149,26 @@ def test_error_paths(libs, tmp_path):
     bad.write_bytes(b"notamodel" * 10)
     assert not L.llama_load_model(ctx, os.fsencode(str(bad)))
     L.llama_free_context(ctx)
+
+
+@pytest.mark.parametrize("n_parts", [2, 4])
+def test_multi_part_checkpoint_merges_to_the_same_model(tmp_path_factory, n_parts):
+    """<path>, <path>.1, ... (tok_embeddings / wo / w2 split by columns, the other matrices by rows) load to exactly the
+    model of the single file: same logits bit for bit (file_loader.hpp:377-453, tensor/utils.hpp:93-112)."""
+    port = oracle.Port()
+    cfg, qtype = ggjt.SMALL, ggjt.Q4_1
+    tensors = ggjt.synth_tensors(cfg, qtype, port.quantize_q4, seed=77)
+    d = tmp_path_factory.mktemp("parts")
+    one, many = str(d / "one.bin"), str(d / "many.bin")
+    ggjt.write_ggjt(one, cfg, qtype, tensors)
+    ggjt.write_ggjt_parts(many, cfg, qtype, tensors, n_parts)
+    lib = llama_capi.LlamaLib(OURS)
+    text = "multi part checkpoints merge on load"
+    a = llama_capi.Session(lib, one, n_ctx=64, n_batch=64, all_logits=True)
+    b = llama_capi.Session(lib, many, n_ctx=64, n_batch=64, all_logits=True)
+    assert a.perplexity(text) == b.perplexity(text)
+    assert np.array_equal(a.logits(), b.logits())
+    a.close(); b.close()
+    os.remove(many + ".1")
+    with pytest.raises(RuntimeError):
+        llama_capi.Session(lib, many, n_ctx=64, n_batch=64)
