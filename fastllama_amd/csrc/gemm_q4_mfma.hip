@@ -168,11 +168,12 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
 
     // Accumulators live in groups of four 16x16 tiles (v16f = the D operand of one 4-block f32 MFMA).  Tiles of one
     // K-step are numbered flat = b*TT + i*TN + j; group u = flat/4 shares one "scale MFMA", lane group k = flat%4.
-    // TT = 2 (one 16x32 wave tile): the group is {b even, b odd} x {j0, j1} -- even/odd blocks accumulate apart.
+    // Every output accumulates its blocks in K order whatever the tile shape: results do not depend on the configuration.
     constexpr int TT = TM * TN;
+    // TT = 2 (16x32 wave tile): one scale MFMA serves the two blocks of a K-step (lane groups {b0 j0, b0 j1, b1 j0, b1 j1});
+    // both blocks still accumulate into the same two accumulator slots, in K order.
     static_assert(TT == 2 || TT % 4 == 0, "wave tile must be 2 or a multiple of 4 MFMA tiles");
     static_assert(TN == 2 || TN == 4, "TN must be 2 or 4");
-    static_assert(TT != 2 || GM_KS % 2 == 0, "16x32 wave tiles pair up two quant blocks");
     constexpr int G = TT == 2 ? 1 : TT / 4;            // accumulator groups
     v16f acc[G], msacc[G];
 #pragma unroll
@@ -195,13 +196,17 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
     else { ki = lg >> 1; kj = lg & 1; kb = 0; }
     const int sa_off = Cfg::OFF_PL + (((wm * TM + ki) * GM_KS + kb) * 16 + l15) * 4;          // d_w (m_w: +2048)
     const int sb_off = Cfg::OFF_PL + 1024 + (((wn * TN + kj) * GM_KS + kb) * 16 + l15) * 4;   // d_x (s_x: +2048)
+    // TT = 2, Q4_1: the m_w x s_x MFMA is issued per block (lane groups {j0, j1, j0, j1} of THAT block) so that its
+    // accumulator sees the blocks in K order like every other configuration
+    const int ma_off = Cfg::OFF_PL + 2048 + ((wm * TM) * GM_KS * 16 + l15) * 4;
+    const int mb_off = Cfg::OFF_PL + 1024 + 2048 + ((wn * TN + (lg & 1)) * GM_KS * 16 + l15) * 4;
 
     // ---- block-granular software pipeline (GM_KS = 2 blocks per stage) --------------------------------------------
     //   registers hold the operands of two quant blocks: the one the MFMAs are consuming and the one whose LDS reads are
     //   in flight.  Step t:   read(t, b1) | tiles of (t, b0) | wait + barrier + fill(stage t+3) + read(t+1, b0) | tiles of (t, b1)
     //   so LDS latency, the barrier and the fill issue all sit under a full block of MFMA/VALU work of the same wave.
     static_assert(GM_KS == 2 && GM_NSTAGE >= 3, "pipeline below is written for 2 blocks per stage, >= 3 stages");
-    constexpr int UB = TT == 2 ? 1 : TT / 4;           // scale MFMAs per block (TT == 2: one per STEP, read with block 0)
+    constexpr int UB = TT == 2 ? 1 : TT / 4;           // scale MFMAs per block (TT == 2: one per K-step, read with block 0)
     struct Ops {
         uint32_t araw[TM];                             // packed nibbles as read from LDS (unpacked right before use)
         long bq[TN];
@@ -212,13 +217,19 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
         for (int i = 0; i < TM; ++i) o.araw[i] = *reinterpret_cast<const uint32_t *>(base + a_off + (i * GM_KS + b) * 256);
 #pragma unroll
         for (int j = 0; j < TN; ++j) o.bq[j] = *reinterpret_cast<const long *>(base + b_off + (j * GM_KS + b) * 512);
-        if (TT == 2 && b != 0) return;
+        if constexpr (TT == 2) {
+            if (TYPE == FL_TYPE_Q4_1) {
+                o.ma[0] = *reinterpret_cast<const float *>(base + ma_off + b * 64);
+                o.mb[0] = *reinterpret_cast<const float *>(base + mb_off + b * 64);
+            }
+            if (b != 0) return;
+            o.sa[0] = *reinterpret_cast<const float *>(base + sa_off);
+            o.sb[0] = *reinterpret_cast<const float *>(base + sb_off);
+            return;
+        }
 #pragma unroll
         for (int ub = 0; ub < UB; ++ub) {
-            int cu_i;                                  // compile-time part of i for group ub (lane part is in sa_off)
-            if constexpr (TT == 2) cu_i = 0;
-            else if constexpr (TN == 4) cu_i = ub;
-            else cu_i = ub * 2;
+            const int cu_i = TN == 4 ? ub : ub * 2;    // compile-time part of i for group ub (lane part is in sa_off)
             const int oa = (cu_i * GM_KS + b) * 64, ob = b * 64;
             o.sa[ub] = *reinterpret_cast<const float *>(base + sa_off + oa);
             o.sb[ub] = *reinterpret_cast<const float *>(base + sb_off + ob);
@@ -262,15 +273,13 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
             }
         };
         auto tile_mfma = [&](int flat) FL_NOPK __attribute__((always_inline)) -> v4i {
-            int b, i, j;
-            if constexpr (TT == 2) { b = flat / 2; i = 0; j = flat % 2; }
-            else { b = flat / TT; i = (flat % TT) / TN; j = flat % TN; }
+            const int b = flat / TT, i = (flat % TT) / TN, j = flat % TN;   // (TT == 2: i = 0)
             return FL_MFMA(afrag[b][i], ops[b].bq[j], magic);
         };
         auto scale_mfma = [&](int u, v16f &P) FL_NOPK __attribute__((always_inline)) {   // group u of the step
             const int b = TT == 2 ? 0 : u / UB, ub = TT == 2 ? 0 : u % UB;
             P = __builtin_amdgcn_mfma_f32_16x16x1f32(ops[b].sa[ub], ops[b].sb[ub], zero16, 0, 0, 0);
-            if (TYPE == FL_TYPE_Q4_1)
+            if (TYPE == FL_TYPE_Q4_1 && TT != 2)
                 msacc[u % G] = __builtin_amdgcn_mfma_f32_16x16x1f32(ops[b].ma[ub], ops[b].mb[ub], msacc[u % G], 0, 0, 0);
         };
         v16f P0, P1 = zero16;
@@ -296,12 +305,15 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
             }
             __builtin_amdgcn_sched_barrier(0);
             const int u = tt / 4, k = tt % 4, g = u % G;
+            const int ka = TT == 2 ? (k & 1) : k;                                      // accumulator slot of the tile
+            if (TT == 2 && TYPE == FL_TYPE_Q4_1 && (tt % TT) == 0)                      // per block, slots {j0, j1}
+                msacc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(ops[tt / TT].ma[0], ops[tt / TT].mb[0], msacc[0], 0, 0, 0);
             const v4f f = __builtin_bit_cast(v4f, (tt & 1) ? r1 : r0) + negmagic;   // exact: float(isum)
             const v16f &P = (u & 1) ? P1 : P0;
             const v4f p = {P[4 * k], P[4 * k + 1], P[4 * k + 2], P[4 * k + 3]};        // d_w*d_x (ggml.c:2452)
-            v4f a = {acc[g][4 * k], acc[g][4 * k + 1], acc[g][4 * k + 2], acc[g][4 * k + 3]};
+            v4f a = {acc[g][4 * ka], acc[g][4 * ka + 1], acc[g][4 * ka + 2], acc[g][4 * ka + 3]};
             a = __builtin_elementwise_fma(f, p, a);                                     // fma(d, isum, acc) (:2478)
-            acc[g][4 * k] = a[0]; acc[g][4 * k + 1] = a[1]; acc[g][4 * k + 2] = a[2]; acc[g][4 * k + 3] = a[3];
+            acc[g][4 * ka] = a[0]; acc[g][4 * ka + 1] = a[1]; acc[g][4 * ka + 2] = a[2]; acc[g][4 * ka + 3] = a[3];
             __builtin_amdgcn_sched_barrier(0);
             if (tt == TT - 1) {
                 // every MFMA of block 0 has been issued: its operand registers are free.  Stage t+1 must have landed
@@ -332,13 +344,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
         for (int j = 0; j < TN; ++j) {
             const int n = (ng0 + wn * TN + j) * 16 + l15;
             v4f o;
-            if constexpr (TT == 2) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o[e] = acc[0][4 * j + e] + acc[0][8 + 4 * j + e];          // even + odd quant blocks
-                    if (TYPE == FL_TYPE_Q4_1) o[e] += msacc[0][4 * j + e] + msacc[0][8 + 4 * j + e];
-                }
-            } else {
+            {
                 const int flat = i * TN + j, g = flat / 4, k = flat % 4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -369,8 +375,11 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
     X(1, 2, 2, 2, 4, 4) /*  64x128   4 waves of 32x64                    */ \
     X(2, 4, 2, 2, 4, 2) /* 128x128   8 waves of 32x64                    */ \
     X(3, 4, 2, 1, 4, 2) /*  64x128   8 waves of 16x64                    */ \
-    X(4, 4, 4, 1, 2, 1) /*  64x128  16 waves of 16x32                    */ \
-    X(5, 4, 4, 2, 2, 1) /* 128x128  16 waves of 32x32                    */
+    X(4, 4, 4, 2, 2, 1) /* 128x128  16 waves of 32x32                    */ \
+    X(5, 2, 2, 2, 2, 4) /*  64x64    4 waves of 32x32                    */ \
+    X(6, 2, 4, 2, 2, 2) /*  64x128   8 waves of 32x32                    */ \
+    X(7, 4, 2, 2, 2, 2) /* 128x64    8 waves of 32x32                    */ \
+    X(8, 4, 4, 1, 2, 1) /*  64x128  16 waves of 16x32                    */
 
 int g_gemm_force_cfg = -1;  // debug / autotune hook: >= 0 forces one configuration
 
@@ -393,17 +402,30 @@ static hipError_t launch_gemm(const fl_qtensor &W, const fl_qact &xq, int N, flo
     return hipGetLastError();
 }
 
-// Choose the workgroup shape from the problem shape.  The quantity that matters (measured) is
-// waves per SIMD actually doing epilogue VALU work: tiles are cheap to shrink (QW16/QA16 keep the fills
-// linear), idle SIMDs are not.
-static int pick_config(int MGT, int NGT) {
+// Choose the workgroup shape from the problem shape (sweeps: scripts/sweep_cfg.py, profiles/r01_gemm_cfg_sweep.txt).
+// Two things decide: (1) how evenly the workgroups cover the 256 CUs -- `quant` = work of the busiest CU relative to a
+// perfect split, which is what makes e.g. M = 5120 or 27648 prefer the smaller tiles; (2) among equally balanced
+// shapes the larger wave tile wins when there is plenty of work (fewer LDS bytes and barriers per MFMA), the many-small-
+// waves shape when there is little (all 1024 SIMDs busy, latency hidden by occupancy).
+static int pick_config(int MGT, int NGT, int type) {
     if (g_gemm_force_cfg >= 0) return g_gemm_force_cfg;
-    const int64_t tiles16 = (int64_t)MGT * NGT;      // 16x16 output tiles
-    const double per_simd = (double)tiles16 / 1024;  // MI355X: 256 CUs x 4 SIMDs
-    // thresholds from scripts/sweep_cfg.py on MI355X at N=512 (profiles/r01_gemm_cfg_sweep.txt)
-    if (per_simd >= 40) return 2;                    // plenty of work: 128x128 tiles, 8 waves of 32x64
-    if (per_simd >= 12) return 1;                    // 64x128 tiles, 4 waves of 32x64, 4 workgroups per CU
-    return 4;                                        // small outputs: 64x128 tiles, 16 waves of 16x32
+    const double tiles16 = (double)MGT * NGT;        // 16x16 output tiles
+    const double per_simd = tiles16 / 1024;          // MI355X: 256 CUs x 4 SIMDs
+    auto quant = [&](int MG, int NG) {
+        const int64_t wgs = (int64_t)((MGT + MG - 1) / MG) * ((NGT + NG - 1) / NG);
+        return (double)((wgs + 255) / 256) * 256.0 * MG * NG / tiles16;
+    };
+    const double q2 = quant(8, 8), q1 = quant(4, 8), q5 = quant(4, 4), q7 = quant(8, 4);
+    if (per_simd < 12) {                                                         // small outputs
+        if (type == FL_TYPE_Q4_1) return q7 > 1.1 * q5 ? 5 : 7;                  // (16x32 tiles pay an extra m*s MFMA per block)
+        return q1 > 1.1 * q5 ? 5 : 8;                                            // 16 waves of 16x32 on a 64x128 tile
+    }
+    int best = 2;
+    double qb = q2;
+    if (q1 < 0.96 * qb) { best = 1; qb = q1; }
+    if (q5 < 0.96 * qb) { best = 5; qb = q5; }
+    if (per_simd < 40 && best == 2 && q1 <= q2) best = 1;                         // mid-size: 4 workgroups of 4 waves per CU
+    return best;
 }
 
 hipError_t gemm_q4_mfma(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
@@ -411,7 +433,7 @@ hipError_t gemm_q4_mfma(const fl_qtensor &W, const fl_qact &xq, int N, float *y,
     if (resid && ((ldr & 3) != 0 || (reinterpret_cast<uintptr_t>(resid) & 15) != 0)) return hipErrorInvalidValue;
     if ((ldy & 3) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return hipErrorInvalidValue;
     const int MGT = W.M16 / 16, NGT = fl_roundup(N, 16) / 16;
-    const int cfg = pick_config(MGT, NGT);
+    const int cfg = pick_config(MGT, NGT, W.type);
 #define X(ID, WM, WN, TM, TN, MINW)                                                                         \
     if (cfg == ID)                                                                                          \
         return W.type == FL_TYPE_Q4_0 ? launch_gemm<FL_TYPE_Q4_0, WM, WN, TM, TN, MINW>(W, xq, N, y, ldy, st, resid, ldr) \
