@@ -22,6 +22,11 @@ hipError_t gemm_f32_abt(const float *A, int lda, int64_t sAz, const float *B, in
                         hipStream_t st, const int *dyn_past = nullptr, int nn_max = 0);
 hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab,
                         hipStream_t st, const int *dyn_past = nullptr);
+// prefill: KQ*scale + mask + soft_max + KQV per (head, 32 query rows), score rows in LDS; q = roped Q rows of qkv,
+// kc / vc already hold the new positions.  hipErrorInvalidValue: shape does not fit -> use the three-kernel path.
+hipError_t prefill_attention(const float *qkv, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc,
+                             const float *vc, const uint16_t *exp_tab, int tab_n, float scale, float *ao, int ldo,
+                             hipStream_t st);
 // decode (N = 1): rope + KV store + KQ + soft_max + KQV + Q8_0 of the result, one workgroup per head
 hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab, float *kc,
                             float *vc, const uint16_t *exp_tab, float scale, const fl_qact *out, hipStream_t st,

@@ -340,6 +340,320 @@ hipError_t gemm_f32_abt(const float *A, int lda, int64_t sAz, const float *B, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// prefill attention: KQ*scale -> diag_mask_inf + soft_max -> KQV with the score rows kept in LDS
+// (lib/llama.cpp:364-398 without the [heads][N][n_ctx] round trip through HBM).
+//
+// One 512-thread workgroup per (head, PAIR of 32-row query blocks {x, nb-1-x}): causal attention gives block i
+// (i+1) key tiles, so pairing the lightest with the heaviest makes every workgroup equally heavy -- with one
+// workgroup per CU resident from the start there is no second scheduling round to even things out.
+//   phase 0  the useful part of the fp16 exp table (arguments in [-17.4, -0]; everything below is 0) -> LDS
+//   phase 1  wave w computes 32x32 score tiles w, w+8, ... of block a, then of block b (exact-f32 MFMA, the k pairing
+//            and order of gemm_f32_abt_kernel; Q fragments in registers, next K tile prefetched during the MFMAs)
+//   phase 2  soft_max of the 64 rows (the arithmetic of softmax_rows_kernel; table lookups from LDS, four rows'
+//            lookups in flight together)
+//   phase 3  wave w: block w/4, output columns [32(w%4), +32) of the head: A = probabilities (LDS), B = transposed V
+// Per output the MFMA sequence is the one of gemm_f32_abt(KQ) -> softmax_rows -> gemm_f32_abt(KQV): bit-identical,
+// and independent of how rows are grouped into blocks.
+// ------------------------------------------------------------------------------------------------
+// wave-wide reductions with DPP for the in-row steps (ds_bpermute, which __shfl_xor compiles to, costs an LDS round
+// trip per step): quad_perm xor 1 / xor 2, row_half_mirror, row_mirror, then two cross-row shuffles.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ float wave_max_f32(float m) {
+    m = fmaxf(m, __builtin_bit_cast(float, dpp_i32<0xB1>(__builtin_bit_cast(int, m))));    // quad_perm [1,0,3,2]
+    m = fmaxf(m, __builtin_bit_cast(float, dpp_i32<0x4E>(__builtin_bit_cast(int, m))));    // quad_perm [2,3,0,1]
+    m = fmaxf(m, __builtin_bit_cast(float, dpp_i32<0x141>(__builtin_bit_cast(int, m))));   // row_half_mirror
+    m = fmaxf(m, __builtin_bit_cast(float, dpp_i32<0x140>(__builtin_bit_cast(int, m))));   // row_mirror
+    m = fmaxf(m, __shfl_xor(m, 16));
+    return fmaxf(m, __shfl_xor(m, 32));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)dpp_i32<CTRL>((int)(unsigned)b), hi = (unsigned)dpp_i32<CTRL>((int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double s) {
+    s += dpp_f64<0xB1>(s);
+    s += dpp_f64<0x4E>(s);
+    s += dpp_f64<0x141>(s);
+    s += dpp_f64<0x140>(s);
+    s += __shfl_xor(s, 16);
+    return s + __shfl_xor(s, 32);
+}
+
+// soft_max of FOUR score rows held in LDS by one wave: IT 64-column steps cover the longest of them.  Straight-line
+// code (clamped addresses + selects, no branches) so that the LDS round trips of all columns overlap.  The f64 sum of
+// fp16-valued terms is exact, so its order is free; everything else is the arithmetic of softmax_rows_kernel.
+template <int IT>
+__device__ __forceinline__ void pa_softmax4(float *const (&rowp)[4], const int (&Ls)[4], int ncol, const uint16_t *tab,
+                                            int tab_n, int lane) {
+    float x[4][IT];
+#pragma unroll
+    for (int u4 = 0; u4 < 4; ++u4)
+#pragma unroll
+        for (int u = 0; u < IT; ++u) {
+            const int i = lane + 64 * u;
+            const float v = rowp[u4][min(i, ncol - 1)];                 // always a valid LDS address of this row
+            x[u4][u] = i < Ls[u4] ? v : -INFINITY;
+        }
+    float mx[4];
+#pragma unroll
+    for (int u4 = 0; u4 < 4; ++u4) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < IT; ++u) m = fmaxf(m, x[u4][u]);
+        mx[u4] = wave_max_f32(m);
+    }
+#pragma unroll
+    for (int u4 = 0; u4 < 4; ++u4) {
+        double sum = 0.0;
+#pragma unroll
+        for (int u = 0; u < IT; ++u) {
+            const float xv = x[u4][u];
+            const uint16_t hb = __half_as_ushort(__float2half_rn(xv - mx[u4]));
+            const int idx = (int)hb - 0x8000;
+            const uint16_t t = tab[min(max(idx, 0), tab_n - 1)];
+            // hb == 0: exp(+0) = 1; [0x8000, 0x8000+tab_n): the table; up to -inf (0xFC00): underflows to 0 in fp16
+            // (host-checked bound); anything else is a NaN (or a positive difference, impossible): NaN like the table
+            const uint16_t e = hb == 0 ? (uint16_t)0x3C00 : idx < 0 ? (uint16_t)0x7E00 : idx < tab_n ? t : hb <= 0xFC00 ? (uint16_t)0 : (uint16_t)0x7E00;
+            const float v = (xv != -INFINITY) ? __half2float(__ushort_as_half(e)) : 0.f;   // masked / beyond the row: nothing
+            x[u4][u] = v;
+            sum += (double)v;
+        }
+        sum = wave_sum_f64(sum);
+        const float inv = (float)(1.0 / sum);
+#pragma unroll
+        for (int u = 0; u < IT; ++u) {
+            const int i = lane + 64 * u;
+            if (i < ncol) rowp[u4][i] = i < Ls[u4] ? __fmul_rn(x[u4][u], inv) : 0.f;
+        }
+    }
+}
+
+#ifdef PA_TIMING   // development build only: per-phase clocks of a few workgroups (scripts/attn_only.py)
+__device__ long long pa_dbg[64 * 8];
+#define PA_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y < 8) pa_dbg[blockIdx.y * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define PA_STAMP(k) do {} while (0)
+#endif
+constexpr int PA_T = 512, PA_SM_IT = 15;                              // threads; 64-column steps of a row (P <= 960)
+
+template <int NSTEP>   // head_dim / 8
+__global__ __launch_bounds__(PA_T) void prefill_attention_kernel(const float *__restrict__ qkv, int ldq, int N, int n_past,
+                                                                 int n_ctx, int E, const float *__restrict__ kc,
+                                                                 const float *__restrict__ vc,
+                                                                 const uint16_t *__restrict__ exp_tab, int tab_n,
+                                                                 float scale, float *__restrict__ ao, int ldo, int pair) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    constexpr int D = NSTEP * 8;
+    // grid = (heads, block pairs): consecutive workgroup ids go to consecutive XCDs, so all workgroups of a head share
+    // one XCD's L2 (its K and V, 2 x n_ctx x 512 B, are read by every one of them)
+    const int h = blockIdx.x, bx = blockIdx.y;
+    const int nb = (N + 31) >> 5;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, kk = lane >> 5;
+    const int P = n_past + N;
+    // the two blocks of this workgroup: mb0 (light), mb1 (heavy; -1 if none).  Scalars + selects, not arrays: a
+    // runtime-indexed array would live in scratch.
+    const int mb0 = bx;
+    int mb1 = pair ? nb - 1 - bx : -1;
+    if (pair && mb1 <= mb0) mb1 = -1;                                   // middle block of an odd count: alone
+    const int kend0 = min(P, n_past + mb0 * 32 + 32);                  // keys any row of the block can see
+    const int kend1 = mb1 >= 0 ? min(P, n_past + mb1 * 32 + 32) : 0;
+    const int ntl0 = (kend0 + 31) >> 5, ntl1 = (kend1 + 31) >> 5;
+    const int strd0 = ntl0 * 32 + 4, strd1 = ntl1 * 32 + 4;           // + 4 floats: rows land on different LDS banks
+    float *const S0 = reinterpret_cast<float *>(psm);
+    float *const S1 = S0 + 32 * strd0;
+    float *base = S1 + 32 * strd1;
+#define PA_SEL(q, a, b) ((q) ? (b) : (a))
+    uint16_t *tab = reinterpret_cast<uint16_t *>(base);                  // exp table for fp16 arguments 0x8000 + [0, tab_n)
+
+    PA_STAMP(0);
+    // ---- phase 0 (the table copy) is issued by every thread right after its first Q/K loads: one memory round trip ----
+    bool table_done = false;
+    auto copy_table = [&] {
+        for (int i = threadIdx.x; i * 8 < tab_n; i += PA_T)
+            reinterpret_cast<uint4 *>(tab)[i] = reinterpret_cast<const uint4 *>(exp_tab + 0x8000)[i];
+        table_done = true;
+    };
+
+#ifndef PA_ABL
+#define PA_ABL 0
+#endif
+    PA_STAMP(1);
+    // ---- phase 1: scores ----   (PA_ABL: timing experiments only, never defined in the product)
+    if (!(PA_ABL & 1)) {
+#pragma unroll 1
+        for (int q = 0; q < 2; ++q) {
+            const int mbq = PA_SEL(q, mb0, mb1), ntlq = PA_SEL(q, ntl0, ntl1), strdq = PA_SEL(q, strd0, strd1);
+            float *const Sq = PA_SEL(q, S0, S1);
+            if (mbq < 0 || wave >= ntlq) continue;
+            const int m0 = mbq * 32;
+            const float *pa = qkv + (int64_t)min(m0 + r, N - 1) * ldq + h * D;
+            float4 qf[NSTEP];                                         // 8 k per step, lane half kk takes k+4kk..
+#pragma unroll
+            for (int j = 0; j < NSTEP; ++j) qf[j] = *reinterpret_cast<const float4 *>(pa + 8 * j + 4 * kk);
+            float4 kf[NSTEP], kn[NSTEP];
+            auto load_k = [&](float4 (&dst)[NSTEP], int kt) {
+                const float *pb = kc + (int64_t)min(kt * 32 + r, P - 1) * E + h * D;
+#pragma unroll
+                for (int j = 0; j < NSTEP; ++j) dst[j] = *reinterpret_cast<const float4 *>(pb + 8 * j + 4 * kk);
+            };
+            load_k(kf, wave);
+            if (!table_done) copy_table();
+            for (int kt = wave; kt < ntlq; kt += PA_T / 64) {
+                if (kt + PA_T / 64 < ntlq && !(PA_ABL & 8)) load_k(kn, kt + PA_T / 64);
+                v16f acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+                for (int j = 0; j < NSTEP; ++j) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].x, kf[j].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].y, kf[j].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].z, kf[j].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].w, kf[j].w, acc, 0, 0, 0);
+                }
+                const int col = kt * 32 + r;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = (i & 3) + 8 * (i >> 2) + 4 * kk;
+                    if (!(PA_ABL & 16) || acc[i] == 1.2345f) Sq[row * strdq + col] = __fmul_rn(acc[i], scale);
+                }
+                if (!(PA_ABL & 8)) {
+#pragma unroll
+                    for (int j = 0; j < NSTEP; ++j) kf[j] = kn[j];
+                }
+            }
+        }
+    }
+    if (!table_done) copy_table();
+    PA_STAMP(2);
+    __syncthreads();
+    PA_STAMP(3);
+    // ---- phase 2: soft_max; wave w owns rows w, w+8, ... of the 64.  Four rows at a time with every table lookup of
+    //      the four rows in flight together; per lane the terms are added in increasing column order: the f64 sums of
+    //      softmax_rows_kernel.
+    for (int rb = 0; rb < ((PA_ABL & 2) ? 0 : 8); rb += 4) {          // rows wave + 8*(rb..rb+3): one block per batch
+        const int q = rb >> 2;
+        const int mbq = PA_SEL(q, mb0, mb1), ncol = PA_SEL(q, ntl0, ntl1) * 32;
+        if (mbq < 0) continue;
+        float *rowp[4];
+        int Ls[4];
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) {
+            const int row = wave + 8 * u4;                              // 0..31 inside the block
+            rowp[u4] = PA_SEL(q, S0, S1) + row * PA_SEL(q, strd0, strd1);
+            Ls[u4] = min(P, n_past + mbq * 32 + row + 1);              // rows >= N: clamped duplicates, never stored
+        }
+        const int nit = (ncol + 63) >> 6;                              // uniform: 64-column steps that hold any data
+        if (nit <= 2) pa_softmax4<2>(rowp, Ls, ncol, tab, tab_n, lane);
+        else if (nit <= 4) pa_softmax4<4>(rowp, Ls, ncol, tab, tab_n, lane);
+        else if (nit <= 8) pa_softmax4<8>(rowp, Ls, ncol, tab, tab_n, lane);
+        else pa_softmax4<PA_SM_IT>(rowp, Ls, ncol, tab, tab_n, lane);
+    }
+    PA_STAMP(4);
+    __syncthreads();
+    PA_STAMP(5);
+    // ---- phase 3: KQV ----
+    {
+        const int q = wave >> 2, d0 = (wave & 3) * 32;
+        const int mbq = PA_SEL(q, mb0, mb1);
+        if (mbq >= 0 && d0 < D && !(PA_ABL & 4)) {
+            const int m0 = mbq * 32, ke = PA_SEL(q, kend0, kend1);
+            const float *pa = PA_SEL(q, S0, S1) + r * PA_SEL(q, strd0, strd1);   // probabilities of query row r
+            const float *pb = vc + (int64_t)(h * D + d0 + r) * n_ctx;     // transposed V cache row (d0 + r)
+            v16f acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            int k = 0;
+            float4 b0 = {0, 0, 0, 0}, b1 = b0, b2 = b0, b3 = b0;
+            auto load_v = [&](int kb) {                                   // 32 k: four float4 per lane
+                b0 = *reinterpret_cast<const float4 *>(pb + kb + 4 * kk);
+                b1 = *reinterpret_cast<const float4 *>(pb + kb + 8 + 4 * kk);
+                b2 = *reinterpret_cast<const float4 *>(pb + kb + 16 + 4 * kk);
+                b3 = *reinterpret_cast<const float4 *>(pb + kb + 24 + 4 * kk);
+            };
+            if (k + 32 <= ke) load_v(0);
+            for (; k + 32 <= ke; k += 32) {
+                const float4 c0 = b0, c1 = b1, c2 = b2, c3 = b3;
+                if (k + 64 <= ke) load_v(k + 32);
+                const float4 a0 = *reinterpret_cast<const float4 *>(pa + k + 4 * kk);
+                const float4 a1 = *reinterpret_cast<const float4 *>(pa + k + 8 + 4 * kk);
+                const float4 a2 = *reinterpret_cast<const float4 *>(pa + k + 16 + 4 * kk);
+                const float4 a3 = *reinterpret_cast<const float4 *>(pa + k + 24 + 4 * kk);
+#define FL_PV4(a, b)                                                      \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);   \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);   \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);   \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+                FL_PV4(a0, c0) FL_PV4(a1, c1) FL_PV4(a2, c2) FL_PV4(a3, c3)
+            }
+            for (; k + 8 <= ke; k += 8) {
+                const float4 a0 = *reinterpret_cast<const float4 *>(pa + k + 4 * kk);
+                const float4 c0 = *reinterpret_cast<const float4 *>(pb + k + 4 * kk);
+                FL_PV4(a0, c0)
+            }
+#undef FL_PV4
+            for (; k < ke; k += 2) {   // tail: plain (k, k+1) pairing
+                const float a = (k + kk < ke) ? pa[k + kk] : 0.f;
+                const float b = (k + kk < ke) ? pb[k + kk] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+            const int col = h * D + d0 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * kk;
+                if (row < N) ao[(int64_t)row * ldo + col] = acc[i];
+            }
+        }
+    }
+    PA_STAMP(6);
+}
+#ifdef PA_TIMING
+extern "C" int fl_debug_pa_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pa_dbg), sizeof(long long) * 64 * 8); }
+#endif
+
+#undef PA_SEL
+
+// tab_n: number of fp16 exp-table entries after 0x8000 that are kept in LDS; every entry in (0x8000 + tab_n, 0xFC00] must
+// be 0 (the caller checks that on the host table).  Returns hipErrorInvalidValue when the shape does not fit
+// (caller falls back to the three-kernel path).
+hipError_t prefill_attention(const float *qkv, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc,
+                             const float *vc, const uint16_t *exp_tab, int tab_n, float scale, float *ao, int ldo,
+                             hipStream_t st) {
+    const int P = n_past + N, nb = (N + 31) / 32;
+    if (D % 32 != 0 || D > 128 || (n_ctx & 3) != 0 || P > 64 * PA_SM_IT || tab_n < 0 || tab_n > 24576 || (tab_n & 7)) return hipErrorInvalidValue;
+    const size_t tab_bytes = (size_t)tab_n * 2;
+    // pair mode: rows of block x and of block nb-1-x: 32 * (2 n_past + 32 (nb + 1) + 8) floats
+    const size_t lds_pair = (size_t)32 * (2 * (size_t)n_past + 32 * (size_t)(nb + 1) + 8 + 64) * 4 + tab_bytes;   // (+64: round-ups)
+    const size_t lds_single = (size_t)32 * (((size_t)P + 31) / 32 * 32 + 4 + 4) * 4 + tab_bytes;
+    const size_t cap = 160 * 1024;
+    int pair = nb >= 2 && lds_pair <= cap ? 1 : 0;
+    if (!pair && lds_single > cap) return hipErrorInvalidValue;
+    const size_t lds = pair ? lds_pair : lds_single;
+    const dim3 grid(H, pair ? (nb + 1) / 2 : nb);
+#define FL_PA(NS)                                                                                                       \
+    do {                                                                                                                \
+        static bool attr_set = false;                                                                                   \
+        if (!attr_set) {                                                                                                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(prefill_attention_kernel<NS>),            \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);                   \
+            if (e != hipSuccess) return e;                                                                              \
+            attr_set = true;                                                                                            \
+        }                                                                                                               \
+        hipLaunchKernelGGL(prefill_attention_kernel<NS>, grid, dim3(PA_T), lds, st, qkv, ldq, N, n_past, n_ctx, E, kc, vc, \
+                           exp_tab, tab_n, scale, ao, ldo, pair);                                                       \
+    } while (0)
+    if (D == 128) FL_PA(16);
+    else if (D == 96) FL_PA(12);
+    else if (D == 64) FL_PA(8);
+    else FL_PA(4);
+#undef FL_PA
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // diag_mask_inf + soft_max over one score row [0, P):  valid length L = n_past + n + 1
 //   max over the row; val = fp16->f32(exp_tab[fp32->fp16(s - max)]); sum in f64 (exact: fp16 terms);
 //   p = val * (float)(1.0 / sum); masked entries become 0.          lib/ggml.c:8558-8580

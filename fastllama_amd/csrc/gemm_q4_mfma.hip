@@ -423,7 +423,7 @@ static int pick_config(int MGT, int NGT, int type) {
     int best = 2;
     double qb = q2;
     if (q1 < 0.96 * qb) { best = 1; qb = q1; }
-    if (q5 < 0.96 * qb) { best = 5; qb = q5; }
+    if (q5 < 0.92 * qb) { best = 5; qb = q5; }
     if (per_simd < 40 && best == 2 && q1 <= q2) best = 1;                         // mid-size: 4 workgroups of 4 waves per CU
     return best;
 }

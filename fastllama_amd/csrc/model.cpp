@@ -70,6 +70,8 @@ struct fl_model {
     // decode hipGraph
     bool graph_enabled = true;
     bool fuse_decode = true;     // N == 1: norm-in-GEMV + one attention kernel per layer
+    bool fuse_prefill_attn = true;   // N >= 9: KQ + soft_max + KQV in one launch
+    int exp_tab_n = 0;               // fp16 exp-table entries after 0x8000 that are non-zero (rounded up to 8): the LDS copy
     // LoRA: originals of the tensors an adapter touched (the reference's use_mmap path keeps them too, llama.cpp:868-874)
     struct LoraBackup { fl_qtensor *t; void *qs, *d, *mm; };
     std::vector<LoraBackup> lora_backups;
@@ -275,6 +277,11 @@ int fl_model_finalize(fl_model *m) {
             te[i] = f32_to_f16_bits(expf(f));
             ts[i] = f32_to_f16_bits(f / (1.0f + expf(-f)));   // ggml_silu_f32, lib/ggml.c:3196-3198
         }
+        {   // exp(x) for fp16 x in [-0, -inf]: find where the table becomes (and stays) zero
+            int last_nz = 0;
+            for (int i = 0x8000; i <= 0xFC00; ++i) if (te[i] != 0) last_nz = i - 0x8000;
+            m->exp_tab_n = (last_nz + 1 + 7) & ~7;
+        }
         if ((rc = dev_alloc(m, (void **)&m->exp_tab, 2 << 16)) != FL_OK) return rc;
         if ((rc = dev_alloc(m, (void **)&m->silu_tab, 2 << 16)) != FL_OK) return rc;
         M_HIP(hipMemcpy(m->exp_tab, te.data(), 2 << 16, hipMemcpyHostToDevice));
@@ -401,13 +408,21 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn) {
             M_HIP(rmsnorm_quant(inp, E, ly.attn_norm, N, E, nullptr, 0, &m->qE, layout, st));
             M_HIP(mm(m, ly.wqkv, m->qE, N, m->qkv, 3 * El, nullptr, 0));                               // wq, wk, wv  :328-334
             M_HIP(rope_kv(m->qkv, 3 * El, N, El, D, n_past, n_ctx, m->rope_tab, kc, vc, st, dyn));     // rope, store :328-347
-            // KQ, scale, mask, soft_max                                                                :364-379
-            M_HIP(gemm_f32_abt(m->qkv, 3 * El, D, kc, El, D, m->att, n_ctx, (int64_t)N * n_ctx, N, P, D, Hl,
-                               1.0f / sqrtf((float)E / (float)m->H), 1, n_past, st, dyn, n_ctx));
-            M_HIP(softmax_rows(m->att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, Hl, m->exp_tab, st, dyn));
-            // KQV, merged back to [N, n_embd]                                                          :389-398
-            M_HIP(gemm_f32_abt(m->att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, m->ao, El, D, N, D, P, Hl,
-                               1.0f, 2, n_past, st, dyn, n_ctx));
+            const float kq_scale = 1.0f / sqrtf((float)E / (float)m->H);
+            // KQ, scale, mask, soft_max, KQV in one launch with the score rows in LDS when they fit       :364-398
+            hipError_t pe = (N >= 9 && !dyn && m->fuse_prefill_attn)
+                                ? prefill_attention(m->qkv, 3 * El, D, Hl, N, n_past, n_ctx, El, kc, vc, m->exp_tab, m->exp_tab_n, kq_scale, m->ao, El, st)
+                                : hipErrorInvalidValue;
+            if (pe != hipSuccess) {
+                (void)hipGetLastError();
+                // KQ, scale, mask, soft_max                                                            :364-379
+                M_HIP(gemm_f32_abt(m->qkv, 3 * El, D, kc, El, D, m->att, n_ctx, (int64_t)N * n_ctx, N, P, D, Hl, kq_scale, 1, n_past,
+                                   st, dyn, n_ctx));
+                M_HIP(softmax_rows(m->att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, Hl, m->exp_tab, st, dyn));
+                // KQV, merged back to [N, n_embd]                                                      :389-398
+                M_HIP(gemm_f32_abt(m->att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, m->ao, El, D, N, D, P, Hl,
+                                   1.0f, 2, n_past, st, dyn, n_ctx));
+            }
             M_HIP((layout == 16 ? quantize_q8_qa16 : quantize_q8_qa1)(m->ao, El, N, El, m->qEl, st));
         }
         // wo projection + residual                                                                 :401-407
@@ -505,6 +520,7 @@ int fl_model_set_graph(fl_model *m, int mode) {
     if (!m) return set_error(FL_EINVAL, "null model");
     m->graph_enabled = (mode & 1) != 0;
     const bool fuse = (mode & 2) == 0;
+    m->fuse_prefill_attn = (mode & 4) == 0;
     if (fuse != m->fuse_decode && m->graph_exec) {
         (void)hipGraphExecDestroy(m->graph_exec);
         m->graph_exec = nullptr;
@@ -769,6 +785,18 @@ int fl_debug_gemv_norm(const fl_qtensor *W, const float *x, const float *norm_w,
 int fl_debug_gemv_silu(const fl_qtensor *W, const float *h13, const uint16_t *silu_tab, float *y, const float *resid,
                        void *stream) {
     M_HIP(gemv_q4_silu(*W, h13, silu_tab, y, resid, (hipStream_t)stream));
+    return FL_OK;
+}
+int fl_debug_prefill_attention(const float *qkv, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc,
+                               const float *vc, const uint16_t *exp_tab_dev, float scale, float *ao, int ldo, void *stream) {
+    static int tab_n = -1;
+    if (tab_n < 0) {                                   // same bound as fl_model_finalize computes
+        int last_nz = 0;
+        for (int i = 0x8000; i <= 0xFC00; ++i)
+            if (f32_to_f16_bits(expf(f16_bits_to_f32((uint16_t)i))) != 0) last_nz = i - 0x8000;
+        tab_n = (last_nz + 1 + 7) & ~7;
+    }
+    M_HIP(prefill_attention(qkv, ldq, D, H, N, n_past, n_ctx, E, kc, vc, exp_tab_dev, tab_n, scale, ao, ldo, (hipStream_t)stream));
     return FL_OK;
 }
 int fl_debug_decode_attention(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab_dev,

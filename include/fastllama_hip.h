@@ -173,7 +173,7 @@ int fl_model_eval(fl_model *m, const int32_t *tokens_host, int N, int n_past, fl
  * accumulated totals so far are returned through the two pointers (either may be NULL). */
 int fl_model_profile(fl_model *m, int enable, double *mm_ms_total, long *mm_launches);
 /* decode (N = 1) evals replay a captured hipGraph by default; 0 switches to plain launches */
-int fl_model_set_graph(fl_model *m, int mode); /* bit0: hipGraph replay for decode (default on); bit1: generic per-op decode kernels */
+int fl_model_set_graph(fl_model *m, int mode); /* bit0: hipGraph replay for decode (default on); bit1: generic per-op decode kernels; bit2: three-kernel prefill attention */
 /* LoRA on the resident Q4 weights -- replaces Model::attach_lora / detach_lora (lib/llama.cpp:697-944) and its
  * ggml_compute_forward_add_q_f32 (lib/ggml.c:6414-6520): W <- quantize_row_q(dequantize_row_q(W) + sign * BA), with the
  * reference's SIMD quantizer arithmetic.  base_name is the base tensor ("layers.3.attention.wq.weight"); pass either
@@ -203,6 +203,9 @@ int fl_debug_gemv_norm(const fl_qtensor *W, const float *x_dev, const float *nor
                        void *stream);  /* y = W . Q8_0(norm_w * rms_norm(x)), one launch (decode) */
 int fl_debug_gemv_silu(const fl_qtensor *W, const float *h13_dev, const uint16_t *silu_tab_dev, float *y_dev,
                        const float *resid_dev, void *stream); /* y = W . Q8_0(silu(h13[:K]) * h13[K:]) + resid, one launch */
+int fl_debug_prefill_attention(const float *qkv_dev, int ldq, int D, int H, int N, int n_past, int n_ctx, int E,
+                               const float *kc, const float *vc, const uint16_t *exp_tab_dev, float scale, float *ao_dev,
+                               int ldo, void *stream); /* KQ*scale + mask + soft_max + KQV, one launch (prefill) */
 int fl_debug_decode_attention(const float *qkv_dev, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab_dev,
                               float *kc, float *vc, const uint16_t *exp_tab_dev, float scale, fl_qact *out, void *stream);
 int fl_debug_silu_mul_quant(const float *h13_dev, int ld, int N, int F, const uint16_t *silu_tab_dev, fl_qact *out,

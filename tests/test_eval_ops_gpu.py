@@ -250,3 +250,43 @@ def test_gemv_silu_fused_equals_unfused(env, qtype, M, F):
     assert np.array_equal(y1.cpu().numpy(), y0.cpu().numpy() + res)
     want = port.mul_mat_q(qtype, wq, (le.silu(h[:, :F]) * h[:, F:]).astype(np.float32))[0]
     assert np.max(np.abs(y0.cpu().numpy() - want)) <= 2e-5 * np.max(np.abs(want))
+
+
+@pytest.mark.parametrize("N,P0,D,H,n_ctx", [(20, 0, 32, 8, 128), (96, 0, 128, 32, 128), (40, 23, 128, 4, 128), (33, 7, 64, 3, 64),
+                                            (512, 0, 128, 32, 1024), (100, 800, 128, 2, 1024), (9, 0, 96, 2, 64), (480, 0, 128, 3, 512), (300, 200, 128, 2, 512)])
+def test_prefill_attention_fused_equals_three_kernels(env, N, P0, D, H, n_ctx):
+    """KQ*scale + mask + soft_max + KQV in ONE launch (score rows in LDS) == gemm_f32_abt -> softmax_rows -> gemm_f32_abt,
+    bit for bit (same MFMA sequence per output), on every valid output row."""
+    torch, hip, ops, L, port = env
+    E, P = H * D, P0 + N
+    rng = np.random.default_rng(N + D + H + P0)
+    qkv = rng.standard_normal((N, 3 * E)).astype(np.float32)
+    kc = np.zeros((n_ctx, E), np.float32)
+    vc = np.zeros((E, n_ctx), np.float32)
+    kc[:P] = rng.standard_normal((P, E))
+    vc[:, :P] = rng.standard_normal((E, P))
+    e = np.empty(1 << 16, np.uint16)
+    L.fl_debug_tables(e.ctypes.data_as(C.c_void_p), None)
+    ed, qd, kd, vd = dev(torch, e.view(np.int16)), dev(torch, qkv), dev(torch, kc), dev(torch, vc)
+    scale = float(np.float32(1.0) / np.sqrt(np.float32(D)))
+    att = torch.full((H, N, n_ctx), 7.0, device="cuda")
+    ao0 = torch.zeros((N, E), device="cuda")
+    hip.check(L.fl_debug_gemm_f32_abt(qd.data_ptr(), 3 * E, D, kd.data_ptr(), E, D, att.data_ptr(), n_ctx, N * n_ctx, N, P, D, H,
+                                      scale, 1, P0, None))
+    hip.check(L.fl_debug_softmax_rows(att.data_ptr(), n_ctx, N * n_ctx, N, P, P0, H, ed.data_ptr(), None))
+    hip.check(L.fl_debug_gemm_f32_abt(att.data_ptr(), n_ctx, N * n_ctx, vd.data_ptr(), n_ctx, D * n_ctx, ao0.data_ptr(), E, D,
+                                      N, D, P, H, 1.0, 2, P0, None))
+    ao1 = torch.full((N, E), -3.0, device="cuda")
+    hip.check(L.fl_debug_prefill_attention(qd.data_ptr(), 3 * E, D, H, N, P0, n_ctx, E, kd.data_ptr(), vd.data_ptr(), ed.data_ptr(),
+                                           scale, ao1.data_ptr(), E, None))
+    torch.cuda.synchronize()
+    assert torch.equal(ao1, ao0)
+    # and against numpy on a few rows (the three-kernel path is itself checked against numpy above)
+    for n in (0, N - 1):
+        for h in (0, H - 1):
+            sl = slice(h * D, (h + 1) * D)
+            Lr = P0 + n + 1
+            s = ((qkv[n:n + 1, sl] @ kc[:Lr, sl].T).astype(np.float32) * np.float32(scale)).astype(np.float32)
+            want = (le.soft_max_rows(s) @ vc[sl, :Lr].T).astype(np.float32)[0]
+            got = ao1[n, sl].cpu().numpy()
+            assert np.max(np.abs(got - want)) <= 2e-5 * max(1.0, np.max(np.abs(want)))
