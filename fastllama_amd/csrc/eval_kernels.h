@@ -11,7 +11,8 @@ hipError_t rmsnorm_quant(const float *x, int ldx, const float *w, int N, int E, 
                          const fl_qact *out, int layout, hipStream_t st);
 // silu_table(h13[:, :F]) * h13[:, F:2F] -> Q8_0
 hipError_t silu_mul_quant(const float *h13, int ld, int N, int F, const uint16_t *silu_tab, const fl_qact *out,
-                          int layout, hipStream_t st);
+                          int layout, hipStream_t st,
+                          bool woven = false);   // woven: h13 = [w1 x 16 | w3 x 16 | ...] instead of [w1 x (F) | w3 x (F)]
 // rope on q (in place) and k (-> kc rows n_past..), v -> vc columns n_past..
 hipError_t rope_kv(float *qkv, int ld, int N, int E, int D, int n_past, int n_ctx, const float *rope_tab, float *kc,
                    float *vc, hipStream_t st, const int *dyn_past = nullptr);
@@ -32,7 +33,7 @@ hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, i
                             float *vc, const uint16_t *exp_tab, float scale, const fl_qact *out, hipStream_t st,
                             const int *dyn_past = nullptr);
 // LoRA merge on reference AoS blocks (lora_kernels.hip): rows [row0, row0+rows) <- quantize(dequantize + sign * BA)
-hipError_t lora_add_aos(int type, void *aos, int KB, int row0, int rows, const float *ba, int64_t ldba, const float *A,
+hipError_t lora_add_aos(int type, void *aos, int KB, int row0, int rows, int il_part, const float *ba, int64_t ldba, const float *A,
                         const float *B, int r, int ba_row0, int ba_col0, float sign, hipStream_t st);
 hipError_t add_rows(const float *a, int lda, const float *b, int ldb, float *o, int ldo, int N, int E, hipStream_t st);
 

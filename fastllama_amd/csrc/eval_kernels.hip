@@ -148,7 +148,7 @@ hipError_t rmsnorm_quant(const float *x, int ldx, const float *w, int N, int E, 
 __global__ __launch_bounds__(256) void silu_mul_quant_kernel(const float *__restrict__ h13, int ld, int N, int NP,
                                                              int F, const uint16_t *__restrict__ silu_tab,
                                                              int layout, int8_t *__restrict__ q,
-                                                             float *__restrict__ d, float *__restrict__ s) {
+                                                             float *__restrict__ d, float *__restrict__ s, int woven) {
     const int gpr = F >> 3, KB = F >> 5;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)NP * gpr;
@@ -156,9 +156,11 @@ __global__ __launch_bounds__(256) void silu_mul_quant_kernel(const float *__rest
     const int n = live ? (int)(gid / gpr) : 0, kg = live ? (int)(gid % gpr) : 0;
     float o[8];
     if (live && n < N) {
-        const float *pa = h13 + (int64_t)n * ld + kg * 8;
+        // features 8kg .. 8kg+7 of w1 x, and the same features of w3 x (16-row groups woven: +16, else +F)
+        const float *pa = h13 + (int64_t)n * ld + (woven ? ((kg >> 1) << 5) + ((kg & 1) << 3) : kg * 8);
+        const int boff = woven ? 16 : F;
         const float4 a0 = *reinterpret_cast<const float4 *>(pa), a1 = *reinterpret_cast<const float4 *>(pa + 4);
-        const float4 b0 = *reinterpret_cast<const float4 *>(pa + F), b1 = *reinterpret_cast<const float4 *>(pa + F + 4);
+        const float4 b0 = *reinterpret_cast<const float4 *>(pa + boff), b1 = *reinterpret_cast<const float4 *>(pa + boff + 4);
         const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
         const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
@@ -176,11 +178,11 @@ __global__ __launch_bounds__(256) void silu_mul_quant_kernel(const float *__rest
 }
 
 hipError_t silu_mul_quant(const float *h13, int ld, int N, int F, const uint16_t *silu_tab, const fl_qact *out,
-                          int layout, hipStream_t st) {
+                          int layout, hipStream_t st, bool woven) {
     const int NP = layout == 16 ? fl_roundup(N, 16) : N;
     const int64_t total = (int64_t)NP * (F >> 3);
     hipLaunchKernelGGL(silu_mul_quant_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st, h13, ld, N, NP, F,
-                       silu_tab, layout, out->q, out->d, out->s);
+                       silu_tab, layout, out->q, out->d, out->s, woven ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -33,6 +33,7 @@
 //     (q4_layout.h; SQ_LDS_BANK_CONFLICT = 0 in profiles/).
 //   * XCD-aware bijective tile order: the N-tiles that share a W row panel run on one XCD's L2.
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 #include "q4_device.h"
 #include "q4_kernels.h"
@@ -84,12 +85,23 @@ struct GemmCfg {
 #define FL_NOPK   /* the host pass only needs the launch stub */
 #endif
 
+// Optional epilogue for the fused w1|w3 matrix (rows interleaved by 16-row groups: even groups w1, odd groups w3, see
+// model.cpp): instead of storing y, the workgroup computes silu(w1 x) * (w3 x) for its features, and writes it
+// re-quantized to Q8_0 in the QA16 layout the w2 matmul reads -- ggml_silu + ggml_mul (lib/llama.cpp:428-431) and the
+// INIT phase of the next mul_mat (quantize_row_q8_0) without the [N][2 n_ff] f32 round trip through HBM.
+struct GemmSiluEpi {
+    const uint16_t *silu_tab;   // fp16 SiLU table (null: plain store)
+    int8_t *oq;
+    float *od, *os;
+    int KBo;                    // n_ff / 32
+};
+
 template <int TYPE, int WM, int WN, int TM, int TN, int MINW>
 __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ? 3 : MINW) FL_NOPK void gemm_q4_mfma_kernel(
     const uint4 *__restrict__ qs, const float *__restrict__ dW, const float *__restrict__ mW,
     const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs, int N, int M,
     int MGT /* row groups total */, int NGT /* col groups total */, int KB, float *__restrict__ y, int ldy,
-    const float *__restrict__ resid, int ldr) {
+    const float *__restrict__ resid, int ldr, GemmSiluEpi epi) {
     using Cfg = GemmCfg<TYPE, WM, WN, TM, TN>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -336,6 +348,66 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the (zero) tail fills before the wave ends
 
+    if (epi.silu_tab) {
+        if constexpr (TM % 2 == 0) {
+            // ---- silu(w1 x) * (w3 x) -> Q8_0 (QA16).  Tiles i (even) / i+1 hold the same 16 features of w1 / w3.
+            constexpr int ACT_LD = Cfg::NG * 16, NFEAT = Cfg::MG * 8;
+            static_assert(NFEAT % 32 == 0 && NFEAT * ACT_LD * 4 <= Cfg::LDS_BYTES, "activation tile must fit the operand ring");
+            float *act = reinterpret_cast<float *>(smem);           // [NFEAT][ACT_LD] f32
+            __syncthreads();                                         // every wave is done with the operand ring
+#pragma unroll
+            for (int i = 0; i < TM; i += 2)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int f1 = i * TN + j, f3 = (i + 1) * TN + j;
+                    const int fl0 = ((wm * TM + i) >> 1) * 16 + lg * 4, nl = (wn * TN + j) * 16 + l15;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a1 = acc[f1 / 4][4 * (f1 % 4) + e], a3 = acc[f3 / 4][4 * (f3 % 4) + e];
+                        if (TYPE == FL_TYPE_Q4_1) { a1 += msacc[f1 / 4][4 * (f1 % 4) + e]; a3 += msacc[f3 / 4][4 * (f3 % 4) + e]; }
+                        const uint16_t hx = __half_as_ushort(__float2half_rn(a1));            // GGML_FP32_TO_FP16
+                        const float sl = __half2float(__ushort_as_half(epi.silu_tab[hx]));   // table_silu_f16
+                        act[(fl0 + e) * ACT_LD + nl] = __fmul_rn(sl, a3);                    // ggml_mul(silu, tmp)
+                    }
+                }
+            __syncthreads();
+            // one thread = one (token, 32-feature block): quantize_row_q8_0 arithmetic (lib/ggml.c:1341-1403, 1433-1440)
+            for (int u = tid; u < (NFEAT / 32) * ACT_LD; u += 64 * WM * WN) {
+                const int fb = u / ACT_LD, nl = u % ACT_LD;
+                const int n = ng0 * 16 + nl, gfb = (mg0 >> 2) + fb;
+                if (n >= NGT * 16 || gfb >= epi.KBo) continue;
+                float v[32];
+                float amax = 0.f;
+#pragma unroll
+                for (int e = 0; e < 32; ++e) {
+                    v[e] = act[(fb * 32 + e) * ACT_LD + nl];
+                    amax = fmaxf(amax, fabsf(v[e]));
+                }
+                const float dd = __fdiv_rn(amax, 127.0f);
+                const float id = amax != 0.0f ? __fdiv_rn(127.0f, amax) : 0.0f;
+                int qi[32], sum = 0;
+#pragma unroll
+                for (int e = 0; e < 32; ++e) {
+                    qi[e] = (int)rintf(__fmul_rn(v[e], id));
+                    sum += qi[e];
+                }
+                const int c = n & 15;
+                const int64_t cb = ((int64_t)(n >> 4) * epi.KBo + gfb) * 16 + c;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    auto pk = [](int a, int b, int cc, int d) -> uint32_t {
+                        return (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(cc & 0xFF) << 16) | ((uint32_t)(d & 0xFF) << 24);
+                    };
+                    const uint2 w2 = make_uint2(pk(qi[8 * g], qi[8 * g + 2], qi[8 * g + 4], qi[8 * g + 6]),
+                                                pk(qi[8 * g + 1], qi[8 * g + 3], qi[8 * g + 5], qi[8 * g + 7]));
+                    *reinterpret_cast<uint2 *>(epi.oq + cb * 32 + qw16_pos(c, g) * 8) = w2;
+                }
+                epi.od[cb] = dd;
+                epi.os[cb] = __fmul_rn(dd, (float)sum);
+            }
+        }
+        return;
+    }
     // ---- store: lane holds rows m = 16*g + 4*lg + {0..3} of column n = 16*h + l15 -> one 16-byte store
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -385,7 +457,7 @@ int g_gemm_force_cfg = -1;  // debug / autotune hook: >= 0 forces one configurat
 
 template <int TYPE, int WM, int WN, int TM, int TN, int MINW>
 static hipError_t launch_gemm(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
-                              const float *resid, int ldr) {
+                              const float *resid, int ldr, const GemmSiluEpi &epi) {
     using Cfg = GemmCfg<TYPE, WM, WN, TM, TN>;
     const int MGT = W.M16 / 16, NGT = fl_roundup(N, 16) / 16;
     const int tiles = ((MGT + Cfg::MG - 1) / Cfg::MG) * ((NGT + Cfg::NG - 1) / Cfg::NG);
@@ -398,7 +470,7 @@ static hipError_t launch_gemm(const fl_qtensor &W, const fl_qact &xq, int N, flo
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), Cfg::LDS_BYTES, st, reinterpret_cast<const uint4 *>(W.qs), W.d,
-                       W.m, xq.q, xq.d, xq.s, N, W.M, MGT, NGT, W.KB, y, ldy, resid, ldr);
+                       W.m, xq.q, xq.d, xq.s, N, W.M, MGT, NGT, W.KB, y, ldy, resid, ldr, epi);
     return hipGetLastError();
 }
 
@@ -423,24 +495,38 @@ static int pick_config(int MGT, int NGT, int type) {
     int best = 2;
     double qb = q2;
     if (q1 < 0.96 * qb) { best = 1; qb = q1; }
-    if (q5 < 0.92 * qb) { best = 5; qb = q5; }
+    if (q5 < 0.90 * qb) { best = 5; qb = q5; }
     if (per_simd < 40 && best == 2 && q1 <= q2) best = 1;                         // mid-size: 4 workgroups of 4 waves per CU
     return best;
 }
 
-hipError_t gemm_q4_mfma(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
-                        const float *resid, int ldr) {
+static hipError_t gemm_dispatch(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
+                                const float *resid, int ldr, const GemmSiluEpi &epi) {
     if (resid && ((ldr & 3) != 0 || (reinterpret_cast<uintptr_t>(resid) & 15) != 0)) return hipErrorInvalidValue;
     if ((ldy & 3) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return hipErrorInvalidValue;
     const int MGT = W.M16 / 16, NGT = fl_roundup(N, 16) / 16;
-    const int cfg = pick_config(MGT, NGT, W.type);
+    int cfg = pick_config(MGT, NGT, W.type);
+    if (epi.silu_tab && (cfg == 3 || cfg == 8)) cfg = 5;   // the silu epilogue pairs two row groups per wave: TM must be even
 #define X(ID, WM, WN, TM, TN, MINW)                                                                         \
     if (cfg == ID)                                                                                          \
-        return W.type == FL_TYPE_Q4_0 ? launch_gemm<FL_TYPE_Q4_0, WM, WN, TM, TN, MINW>(W, xq, N, y, ldy, st, resid, ldr) \
-                                      : launch_gemm<FL_TYPE_Q4_1, WM, WN, TM, TN, MINW>(W, xq, N, y, ldy, st, resid, ldr);
+        return W.type == FL_TYPE_Q4_0 ? launch_gemm<FL_TYPE_Q4_0, WM, WN, TM, TN, MINW>(W, xq, N, y, ldy, st, resid, ldr, epi) \
+                                      : launch_gemm<FL_TYPE_Q4_1, WM, WN, TM, TN, MINW>(W, xq, N, y, ldy, st, resid, ldr, epi);
     FL_GEMM_CONFIGS(X)
 #undef X
     return hipErrorInvalidValue;
+}
+
+hipError_t gemm_q4_mfma(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
+                        const float *resid, int ldr) {
+    return gemm_dispatch(W, xq, N, y, ldy, st, resid, ldr, GemmSiluEpi{nullptr, nullptr, nullptr, nullptr, 0});
+}
+
+// W = w1|w3 with 16-row groups interleaved (group 2p = w1 rows [16p, 16p+16), group 2p+1 = the same rows of w3);
+// out <- Q8_0(silu(w1 x) * (w3 x)) in QA16, n_ff = W.M / 2 features
+hipError_t gemm_q4_mfma_silu(const fl_qtensor &W, const fl_qact &xq, int N, const uint16_t *silu_tab, const fl_qact &out,
+                             hipStream_t st) {
+    if (!silu_tab || W.M % 64 != 0) return hipErrorInvalidValue;
+    return gemm_dispatch(W, xq, N, nullptr, 4, st, nullptr, 0, GemmSiluEpi{silu_tab, out.q, out.d, out.s, W.M / 64});
 }
 
 }  // namespace fl

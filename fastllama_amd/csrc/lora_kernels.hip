@@ -51,7 +51,7 @@ __device__ __forceinline__ float vec_dot_f32_avx2(int n, const float *__restrict
 // delta(m, k) = ba[(ba_row0 + m) * ldba + ba_col0 + k]                          (cached adapter), or
 //             = vec_dot_f32(r, A[(ba_col0 + k) * r ...], B[(ba_row0 + m) * r ...])   (A: [K_full][r], B: [M_full][r])
 template <int TYPE>
-__global__ __launch_bounds__(256) void lora_add_aos_kernel(unsigned char *__restrict__ aos, int KB, int row0, int rows,
+__global__ __launch_bounds__(256) void lora_add_aos_kernel(unsigned char *__restrict__ aos, int KB, int row0, int rows, int il_part,
                                                            const float *__restrict__ ba, int64_t ldba,
                                                            const float *__restrict__ A, const float *__restrict__ B, int r,
                                                            int ba_row0, int ba_col0, float sign) {
@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void lora_add_aos_kernel(unsigned char *__rest
     if (gid >= (int64_t)rows * KB) return;
     const int m = (int)(gid / KB), b = (int)(gid % KB);
     constexpr int BS = TYPE == FL_TYPE_Q4_0 ? 20 : 24;
-    unsigned char *blk = aos + ((int64_t)(row0 + m) * KB + b) * BS;
+    // il_part >= 0: the tensor's rows are woven by 16 with a sibling (w1|w3): row m sits at 32 (m / 16) + 16 il_part + m % 16
+    const int frow = il_part >= 0 ? ((m >> 4) << 5) + (il_part << 4) + (m & 15) : row0 + m;
+    unsigned char *blk = aos + ((int64_t)frow * KB + b) * BS;
     const float d = *reinterpret_cast<const float *>(blk);
     const float mn0 = TYPE == FL_TYPE_Q4_1 ? *reinterpret_cast<const float *>(blk + 4) : 0.f;
     unsigned char *qs = blk + (TYPE == FL_TYPE_Q4_0 ? 4 : 8);
@@ -115,17 +117,17 @@ __global__ __launch_bounds__(256) void lora_add_aos_kernel(unsigned char *__rest
     }
 }
 
-hipError_t lora_add_aos(int type, void *aos, int KB, int row0, int rows, const float *ba, int64_t ldba, const float *A,
+hipError_t lora_add_aos(int type, void *aos, int KB, int row0, int rows, int il_part, const float *ba, int64_t ldba, const float *A,
                         const float *B, int r, int ba_row0, int ba_col0, float sign, hipStream_t st) {
     if ((!ba && (!A || !B || r < 1)) || rows < 1 || KB < 1) return hipErrorInvalidValue;
     const int64_t total = (int64_t)rows * KB;
     const dim3 grid((unsigned)((total + 255) / 256));
     unsigned char *p = static_cast<unsigned char *>(aos);
     if (type == FL_TYPE_Q4_0)
-        hipLaunchKernelGGL(lora_add_aos_kernel<FL_TYPE_Q4_0>, grid, dim3(256), 0, st, p, KB, row0, rows, ba, ldba, A, B, r,
+        hipLaunchKernelGGL(lora_add_aos_kernel<FL_TYPE_Q4_0>, grid, dim3(256), 0, st, p, KB, row0, rows, il_part, ba, ldba, A, B, r,
                            ba_row0, ba_col0, sign);
     else
-        hipLaunchKernelGGL(lora_add_aos_kernel<FL_TYPE_Q4_1>, grid, dim3(256), 0, st, p, KB, row0, rows, ba, ldba, A, B, r,
+        hipLaunchKernelGGL(lora_add_aos_kernel<FL_TYPE_Q4_1>, grid, dim3(256), 0, st, p, KB, row0, rows, il_part, ba, ldba, A, B, r,
                            ba_row0, ba_col0, sign);
     return hipGetLastError();
 }

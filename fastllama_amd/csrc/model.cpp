@@ -71,6 +71,7 @@ struct fl_model {
     bool graph_enabled = true;
     bool fuse_decode = true;     // N == 1: norm-in-GEMV + one attention kernel per layer
     bool fuse_prefill_attn = true;   // N >= 9: KQ + soft_max + KQV in one launch
+    bool w13_il = false;             // w1|w3 woven by 16-row groups (n_ff/tp a multiple of 32): silu epilogue in the matmul
     int exp_tab_n = 0;               // fp16 exp-table entries after 0x8000 that are non-zero (rounded up to 8): the LDS copy
     // LoRA: originals of the tensors an adapter touched (the reference's use_mmap path keeps them too, llama.cpp:868-874)
     struct LoraBackup { fl_qtensor *t; void *qs, *d, *mm; };
@@ -141,6 +142,7 @@ fl_model *fl_model_create(const fl_model_params *p) {
     m->n_ctx = p->n_ctx; m->B = p->max_batch; m->qtype = p->qtype;
     m->G = G; m->rank = p->tp_rank;
     m->El = m->E / G; m->Hl = m->H / G; m->Fl = m->F / G;
+    m->w13_il = m->Fl % 32 == 0;
     m->layers.resize(m->L);
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
         set_error(FL_EHIP, "hipStreamCreate failed");
@@ -172,16 +174,27 @@ static int make_qtensor(fl_model *m, fl_qtensor **out, const void *aos_dev, int 
     return FL_OK;
 }
 
+// interleave16: the parts are woven by 16-row groups (group 2p = part 0 rows [16p, 16p+16), group 2p+1 = part 1 ...):
+// the layout the silu epilogue of the w1|w3 matmul needs (gemm_q4_mfma.hip, GemmSiluEpi)
 static int stage_part(fl_model *m, StagedFuse &sf, fl_qtensor **out, int nparts, int part, const void *host, int bs,
-                      int KB_full, int row0, int rows, int K) {
+                      int KB_full, int row0, int rows, int K, bool interleave16 = false) {
     if (!sf.aos) {
         sf.parts_needed = nparts;
         sf.rows_per_part = rows;
         sf.K = K;
         M_HIP(hipMalloc(&sf.aos, (size_t)nparts * rows * (K / FL_QK) * bs));
     }
-    void *dst = (char *)sf.aos + (size_t)part * rows * (K / FL_QK) * bs;
-    int rc = stage_rows(host, bs, KB_full, row0, rows, 0, K / FL_QK, dst);
+    int rc;
+    if (interleave16) {
+        const size_t rowb = (size_t)(K / FL_QK) * bs;     // (KB_full == K/32: w1 / w3 are never split along K)
+        const char *src = (const char *)host + (size_t)row0 * rowb;
+        M_HIP(hipMemcpy2D((char *)sf.aos + (size_t)part * 16 * rowb, (size_t)nparts * 16 * rowb, src, 16 * rowb, 16 * rowb,
+                          (size_t)rows / 16, hipMemcpyDefault));
+        rc = FL_OK;
+    } else {
+        void *dst = (char *)sf.aos + (size_t)part * rows * (K / FL_QK) * bs;
+        rc = stage_rows(host, bs, KB_full, row0, rows, 0, K / FL_QK, dst);
+    }
     if (rc != FL_OK) return rc;
     if (++sf.parts_have == sf.parts_needed) {
         rc = make_qtensor(m, out, sf.aos, nparts * rows, K);
@@ -237,7 +250,7 @@ int fl_model_set_tensor(fl_model *m, const char *name, int type, const void *hos
     if (sub == "feed_forward.w1.weight" || sub == "feed_forward.w3.weight") {
         if ((rc = want_q(E, F)) != FL_OK) return rc;
         const int part = sub[14] == '1' ? 0 : 1;
-        return stage_part(m, ly.s_13, &ly.w13, 2, part, host, bs, E / FL_QK, r * m->Fl, m->Fl, E);
+        return stage_part(m, ly.s_13, &ly.w13, 2, part, host, bs, E / FL_QK, r * m->Fl, m->Fl, E, m->w13_il);
     }
     if (sub == "attention.wo.weight" || sub == "feed_forward.w2.weight") {
         const bool is_wo = sub[0] == 'a';
@@ -368,12 +381,22 @@ static hipError_t mm_norm(fl_model *m, const fl_qtensor *W, const float *x, cons
     return r;
 }
 
+// prefill: Q8_0(silu(w1 x) * (w3 x)) straight from the w1|w3 matmul (rows woven by 16) into the w2 matmul's operand
+static hipError_t mm_silu_gemm(fl_model *m, const fl_qtensor *W, const fl_qact &a, int N) {
+    hipEvent_t e1;
+    hipError_t r = prof_begin(m, &e1);
+    if (r != hipSuccess) return r;
+    r = gemm_q4_mfma_silu(*W, a, N, m->silu_tab, m->qF, m->stream);
+    prof_end(m, e1);
+    return r;
+}
+
 // decode: y = W . Q8_0(silu(h13[:F]) * h13[F:]) (+ resid) in one launch
 static hipError_t mm_silu(fl_model *m, const fl_qtensor *W, const float *h13, float *y, const float *resid) {
     hipEvent_t e1;
     hipError_t r = prof_begin(m, &e1);
     if (r != hipSuccess) return r;
-    r = gemv_q4_silu(*W, h13, m->silu_tab, y, resid, m->stream);
+    r = gemv_q4_silu(*W, h13, m->silu_tab, y, resid, m->stream, m->w13_il);
     prof_end(m, e1);
     return r;
 }
@@ -435,13 +458,15 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn) {
             M_HIP(add_rows(m->part, E, inp, E, mid, E, N, E, st));
         }
         // feed-forward                                                                             :412-436
+        const bool silu_in_gemm = N >= 9 && m->w13_il;    // silu * mul -> Q8_0 is the epilogue of the w1|w3 matmul
         if (fused) {
             M_HIP(mm_norm(m, ly.w13, mid, ly.ffn_norm, nullptr, m->h13));
         } else {
             M_HIP(rmsnorm_quant(mid, E, ly.ffn_norm, N, E, nullptr, 0, &m->qE, layout, st));
-            M_HIP(mm(m, ly.w13, m->qE, N, m->h13, 2 * Fl, nullptr, 0));
+            if (silu_in_gemm) M_HIP(mm_silu_gemm(m, ly.w13, m->qE, N));
+            else M_HIP(mm(m, ly.w13, m->qE, N, m->h13, 2 * Fl, nullptr, 0));
         }
-        if (!fused) M_HIP(silu_mul_quant(m->h13, 2 * Fl, N, Fl, m->silu_tab, &m->qF, layout, st));
+        if (!fused && !silu_in_gemm) M_HIP(silu_mul_quant(m->h13, 2 * Fl, N, Fl, m->silu_tab, &m->qF, layout, st, m->w13_il));
         if (!tp) {
             if (fused) M_HIP(mm_silu(m, ly.w2, m->h13, inp, mid));
             else M_HIP(mm(m, ly.w2, m->qF, N, inp, E, mid, E));                                   // + inpFF :441
@@ -568,6 +593,7 @@ namespace {
 struct TensorRef {
     fl_qtensor *t = nullptr;
     int row0 = 0, rows = 0;        // rows of the (possibly fused) device tensor that hold this base tensor's shard
+    int il_part = -1;              // >= 0: rows are woven by 16 (w1|w3): local row r sits at 32 (r / 16) + 16 il_part + r % 16
     int grow0 = 0, gcol0 = 0;      // where the shard sits in the FULL base tensor (tensor parallel): row / column offset
     int Kfull = 0, Mfull = 0;      // full base tensor: ne0, ne1
 };
@@ -594,6 +620,7 @@ static int locate_tensor(fl_model *m, const char *name, TensorRef *o) {
     if (sub == "feed_forward.w1.weight" || sub == "feed_forward.w3.weight") {
         const int part = sub[14] == '1' ? 0 : 1;
         o->t = ly.w13; o->row0 = part * m->Fl; o->rows = m->Fl; o->grow0 = r * m->Fl; o->Kfull = E; o->Mfull = F;
+        if (m->w13_il) { o->il_part = part; o->row0 = 0; }
         return FL_OK;
     }
     if (sub == "attention.wo.weight") {
@@ -673,7 +700,7 @@ extern "C" int fl_model_lora_apply(fl_model *m, const char *base_name, const flo
     if (rc != FL_OK) { cleanup(); return rc; }
     e = unpack_from_qw16(t->type, t->qs, t->d, t->m, t->M, t->K, aos, m->stream);
     if (e == hipSuccess)
-        e = lora_add_aos(t->type, aos, t->KB, tr.row0, tr.rows, dba, tr.Kfull, da, db, r, tr.grow0, tr.gcol0, sign, m->stream);
+        e = lora_add_aos(t->type, aos, t->KB, tr.row0, tr.rows, tr.il_part, dba, tr.Kfull, da, db, r, tr.grow0, tr.gcol0, sign, m->stream);
     if (e == hipSuccess) e = hipMemsetAsync(flag, 0, 4, m->stream);
     if (e == hipSuccess) e = repack_to_qw16(t->type, aos, t->M, t->K, t->qs, t->d, t->m, flag, m->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, m->stream);
@@ -711,8 +738,12 @@ extern "C" int fl_model_tensor_download(fl_model *m, const char *base_name, void
     void *aos = nullptr;
     M_HIP(hipMalloc(&aos, (size_t)t->M * t->KB * bs));
     hipError_t e = unpack_from_qw16(t->type, t->qs, t->d, t->m, t->M, t->K, aos, m->stream);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(aos_host, (char *)aos + (size_t)tr.row0 * t->KB * bs, (size_t)tr.rows * t->KB * bs, hipMemcpyDeviceToHost, m->stream);
+    const size_t rowb = (size_t)t->KB * bs;
+    if (e == hipSuccess && tr.il_part >= 0)
+        e = hipMemcpy2DAsync(aos_host, 16 * rowb, (char *)aos + (size_t)tr.il_part * 16 * rowb, 32 * rowb, 16 * rowb, (size_t)tr.rows / 16,
+                             hipMemcpyDeviceToHost, m->stream);
+    else if (e == hipSuccess)
+        e = hipMemcpyAsync(aos_host, (char *)aos + (size_t)tr.row0 * rowb, (size_t)tr.rows * rowb, hipMemcpyDeviceToHost, m->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
     (void)hipFree(aos);
     return e == hipSuccess ? FL_OK : hip_fail(e, "fl_model_tensor_download");
@@ -784,7 +815,7 @@ int fl_debug_gemv_norm(const fl_qtensor *W, const float *x, const float *norm_w,
 }
 int fl_debug_gemv_silu(const fl_qtensor *W, const float *h13, const uint16_t *silu_tab, float *y, const float *resid,
                        void *stream) {
-    M_HIP(gemv_q4_silu(*W, h13, silu_tab, y, resid, (hipStream_t)stream));
+    M_HIP(gemv_q4_silu(*W, h13, silu_tab, y, resid, (hipStream_t)stream, false));
     return FL_OK;
 }
 int fl_debug_prefill_attention(const float *qkv, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc,
@@ -806,7 +837,7 @@ int fl_debug_decode_attention(const float *qkv, int E, int D, int H, int n_past,
 }
 int fl_debug_silu_mul_quant(const float *h13, int ld, int N, int F, const uint16_t *silu_tab_dev, fl_qact *out, int layout,
                             void *stream) {
-    M_HIP(silu_mul_quant(h13, ld, N, F, silu_tab_dev, out, layout, (hipStream_t)stream));
+    M_HIP(silu_mul_quant(h13, ld, N, F, silu_tab_dev, out, layout, (hipStream_t)stream, false));
     return FL_OK;
 }
 int fl_debug_rope_kv(float *qkv, int ld, int N, int E, int D, int n_past, int n_ctx, const float *rope_tab_dev, float *kc,

@@ -34,11 +34,13 @@ hipError_t vec_dot_aos(int type, int n, float *s_dev, const void *x_aos, const v
 // resid (optional): y = mul_mat + resid, the ggml_add that follows wo / w2 (lib/llama.cpp:407,441), fused into the store
 hipError_t gemv_q4_norm(const fl_qtensor &W, const float *x, const float *norm_w, float *ynorm, float *y, hipStream_t st);
 hipError_t gemv_q4_silu(const fl_qtensor &W, const float *h13, const uint16_t *silu_tab, float *y, const float *resid,
-                        hipStream_t st);
+                        hipStream_t st, bool woven = false);
 hipError_t gemv_q4(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                    const float *resid = nullptr, int ldr = 0);
 hipError_t gemm_q4_mfma(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                         const float *resid = nullptr, int ldr = 0);
+hipError_t gemm_q4_mfma_silu(const fl_qtensor &W, const fl_qact &xq, int N, const uint16_t *silu_tab, const fl_qact &out,
+                             hipStream_t st);
 hipError_t gemm_q4_naive(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st);
 
 size_t qact_bytes_q(int N, int K);      // bytes of the q plane for N columns (padded to 16)

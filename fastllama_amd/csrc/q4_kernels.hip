@@ -481,7 +481,7 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
                                                       float *__restrict__ y, int ldy,
                                                       const float *__restrict__ resid, int ldr,
                                                       const float *__restrict__ xf, const void *__restrict__ aux,
-                                                      float *__restrict__ ynorm) {
+                                                      float *__restrict__ ynorm, int woven) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     const int grp = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -545,9 +545,11 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
         for (int it = 0; it < SIT; ++it) {
             const int kg = threadIdx.x + it * 64 * NWAVES;
             if (kg < gpr) {
-                const float *pa = xf + kg * 8;
+                // features 8kg..8kg+7 of w1 x and of w3 x (woven: 16-feature groups alternate, else the halves [F | F])
+                const float *pa = xf + (woven ? ((kg >> 1) << 5) + ((kg & 1) << 3) : kg * 8);
+                const int boff = woven ? 16 : F;
                 const float4 a0 = *reinterpret_cast<const float4 *>(pa), a1 = *reinterpret_cast<const float4 *>(pa + 4);
-                const float4 b0 = *reinterpret_cast<const float4 *>(pa + F), b1 = *reinterpret_cast<const float4 *>(pa + F + 4);
+                const float4 b0 = *reinterpret_cast<const float4 *>(pa + boff), b1 = *reinterpret_cast<const float4 *>(pa + boff + 4);
                 sa_[it][0] = a0.x; sa_[it][1] = a0.y; sa_[it][2] = a0.z; sa_[it][3] = a0.w;
                 sa_[it][4] = a1.x; sa_[it][5] = a1.y; sa_[it][6] = a1.z; sa_[it][7] = a1.w;
                 sb_[it][0] = b0.x; sb_[it][1] = b0.y; sb_[it][2] = b0.z; sb_[it][3] = b0.w;
@@ -622,9 +624,10 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
             quantize_group_lds(o, kg, lq, ld_, ls_);
         }
         for (int kg = threadIdx.x + SIT * 64 * NWAVES; kg < gpr; kg += 64 * NWAVES) {   // very wide rows: the rest
-            const float *pa = xf + kg * 8;
+            const float *pa = xf + (woven ? ((kg >> 1) << 5) + ((kg & 1) << 3) : kg * 8);
+            const int boff = woven ? 16 : F;
             const float4 a0 = *reinterpret_cast<const float4 *>(pa), a1 = *reinterpret_cast<const float4 *>(pa + 4);
-            const float4 b0 = *reinterpret_cast<const float4 *>(pa + F), b1 = *reinterpret_cast<const float4 *>(pa + F + 4);
+            const float4 b0 = *reinterpret_cast<const float4 *>(pa + boff), b1 = *reinterpret_cast<const float4 *>(pa + boff + 4);
             const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
             const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
             float o[8];
@@ -710,7 +713,7 @@ static inline int gemv_waves(int groups) { return groups >= 1024 ? 4 : groups >=
 // single-token launches: (NWAVES by M, U by K) so that one pass covers the row when NWAVES * 8 >= K/128
 template <int TYPE, int PRO>
 static hipError_t launch_gemv1(const fl_qtensor &W, const fl_qact *xq, float *y, hipStream_t st, const float *resid,
-                               const float *xf, const void *aux, float *ynorm) {
+                               const float *xf, const void *aux, float *ynorm, int woven = 0) {
     const dim3 grid(W.M16 / 16);
     const uint4 *qs = reinterpret_cast<const uint4 *>(W.qs);
     const int nw = gemv_waves(W.M16 / 16);
@@ -720,7 +723,7 @@ static hipError_t launch_gemv1(const fl_qtensor &W, const fl_qact *xq, float *y,
 #define FL_GEMV(NW, UU)                                                                                              \
     hipLaunchKernelGGL((gemv_q4_kernel<TYPE, 1, NW, PRO, UU>), grid, dim3(64 * NW), lds, st, qs, W.d, W.m,           \
                        xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, 1, W.M, W.KB, y, 0, resid, 0, \
-                       xf, aux, ynorm)
+                       xf, aux, ynorm, woven)
 #define FL_GEMV_U(NW)                   \
     do {                                \
         if (u == 2) FL_GEMV(NW, 2);     \
@@ -747,7 +750,7 @@ static hipError_t launch_gemv(const fl_qtensor &W, const fl_qact &xq, int N, flo
     const int nw = gemv_waves(W.M16 / 16);
 #define FL_GEMV(NC, NW, UU)                                                                                             \
     hipLaunchKernelGGL((gemv_q4_kernel<TYPE, NC, NW, 0, UU>), grid, dim3(64 * NW), 0, st, qs, W.d, W.m, xq.q, xq.d, xq.s, \
-                       N, W.M, W.KB, y, ldy, resid, ldr, nullptr, nullptr, nullptr)
+                       N, W.M, W.KB, y, ldy, resid, ldr, nullptr, nullptr, nullptr, 0)
 #define FL_GEMV_NW(NC, UU)                       \
     do {                                         \
         if (nw == 4) FL_GEMV(NC, 4, UU);         \
@@ -771,10 +774,10 @@ hipError_t gemv_q4_norm(const fl_qtensor &W, const float *x, const float *norm_w
 
 // y[M] = W . Q8_0(silu(h13[0:K]) * h13[K:2K]) (+ resid)   -- decode feed-forward down projection in one launch
 hipError_t gemv_q4_silu(const fl_qtensor &W, const float *h13, const uint16_t *silu_tab, float *y, const float *resid,
-                        hipStream_t st) {
+                        hipStream_t st, bool woven) {
     if (W.K % 32 != 0 || W.K > 32768) return hipErrorInvalidValue;
-    return W.type == FL_TYPE_Q4_0 ? launch_gemv1<FL_TYPE_Q4_0, 2>(W, nullptr, y, st, resid, h13, silu_tab, nullptr)
-                                  : launch_gemv1<FL_TYPE_Q4_1, 2>(W, nullptr, y, st, resid, h13, silu_tab, nullptr);
+    return W.type == FL_TYPE_Q4_0 ? launch_gemv1<FL_TYPE_Q4_0, 2>(W, nullptr, y, st, resid, h13, silu_tab, nullptr, woven ? 1 : 0)
+                                  : launch_gemv1<FL_TYPE_Q4_1, 2>(W, nullptr, y, st, resid, h13, silu_tab, nullptr, woven ? 1 : 0);
 }
 
 hipError_t gemv_q4(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
