@@ -94,6 +94,12 @@ struct GemmSiluEpi {
     int8_t *oq;
     float *od, *os;
     int KBo;                    // n_ff / 32
+    // second optional epilogue, for the fused wq|wk|wv matrix: rope on Q (stored to y) and on K (stored to the K cache
+    // row of the token's position), V stored transposed into the V cache -- ggml_rope + the two ggml_cpy into memory_k /
+    // memory_v (lib/llama.cpp:328-347) without a pass over the [N][3 n_embd] result.  Arithmetic of rope_kv_kernel.
+    const float2 *rope_tab;     // [n_ctx][D/2] {cos, sin} (null: off)
+    float *kc, *vc;             // [n_ctx][El], [El][n_ctx]
+    int El, D, n_past, n_ctx;
 };
 
 template <int TYPE, int WM, int WN, int TM, int TN, int MINW>
@@ -408,6 +414,41 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
         }
         return;
     }
+    if (epi.rope_tab) {
+        // lane holds features row0..row0+3 (two rope pairs) of token n
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row0 = (mg0 + wm * TM + i) * 16 + lg * 4;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = (ng0 + wn * TN + j) * 16 + l15;
+                const int flat = i * TN + j, g = flat / 4, k = flat % 4;
+                v4f o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = acc[g][4 * k + e];
+                    if (TYPE == FL_TYPE_Q4_1) o[e] += msacc[g][4 * k + e];
+                }
+                if (n >= N || row0 >= M) continue;
+                const int part = row0 / epi.El, f = row0 - part * epi.El, pos = epi.n_past + n;
+                if (part < 2) {
+                    const float2 *cs = epi.rope_tab + (int64_t)pos * (epi.D >> 1) + ((f % epi.D) >> 1);
+                    const float2 c0 = cs[0], c1 = cs[1];
+                    v4f q;
+                    q[0] = __builtin_fmaf(o[0], c0.x, -(o[1] * c0.y));
+                    q[1] = __builtin_fmaf(o[0], c0.y, o[1] * c0.x);
+                    q[2] = __builtin_fmaf(o[2], c1.x, -(o[3] * c1.y));
+                    q[3] = __builtin_fmaf(o[2], c1.y, o[3] * c1.x);
+                    float *dst = part == 0 ? y + (int64_t)n * ldy + row0 : epi.kc + (int64_t)pos * epi.El + f;
+                    *reinterpret_cast<v4f *>(dst) = q;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) epi.vc[(int64_t)(f + e) * epi.n_ctx + pos] = o[e];
+                }
+            }
+        }
+        return;
+    }
     // ---- store: lane holds rows m = 16*g + 4*lg + {0..3} of column n = 16*h + l15 -> one 16-byte store
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -518,7 +559,7 @@ static hipError_t gemm_dispatch(const fl_qtensor &W, const fl_qact &xq, int N, f
 
 hipError_t gemm_q4_mfma(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                         const float *resid, int ldr) {
-    return gemm_dispatch(W, xq, N, y, ldy, st, resid, ldr, GemmSiluEpi{nullptr, nullptr, nullptr, nullptr, 0});
+    return gemm_dispatch(W, xq, N, y, ldy, st, resid, ldr, GemmSiluEpi{});
 }
 
 // W = w1|w3 with 16-row groups interleaved (group 2p = w1 rows [16p, 16p+16), group 2p+1 = the same rows of w3);
@@ -526,7 +567,20 @@ hipError_t gemm_q4_mfma(const fl_qtensor &W, const fl_qact &xq, int N, float *y,
 hipError_t gemm_q4_mfma_silu(const fl_qtensor &W, const fl_qact &xq, int N, const uint16_t *silu_tab, const fl_qact &out,
                              hipStream_t st) {
     if (!silu_tab || W.M % 64 != 0) return hipErrorInvalidValue;
-    return gemm_dispatch(W, xq, N, nullptr, 4, st, nullptr, 0, GemmSiluEpi{silu_tab, out.q, out.d, out.s, W.M / 64});
+    GemmSiluEpi epi{};
+    epi.silu_tab = silu_tab; epi.oq = out.q; epi.od = out.d; epi.os = out.s; epi.KBo = W.M / 64;
+    return gemm_dispatch(W, xq, N, nullptr, 4, st, nullptr, 0, epi);
+}
+
+// W = wq|wk|wv stacked ([3 El][K]); y <- rope(Q) rows ([N][ldy], only the first El columns are written), K cache rows
+// n_past.. <- rope(K), transposed V cache columns n_past.. <- V
+hipError_t gemm_q4_mfma_qkv(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, const float *rope_tab, float *kc,
+                            float *vc, int El, int D, int n_past, int n_ctx, hipStream_t st) {
+    if (!rope_tab || W.M != 3 * El || El % 4 != 0 || D % 4 != 0 || (ldy & 3) != 0) return hipErrorInvalidValue;
+    GemmSiluEpi epi{};
+    epi.rope_tab = reinterpret_cast<const float2 *>(rope_tab);
+    epi.kc = kc; epi.vc = vc; epi.El = El; epi.D = D; epi.n_past = n_past; epi.n_ctx = n_ctx;
+    return gemm_dispatch(W, xq, N, y, ldy, st, nullptr, 0, epi);
 }
 
 }  // namespace fl

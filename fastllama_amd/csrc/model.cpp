@@ -381,6 +381,16 @@ static hipError_t mm_norm(fl_model *m, const fl_qtensor *W, const float *x, cons
     return r;
 }
 
+// prefill: the wq|wk|wv matmul with rope + KV-cache stores as its epilogue
+static hipError_t mm_qkv_rope(fl_model *m, const fl_qtensor *W, const fl_qact &a, int N, float *kc, float *vc, int n_past) {
+    hipEvent_t e1;
+    hipError_t r = prof_begin(m, &e1);
+    if (r != hipSuccess) return r;
+    r = gemm_q4_mfma_qkv(*W, a, N, m->qkv, 3 * m->El, m->rope_tab, kc, vc, m->El, m->D, n_past, m->n_ctx, m->stream);
+    prof_end(m, e1);
+    return r;
+}
+
 // prefill: Q8_0(silu(w1 x) * (w3 x)) straight from the w1|w3 matmul (rows woven by 16) into the w2 matmul's operand
 static hipError_t mm_silu_gemm(fl_model *m, const fl_qtensor *W, const fl_qact &a, int N) {
     hipEvent_t e1;
@@ -429,8 +439,12 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn) {
         } else {
             // norm + attention_norm*cur -> Q8_0                                                        llama.cpp:311-319
             M_HIP(rmsnorm_quant(inp, E, ly.attn_norm, N, E, nullptr, 0, &m->qE, layout, st));
-            M_HIP(mm(m, ly.wqkv, m->qE, N, m->qkv, 3 * El, nullptr, 0));                               // wq, wk, wv  :328-334
-            M_HIP(rope_kv(m->qkv, 3 * El, N, El, D, n_past, n_ctx, m->rope_tab, kc, vc, st, dyn));     // rope, store :328-347
+            if (N >= 9 && !dyn && m->fuse_prefill_attn) {
+                M_HIP(mm_qkv_rope(m, ly.wqkv, m->qE, N, kc, vc, n_past));                              // wq, wk, wv + rope + KV store
+            } else {
+                M_HIP(mm(m, ly.wqkv, m->qE, N, m->qkv, 3 * El, nullptr, 0));                           // wq, wk, wv  :328-334
+                M_HIP(rope_kv(m->qkv, 3 * El, N, El, D, n_past, n_ctx, m->rope_tab, kc, vc, st, dyn)); // rope, store :328-347
+            }
             const float kq_scale = 1.0f / sqrtf((float)E / (float)m->H);
             // KQ, scale, mask, soft_max, KQV in one launch with the score rows in LDS when they fit       :364-398
             hipError_t pe = (N >= 9 && !dyn && m->fuse_prefill_attn)
