@@ -240,3 +240,48 @@ def test_tensor_parallel_shards_on_one_gpu(tmp_path_factory, port, qtype, cfgnam
         m.free()
     for r in range(G):
         L.fl_comm_destroy(C.c_void_p(comms[r]))
+
+
+@pytest.mark.parametrize("qtype", [ggjt.Q4_0])
+def test_long_context_path_switches_agree(tmp_path_factory, port, qtype):
+    """A 1400-token context evaluated in different chunkings walks through every attention path: the one-launch prefill
+    kernel in pair mode (n_past = 0), in single-block mode (n_past > 0), the three-kernel fallback once n_past + N no
+    longer fits LDS (> 960 keys), the N <= 8 path and the single-token decode kernel.  The KV cache they leave behind
+    must be interchangeable: a fixed probe token evaluated after each chunking gives logits that agree to the usual
+    cross-path bound, and the K/V state agrees bit for bit where the producing kernels are bit-identical by design."""
+    import ctypes as C
+    from fastllama_amd import hip
+    from harness.flmodel import FlModel
+    L = hip.load()
+    cfg = ggjt.SMALL
+    tensors, _ = build(tmp_path_factory, port, cfg, qtype, "long")
+    rng = np.random.default_rng(5)
+    toks = rng.integers(3, 259, 1400).astype(np.int32)
+    n_ctx = 1536
+    E, Ln = cfg["n_embd"], cfg["n_layer"]
+
+    def run(chunks):
+        m = FlModel(cfg, qtype, tensors, n_ctx=n_ctx, max_batch=512)
+        n_past = 0
+        for c in chunks:
+            m.eval(toks[n_past:n_past + c], n_past=n_past)
+            n_past += c
+        assert n_past == 1400
+        k = np.empty((Ln, n_ctx, E), np.float32)
+        v = np.empty((Ln, E, n_ctx), np.float32)
+        hip.check(L.fl_model_kv_read(m.h, k.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)), "kv_read")
+        lg = m.eval([int(toks[7])], n_past=1400)[0].copy()
+        m.free()
+        return k, v, lg
+
+    ka, va, la = run([512, 448, 440])                    # pair mode; single-block mode (P = 960); three-kernel fallback
+    kb, vb, lb = run([500, 300, 300, 300])               # odd block counts, other switch points
+    kc_, vc_, lc = run([512, 512, 368, 8])               # ... and an N <= 8 tail
+    # layer 0 K/V depend only on the token embeddings and the (bit-identical) wqkv + rope epilogue vs kernel pair
+    assert np.array_equal(ka[0, :1400], kb[0, :1400]) and np.array_equal(va[0, :, :1400], vb[0, :, :1400])
+    assert np.array_equal(ka[0, :1392], kc_[0, :1392])
+    for other in (lb, lc):
+        assert relerr(other, la) <= 5e-2
+    # deeper layers: same values up to the rounding-flip noise of the algorithm (DESIGN.md section 4)
+    d = np.abs(ka[:, :1400] - kb[:, :1400]).max() / np.abs(ka[:, :1400]).max()
+    assert d <= 5e-2, d
