@@ -538,6 +538,7 @@ static int pick_config(int MGT, int NGT, int type) {
     if (q1 < 0.96 * qb) { best = 1; qb = q1; }
     if (q5 < 0.90 * qb) { best = 5; qb = q5; }
     if (per_simd < 40 && best == 2 && q1 <= q2) best = 1;                         // mid-size: 4 workgroups of 4 waves per CU
+    if (type == FL_TYPE_Q4_1 && best == 2 && q1 <= 1.02 * q2) best = 1;           // Q4_1 (one more MFMA per 4 tiles): measured
     return best;
 }
 
