@@ -43,7 +43,7 @@ int ensure_device() {
 
 }  // namespace fl
 
-namespace fl { extern int g_gemm_force_cfg; }
+namespace fl { extern int g_gemm_force_cfg; extern int g_gemv_force_waves; }
 using namespace fl;
 
 #define FL_HIP(call)                                   \
@@ -390,6 +390,7 @@ int fl_quantize_q8(fl_qact *a, const float *x, int ldx, int N, int K, void *st) 
 
 int fl_debug_set(int what, int value) {
     if (what == 0) fl::g_gemm_force_cfg = value;
+    if (what == 1) fl::g_gemv_force_waves = value;   // 0 = automatic, else 4 / 8 / 16 waves per 16-row group
     return FL_OK;
 }
 

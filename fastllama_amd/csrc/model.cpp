@@ -401,6 +401,26 @@ static hipError_t mm_silu_gemm(fl_model *m, const fl_qtensor *W, const fl_qact &
     return r;
 }
 
+// decode: act = silu(w1 . q) * (w3 . q), q = Q8_0(norm_w * rms_norm(x)) in one launch (woven w1|w3)
+static hipError_t mm_norm_silu(fl_model *m, const fl_qtensor *W, const float *x, const float *norm_w, float *act) {
+    hipEvent_t e1;
+    hipError_t r = prof_begin(m, &e1);
+    if (r != hipSuccess) return r;
+    r = gemv_q4_norm_silu(*W, x, norm_w, m->silu_tab, act, m->stream);
+    prof_end(m, e1);
+    return r;
+}
+
+// decode: y = W . Q8_0(act) (+ resid) in one launch
+static hipError_t mm_quant(fl_model *m, const fl_qtensor *W, const float *act, float *y, const float *resid) {
+    hipEvent_t e1;
+    hipError_t r = prof_begin(m, &e1);
+    if (r != hipSuccess) return r;
+    r = gemv_q4_quant(*W, act, y, resid, m->stream);
+    prof_end(m, e1);
+    return r;
+}
+
 // decode: y = W . Q8_0(silu(h13[:F]) * h13[F:]) (+ resid) in one launch
 static hipError_t mm_silu(fl_model *m, const fl_qtensor *W, const float *h13, float *y, const float *resid) {
     hipEvent_t e1;
@@ -473,7 +493,10 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn) {
         }
         // feed-forward                                                                             :412-436
         const bool silu_in_gemm = N >= 9 && m->w13_il;    // silu * mul -> Q8_0 is the epilogue of the w1|w3 matmul
-        if (fused) {
+        const bool silu_in_gemv = fused && m->w13_il;         // decode: silu * mul is the epilogue of the w1|w3 GEMV
+        if (silu_in_gemv) {
+            M_HIP(mm_norm_silu(m, ly.w13, mid, ly.ffn_norm, m->h13));
+        } else if (fused) {
             M_HIP(mm_norm(m, ly.w13, mid, ly.ffn_norm, nullptr, m->h13));
         } else {
             M_HIP(rmsnorm_quant(mid, E, ly.ffn_norm, N, E, nullptr, 0, &m->qE, layout, st));
@@ -482,10 +505,12 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn) {
         }
         if (!fused && !silu_in_gemm) M_HIP(silu_mul_quant(m->h13, 2 * Fl, N, Fl, m->silu_tab, &m->qF, layout, st, m->w13_il));
         if (!tp) {
-            if (fused) M_HIP(mm_silu(m, ly.w2, m->h13, inp, mid));
+            if (silu_in_gemv) M_HIP(mm_quant(m, ly.w2, m->h13, inp, mid));
+            else if (fused) M_HIP(mm_silu(m, ly.w2, m->h13, inp, mid));
             else M_HIP(mm(m, ly.w2, m->qF, N, inp, E, mid, E));                                   // + inpFF :441
         } else {
-            if (fused) M_HIP(mm_silu(m, ly.w2, m->h13, m->part, nullptr));
+            if (silu_in_gemv) M_HIP(mm_quant(m, ly.w2, m->h13, m->part, nullptr));
+            else if (fused) M_HIP(mm_silu(m, ly.w2, m->h13, m->part, nullptr));
             else M_HIP(mm(m, ly.w2, m->qF, N, m->part, E, nullptr, 0));
             int rc = allreduce_if_tp(m, m->part, (size_t)N * E);
             if (rc != FL_OK) return rc;
@@ -842,6 +867,15 @@ int fl_debug_prefill_attention(const float *qkv, int ldq, int D, int H, int N, i
         tab_n = (last_nz + 1 + 7) & ~7;
     }
     M_HIP(prefill_attention(qkv, ldq, D, H, N, n_past, n_ctx, E, kc, vc, exp_tab_dev, tab_n, scale, ao, ldo, (hipStream_t)stream));
+    return FL_OK;
+}
+int fl_debug_gemv_norm_silu(const fl_qtensor *W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act,
+                            void *stream) {
+    M_HIP(gemv_q4_norm_silu(*W, x, norm_w, silu_tab, act, (hipStream_t)stream));
+    return FL_OK;
+}
+int fl_debug_gemv_quant(const fl_qtensor *W, const float *x, float *y, const float *resid, void *stream) {
+    M_HIP(gemv_q4_quant(*W, x, y, resid, (hipStream_t)stream));
     return FL_OK;
 }
 int fl_debug_decode_attention(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab_dev,

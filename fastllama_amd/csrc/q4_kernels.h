@@ -35,6 +35,9 @@ hipError_t vec_dot_aos(int type, int n, float *s_dev, const void *x_aos, const v
 hipError_t gemv_q4_norm(const fl_qtensor &W, const float *x, const float *norm_w, float *ynorm, float *y, hipStream_t st);
 hipError_t gemv_q4_silu(const fl_qtensor &W, const float *h13, const uint16_t *silu_tab, float *y, const float *resid,
                         hipStream_t st, bool woven = false);
+hipError_t gemv_q4_norm_silu(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act,
+                             hipStream_t st);
+hipError_t gemv_q4_quant(const fl_qtensor &W, const float *x, float *y, const float *resid, hipStream_t st);
 hipError_t gemv_q4(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                    const float *resid = nullptr, int ldr = 0);
 hipError_t gemm_q4_mfma(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,

@@ -473,7 +473,12 @@ __device__ __forceinline__ void quantize_group_lds(const float o[8], int kg, int
 //   PRO = 2: silu(w1 x) * (w3 x) -> Q8_0 (silu_mul_quant_kernel; xf = [w1 x (K) | w3 x (K)], aux = fp16 silu table)
 // U = block-quads in flight per wave; the launcher picks U so that NWAVES * U covers the row when it can, i.e. all of
 // a workgroup's weight bytes are requested before anything waits.
-template <int TYPE, int NC, int NWAVES, int PRO, int U>
+//   PRO = 3: plain quantize_row_q8_0 of an f32 vector (the activation of the w2 matmul after a PAIR = 1 launch)
+// PAIR = 1 (NC = 1): the workgroup owns TWO consecutive 16-row groups -- w1 rows and the same rows of w3 in the woven
+// w1|w3 matrix (model.cpp) -- and stores silu(w1 x) * (w3 x) for its 16 features instead of the two dots (aux2 = fp16
+// SiLU table): ggml_silu + ggml_mul of lib/llama.cpp:428-431 as the epilogue of the matmul.  Slot u of a wave's U loads
+// belongs to group u & 1.
+template <int TYPE, int NC, int NWAVES, int PRO, int U, int PAIR>
 __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__restrict__ qs, const float *__restrict__ dW,
                                                       const float *__restrict__ mW,
                                                       const int8_t *__restrict__ xq, const float *__restrict__ xd,
@@ -481,15 +486,21 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
                                                       float *__restrict__ y, int ldy,
                                                       const float *__restrict__ resid, int ldr,
                                                       const float *__restrict__ xf, const void *__restrict__ aux,
-                                                      float *__restrict__ ynorm, int woven) {
+                                                      float *__restrict__ ynorm, int woven,
+                                                      const uint16_t *__restrict__ aux2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
-    const int grp = blockIdx.x;
+    static_assert(!PAIR || (NC == 1 && U % 2 == 0), "pair mode: single column, even number of load slots");
+    constexpr int G2 = PAIR ? 2 : 1;
+    constexpr int UQ = PAIR ? U / 2 : U;                       // block-quads per wave and pass (of each group)
+    const int grp = blockIdx.x * G2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, bq = lane >> 4;
     const int xswap = ((r >> 3) & 1) * 16;  // rows 8..15 keep k-groups {2,3} first (qw16_pos)
-    float acc[NC];
+    float acc[G2][NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+    for (int g = 0; g < G2; ++g)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[g][c] = 0.f;
 
     const int nquads = (KB + 3) >> 2;
     const int64_t gbase = (int64_t)grp * KB;
@@ -499,9 +510,10 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
     auto load = [&](int q0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int b = (q0 + u * NWAVES) * 4 + bq;
-            ok[u] = (q0 + u * NWAVES) < nquads && b < KB;
-            const int64_t idx = (gbase + (ok[u] ? b : 0)) * 16 + r;
+            const int g2 = PAIR ? (u & 1) : 0, uq = PAIR ? (u >> 1) : u;
+            const int b = (q0 + uq * NWAVES) * 4 + bq;
+            ok[u] = (q0 + uq * NWAVES) < nquads && b < KB;
+            const int64_t idx = (gbase + (int64_t)g2 * KB + (ok[u] ? b : 0)) * 16 + r;
             w[u] = qs[idx];
             dw[u] = dW[idx];
             mw[u] = TYPE == FL_TYPE_Q4_1 ? mW[idx] : 0.f;
@@ -640,13 +652,22 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
             quantize_group_lds(o, kg, lq, ld_, ls_);
         }
         __syncthreads();
+    } else if constexpr (PRO == 3) {
+        const int gpr = KB * 4;
+        for (int kg = threadIdx.x; kg < gpr; kg += 64 * NWAVES) {   // gpr % 4 == 0: quads stay together
+            const float4 a0 = *reinterpret_cast<const float4 *>(xf + kg * 8), a1 = *reinterpret_cast<const float4 *>(xf + kg * 8 + 4);
+            const float o[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            quantize_group_lds(o, kg, lq, ld_, ls_);
+        }
+        __syncthreads();
     }
 
     while (q0 < nquads) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!ok[u]) continue;
-            const int b = (q0 + u * NWAVES) * 4 + bq;
+            const int g2 = PAIR ? (u & 1) : 0, uq = PAIR ? (u >> 1) : u;
+            const int b = (q0 + uq * NWAVES) * 4 + bq;
             uint32_t lo[4], hi[4];
             unpack_nibbles<TYPE>(w[u].x, lo[0], hi[0]);
             unpack_nibbles<TYPE>(w[u].y, lo[1], hi[1]);
@@ -674,56 +695,78 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
                 isum = dot8(lo[1], hi[1], xa.z, xa.w, isum);
                 isum = dot8(lo[2], hi[2], xc.x, xc.y, isum);
                 isum = dot8(lo[3], hi[3], xc.z, xc.w, isum);
-                acc[c] = __fmaf_rn(__fmul_rn(dw[u], dx), (float)isum, acc[c]);
-                if (TYPE == FL_TYPE_Q4_1) acc[c] = __fmaf_rn(mw[u], sx, acc[c]);
+                acc[g2][c] = __fmaf_rn(__fmul_rn(dw[u], dx), (float)isum, acc[g2][c]);
+                if (TYPE == FL_TYPE_Q4_1) acc[g2][c] = __fmaf_rn(mw[u], sx, acc[g2][c]);
             }
         }
-        q0 += NWAVES * U;
+        q0 += NWAVES * UQ;
         if (q0 < nquads) load(q0);
     }
-    __shared__ float part[NWAVES][NC][16];
+    __shared__ float part[NWAVES][G2 * NC][16];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        float v = acc[c];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (lane < 16) part[wave][c][lane] = v;
-    }
+    for (int g = 0; g < G2; ++g)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float v = acc[g][c];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 16) part[wave][g * NC + c][lane] = v;
+        }
     __syncthreads();
-    if (threadIdx.x < 16 * NC) {
+    auto total = [&](int slot, int rr) -> float {
+        float t[NWAVES];
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) t[w] = part[w][slot][rr];
+#pragma unroll
+        for (int st = 1; st < NWAVES; st <<= 1)           // fixed pairwise tree: deterministic
+#pragma unroll
+            for (int w = 0; w + st < NWAVES; w += 2 * st) t[w] += t[w + st];
+        return t[0];
+    };
+    if constexpr (PAIR) {
+        if (threadIdx.x < 16) {
+            const int rr = threadIdx.x, f = blockIdx.x * 16 + rr;          // feature index; rows 2*16*blockIdx.x + {rr, 16+rr}
+            if (grp * 16 + 16 + rr < M) {
+                const float y1 = total(0, rr), y3 = total(1, rr);
+                const uint16_t hx = __half_as_ushort(__float2half_rn(y1));                // GGML_FP32_TO_FP16
+                const float sl = __half2float(__ushort_as_half(aux2[hx]));               // table_silu_f16
+                y[f] = __fmul_rn(sl, y3);                                                 // ggml_mul(silu, tmp)
+            }
+        }
+    } else if (threadIdx.x < 16 * NC) {
         const int c = threadIdx.x >> 4, rr = threadIdx.x & 15;
         const int row = grp * 16 + rr;
         if (c < N && row < M) {
-            float t[NWAVES];
-#pragma unroll
-            for (int w = 0; w < NWAVES; ++w) t[w] = part[w][c][rr];
-#pragma unroll
-            for (int st = 1; st < NWAVES; st <<= 1)       // fixed pairwise tree: deterministic
-#pragma unroll
-                for (int w = 0; w + st < NWAVES; w += 2 * st) t[w] += t[w + st];
-            float v = t[0];
+            float v = total(c, rr);
             if (resid) v += resid[(int64_t)c * ldr + row];
             y[(int64_t)c * ldy + row] = v;
         }
     }
 }
 
-static inline int gemv_waves(int groups) { return groups >= 1024 ? 4 : groups >= 512 ? 8 : 16; }
+int g_gemv_force_waves = 0;  // debug / tuning hook (fl_debug_set(1, n))
+static inline int gemv_waves(int groups, int KB = 0) {
+    if (g_gemv_force_waves == 4 || g_gemv_force_waves == 8 || g_gemv_force_waves == 16) return g_gemv_force_waves;
+    if (groups >= 1024) return 4;
+    if (groups >= 512) return 8;
+    return KB >= 256 ? 8 : 16;          // few row groups: 16 waves each, unless the rows are long enough to feed 8 deeply
+}
 
 // single-token launches: (NWAVES by M, U by K) so that one pass covers the row when NWAVES * 8 >= K/128
-template <int TYPE, int PRO>
+template <int TYPE, int PRO, int PAIR = 0>
 static hipError_t launch_gemv1(const fl_qtensor &W, const fl_qact *xq, float *y, hipStream_t st, const float *resid,
-                               const float *xf, const void *aux, float *ynorm, int woven = 0) {
-    const dim3 grid(W.M16 / 16);
+                               const float *xf, const void *aux, float *ynorm, int woven = 0, const uint16_t *aux2 = nullptr) {
+    const int groups = W.M16 / 16 / (PAIR ? 2 : 1);             // workgroups
+    const dim3 grid(groups);
     const uint4 *qs = reinterpret_cast<const uint4 *>(W.qs);
-    const int nw = gemv_waves(W.M16 / 16);
-    const int nquads = (W.KB + 3) / 4, per_wave = (nquads + nw - 1) / nw;
+    const int nw = gemv_waves(groups, W.KB);
+    const int nquads = (W.KB + 3) / 4, per_wave = ((nquads + nw - 1) / nw) * (PAIR ? 2 : 1);   // load slots per wave
     const int u = per_wave <= 2 ? 2 : per_wave <= 4 ? 4 : per_wave <= 6 ? 6 : 8;
     const size_t lds = PRO ? (size_t)W.KB * 40 : 0;
 #define FL_GEMV(NW, UU)                                                                                              \
-    hipLaunchKernelGGL((gemv_q4_kernel<TYPE, 1, NW, PRO, UU>), grid, dim3(64 * NW), lds, st, qs, W.d, W.m,           \
+    hipLaunchKernelGGL((gemv_q4_kernel<TYPE, 1, NW, PRO, UU, PAIR>), grid, dim3(64 * NW), lds, st, qs, W.d, W.m,     \
                        xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, 1, W.M, W.KB, y, 0, resid, 0, \
-                       xf, aux, ynorm, woven)
+                       xf, aux, ynorm, woven, aux2)
 #define FL_GEMV_U(NW)                   \
     do {                                \
         if (u == 2) FL_GEMV(NW, 2);     \
@@ -749,8 +792,8 @@ static hipError_t launch_gemv(const fl_qtensor &W, const fl_qact &xq, int N, flo
     // more waves per group (each takes every NWAVES-th block-quad) so that >= ~16 waves per CU are loading.
     const int nw = gemv_waves(W.M16 / 16);
 #define FL_GEMV(NC, NW, UU)                                                                                             \
-    hipLaunchKernelGGL((gemv_q4_kernel<TYPE, NC, NW, 0, UU>), grid, dim3(64 * NW), 0, st, qs, W.d, W.m, xq.q, xq.d, xq.s, \
-                       N, W.M, W.KB, y, ldy, resid, ldr, nullptr, nullptr, nullptr, 0)
+    hipLaunchKernelGGL((gemv_q4_kernel<TYPE, NC, NW, 0, UU, 0>), grid, dim3(64 * NW), 0, st, qs, W.d, W.m, xq.q, xq.d, xq.s, \
+                       N, W.M, W.KB, y, ldy, resid, ldr, nullptr, nullptr, nullptr, 0, nullptr)
 #define FL_GEMV_NW(NC, UU)                       \
     do {                                         \
         if (nw == 4) FL_GEMV(NC, 4, UU);         \
@@ -778,6 +821,21 @@ hipError_t gemv_q4_silu(const fl_qtensor &W, const float *h13, const uint16_t *s
     if (W.K % 32 != 0 || W.K > 32768) return hipErrorInvalidValue;
     return W.type == FL_TYPE_Q4_0 ? launch_gemv1<FL_TYPE_Q4_0, 2>(W, nullptr, y, st, resid, h13, silu_tab, nullptr, woven ? 1 : 0)
                                   : launch_gemv1<FL_TYPE_Q4_1, 2>(W, nullptr, y, st, resid, h13, silu_tab, nullptr, woven ? 1 : 0);
+}
+
+// act[n_ff] = silu(w1 . q) * (w3 . q),  q = Q8_0(norm_w * rms_norm(x));  W = w1|w3 woven by 16-row groups (W.M = 2 n_ff)
+hipError_t gemv_q4_norm_silu(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act,
+                             hipStream_t st) {
+    if (W.K % 32 != 0 || W.K > 8192 || W.M % 32 != 0) return hipErrorInvalidValue;
+    return W.type == FL_TYPE_Q4_0 ? launch_gemv1<FL_TYPE_Q4_0, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab)
+                                  : launch_gemv1<FL_TYPE_Q4_1, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab);
+}
+
+// y[M] = W . Q8_0(x) (+ resid) for an f32 vector x: quantize_row_q8_0 in the prologue
+hipError_t gemv_q4_quant(const fl_qtensor &W, const float *x, float *y, const float *resid, hipStream_t st) {
+    if (W.K % 32 != 0 || W.K > 32768) return hipErrorInvalidValue;
+    return W.type == FL_TYPE_Q4_0 ? launch_gemv1<FL_TYPE_Q4_0, 3>(W, nullptr, y, st, resid, x, nullptr, nullptr)
+                                  : launch_gemv1<FL_TYPE_Q4_1, 3>(W, nullptr, y, st, resid, x, nullptr, nullptr);
 }
 
 hipError_t gemv_q4(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,

@@ -203,6 +203,9 @@ int fl_debug_gemv_norm(const fl_qtensor *W, const float *x_dev, const float *nor
                        void *stream);  /* y = W . Q8_0(norm_w * rms_norm(x)), one launch (decode) */
 int fl_debug_gemv_silu(const fl_qtensor *W, const float *h13_dev, const uint16_t *silu_tab_dev, float *y_dev,
                        const float *resid_dev, void *stream); /* y = W . Q8_0(silu(h13[:K]) * h13[K:]) + resid, one launch */
+int fl_debug_gemv_norm_silu(const fl_qtensor *W_woven, const float *x_dev, const float *norm_w_dev, const uint16_t *silu_tab_dev,
+                            float *act_dev, void *stream);  /* act = silu(w1.q) * (w3.q), q = Q8_0(norm_w * rms_norm(x)) */
+int fl_debug_gemv_quant(const fl_qtensor *W, const float *x_dev, float *y_dev, const float *resid_dev, void *stream);
 int fl_debug_prefill_attention(const float *qkv_dev, int ldq, int D, int H, int N, int n_past, int n_ctx, int E,
                                const float *kc, const float *vc, const uint16_t *exp_tab_dev, float scale, float *ao_dev,
                                int ldo, void *stream); /* KQ*scale + mask + soft_max + KQV, one launch (prefill) */
@@ -221,7 +224,7 @@ int fl_debug_softmax_rows(float *S_dev, int ld, long sz, int N, int P, int n_pas
 int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a, float *y_dev, int ldy, int which /*0 naive,1 mfma,2 gemv*/,
                        void *stream);
 int fl_debug_qact_layout(const fl_qact *a); /* 16 = QA16, 1 = QA1 */
-int fl_debug_set(int what, int value);      /* what 0: force GEMM tile configuration id (-1 = automatic) */
+int fl_debug_set(int what, int value);      /* what 0: force GEMM tile configuration id (-1 = automatic); 1: GEMV waves per row group (0 = automatic) */
 int fl_quantize_q8_layout(fl_qact *a, const float *x_dev, int ldx, int N, int K, int layout, void *stream);
 
 #ifdef __cplusplus

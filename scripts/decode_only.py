@@ -10,6 +10,8 @@ graph = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 cfg = dict(synth.MODELS["7B"])
 m = FlModel(cfg, 2, synth.synth_model_tensors(cfg, 2), n_ctx=1024, max_batch=512)
 hip.load().fl_model_set_graph(m.h, graph)
+if len(sys.argv) > 3:
+    hip.load().fl_debug_set(1, int(sys.argv[3]))      # force GEMV waves per row group
 toks = np.random.default_rng(0).integers(3, 259, 512).astype(np.int32)
 m.eval_nocopy(toks, 0)
 t1 = toks[:1].copy()

@@ -290,3 +290,53 @@ def test_prefill_attention_fused_equals_three_kernels(env, N, P0, D, H, n_ctx):
             want = (le.soft_max_rows(s) @ vc[sl, :Lr].T).astype(np.float32)[0]
             got = ao1[n, sl].cpu().numpy()
             assert np.max(np.abs(got - want)) <= 2e-5 * max(1.0, np.max(np.abs(want)))
+
+
+@pytest.mark.parametrize("qtype", [2, 3])
+@pytest.mark.parametrize("F,K", [(64, 64), (704, 256), (11008, 4096)])
+def test_gemv_pair_silu_epilogue_and_quant_prologue(env, qtype, F, K):
+    """decode feed-forward on the woven w1|w3 matrix: (a) norm prologue + two dots + silu*mul epilogue in ONE launch ==
+    the plain norm-GEMV followed by silu*mul on the woven output, bit for bit; (b) the w2 GEMV that quantizes the f32
+    activation in its prologue == quantize_q8 + GEMV."""
+    torch, hip, ops, L, port = env
+    rng = np.random.default_rng(F + K + qtype)
+    w1 = port.quantize_q4(qtype, (rng.standard_normal((F, K)) * 0.05).astype(np.float32))
+    w3 = port.quantize_q4(qtype, (rng.standard_normal((F, K)) * 0.05).astype(np.float32))
+    rb = w1.shape[1]
+    woven = np.empty((2 * F, rb), np.uint8)
+    wv = woven.reshape(F // 16, 2, 16, rb)
+    wv[:, 0] = w1.reshape(F // 16, 16, rb)
+    wv[:, 1] = w3.reshape(F // 16, 16, rb)
+    W = ops.QTensor(qtype, woven, 2 * F, K)
+    x = (rng.standard_normal((1, K)) * 1.3).astype(np.float32)
+    nw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    s = np.empty(1 << 16, np.uint16)
+    L.fl_debug_tables(None, s.ctypes.data_as(C.c_void_p))
+    xd, nd, sd = dev(torch, x), dev(torch, nw), dev(torch, s.view(np.int16))
+    y = torch.empty(2 * F, device="cuda")
+    act = torch.full((F,), 9.0, device="cuda")
+    # the wave count per row group (chosen from the number of workgroups) fixes the order of the partial sums: pin it
+    # so that both launches add in the same order
+    L.fl_debug_set(1, 8)
+    try:
+        hip.check(L.fl_debug_gemv_norm(W.handle, xd.data_ptr(), nd.data_ptr(), None, y.data_ptr(), None))
+        hip.check(L.fl_debug_gemv_norm_silu(W.handle, xd.data_ptr(), nd.data_ptr(), sd.data_ptr(), act.data_ptr(), None))
+    finally:
+        L.fl_debug_set(1, 0)
+    yv = y.cpu().numpy().reshape(F // 16, 2, 16)
+    want = (le.silu(yv[:, 0].reshape(1, F)) * yv[:, 1].reshape(1, F)).astype(np.float32)[0]
+    assert np.array_equal(act.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    # (b) w2: [E rows][F]
+    E = 48 if F == 64 else 256
+    w2 = port.quantize_q4(qtype, (rng.standard_normal((E, F)) * 0.05).astype(np.float32))
+    W2 = ops.QTensor(qtype, w2, E, F)
+    res = rng.standard_normal(E).astype(np.float32)
+    rd = dev(torch, res)
+    a = ops.QAct(1, F)
+    hip.check(L.fl_quantize_q8_layout(a.handle, act.data_ptr(), F, 1, F, 1, None))
+    a.N, a.K = 1, F
+    y0 = torch.empty(E, device="cuda")
+    hip.check(L.fl_debug_mul_mat_q(W2.handle, a.handle, y0.data_ptr(), E, 2, None))
+    y1 = torch.empty(E, device="cuda")
+    hip.check(L.fl_debug_gemv_quant(W2.handle, act.data_ptr(), y1.data_ptr(), rd.data_ptr(), None))
+    assert np.array_equal(y1.cpu().numpy(), y0.cpu().numpy() + res)
