@@ -348,9 +348,9 @@ hipError_t gemm_f32_abt(const float *A, int lda, int64_t sAz, const float *B, in
 // One 512-thread workgroup per (head, PAIR of 32-row query blocks {x, nb-1-x}): causal attention gives block i
 // (i+1) key tiles, so pairing the lightest with the heaviest makes every workgroup equally heavy -- with one
 // workgroup per CU resident from the start there is no second scheduling round to even things out.
-//   phase 0  the useful part of the fp16 exp table (arguments in [-17.4, -0]; everything below is 0) -> LDS
-//   phase 1  wave w computes 32x32 score tiles w, w+8, ... of block a, then of block b (exact-f32 MFMA, the k pairing
-//            and order of gemm_f32_abt_kernel; Q fragments in registers, next K tile prefetched during the MFMAs)
+//   phase 0  the useful part of the fp16 exp table (arguments in [-17.4, -0]; everything below is 0) and the 64 Q rows -> LDS
+//   phase 1  the workgroup's score tiles (block a's, then block b's) are dealt round-robin to the 8 waves (exact-f32
+//            MFMA, the k pairing and order of gemm_f32_abt_kernel; A fragments from LDS, next K tile prefetched)
 //   phase 2  soft_max of the 64 rows (the arithmetic of softmax_rows_kernel; table lookups from LDS, four rows'
 //            lookups in flight together)
 //   phase 3  wave w: block w/4, output columns [32(w%4), +32) of the head: A = probabilities (LDS), B = transposed V
@@ -472,64 +472,61 @@ __global__ __launch_bounds__(PA_T) void prefill_attention_kernel(const float *__
     uint16_t *tab = reinterpret_cast<uint16_t *>(base);                  // exp table for fp16 arguments 0x8000 + [0, tab_n)
 
     PA_STAMP(0);
-    // ---- phase 0 (the table copy) is issued by every thread right after its first Q/K loads: one memory round trip ----
-    bool table_done = false;
-    auto copy_table = [&] {
-        for (int i = threadIdx.x; i * 8 < tab_n; i += PA_T)
-            reinterpret_cast<uint4 *>(tab)[i] = reinterpret_cast<const uint4 *>(exp_tab + 0x8000)[i];
-        table_done = true;
+    // ---- phase 0: the roped Q rows of both blocks -> LDS (A operand of every score tile, read back per MFMA step), the
+    //      exp table -> LDS, and this wave's first K tile -> registers: one memory round trip for all three ----
+    constexpr int QLD = D + 4;                                        // + 4 floats: conflict-free ds_read_b128 of 32 rows
+    float *const Qs = reinterpret_cast<float *>(tab + ((tab_n + 7) & ~7));   // [2][32][QLD]
+    const int nunits = ntl0 + ntl1;                                  // score tiles of the workgroup: block a's, then block b's
+    float4 kf[NSTEP], kn[NSTEP];
+    auto load_k = [&](float4 (&dst)[NSTEP], int u) {                 // K tile of unit u
+        const int kt = u < ntl0 ? u : u - ntl0;
+        const float *pb = kc + (int64_t)min(kt * 32 + r, P - 1) * E + h * D;
+#pragma unroll
+        for (int j = 0; j < NSTEP; ++j) dst[j] = *reinterpret_cast<const float4 *>(pb + 8 * j + 4 * kk);
     };
-
 #ifndef PA_ABL
 #define PA_ABL 0
 #endif
+    if (wave < nunits && !(PA_ABL & 1)) load_k(kf, wave);
+    for (int i = threadIdx.x; i < 2 * 32 * (D / 4); i += PA_T) {
+        const int q = i / (32 * (D / 4)), row = (i / (D / 4)) & 31, c4 = i % (D / 4);
+        const int mbq = PA_SEL(q, mb0, mb1);
+        if (mbq < 0) continue;
+        const float4 v = *reinterpret_cast<const float4 *>(qkv + (int64_t)min(mbq * 32 + row, N - 1) * ldq + h * D + c4 * 4);
+        *reinterpret_cast<float4 *>(Qs + (q * 32 + row) * QLD + c4 * 4) = v;
+    }
+    for (int i = threadIdx.x; i * 8 < tab_n; i += PA_T)
+        reinterpret_cast<uint4 *>(tab)[i] = reinterpret_cast<const uint4 *>(exp_tab + 0x8000)[i];
+    __syncthreads();
     PA_STAMP(1);
     // ---- phase 1: scores ----   (PA_ABL: timing experiments only, never defined in the product)
     if (!(PA_ABL & 1)) {
-#pragma unroll 1
-        for (int q = 0; q < 2; ++q) {
-            const int mbq = PA_SEL(q, mb0, mb1), ntlq = PA_SEL(q, ntl0, ntl1), strdq = PA_SEL(q, strd0, strd1);
-            float *const Sq = PA_SEL(q, S0, S1);
-            if (mbq < 0 || wave >= ntlq) continue;
-            const int m0 = mbq * 32;
-            const float *pa = qkv + (int64_t)min(m0 + r, N - 1) * ldq + h * D;
-            float4 qf[NSTEP];                                         // 8 k per step, lane half kk takes k+4kk..
+        for (int u = wave; u < nunits; u += PA_T / 64) {
+            if (u + PA_T / 64 < nunits) load_k(kn, u + PA_T / 64);    // next tile's K under this tile's MFMAs
+            const int q = u < ntl0 ? 0 : 1, kt = u < ntl0 ? u : u - ntl0;
+            const float *qa = Qs + (q * 32 + r) * QLD + 4 * kk;
+            v16f acc;
 #pragma unroll
-            for (int j = 0; j < NSTEP; ++j) qf[j] = *reinterpret_cast<const float4 *>(pa + 8 * j + 4 * kk);
-            float4 kf[NSTEP], kn[NSTEP];
-            auto load_k = [&](float4 (&dst)[NSTEP], int kt) {
-                const float *pb = kc + (int64_t)min(kt * 32 + r, P - 1) * E + h * D;
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-                for (int j = 0; j < NSTEP; ++j) dst[j] = *reinterpret_cast<const float4 *>(pb + 8 * j + 4 * kk);
-            };
-            load_k(kf, wave);
-            if (!table_done) copy_table();
-            for (int kt = wave; kt < ntlq; kt += PA_T / 64) {
-                if (kt + PA_T / 64 < ntlq && !(PA_ABL & 8)) load_k(kn, kt + PA_T / 64);
-                v16f acc;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-                for (int j = 0; j < NSTEP; ++j) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].x, kf[j].x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].y, kf[j].y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].z, kf[j].z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].w, kf[j].w, acc, 0, 0, 0);
-                }
-                const int col = kt * 32 + r;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = (i & 3) + 8 * (i >> 2) + 4 * kk;
-                    if (!(PA_ABL & 16) || acc[i] == 1.2345f) Sq[row * strdq + col] = __fmul_rn(acc[i], scale);
-                }
-                if (!(PA_ABL & 8)) {
-#pragma unroll
-                    for (int j = 0; j < NSTEP; ++j) kf[j] = kn[j];
-                }
+            for (int j = 0; j < NSTEP; ++j) {                         // 8 k per step, lane half kk takes k+4kk..
+                const float4 qf = *reinterpret_cast<const float4 *>(qa + 8 * j);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.x, kf[j].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.y, kf[j].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.z, kf[j].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.w, kf[j].w, acc, 0, 0, 0);
             }
+            float *const Sq = PA_SEL(q, S0, S1);
+            const int strdq = PA_SEL(q, strd0, strd1), col = kt * 32 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * kk;
+                Sq[row * strdq + col] = __fmul_rn(acc[i], scale);
+            }
+#pragma unroll
+            for (int j = 0; j < NSTEP; ++j) kf[j] = kn[j];
         }
     }
-    if (!table_done) copy_table();
     PA_STAMP(2);
     __syncthreads();
     PA_STAMP(3);
@@ -626,10 +623,10 @@ hipError_t prefill_attention(const float *qkv, int ldq, int D, int H, int N, int
                              hipStream_t st) {
     const int P = n_past + N, nb = (N + 31) / 32;
     if (D % 32 != 0 || D > 128 || (n_ctx & 3) != 0 || P > 64 * PA_SM_IT || tab_n < 0 || tab_n > 24576 || (tab_n & 7)) return hipErrorInvalidValue;
-    const size_t tab_bytes = (size_t)tab_n * 2;
-    // pair mode: rows of block x and of block nb-1-x: 32 * (2 n_past + 32 (nb + 1) + 8) floats
-    const size_t lds_pair = (size_t)32 * (2 * (size_t)n_past + 32 * (size_t)(nb + 1) + 8 + 64) * 4 + tab_bytes;   // (+64: round-ups)
-    const size_t lds_single = (size_t)32 * (((size_t)P + 31) / 32 * 32 + 4 + 4) * 4 + tab_bytes;
+    const size_t tab_bytes = (size_t)tab_n * 2, qblk = (size_t)32 * (D + 4) * 4;   // exp table; Q rows of one block
+    // pair mode: score rows of block x and of block nb-1-x: 32 * (2 n_past + 32 (nb + 1) + 8) floats (+64: round-ups)
+    const size_t lds_pair = (size_t)32 * (2 * (size_t)n_past + 32 * (size_t)(nb + 1) + 8 + 64) * 4 + tab_bytes + 2 * qblk;
+    const size_t lds_single = (size_t)32 * (((size_t)P + 31) / 32 * 32 + 4 + 4) * 4 + tab_bytes + qblk;
     const size_t cap = 160 * 1024;
     int pair = nb >= 2 && lds_pair <= cap ? 1 : 0;
     if (!pair && lds_single > cap) return hipErrorInvalidValue;
