@@ -32,8 +32,7 @@ __device__ __forceinline__ void quantize_store_group(const float v[8], int n, in
     float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
-    amax = fmaxf(amax, __shfl_xor(amax, 1));
-    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    amax = quad_max_f32(amax);
     const float dd = __fdiv_rn(amax, 127.0f);
     const float id = amax != 0.0f ? __fdiv_rn(127.0f, amax) : 0.0f;
     int qi[8], sum = 0;
@@ -42,8 +41,7 @@ __device__ __forceinline__ void quantize_store_group(const float v[8], int n, in
         qi[i] = (int)rintf(__fmul_rn(v[i], id));
         sum += qi[i];
     }
-    sum += __shfl_xor(sum, 1);
-    sum += __shfl_xor(sum, 2);
+    sum = quad_sum_i32(sum);
     auto pk = [](int a, int b, int c, int e) -> uint32_t {
         return (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(c & 0xFF) << 16) |
                ((uint32_t)(e & 0xFF) << 24);
@@ -69,8 +67,7 @@ __device__ __forceinline__ void quantize_store_group(const float v[8], int n, in
 }
 
 __device__ __forceinline__ double block_sum_f64(double v, double *sh) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v = wave_sum_f64(v);
     const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if ((threadIdx.x & 63) == 0) sh[wave] = v;
     __syncthreads();
@@ -357,33 +354,6 @@ hipError_t gemm_f32_abt(const float *A, int lda, int64_t sAz, const float *B, in
 // Per output the MFMA sequence is the one of gemm_f32_abt(KQ) -> softmax_rows -> gemm_f32_abt(KQV): bit-identical,
 // and independent of how rows are grouped into blocks.
 // ------------------------------------------------------------------------------------------------
-// wave-wide reductions with DPP for the in-row steps (ds_bpermute, which __shfl_xor compiles to, costs an LDS round
-// trip per step): quad_perm xor 1 / xor 2, row_half_mirror, row_mirror, then two cross-row shuffles.
-template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
-__device__ __forceinline__ float wave_max_f32(float m) {
-    m = fmaxf(m, __builtin_bit_cast(float, dpp_i32<0xB1>(__builtin_bit_cast(int, m))));    // quad_perm [1,0,3,2]
-    m = fmaxf(m, __builtin_bit_cast(float, dpp_i32<0x4E>(__builtin_bit_cast(int, m))));    // quad_perm [2,3,0,1]
-    m = fmaxf(m, __builtin_bit_cast(float, dpp_i32<0x141>(__builtin_bit_cast(int, m))));   // row_half_mirror
-    m = fmaxf(m, __builtin_bit_cast(float, dpp_i32<0x140>(__builtin_bit_cast(int, m))));   // row_mirror
-    m = fmaxf(m, __shfl_xor(m, 16));
-    return fmaxf(m, __shfl_xor(m, 32));
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-    const long long b = __builtin_bit_cast(long long, v);
-    const unsigned lo = (unsigned)dpp_i32<CTRL>((int)(unsigned)b), hi = (unsigned)dpp_i32<CTRL>((int)(unsigned)(b >> 32));
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
-}
-__device__ __forceinline__ double wave_sum_f64(double s) {
-    s += dpp_f64<0xB1>(s);
-    s += dpp_f64<0x4E>(s);
-    s += dpp_f64<0x141>(s);
-    s += dpp_f64<0x140>(s);
-    s += __shfl_xor(s, 16);
-    return s + __shfl_xor(s, 32);
-}
-
 // soft_max of FOUR score rows held in LDS by one wave: IT 64-column steps cover the longest of them.  Straight-line
 // code (clamped addresses + selects, no branches) so that the LDS round trips of all columns overlap.  The f64 sum of
 // fp16-valued terms is exact, so its order is free; everything else is the arithmetic of softmax_rows_kernel.
@@ -673,8 +643,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float *__restrict__ S
     const int L = min(P, n_past + n + 1);
     float mx = -INFINITY;
     for (int i = lane; i < L; i += 64) mx = fmaxf(mx, p[i]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max_f32(mx);
     double sum = 0.0;
     for (int i = lane; i < L; i += 64) {
         const float x = p[i];
@@ -686,8 +655,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float *__restrict__ S
         sum += (double)val;
         p[i] = val;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = wave_sum_f64(sum);
     const float inv = (float)(1.0 / sum);
     for (int i = lane; i < P; i += 64) p[i] = i < L ? __fmul_rn(p[i], inv) : 0.f;
 }
@@ -791,9 +759,7 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const float *__r
             a = __fmaf_rn(q4[j].z, k4.z, a);
             a = __fmaf_rn(q4[j].w, k4.w, a);
         }
-        a += __shfl_xor(a, 1);
-        a += __shfl_xor(a, 2);
-        a += __shfl_xor(a, 4);
+        a = group8_sum_f32(a);
         a = __fmul_rn(a, scale);
         if (l8 == 0) sc[p] = a;
         mx = fmaxf(mx, a);
@@ -810,8 +776,7 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const float *__r
             if (j < J && p < pos) kr[j] = *reinterpret_cast<const float4 *>(kbase + (int64_t)p * E + j * 32);
         kq(p, kr);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max_f32(mx);
     if ((tid & 63) == 0) redf[tid >> 6] = mx;
     __syncthreads();
     mx = redf[0];
@@ -861,9 +826,7 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const float *__r
                 if (c * 32 + l8 * 4 < P)
                     a = pv(a, d, c, *reinterpret_cast<const float4 *>(vc + (int64_t)(h * D + d) * n_ctx + c * 32 + l8 * 4));
         }
-        a += __shfl_xor(a, 1);
-        a += __shfl_xor(a, 2);
-        a += __shfl_xor(a, 4);
+        a = group8_sum_f32(a);
         if (d < D && l8 == 0) out[d] = a;
     }
     __syncthreads();

@@ -33,4 +33,49 @@ __device__ __forceinline__ int dot8(uint32_t wlo, uint32_t whi, uint32_t xlo, ui
 }
 
 
+// ---- cross-lane reductions on DPP (ds_bpermute, which __shfl_xor compiles to, costs an LDS round trip per step) ----
+// quad_perm xor 1 / xor 2, row_half_mirror (lane i <-> 7-i of each 8) and row_mirror (i <-> 15-i of each 16) pair every
+// lane with one that holds the other half of the running result, exactly like the xor butterfly.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) { return __builtin_bit_cast(float, dpp_i32<CTRL>(__builtin_bit_cast(int, v))); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)dpp_i32<CTRL>((int)(unsigned)b), hi = (unsigned)dpp_i32<CTRL>((int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+
+__device__ __forceinline__ float quad_max_f32(float m) {      // over 4 adjacent lanes
+    m = fmaxf(m, dpp_f32<DPP_XOR1>(m));
+    return fmaxf(m, dpp_f32<DPP_XOR2>(m));
+}
+__device__ __forceinline__ int quad_sum_i32(int s) {
+    s += dpp_i32<DPP_XOR1>(s);
+    return s + dpp_i32<DPP_XOR2>(s);
+}
+__device__ __forceinline__ float group8_sum_f32(float a) {    // over 8 adjacent lanes: ((a0+a1)+(a2+a3)) + ((a4+a5)+(a6+a7))
+    a += dpp_f32<DPP_XOR1>(a);
+    a += dpp_f32<DPP_XOR2>(a);
+    return a + dpp_f32<DPP_HALF_MIRROR>(a);
+}
+__device__ __forceinline__ float wave_max_f32(float m) {
+    m = fmaxf(m, dpp_f32<DPP_XOR1>(m));
+    m = fmaxf(m, dpp_f32<DPP_XOR2>(m));
+    m = fmaxf(m, dpp_f32<DPP_HALF_MIRROR>(m));
+    m = fmaxf(m, dpp_f32<DPP_MIRROR>(m));
+    m = fmaxf(m, __shfl_xor(m, 16));
+    return fmaxf(m, __shfl_xor(m, 32));
+}
+__device__ __forceinline__ double wave_sum_f64(double s) {
+    s += dpp_f64<DPP_XOR1>(s);
+    s += dpp_f64<DPP_XOR2>(s);
+    s += dpp_f64<DPP_HALF_MIRROR>(s);
+    s += dpp_f64<DPP_MIRROR>(s);
+    s += __shfl_xor(s, 16);
+    return s + __shfl_xor(s, 32);
+}
+
 }  // namespace fl

@@ -128,8 +128,7 @@ __device__ __forceinline__ Q8Quad quantize_group8(const float v[8]) {
     float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
-    amax = fmaxf(amax, __shfl_xor(amax, 1));
-    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    amax = quad_max_f32(amax);
     const float d = __fdiv_rn(amax, 127.0f);
     const float id = amax != 0.0f ? __fdiv_rn(127.0f, amax) : 0.0f;
     int q[8];
@@ -139,8 +138,7 @@ __device__ __forceinline__ Q8Quad quantize_group8(const float v[8]) {
         q[i] = (int)rintf(__fmul_rn(v[i], id));
         sum += q[i];
     }
-    sum += __shfl_xor(sum, 1);
-    sum += __shfl_xor(sum, 2);
+    sum = quad_sum_i32(sum);
     Q8Quad o;
     o.d = d;
     o.s = __fmul_rn(d, (float)sum);
@@ -443,8 +441,7 @@ __device__ __forceinline__ void quantize_group_lds(const float o[8], int kg, int
     float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(o[i]));
-    amax = fmaxf(amax, __shfl_xor(amax, 1));
-    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    amax = quad_max_f32(amax);
     const float dd = __fdiv_rn(amax, 127.0f);
     const float id = amax != 0.0f ? __fdiv_rn(127.0f, amax) : 0.0f;
     int qi[8], isum = 0;
@@ -453,8 +450,7 @@ __device__ __forceinline__ void quantize_group_lds(const float o[8], int kg, int
         qi[i] = (int)rintf(__fmul_rn(o[i], id));
         isum += qi[i];
     }
-    isum += __shfl_xor(isum, 1);
-    isum += __shfl_xor(isum, 2);
+    isum = quad_sum_i32(isum);
     auto pk = [](int a, int b, int c, int e) -> uint32_t {
         return (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(c & 0xFF) << 16) |
                ((uint32_t)(e & 0xFF) << 24);
@@ -597,8 +593,7 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
 #pragma unroll
                 for (int i = 0; i < 8; ++i) sum += (double)__fmul_rn(v[it][i], v[it][i]);
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            sum = wave_sum_f64(sum);                          // same order as block_sum_f64 (eval_kernels.hip)
             if (lane == 0) sh[wave] = sum;
         }
         __syncthreads();
