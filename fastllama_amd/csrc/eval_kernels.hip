@@ -679,6 +679,12 @@ hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, 
 // positions per pass; KQV: 8 lanes share one row of the transposed V cache (32 positions per 128 B piece), 64 rows
 // per pass.  The first 256 positions of both caches are requested before anything else is computed, so the two HBM
 // round trips overlap the rope / soft_max latency chains.
+#ifdef PA_TIMING
+__device__ long long da_dbg[8];
+#define DA_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) da_dbg[k] = wall_clock64(); } while (0)
+#else
+#define DA_STAMP(k) do {} while (0)
+#endif
 constexpr int DA_T = 512, DA_KPRE = 4, DA_VPRE = 8;
 
 __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const float *__restrict__ qkv, int E, int D, int n_past,
@@ -688,6 +694,7 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const float *__r
                                                                 int8_t *__restrict__ oq, float *__restrict__ od,
                                                                 float *__restrict__ os, const int *__restrict__ dyn_past) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    DA_STAMP(0);
     if (dyn_past) n_past = *dyn_past;
     const int h = blockIdx.x, tid = threadIdx.x, pos = n_past, P = n_past + 1;
     float *qs = reinterpret_cast<float *>(dsm);           // [D] roped q
@@ -703,7 +710,19 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const float *__r
     const int nvr = (D + 63) >> 6;                         // row passes of the V phase (<= 2)
     const int nchunk = (P + 31) >> 5;                      // 32-position pieces
 
-    // ---- requests first: K rows [0, 256) and V pieces [0, 256) of this head ----
+    // ---- requests first.  Loads return in order: the few bytes rope needs (this token's q, k, v and the rope table row)
+    //      go out before the K / V history, or rope would wait for all of it ----
+    const float *q = qkv + h * D, *k = qkv + E + h * D, *v = qkv + 2 * E + h * D;
+    float2 cs = {0.f, 0.f}, xq = cs, xk = cs;
+    float vv = 0.f;
+    if (tid < D / 2) {
+        cs = rope_tab[(int64_t)pos * (D >> 1) + tid];
+        xq = *reinterpret_cast<const float2 *>(q + 2 * tid);
+        xk = *reinterpret_cast<const float2 *>(k + 2 * tid);
+    } else if (tid >= 64 && tid < 64 + D) {
+        vv = v[tid - 64];
+    }
+    // K rows [0, 256) and V pieces [0, 256) of this head
     float4 kreg[DA_KPRE][4];
 #pragma unroll
     for (int u = 0; u < DA_KPRE; ++u) {
@@ -722,11 +741,9 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const float *__r
                 vreg[rp][c] = *reinterpret_cast<const float4 *>(vc + (int64_t)(h * D + d) * n_ctx + c * 32 + l8 * 4);
     }
 
+    DA_STAMP(1);
     // ---- rope(q), rope(k) -> LDS + K cache; v -> LDS + V cache ----
-    const float *q = qkv + h * D, *k = qkv + E + h * D, *v = qkv + 2 * E + h * D;
     if (tid < D / 2) {
-        const float2 cs = rope_tab[(int64_t)pos * (D >> 1) + tid];
-        const float2 xq = *reinterpret_cast<const float2 *>(q + 2 * tid), xk = *reinterpret_cast<const float2 *>(k + 2 * tid);
         qs[2 * tid] = __fmaf_rn(xq.x, cs.x, -__fmul_rn(xq.y, cs.y));
         qs[2 * tid + 1] = __fmaf_rn(xq.x, cs.y, __fmul_rn(xq.y, cs.x));
         const float k0 = __fmaf_rn(xk.x, cs.x, -__fmul_rn(xk.y, cs.y)), k1 = __fmaf_rn(xk.x, cs.y, __fmul_rn(xk.y, cs.x));
@@ -735,13 +752,13 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const float *__r
         *reinterpret_cast<float2 *>(kc + (int64_t)pos * E + h * D + 2 * tid) = make_float2(k0, k1);
     } else if (tid >= 64 && tid < 64 + D) {
         const int d = tid - 64;
-        const float vv = v[d];
         vs[d] = vv;
         vc[(int64_t)(h * D + d) * n_ctx + pos] = vv;
     }
     if (tid < 4) sc[P + tid] = 0.f;                        // tail of the last float4 of probabilities
     __syncthreads();
 
+    DA_STAMP(2);
     // ---- scores ----
     float4 q4[4];
 #pragma unroll
@@ -783,6 +800,7 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const float *__r
 #pragma unroll
     for (int i = 1; i < DA_T / 64; ++i) mx = fmaxf(mx, redf[i]);
 
+    DA_STAMP(3);
     // ---- soft_max: fp16 exp table, f64 sum (ggml_compute_forward_soft_max_f32) ----
     double sum = 0.0;
     for (int p = tid; p < P; p += DA_T) {
@@ -796,6 +814,7 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const float *__r
     for (int p = tid; p < P; p += DA_T) sc[p] = __fmul_rn(sc[p], inv);
     __syncthreads();
 
+    DA_STAMP(4);
     // ---- KQV ----
     auto pv = [&](float a, int d, int c, float4 v4) -> float {
         const int p0 = c * 32 + l8 * 4;
@@ -830,6 +849,7 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const float *__r
         if (d < D && l8 == 0) out[d] = a;
     }
     __syncthreads();
+    DA_STAMP(5);
     // ---- Q8_0 of the head's outputs: D/8 groups, 4 adjacent lanes per block ----
     if (tid < D / 8) {
         float o8[8];
@@ -837,7 +857,11 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const float *__r
         for (int i = 0; i < 8; ++i) o8[i] = out[tid * 8 + i];
         quantize_store_group(o8, 0, (h * D >> 3) + tid, E >> 5, 1, oq, od, os);
     }
+    DA_STAMP(6);
 }
+#ifdef PA_TIMING
+extern "C" int fl_debug_da_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(da_dbg), sizeof(long long) * 8); }
+#endif
 
 hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab, float *kc,
                             float *vc, const uint16_t *exp_tab, float scale, const fl_qact *out, hipStream_t st,

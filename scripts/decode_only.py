@@ -22,3 +22,12 @@ for i in range(steps):
     m.eval_nocopy(t1, 131 + i)
 dt = (time.perf_counter() - t0) / steps
 print(f"decode {dt*1e3:.3f} ms/token  {1/dt:.1f} tok/s (graph={graph})")
+
+L = hip.load()
+if hasattr(L, "fl_debug_da_timing"):
+    import ctypes as C
+    buf = (C.c_longlong * 8)()
+    L.fl_debug_da_timing.argtypes = [C.c_void_p]
+    L.fl_debug_da_timing(buf)
+    t = np.array(buf[:7]); d = (t[1:] - t[:-1]) * 10.0 / 1e3
+    print("decode_attention wg0 (us): n_past+prefetch issue %.2f  rope+stores %.2f  (sync) scores %.2f  max/exp %.2f  softmax->probs %.2f  kqv %.2f | total %.2f" % (d[0], d[1], d[2], d[3], d[4], d[5], (t[6]-t[0])*10/1e3))
