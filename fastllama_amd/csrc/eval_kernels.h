@@ -27,7 +27,7 @@ hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, 
 // kc / vc already hold the new positions.  hipErrorInvalidValue: shape does not fit -> use the three-kernel path.
 hipError_t prefill_attention(const float *qkv, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc,
                              const float *vc, const uint16_t *exp_tab, int tab_n, float scale, float *ao, int ldo,
-                             hipStream_t st);
+                             hipStream_t st, const fl_qact *qout = nullptr);   // qout: write Q8_0 (QA16) instead of ao
 // decode (N = 1): rope + KV store + KQ + soft_max + KQV + Q8_0 of the result, one workgroup per head
 hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab, float *kc,
                             float *vc, const uint16_t *exp_tab, float scale, const fl_qact *out, hipStream_t st,

@@ -416,7 +416,9 @@ __global__ __launch_bounds__(PA_T) void prefill_attention_kernel(const float *__
                                                                  int n_ctx, int E, const float *__restrict__ kc,
                                                                  const float *__restrict__ vc,
                                                                  const uint16_t *__restrict__ exp_tab, int tab_n,
-                                                                 float scale, float *__restrict__ ao, int ldo, int pair) {
+                                                                 float scale, float *__restrict__ ao, int ldo, int pair,
+                                                                 int8_t *__restrict__ oq, float *__restrict__ od,
+                                                                 float *__restrict__ os) {
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
     constexpr int D = NSTEP * 8;
     // grid = (heads, block pairs): consecutive workgroup ids go to consecutive XCDs, so all workgroups of a head share
@@ -569,11 +571,57 @@ __global__ __launch_bounds__(PA_T) void prefill_attention_kernel(const float *__
                 const float b = (k + kk < ke) ? pb[k + kk] : 0.f;
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
             }
-            const int col = h * D + d0 + r;
+            if (!oq) {
+                const int col = h * D + d0 + r;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * kk;
-                if (row < N) ao[(int64_t)row * ldo + col] = acc[i];
+                for (int i = 0; i < 16; ++i) {
+                    const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * kk;
+                    if (row < N) ao[(int64_t)row * ldo + col] = acc[i];
+                }
+            } else {
+                // the 32x32 tile goes to the (now free) Q area: [block][column tile][32 rows][33]
+                float *T = Qs + (q * (D / 32) + (wave & 3)) * (32 * 33);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) T[((i & 3) + 8 * (i >> 2) + 4 * kk) * 33 + r] = acc[i];
+            }
+        }
+    }
+    if (oq) {
+        // ---- phase 4: quantize_row_q8_0 of the result (lib/ggml.c:1341-1403,1433-1440), straight into the QA16 operand of
+        //      the wo matmul: one thread = one (token, 32 output columns = one quant block) ----
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            const int w = threadIdx.x >> 5, rr = threadIdx.x & 31;
+            const int q = w >> 2, d0 = (w & 3) * 32, mbq = PA_SEL(q, mb0, mb1);
+            const int n = mbq * 32 + rr, KBo = E >> 5, N16 = (N + 15) & ~15;
+            if (mbq >= 0 && d0 < D && n < N16) {
+                const float *T = Qs + (q * (D / 32) + (w & 3)) * (32 * 33) + rr * 33;
+                float v[32], amax = 0.f;
+#pragma unroll
+                for (int e = 0; e < 32; ++e) {
+                    v[e] = n < N ? T[e] : 0.f;                         // columns N..N16-1 of the operand are zero blocks
+                    amax = fmaxf(amax, fabsf(v[e]));
+                }
+                const float dd = __fdiv_rn(amax, 127.0f);
+                const float id = amax != 0.0f ? __fdiv_rn(127.0f, amax) : 0.0f;
+                int qi[32], sum = 0;
+#pragma unroll
+                for (int e = 0; e < 32; ++e) {
+                    qi[e] = (int)rintf(__fmul_rn(v[e], id));
+                    sum += qi[e];
+                }
+                const int c = n & 15;
+                const int64_t cb = ((int64_t)(n >> 4) * KBo + ((h * D + d0) >> 5)) * 16 + c;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    auto pk = [](int a, int b, int cc, int d) -> uint32_t {
+                        return (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(cc & 0xFF) << 16) | ((uint32_t)(d & 0xFF) << 24);
+                    };
+                    *reinterpret_cast<uint2 *>(oq + cb * 32 + qw16_pos(c, g) * 8) =
+                        make_uint2(pk(qi[8 * g], qi[8 * g + 2], qi[8 * g + 4], qi[8 * g + 6]), pk(qi[8 * g + 1], qi[8 * g + 3], qi[8 * g + 5], qi[8 * g + 7]));
+                }
+                od[cb] = dd;
+                os[cb] = __fmul_rn(dd, (float)sum);
             }
         }
     }
@@ -590,8 +638,9 @@ extern "C" int fl_debug_pa_timing(long long *out) { return (int)hipMemcpyFromSym
 // (caller falls back to the three-kernel path).
 hipError_t prefill_attention(const float *qkv, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc,
                              const float *vc, const uint16_t *exp_tab, int tab_n, float scale, float *ao, int ldo,
-                             hipStream_t st) {
+                             hipStream_t st, const fl_qact *qout) {
     const int P = n_past + N, nb = (N + 31) / 32;
+    if (qout && (E % 32 != 0)) return hipErrorInvalidValue;
     if (D % 32 != 0 || D > 128 || (n_ctx & 3) != 0 || P > 64 * PA_SM_IT || tab_n < 0 || tab_n > 24576 || (tab_n & 7)) return hipErrorInvalidValue;
     const size_t tab_bytes = (size_t)tab_n * 2, qblk = (size_t)32 * (D + 4) * 4;   // exp table; Q rows of one block
     // pair mode: score rows of block x and of block nb-1-x: 32 * (2 n_past + 32 (nb + 1) + 8) floats (+64: round-ups)
@@ -612,7 +661,8 @@ hipError_t prefill_attention(const float *qkv, int ldq, int D, int H, int N, int
             attr_set = true;                                                                                            \
         }                                                                                                               \
         hipLaunchKernelGGL(prefill_attention_kernel<NS>, grid, dim3(PA_T), lds, st, qkv, ldq, N, n_past, n_ctx, E, kc, vc, \
-                           exp_tab, tab_n, scale, ao, ldo, pair);                                                       \
+                           exp_tab, tab_n, scale, ao, ldo, pair, qout ? qout->q : nullptr, qout ? qout->d : nullptr,    \
+                           qout ? qout->s : nullptr);                                                                   \
     } while (0)
     if (D == 128) FL_PA(16);
     else if (D == 96) FL_PA(12);

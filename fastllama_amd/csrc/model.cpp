@@ -468,7 +468,7 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn) {
             const float kq_scale = 1.0f / sqrtf((float)E / (float)m->H);
             // KQ, scale, mask, soft_max, KQV in one launch with the score rows in LDS when they fit       :364-398
             hipError_t pe = (N >= 9 && !dyn && m->fuse_prefill_attn)
-                                ? prefill_attention(m->qkv, 3 * El, D, Hl, N, n_past, n_ctx, El, kc, vc, m->exp_tab, m->exp_tab_n, kq_scale, m->ao, El, st)
+                                ? prefill_attention(m->qkv, 3 * El, D, Hl, N, n_past, n_ctx, El, kc, vc, m->exp_tab, m->exp_tab_n, kq_scale, m->ao, El, st, &m->qEl)
                                 : hipErrorInvalidValue;
             if (pe != hipSuccess) {
                 (void)hipGetLastError();
@@ -479,8 +479,8 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn) {
                 // KQV, merged back to [N, n_embd]                                                      :389-398
                 M_HIP(gemm_f32_abt(m->att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, m->ao, El, D, N, D, P, Hl,
                                    1.0f, 2, n_past, st, dyn, n_ctx));
-            }
-            M_HIP((layout == 16 ? quantize_q8_qa16 : quantize_q8_qa1)(m->ao, El, N, El, m->qEl, st));
+                M_HIP((layout == 16 ? quantize_q8_qa16 : quantize_q8_qa1)(m->ao, El, N, El, m->qEl, st));
+            }   // (the one-launch kernel wrote the Q8_0 operand of the wo matmul itself)
         }
         // wo projection + residual                                                                 :401-407
         if (!tp) {
@@ -858,7 +858,8 @@ int fl_debug_gemv_silu(const fl_qtensor *W, const float *h13, const uint16_t *si
     return FL_OK;
 }
 int fl_debug_prefill_attention(const float *qkv, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc,
-                               const float *vc, const uint16_t *exp_tab_dev, float scale, float *ao, int ldo, void *stream) {
+                               const float *vc, const uint16_t *exp_tab_dev, float scale, float *ao, int ldo, fl_qact *qout,
+                               void *stream) {
     static int tab_n = -1;
     if (tab_n < 0) {                                   // same bound as fl_model_finalize computes
         int last_nz = 0;
@@ -866,7 +867,7 @@ int fl_debug_prefill_attention(const float *qkv, int ldq, int D, int H, int N, i
             if (f32_to_f16_bits(expf(f16_bits_to_f32((uint16_t)i))) != 0) last_nz = i - 0x8000;
         tab_n = (last_nz + 1 + 7) & ~7;
     }
-    M_HIP(prefill_attention(qkv, ldq, D, H, N, n_past, n_ctx, E, kc, vc, exp_tab_dev, tab_n, scale, ao, ldo, (hipStream_t)stream));
+    M_HIP(prefill_attention(qkv, ldq, D, H, N, n_past, n_ctx, E, kc, vc, exp_tab_dev, tab_n, scale, ao, ldo, (hipStream_t)stream, qout));
     return FL_OK;
 }
 int fl_debug_gemv_norm_silu(const fl_qtensor *W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act,

@@ -113,7 +113,7 @@ _PROTOS = {
     "fl_debug_gemv_norm_silu": (C.c_int, [C.c_void_p] * 6),
     "fl_debug_gemv_quant": (C.c_int, [C.c_void_p] * 5),
     "fl_debug_prefill_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                             C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+                                             C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "fl_debug_decode_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "fl_debug_silu_mul_quant": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -208,7 +208,8 @@ int fl_debug_gemv_norm_silu(const fl_qtensor *W_woven, const float *x_dev, const
 int fl_debug_gemv_quant(const fl_qtensor *W, const float *x_dev, float *y_dev, const float *resid_dev, void *stream);
 int fl_debug_prefill_attention(const float *qkv_dev, int ldq, int D, int H, int N, int n_past, int n_ctx, int E,
                                const float *kc, const float *vc, const uint16_t *exp_tab_dev, float scale, float *ao_dev,
-                               int ldo, void *stream); /* KQ*scale + mask + soft_max + KQV, one launch (prefill) */
+                               int ldo, fl_qact *qout /* NULL: f32 result to ao; else Q8_0 (QA16) of it */, void *stream);
+                               /* KQ*scale + mask + soft_max + KQV (+ quantize_row_q8_0), one launch (prefill) */
 int fl_debug_decode_attention(const float *qkv_dev, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab_dev,
                               float *kc, float *vc, const uint16_t *exp_tab_dev, float scale, fl_qact *out, void *stream);
 int fl_debug_silu_mul_quant(const float *h13_dev, int ld, int N, int F, const uint16_t *silu_tab_dev, fl_qact *out,

@@ -278,9 +278,22 @@ def test_prefill_attention_fused_equals_three_kernels(env, N, P0, D, H, n_ctx):
                                       N, D, P, H, 1.0, 2, P0, None))
     ao1 = torch.full((N, E), -3.0, device="cuda")
     hip.check(L.fl_debug_prefill_attention(qd.data_ptr(), 3 * E, D, H, N, P0, n_ctx, E, kd.data_ptr(), vd.data_ptr(), ed.data_ptr(),
-                                           scale, ao1.data_ptr(), E, None))
+                                           scale, ao1.data_ptr(), E, None, None))
     torch.cuda.synchronize()
     assert torch.equal(ao1, ao0)
+    # the same launch writing the Q8_0 operand of the wo matmul instead: == quantize_row_q8_0 of the f32 rows, and zero
+    # blocks for the padding columns N..N16-1
+    if N >= 9:
+        a = ops.QAct(N, E)
+        hip.check(L.fl_quantize_q8_layout(a.handle, ao0.data_ptr(), E, N, E, 16, None))      # sizes / layout bookkeeping
+        a.N, a.K = N, E
+        junk = torch.full((N, E), 5.0, device="cuda")
+        hip.check(L.fl_quantize_q8_layout(a.handle, junk.data_ptr(), E, N, E, 16, None))     # poison the workspace
+        hip.check(L.fl_debug_prefill_attention(qd.data_ptr(), 3 * E, D, H, N, P0, n_ctx, E, kd.data_ptr(), vd.data_ptr(),
+                                               ed.data_ptr(), scale, ao1.data_ptr(), E, a.handle, None))
+        got_q8 = a.export().cpu().numpy()
+        want_q8 = np.stack([port.quantize_row_q8_0(r_) for r_ in ao0.cpu().numpy()])
+        assert np.array_equal(got_q8, want_q8)
     # and against numpy on a few rows (the three-kernel path is itself checked against numpy above)
     for n in (0, N - 1):
         for h in (0, H - 1):
