@@ -49,31 +49,30 @@ __device__ const uint4 fl_zero_chunk[1] = {{0u, 0u, 0u, 0u}};  // source of out-
 #define FL_ABL 0
 #endif
 
-constexpr int GM_KS = 2;      // quant blocks per K-step
-#ifndef FL_NSTAGE
-#define FL_NSTAGE 3
-#endif
-constexpr int GM_NSTAGE = FL_NSTAGE;  // LDS ring depth: fills run GM_NSTAGE-1 K-steps ahead of the MFMAs
-
-template <int TYPE, int WM, int WN, int TM, int TN>
+// KS = quant blocks per K-step (LDS stage).  KS = 2 runs a 3-deep LDS ring, KS = 4 a 2-deep one (about the same LDS
+// bytes and the same prefetch distance in blocks): half as many barriers and fill bookkeeping per MFMA.
+template <int TYPE, int WM, int WN, int TM, int TN, int KS>
 struct GemmCfg {
+    static constexpr int NSTAGE = KS == 2 ? 3 : 2;            // LDS ring depth
     static constexpr int NW = WM * WN;                        // waves per workgroup
     static constexpr int MG = WM * TM;                        // W row groups (16 rows) per workgroup tile
     static constexpr int NG = WN * TN;                        // activation column groups per workgroup tile
-    static constexpr int A_BYTES = MG * GM_KS * 256;          // packed nibbles
-    static constexpr int B_BYTES = NG * GM_KS * 512;          // int8 activations
+    static constexpr int A_BYTES = MG * KS * 256;             // packed nibbles
+    static constexpr int B_BYTES = NG * KS * 512;             // int8 activations
     static constexpr int A_PIECES = A_BYTES / 1024;           // 1-KiB global_load_lds pieces
     static constexpr int B_PIECES = B_BYTES / 1024;
-    static constexpr int N_PLANES = TYPE == FL_TYPE_Q4_1 ? 4 : 2;   // dW, dX (, mW, sX): one piece each, padded
-    static constexpr int PIECES = A_PIECES + B_PIECES + N_PLANES;
+    static constexpr int N_PLANES = TYPE == FL_TYPE_Q4_1 ? 4 : 2;   // dW, dX (, mW, sX)
+    static constexpr int PLP = ((MG > NG ? MG : NG) * KS * 64 + 1023) / 1024;   // pieces per scale plane (padded)
+    static constexpr int PL_STRIDE = PLP * 1024;
+    static constexpr int PIECES = A_PIECES + B_PIECES + N_PLANES * PLP;
     static constexpr int LPW = (PIECES + NW - 1) / NW;        // pieces issued by EVERY wave per stage
     static constexpr int OFF_B = A_BYTES;
-    static constexpr int OFF_PL = OFF_B + B_BYTES;            // planes, 1 KiB apart: dW | dX | mW | sX
-    static constexpr int STAGE = OFF_PL + N_PLANES * 1024;
-    static constexpr int OFF_SINK = GM_NSTAGE * STAGE;        // 1 KiB sink for padding pieces
+    static constexpr int OFF_PL = OFF_B + B_BYTES;            // planes, PL_STRIDE apart: dW | dX | mW | sX
+    static constexpr int STAGE = OFF_PL + N_PLANES * PL_STRIDE;
+    static constexpr int OFF_SINK = NSTAGE * STAGE;           // 1 KiB sink for padding pieces
     static constexpr int LDS_BYTES = OFF_SINK + 1024;
+    static_assert(KS == 2 || KS == 4, "K-step of 2 or 4 quant blocks");
     static_assert(A_BYTES % 1024 == 0 && B_BYTES % 1024 == 0, "tile must be made of whole 1-KiB pieces");
-    static_assert(MG * GM_KS * 64 <= 1024 && NG * GM_KS * 64 <= 1024, "scale plane must fit one piece");
 };
 
 // gfx950: a v_pk_*_f32 cannot issue while an MFMA is executing (scripts/ubench/coexec.hip: 8 x (mfma + 1 v_pk_fma) takes
@@ -102,13 +101,14 @@ struct GemmSiluEpi {
     int El, D, n_past, n_ctx;
 };
 
-template <int TYPE, int WM, int WN, int TM, int TN, int MINW>
+template <int TYPE, int WM, int WN, int TM, int TN, int MINW, int KS>
 __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ? 3 : MINW) FL_NOPK void gemm_q4_mfma_kernel(
     const uint4 *__restrict__ qs, const float *__restrict__ dW, const float *__restrict__ mW,
     const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs, int N, int M,
     int MGT /* row groups total */, int NGT /* col groups total */, int KB, float *__restrict__ y, int ldy,
     const float *__restrict__ resid, int ldr, GemmSiluEpi epi) {
-    using Cfg = GemmCfg<TYPE, WM, WN, TM, TN>;
+    using Cfg = GemmCfg<TYPE, WM, WN, TM, TN, KS>;
+    constexpr int GM_KS = KS, GM_NSTAGE = Cfg::NSTAGE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -158,12 +158,13 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
                 step_bytes[s] = GM_KS * 512;
             }
         } else if (p < Cfg::PIECES) {
-            const int pl = p - Cfg::A_PIECES - Cfg::B_PIECES;  // 0 dW, 1 dX, 2 mW, 3 sX
-            const int gi = lane / (GM_KS * 4), e = lane % (GM_KS * 4);
+            const int idx = p - Cfg::A_PIECES - Cfg::B_PIECES;
+            const int pl = idx / Cfg::PLP, pp = idx % Cfg::PLP;    // plane 0 dW, 1 dX, 2 mW, 3 sX; piece inside the plane
+            const int c = pp * 64 + lane, gi = c / (GM_KS * 4), e = c % (GM_KS * 4);
             const bool wside = (pl & 1) == 0;
             const float *plane = pl == 0 ? dW : pl == 1 ? xd : pl == 2 ? mW : xs;
             const int g = (wside ? mg0 : ng0) + gi;
-            lds_off[s] = Cfg::OFF_PL + pl * 1024;
+            lds_off[s] = Cfg::OFF_PL + pl * Cfg::PL_STRIDE + pp * 1024;
             blk_of_lane[s] = e / 4;
             if (wside ? (gi < Cfg::MG && g < MGT) : (gi < Cfg::NG && g < NGT)) {
                 src[s] = reinterpret_cast<const unsigned char *>(plane + ((int64_t)g * KB) * 16 + e * 4);
@@ -212,18 +213,18 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
     if constexpr (TT == 2) { ki = 0; kj = lg & 1; kb = lg >> 1; }
     else if constexpr (TN == 4) { ki = 0; kj = lg; kb = 0; }
     else { ki = lg >> 1; kj = lg & 1; kb = 0; }
-    const int sa_off = Cfg::OFF_PL + (((wm * TM + ki) * GM_KS + kb) * 16 + l15) * 4;          // d_w (m_w: +2048)
-    const int sb_off = Cfg::OFF_PL + 1024 + (((wn * TN + kj) * GM_KS + kb) * 16 + l15) * 4;   // d_x (s_x: +2048)
+    const int sa_off = Cfg::OFF_PL + (((wm * TM + ki) * GM_KS + kb) * 16 + l15) * 4;          // d_w (m_w: +2 planes)
+    const int sb_off = Cfg::OFF_PL + Cfg::PL_STRIDE + (((wn * TN + kj) * GM_KS + kb) * 16 + l15) * 4;   // d_x (s_x: +2 planes)
     // TT = 2, Q4_1: the m_w x s_x MFMA is issued per block (lane groups {j0, j1, j0, j1} of THAT block) so that its
     // accumulator sees the blocks in K order like every other configuration
-    const int ma_off = Cfg::OFF_PL + 2048 + ((wm * TM) * GM_KS * 16 + l15) * 4;
-    const int mb_off = Cfg::OFF_PL + 1024 + 2048 + ((wn * TN + (lg & 1)) * GM_KS * 16 + l15) * 4;
+    const int ma_off = Cfg::OFF_PL + 2 * Cfg::PL_STRIDE + ((wm * TM) * GM_KS * 16 + l15) * 4;
+    const int mb_off = Cfg::OFF_PL + 3 * Cfg::PL_STRIDE + ((wn * TN + (lg & 1)) * GM_KS * 16 + l15) * 4;
 
     // ---- block-granular software pipeline (GM_KS = 2 blocks per stage) --------------------------------------------
     //   registers hold the operands of two quant blocks: the one the MFMAs are consuming and the one whose LDS reads are
     //   in flight.  Step t:   read(t, b1) | tiles of (t, b0) | wait + barrier + fill(stage t+3) + read(t+1, b0) | tiles of (t, b1)
     //   so LDS latency, the barrier and the fill issue all sit under a full block of MFMA/VALU work of the same wave.
-    static_assert(GM_KS == 2 && GM_NSTAGE >= 3, "pipeline below is written for 2 blocks per stage, >= 3 stages");
+    static_assert(TT != 2 || GM_KS == 2, "the 16x32 wave tile pairs the two blocks of a 2-block K-step");
     constexpr int UB = TT == 2 ? 1 : TT / 4;           // scale MFMAs per block (TT == 2: one per K-step, read with block 0)
     struct Ops {
         uint32_t araw[TM];                             // packed nibbles as read from LDS (unpacked right before use)
@@ -252,8 +253,8 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
             o.sa[ub] = *reinterpret_cast<const float *>(base + sa_off + oa);
             o.sb[ub] = *reinterpret_cast<const float *>(base + sb_off + ob);
             if (TYPE == FL_TYPE_Q4_1) {
-                o.ma[ub] = *reinterpret_cast<const float *>(base + sa_off + 2048 + oa);
-                o.mb[ub] = *reinterpret_cast<const float *>(base + sb_off + 2048 + ob);
+                o.ma[ub] = *reinterpret_cast<const float *>(base + sa_off + 2 * Cfg::PL_STRIDE + oa);
+                o.mb[ub] = *reinterpret_cast<const float *>(base + sb_off + 2 * Cfg::PL_STRIDE + ob);
             }
         }
     };
@@ -278,39 +279,60 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
     for (int t = 0; t < nsteps; ++t) {
         const unsigned char *base = smem + cur * Cfg::STAGE;
         int nxt = cur + 1 == GM_NSTAGE ? 0 : cur + 1;
-        long afrag[GM_KS][TM];
+        long afrag[2][TM];                              // unpacked A fragments of the block in flight / the next one
         // MFMA stream of the step: P(0) T(0) T(1) | E(0) T(2) | E(1) T(3) | E(2) P(1) T(4) | ...  (E = VALU scale-accumulate)
         // The d_w x d_x outer products of four tiles come from ONE v_mfma_f32_16x16x1 (4 blocks): 8 passes of the matrix
-        // pipe instead of four VALU multiplies per tile.
+        // pipe instead of four VALU multiplies per tile.  Block b lives in ops[b & 1] / afrag[b & 1].
         auto unpack_block = [&](int b) FL_NOPK __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 uint32_t lo, hi;
-                unpack_nibbles<TYPE>(ops[b].araw[i], lo, hi);
-                afrag[b][i] = (long)(((uint64_t)hi << 32) | lo);
+                unpack_nibbles<TYPE>(ops[b & 1].araw[i], lo, hi);
+                afrag[b & 1][i] = (long)(((uint64_t)hi << 32) | lo);
             }
         };
         auto tile_mfma = [&](int flat) FL_NOPK __attribute__((always_inline)) -> v4i {
             const int b = flat / TT, i = (flat % TT) / TN, j = flat % TN;   // (TT == 2: i = 0)
-            return FL_MFMA(afrag[b][i], ops[b].bq[j], magic);
+            return FL_MFMA(afrag[b & 1][i], ops[b & 1].bq[j], magic);
         };
         auto scale_mfma = [&](int u, v16f &P) FL_NOPK __attribute__((always_inline)) {   // group u of the step
             const int b = TT == 2 ? 0 : u / UB, ub = TT == 2 ? 0 : u % UB;
-            P = __builtin_amdgcn_mfma_f32_16x16x1f32(ops[b].sa[ub], ops[b].sb[ub], zero16, 0, 0, 0);
+            P = __builtin_amdgcn_mfma_f32_16x16x1f32(ops[b & 1].sa[ub], ops[b & 1].sb[ub], zero16, 0, 0, 0);
             if (TYPE == FL_TYPE_Q4_1 && TT != 2)
-                msacc[u % G] = __builtin_amdgcn_mfma_f32_16x16x1f32(ops[b].ma[ub], ops[b].mb[ub], msacc[u % G], 0, 0, 0);
+                msacc[u % G] = __builtin_amdgcn_mfma_f32_16x16x1f32(ops[b & 1].ma[ub], ops[b & 1].mb[ub], msacc[u % G], 0, 0, 0);
+        };
+        // The operands of block nb+1 are requested when block nb starts (its first MFMA is out, so the registers of block
+        // nb-1 are free).  For the last block of the step the next block is block 0 of the NEXT stage: that is where the
+        // stage hand-over sits -- this wave's pieces of stage t+1 landed (vmcnt), everyone's did and everyone finished
+        // reading stage t (barrier), the freed buffer is refilled, and the wave moves on with MFMAs already in flight.
+        auto start_of_block = [&](int nb) FL_NOPK __attribute__((always_inline)) {
+            if (nb < GM_KS - 1) {
+#if !(FL_ABL & 2)
+                read_ops(ops[(nb + 1) & 1], base, nb + 1);
+#endif
+            } else {
+#if !(FL_ABL & 1)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::LPW * (GM_NSTAGE - 2)) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !(FL_ABL & 4)
+                __builtin_amdgcn_s_barrier();
+#endif
+                fill(cur, (t + GM_NSTAGE) * GM_KS);    // stage t+NSTAGE into the buffer stage t occupied
+#endif
+#if !(FL_ABL & 2)
+                read_ops(ops[(nb + 1) & 1], smem + nxt * Cfg::STAGE, 0);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
         };
         v16f P0, P1 = zero16;
         unpack_block(0);
         scale_mfma(0, P0);
         v4i r0 = tile_mfma(0), r1 = magic;
         __builtin_amdgcn_sched_barrier(0);
-        // block 1's LDS reads go out only now: hipcc waits with lgkmcnt(0) before the first use of block 0's operands
-        // (the counter state is unknown across the back edge), and that wait must not cover these reads.
-#if !(FL_ABL & 2)
-        read_ops(ops[1], base, 1);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
+        // (block 1's LDS reads go out only now: hipcc waits with lgkmcnt(0) before the first use of block 0's operands --
+        // the counter state is unknown across the back edge -- and that wait must not cover these reads)
+        start_of_block(0);
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
             if (tt + 1 < NT) {
@@ -325,7 +347,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
             const int u = tt / 4, k = tt % 4, g = u % G;
             const int ka = TT == 2 ? (k & 1) : k;                                      // accumulator slot of the tile
             if (TT == 2 && TYPE == FL_TYPE_Q4_1 && (tt % TT) == 0)                      // per block, slots {j0, j1}
-                msacc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(ops[tt / TT].ma[0], ops[tt / TT].mb[0], msacc[0], 0, 0, 0);
+                msacc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(ops[(tt / TT) & 1].ma[0], ops[(tt / TT) & 1].mb[0], msacc[0], 0, 0, 0);
             const v4f f = __builtin_bit_cast(v4f, (tt & 1) ? r1 : r0) + negmagic;   // exact: float(isum)
             const v16f &P = (u & 1) ? P1 : P0;
             const v4f p = {P[4 * k], P[4 * k + 1], P[4 * k + 2], P[4 * k + 3]};        // d_w*d_x (ggml.c:2452)
@@ -333,22 +355,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
             a = __builtin_elementwise_fma(f, p, a);                                     // fma(d, isum, acc) (:2478)
             acc[g][4 * ka] = a[0]; acc[g][4 * ka + 1] = a[1]; acc[g][4 * ka + 2] = a[2]; acc[g][4 * ka + 3] = a[3];
             __builtin_amdgcn_sched_barrier(0);
-            if (tt == TT - 1) {
-                // every MFMA of block 0 has been issued: its operand registers are free.  Stage t+1 must have landed
-                // (this wave's pieces: vmcnt; everyone's: barrier); everyone has also finished reading stage t.
-#if !(FL_ABL & 1)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::LPW * (GM_NSTAGE - 2)) : "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if !(FL_ABL & 4)
-                __builtin_amdgcn_s_barrier();
-#endif
-                fill(cur, (t + GM_NSTAGE) * GM_KS);    // stage t+NSTAGE into the buffer stage t occupied
-#endif
-#if !(FL_ABL & 2)
-                read_ops(ops[0], smem + nxt * Cfg::STAGE, 0);
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            if (tt % TT == TT - 1 && tt + 1 < NT) start_of_block(tt / TT + 1);   // the next block's first MFMA is already out
         }
         cur = nxt;
     }
@@ -482,27 +489,30 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
 // ------------------------------------------------------------------------------------------------
 // configurations and the shape-driven choice
 // ------------------------------------------------------------------------------------------------
-//                      WM WN TM TN  minwaves/SIMD          tile      waves
-#define FL_GEMM_CONFIGS(X)                                                   \
-    X(0, 2, 2, 4, 4, 2) /* 128x128   4 waves of 64x64                    */ \
-    X(1, 2, 2, 2, 4, 4) /*  64x128   4 waves of 32x64                    */ \
-    X(2, 4, 2, 2, 4, 2) /* 128x128   8 waves of 32x64                    */ \
-    X(3, 4, 2, 1, 4, 2) /*  64x128   8 waves of 16x64                    */ \
-    X(4, 4, 4, 2, 2, 1) /* 128x128  16 waves of 32x32                    */ \
-    X(5, 2, 2, 2, 2, 4) /*  64x64    4 waves of 32x32                    */ \
-    X(6, 2, 4, 2, 2, 2) /*  64x128   8 waves of 32x32                    */ \
-    X(7, 4, 2, 2, 2, 2) /* 128x64    8 waves of 32x32                    */ \
-    X(8, 4, 4, 1, 2, 1) /*  64x128  16 waves of 16x32                    */
+//                      WM WN TM TN  minwaves/SIMD  KS     tile      waves
+#define FL_GEMM_CONFIGS(X)                                                      \
+    X(0, 2, 2, 4, 4, 2, 2)  /* 128x128   4 waves of 64x64                    */ \
+    X(1, 2, 2, 2, 4, 4, 2)  /*  64x128   4 waves of 32x64                    */ \
+    X(2, 4, 2, 2, 4, 2, 2)  /* 128x128   8 waves of 32x64                    */ \
+    X(3, 4, 2, 1, 4, 2, 2)  /*  64x128   8 waves of 16x64                    */ \
+    X(4, 4, 4, 2, 2, 1, 2)  /* 128x128  16 waves of 32x32                    */ \
+    X(5, 2, 2, 2, 2, 4, 2)  /*  64x64    4 waves of 32x32                    */ \
+    X(6, 2, 4, 2, 2, 2, 2)  /*  64x128   8 waves of 32x32                    */ \
+    X(7, 4, 2, 2, 2, 2, 2)  /* 128x64    8 waves of 32x32                    */ \
+    X(8, 4, 4, 1, 2, 1, 2)  /*  64x128  16 waves of 16x32                    */ \
+    X(9, 4, 2, 2, 4, 2, 4)  /* 128x128   8 waves of 32x64, 4-block K-steps   */ \
+    X(10, 2, 2, 2, 4, 3, 4) /*  64x128   4 waves of 32x64, 4-block K-steps   */ \
+    X(11, 4, 2, 2, 2, 2, 4) /* 128x64    8 waves of 32x32, 4-block K-steps   */
 
 int g_gemm_force_cfg = -1;  // debug / autotune hook: >= 0 forces one configuration
 
-template <int TYPE, int WM, int WN, int TM, int TN, int MINW>
+template <int TYPE, int WM, int WN, int TM, int TN, int MINW, int KS>
 static hipError_t launch_gemm(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                               const float *resid, int ldr, const GemmSiluEpi &epi) {
-    using Cfg = GemmCfg<TYPE, WM, WN, TM, TN>;
+    using Cfg = GemmCfg<TYPE, WM, WN, TM, TN, KS>;
     const int MGT = W.M16 / 16, NGT = fl_roundup(N, 16) / 16;
     const int tiles = ((MGT + Cfg::MG - 1) / Cfg::MG) * ((NGT + Cfg::NG - 1) / Cfg::NG);
-    auto kern = gemm_q4_mfma_kernel<TYPE, WM, WN, TM, TN, MINW>;
+    auto kern = gemm_q4_mfma_kernel<TYPE, WM, WN, TM, TN, MINW, KS>;
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS_BYTES > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -529,16 +539,13 @@ static int pick_config(int MGT, int NGT, int type) {
         return (double)((wgs + 255) / 256) * 256.0 * MG * NG / tiles16;
     };
     const double q2 = quant(8, 8), q1 = quant(4, 8), q5 = quant(4, 4), q7 = quant(8, 4);
-    if (per_simd < 12) {                                                         // small outputs
-        if (type == FL_TYPE_Q4_1) return q7 > 1.1 * q5 ? 5 : 7;                  // (16x32 tiles pay an extra m*s MFMA per block)
-        return q1 > 1.1 * q5 ? 5 : 8;                                            // 16 waves of 16x32 on a 64x128 tile
-    }
+    if (per_simd < 12) return q7 > 1.1 * q5 ? 5 : 11;                            // small outputs: 8 waves of 32x32, 4-block K-steps
     int best = 2;
     double qb = q2;
-    if (q1 < 0.96 * qb) { best = 1; qb = q1; }
+    if (q1 < 0.96 * qb) { best = 10; qb = q1; }
     if (q5 < 0.90 * qb) { best = 5; qb = q5; }
-    if (per_simd < 40 && best == 2 && q1 <= q2) best = 1;                         // mid-size: 4 workgroups of 4 waves per CU
-    if (type == FL_TYPE_Q4_1 && best == 2 && q1 <= 1.02 * q2) best = 1;           // Q4_1 (one more MFMA per 4 tiles): measured
+    if (per_simd < 56 && best == 2 && q1 <= q2) best = 10;                        // mid-size: 64x128 tiles of 4 waves, 4-block K-steps
+    if (type == FL_TYPE_Q4_1 && best == 2 && q1 <= 1.02 * q2) best = 10;          // Q4_1 (one more MFMA per 4 tiles): measured
     return best;
 }
 
@@ -549,10 +556,10 @@ static hipError_t gemm_dispatch(const fl_qtensor &W, const fl_qact &xq, int N, f
     const int MGT = W.M16 / 16, NGT = fl_roundup(N, 16) / 16;
     int cfg = pick_config(MGT, NGT, W.type);
     if (epi.silu_tab && (cfg == 3 || cfg == 8)) cfg = 5;   // the silu epilogue pairs two row groups per wave: TM must be even
-#define X(ID, WM, WN, TM, TN, MINW)                                                                         \
+#define X(ID, WM, WN, TM, TN, MINW, KS)                                                                     \
     if (cfg == ID)                                                                                          \
-        return W.type == FL_TYPE_Q4_0 ? launch_gemm<FL_TYPE_Q4_0, WM, WN, TM, TN, MINW>(W, xq, N, y, ldy, st, resid, ldr, epi) \
-                                      : launch_gemm<FL_TYPE_Q4_1, WM, WN, TM, TN, MINW>(W, xq, N, y, ldy, st, resid, ldr, epi);
+        return W.type == FL_TYPE_Q4_0 ? launch_gemm<FL_TYPE_Q4_0, WM, WN, TM, TN, MINW, KS>(W, xq, N, y, ldy, st, resid, ldr, epi) \
+                                      : launch_gemm<FL_TYPE_Q4_1, WM, WN, TM, TN, MINW, KS>(W, xq, N, y, ldy, st, resid, ldr, epi);
     FL_GEMM_CONFIGS(X)
 #undef X
     return hipErrorInvalidValue;
