@@ -539,13 +539,13 @@ static int pick_config(int MGT, int NGT, int type) {
         return (double)((wgs + 255) / 256) * 256.0 * MG * NG / tiles16;
     };
     const double q2 = quant(8, 8), q1 = quant(4, 8), q5 = quant(4, 4), q7 = quant(8, 4);
-    if (per_simd < 12) return q7 > 1.1 * q5 ? 5 : 11;                            // small outputs: 8 waves of 32x32, 4-block K-steps
+    if (per_simd < 12 || type == FL_TYPE_Q4_1) return q7 > 1.1 * q5 ? 5 : 11;    // small outputs (and every Q4_1 shape, measured):
+                                                                                 // 8 waves of 32x32, 4-block K-steps
     int best = 2;
     double qb = q2;
     if (q1 < 0.96 * qb) { best = 10; qb = q1; }
     if (q5 < 0.90 * qb) { best = 5; qb = q5; }
     if (per_simd < 56 && best == 2 && q1 <= q2) best = 10;                        // mid-size: 64x128 tiles of 4 waves, 4-block K-steps
-    if (type == FL_TYPE_Q4_1 && best == 2 && q1 <= 1.02 * q2) best = 10;          // Q4_1 (one more MFMA per 4 tiles): measured
     return best;
 }
 
