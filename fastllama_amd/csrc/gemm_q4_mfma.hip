@@ -502,7 +502,9 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
     X(8, 4, 4, 1, 2, 1, 2)  /*  64x128  16 waves of 16x32                    */ \
     X(9, 4, 2, 2, 4, 2, 4)  /* 128x128   8 waves of 32x64, 4-block K-steps   */ \
     X(10, 2, 2, 2, 4, 3, 4) /*  64x128   4 waves of 32x64, 4-block K-steps   */ \
-    X(11, 4, 2, 2, 2, 2, 4) /* 128x64    8 waves of 32x32, 4-block K-steps   */
+    X(11, 4, 2, 2, 2, 2, 4) /* 128x64    8 waves of 32x32, 4-block K-steps   */ \
+    X(12, 2, 2, 2, 2, 4, 4) /*  64x64    4 waves of 32x32, 4-block K-steps   */ \
+    X(13, 2, 4, 2, 2, 2, 4) /*  64x128   8 waves of 32x32, 4-block K-steps   */
 
 int g_gemm_force_cfg = -1;  // debug / autotune hook: >= 0 forces one configuration
 
@@ -539,13 +541,14 @@ static int pick_config(int MGT, int NGT, int type) {
         return (double)((wgs + 255) / 256) * 256.0 * MG * NG / tiles16;
     };
     const double q2 = quant(8, 8), q1 = quant(4, 8), q5 = quant(4, 4), q7 = quant(8, 4);
-    if (per_simd < 12 || type == FL_TYPE_Q4_1) return q7 > 1.1 * q5 ? 5 : 11;    // small outputs (and every Q4_1 shape, measured):
-                                                                                 // 8 waves of 32x32, 4-block K-steps
+    if (type == FL_TYPE_Q4_1) return q7 > 1.1 * q5 ? 12 : 11;                    // every Q4_1 shape (measured): 8 waves of 32x32
+    if (per_simd < 12) return q1 > 1.1 * q5 ? 12 : 13;                           // small outputs: 32x32 wave tiles, 4-block K-steps
     int best = 2;
     double qb = q2;
     if (q1 < 0.96 * qb) { best = 10; qb = q1; }
-    if (q5 < 0.90 * qb) { best = 5; qb = q5; }
-    if (per_simd < 56 && best == 2 && q1 <= q2) best = 10;                        // mid-size: 64x128 tiles of 4 waves, 4-block K-steps
+    if (q5 < 0.93 * qb) { best = 12; qb = q5; }
+    if (per_simd < 80 && best == 2 && q1 <= q2) best = 10;                        // 64x128 tiles of 4 waves, 4-block K-steps
+    (void)q7;
     return best;
 }
 
@@ -555,7 +558,7 @@ static hipError_t gemm_dispatch(const fl_qtensor &W, const fl_qact &xq, int N, f
     if ((ldy & 3) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return hipErrorInvalidValue;
     const int MGT = W.M16 / 16, NGT = fl_roundup(N, 16) / 16;
     int cfg = pick_config(MGT, NGT, W.type);
-    if (epi.silu_tab && (cfg == 3 || cfg == 8)) cfg = 5;   // the silu epilogue pairs two row groups per wave: TM must be even
+    if (epi.silu_tab && (cfg == 3 || cfg == 8)) cfg = 12;   // the silu epilogue pairs two row groups per wave: TM must be even
 #define X(ID, WM, WN, TM, TN, MINW, KS)                                                                     \
     if (cfg == ID)                                                                                          \
         return W.type == FL_TYPE_Q4_0 ? launch_gemm<FL_TYPE_Q4_0, WM, WN, TM, TN, MINW, KS>(W, xq, N, y, ldy, st, resid, ldr, epi) \

@@ -742,7 +742,7 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
 int g_gemv_force_waves = 0;  // debug / tuning hook (fl_debug_set(1, n))
 static inline int gemv_waves(int groups, int KB = 0) {
     if (g_gemv_force_waves == 4 || g_gemv_force_waves == 8 || g_gemv_force_waves == 16) return g_gemv_force_waves;
-    if (groups >= 1024) return 4;
+    if (groups >= 640) return 4;
     if (groups >= 512) return 8;
     return KB >= 256 ? 8 : 16;          // few row groups: 16 waves each, unless the rows are long enough to feed 8 deeply
 }
