@@ -541,7 +541,7 @@ static int pick_config(int MGT, int NGT, int type) {
         return (double)((wgs + 255) / 256) * 256.0 * MG * NG / tiles16;
     };
     const double q2 = quant(8, 8), q1 = quant(4, 8), q5 = quant(4, 4), q7 = quant(8, 4);
-    if (type == FL_TYPE_Q4_1) return q7 > 1.1 * q5 ? 12 : 11;                    // every Q4_1 shape (measured): 8 waves of 32x32
+    if (type == FL_TYPE_Q4_1) return 12;                                         // every Q4_1 shape (measured): 64x64 tiles, 4 waves of 32x32
     if (per_simd < 12) return q1 > 1.1 * q5 ? 12 : 13;                           // small outputs: 32x32 wave tiles, 4-block K-steps
     int best = 2;
     double qb = q2;
