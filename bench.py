@@ -109,12 +109,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path to measure")
+    # development overrides (a 1-GPU box can still run the world > 1 code path: two replicas on one device, gloo for
+    # the timing reduction): FL_BENCH_DEVICE pins the device index, FL_BENCH_BACKEND selects the process-group backend
+    if "FL_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["FL_BENCH_DEVICE"])
+    backend = os.environ.get("FL_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from fastllama_amd import hip
     from harness import synth
@@ -161,7 +169,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         barrier()
