@@ -923,6 +923,189 @@ hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, i
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// decode attention for long contexts: the same arithmetic in TWO launches that spread one head over many CUs.
+// One workgroup per head streams 8 KiB of K/V per cached position through a single CU -- beyond a few hundred
+// positions that dominates the token (7B, n_past 1900: 95 us of a 133 us layer).
+//   decode_scores_kernel  grid (heads, 256-position slices): rope(q) [+ rope(k), KV store in the slice that owns the
+//                         fresh position], scaled K.q of the slice -> scores[head][p] in HBM
+//   decode_pv_kernel      grid (heads, D/32): soft_max of the head's score row in LDS (every workgroup repeats it: P
+//                         table lookups), KQV for 32 output features, Q8_0 block of those 32 features
+// Every dot is accumulated in the order decode_attention_kernel uses (8 lanes per row, float4 pieces ascending), the
+// max is exact and the f64 sum of fp16 table values is exact in any order: the result is bit-identical to the
+// one-launch kernel (tests/test_eval_ops_gpu.py::test_decode_attention_split_equals_fused).
+// ------------------------------------------------------------------------------------------------
+constexpr int DS_T = 512, DS_POS = 128, DP_T = 256, DP_BATCH = 16;
+
+__global__ __launch_bounds__(DS_T) void decode_scores_kernel(const float *__restrict__ qkv, int E, int D, int n_past,
+                                                             int n_ctx, const float2 *__restrict__ rope_tab,
+                                                             float *__restrict__ kc, float *__restrict__ vc, float scale,
+                                                             float *__restrict__ scores, const int *__restrict__ dyn_past) {
+    __shared__ __attribute__((aligned(16))) float qs[128], ks[128];
+    if (dyn_past) n_past = *dyn_past;
+    const int h = blockIdx.x, tid = threadIdx.x, pos = n_past, P = n_past + 1;
+    const int p0 = blockIdx.y * DS_POS;
+    if (p0 >= P) return;                                   // the grid is sized for n_ctx when the position is dynamic
+    const bool owner = pos < p0 + DS_POS;                  // this slice holds the fresh position
+    const int l8 = tid & 7, r64 = tid >> 3, J = D >> 5;
+    const float *q = qkv + h * D, *k = qkv + E + h * D, *v = qkv + 2 * E + h * D;
+    float2 cs = {0.f, 0.f}, xq = cs, xk = cs;
+    float vv = 0.f;
+    if (tid < D / 2) {
+        cs = rope_tab[(int64_t)pos * (D >> 1) + tid];
+        xq = *reinterpret_cast<const float2 *>(q + 2 * tid);
+        if (owner) xk = *reinterpret_cast<const float2 *>(k + 2 * tid);
+    } else if (owner && tid >= 64 && tid < 64 + D) {
+        vv = v[tid - 64];
+    }
+    const float *kbase = kc + h * D + l8 * 4;
+    float4 kreg[DS_POS / 64][4];
+#pragma unroll
+    for (int u = 0; u < DS_POS / 64; ++u) {
+        const int p = p0 + u * 64 + r64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < J && p < pos) kreg[u][j] = *reinterpret_cast<const float4 *>(kbase + (int64_t)p * E + j * 32);
+    }
+    if (tid < D / 2) {
+        qs[2 * tid] = __fmaf_rn(xq.x, cs.x, -__fmul_rn(xq.y, cs.y));
+        qs[2 * tid + 1] = __fmaf_rn(xq.x, cs.y, __fmul_rn(xq.y, cs.x));
+        if (owner) {
+            const float k0 = __fmaf_rn(xk.x, cs.x, -__fmul_rn(xk.y, cs.y)), k1 = __fmaf_rn(xk.x, cs.y, __fmul_rn(xk.y, cs.x));
+            ks[2 * tid] = k0;
+            ks[2 * tid + 1] = k1;
+            *reinterpret_cast<float2 *>(kc + (int64_t)pos * E + h * D + 2 * tid) = make_float2(k0, k1);
+        }
+    } else if (owner && tid >= 64 && tid < 64 + D) {
+        vc[(int64_t)(h * D + tid - 64) * n_ctx + pos] = vv;
+    }
+    __syncthreads();
+    float4 q4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < J) q4[j] = *reinterpret_cast<const float4 *>(qs + l8 * 4 + j * 32);
+#pragma unroll
+    for (int u = 0; u < DS_POS / 64; ++u) {
+        const int p = p0 + u * 64 + r64;
+        if (p >= P) continue;
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j >= J) break;
+            const float4 k4 = p == pos ? *reinterpret_cast<const float4 *>(ks + l8 * 4 + j * 32) : kreg[u][j];
+            a = __fmaf_rn(q4[j].x, k4.x, a);
+            a = __fmaf_rn(q4[j].y, k4.y, a);
+            a = __fmaf_rn(q4[j].z, k4.z, a);
+            a = __fmaf_rn(q4[j].w, k4.w, a);
+        }
+        a = group8_sum_f32(a);
+        if (l8 == 0) scores[(int64_t)h * n_ctx + p] = __fmul_rn(a, scale);
+    }
+}
+
+__global__ __launch_bounds__(DP_T) void decode_pv_kernel(const float *__restrict__ scores, int E, int D, int n_past,
+                                                         int n_ctx, const float *__restrict__ vc,
+                                                         const uint16_t *__restrict__ exp_tab, int8_t *__restrict__ oq,
+                                                         float *__restrict__ od, float *__restrict__ os,
+                                                         const int *__restrict__ dyn_past) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    if (dyn_past) n_past = *dyn_past;
+    const int h = blockIdx.x, tid = threadIdx.x, pos = n_past, P = n_past + 1;
+    double *red = reinterpret_cast<double *>(dsm);         // [4]
+    float *redf = reinterpret_cast<float *>(red + 4);      // [4]
+    float *out = redf + 4;                                 // [32]
+    float *sc = out + 32;                                  // [roundup(n_ctx, 512) + 512] scores / probabilities
+    const int l8 = tid & 7, d = blockIdx.y * 32 + (tid >> 3);
+    const int nbatch = (P + DP_BATCH * 32 - 1) / (DP_BATCH * 32);   // batches of 16 pieces of 32 positions
+    const float *vrow = vc + (int64_t)(h * D + d) * n_ctx;
+    // Loads are unconditional (a piece past the position re-reads the row's first piece, which is cache-hot, and is
+    // zeroed on use): a load under a lane- or even wave-dependent condition makes the compiler wait for ALL loads in
+    // flight before it (s_waitcnt vmcnt(0) per load -- measured 33 us instead of 17 us at 1900 positions, 7B).
+    float4 va[DP_BATCH], vb[DP_BATCH];
+    auto load = [&](float4 *r, int b) {
+#pragma unroll
+        for (int c = 0; c < DP_BATCH; ++c) {
+            const int pp = (b * DP_BATCH + c) * 32 + l8 * 4;
+            r[c] = *reinterpret_cast<const float4 *>(vrow + (pp < P ? pp : l8 * 4));
+        }
+    };
+    load(va, 0);                                           // V does not depend on the scores: in flight under the soft_max
+
+    // ---- soft_max of the head's row: fp16 exp table, f64 sum (ggml_compute_forward_soft_max_f32) ----
+    const float *srow = scores + (int64_t)h * n_ctx;
+    float mx = -INFINITY;
+    for (int p = tid; p < P; p += DP_T) {
+        const float x = srow[p];
+        sc[p] = x;
+        mx = fmaxf(mx, x);
+    }
+    mx = wave_max_f32(mx);
+    if ((tid & 63) == 0) redf[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    double sum = 0.0;
+    for (int p = tid; p < P; p += DP_T) {                  // each thread revisits its own entries
+        const uint16_t hb = __half_as_ushort(__float2half_rn(sc[p] - mx));
+        const float val = __half2float(__ushort_as_half(exp_tab[hb]));
+        sum += (double)val;
+        sc[p] = val;
+    }
+    sum = block_sum_f64(sum, red);
+    const float inv = (float)(1.0 / sum);
+    for (int p = tid; p < P; p += DP_T) sc[p] = __fmul_rn(sc[p], inv);
+    for (int p = P + tid; p < (nbatch + 1) * DP_BATCH * 32; p += DP_T) sc[p] = 0.f;   // probabilities the batches over-read
+    __syncthreads();
+
+    // ---- KQV for feature d: lane l8 owns positions 32c + 4 l8 .. +3, pieces in ascending order ----
+    float a = 0.f;
+    auto consume = [&](const float4 *r, int b) {
+#pragma unroll
+        for (int c = 0; c < DP_BATCH; ++c) {
+            const int pp = (b * DP_BATCH + c) * 32 + l8 * 4;
+            float4 v4 = r[c];
+            v4.x = pp > pos ? 0.f : v4.x;                  // beyond the fresh position: stale cache / clamped loads
+            v4.y = pp + 1 > pos ? 0.f : v4.y;
+            v4.z = pp + 2 > pos ? 0.f : v4.z;
+            v4.w = pp + 3 > pos ? 0.f : v4.w;
+            const float4 p4 = *reinterpret_cast<const float4 *>(sc + pp);
+            a = __fmaf_rn(p4.x, v4.x, a);
+            a = __fmaf_rn(p4.y, v4.y, a);
+            a = __fmaf_rn(p4.z, v4.z, a);
+            a = __fmaf_rn(p4.w, v4.w, a);
+        }
+    };
+    for (int b = 0; b < nbatch; b += 2) {
+        load(vb, b + 1);
+        consume(va, b);
+        load(va, b + 2);
+        consume(vb, b + 1);
+    }
+    a = group8_sum_f32(a);
+    if (l8 == 0) out[tid >> 3] = a;
+    __syncthreads();
+    if (tid < 4) {                                         // one Q8_0 block: 4 adjacent lanes x 8 features
+        float o8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o8[i] = out[tid * 8 + i];
+        quantize_store_group(o8, 0, ((h * D + blockIdx.y * 32) >> 3) + tid, E >> 5, 1, oq, od, os);
+    }
+}
+
+hipError_t decode_attention_split(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab,
+                                  float *kc, float *vc, const uint16_t *exp_tab, float scale, float *scores,
+                                  const fl_qact *out, hipStream_t st, const int *dyn_past) {
+    if (D % 32 != 0 || D > 128 || n_ctx % 4 != 0 || E % 4 != 0) return hipErrorInvalidValue;
+    const int slices = dyn_past ? (n_ctx + DS_POS - 1) / DS_POS : (n_past + DS_POS) / DS_POS;
+    hipLaunchKernelGGL(decode_scores_kernel, dim3(H, slices), dim3(DS_T), 0, st, qkv, E, D, n_past, n_ctx,
+                       reinterpret_cast<const float2 *>(rope_tab), kc, vc, scale, scores, dyn_past);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const size_t lds = 4 * 8 + 4 * 4 + 32 * 4 + (size_t)((n_ctx + 511) / 512 * 512 + 512) * 4;
+    hipLaunchKernelGGL(decode_pv_kernel, dim3(H, D / 32), dim3(DP_T), lds, st, scores, E, D, n_past, n_ctx, vc, exp_tab,
+                       out->q, out->d, out->s, dyn_past);
+    return hipGetLastError();
+}
+
 // local (single-process) all-reduce of the tensor-parallel partial sums: rank-order sum written back to every shard
 struct SumBufs { float *p[FL_COMM_MAX_LOCAL]; };
 __global__ __launch_bounds__(256) void sum_buffers_kernel(SumBufs b, int world, size_t count) {

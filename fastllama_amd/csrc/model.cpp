@@ -16,6 +16,7 @@
 // multi-part checkpoints (include/tensor/utils.hpp:93-112): wq/wk/wv/w1/w3 by rows (whole heads per rank),
 // wo/w2 by columns (K blocks), so each layer needs two all-reduces of the [N, n_embd] partial sums.
 #include <hip/hip_runtime.h>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -76,7 +77,9 @@ struct fl_model {
     // LoRA: originals of the tensors an adapter touched (the reference's use_mmap path keeps them too, llama.cpp:868-874)
     struct LoraBackup { fl_qtensor *t; void *qs, *d, *mm; };
     std::vector<LoraBackup> lora_backups;
-    hipGraphExec_t graph_exec = nullptr;
+    hipGraphExec_t graph_exec = nullptr;         // [0] short contexts: one attention launch per layer
+    hipGraphExec_t graph_exec_long = nullptr;    // [1] n_past >= split_past: attention split over (head, slice) workgroups
+    int split_past = 256;                        // first position that takes the two-launch decode attention
     int *npast_dev = nullptr;
     int32_t *pinned = nullptr;   // [token, n_past] staging in pinned host memory
     // live per-kernel timing of the quantized matmuls (bench.py roofline leg)
@@ -439,7 +442,7 @@ static int allreduce_if_tp(fl_model *m, float *buf, size_t count) {
 
 // The fixed kernel sequence of one eval (what ggml_graph_compute walks node by node in the reference).  `dyn` != null:
 // positions are read from device memory (m->npast_dev) instead of the n_past argument -- the decode hipGraph.
-static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn) {
+static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool split_attn = false) {
     const int E = m->E, El = m->El, Fl = m->Fl, D = m->D, Hl = m->Hl, V = m->V, n_ctx = m->n_ctx;
     const int layout = N <= 8 ? 1 : 16;
     const int P = n_past + N;
@@ -454,8 +457,13 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn) {
         if (fused) {
             // decode: norm folded into the matmul, attention in one launch per layer (rope .. KQV .. Q8_0)
             M_HIP(mm_norm(m, ly.wqkv, inp, ly.attn_norm, nullptr, m->qkv));
-            M_HIP(decode_attention(m->qkv, El, D, Hl, n_past, n_ctx, m->rope_tab, kc, vc, m->exp_tab,
-                                   1.0f / sqrtf((float)E / (float)m->H), &m->qEl, st, dyn));
+            const float kq_scale = 1.0f / sqrtf((float)E / (float)m->H);
+            if (split_attn)
+                M_HIP(decode_attention_split(m->qkv, El, D, Hl, n_past, n_ctx, m->rope_tab, kc, vc, m->exp_tab, kq_scale,
+                                             m->att, &m->qEl, st, dyn));
+            else
+                M_HIP(decode_attention(m->qkv, El, D, Hl, n_past, n_ctx, m->rope_tab, kc, vc, m->exp_tab, kq_scale,
+                                       &m->qEl, st, dyn));
         } else {
             // norm + attention_norm*cur -> Q8_0                                                        llama.cpp:311-319
             M_HIP(rmsnorm_quant(inp, E, ly.attn_norm, N, E, nullptr, 0, &m->qE, layout, st));
@@ -536,28 +544,31 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
     const int E = m->E, V = m->V;
     hipStream_t st = m->stream;
 
-    // Decode (N = 1) is launch-bound (~450 short kernels per token): the whole sequence is captured ONCE into a
-    // hipGraph whose kernels read the position from device memory, and replayed per token.
+    // Decode (N = 1) is launch-bound (~160 short kernels per token): the whole sequence is captured ONCE into a
+    // hipGraph whose kernels read the position from device memory, and replayed per token.  Two captures: past
+    // split_past positions a single workgroup per head no longer keeps up with the K/V stream (decode_attention_split).
     const bool use_graph = N == 1 && m->G == 1 && m->graph_enabled && !m->profile;
+    const bool split_attn = N == 1 && n_past >= m->split_past;
     if (use_graph) {
+        hipGraphExec_t &exec = split_attn ? m->graph_exec_long : m->graph_exec;
         m->pinned[0] = tokens[0];
         m->pinned[1] = n_past;
         M_HIP(hipMemcpyAsync(m->tok_dev, &m->pinned[0], 4, hipMemcpyHostToDevice, st));
         M_HIP(hipMemcpyAsync(m->npast_dev, &m->pinned[1], 4, hipMemcpyHostToDevice, st));
-        if (!m->graph_exec) {
+        if (!exec) {
             hipGraph_t g = nullptr;
             M_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            const int rc = run_eval_kernels(m, 1, 0, m->npast_dev);
+            const int rc = run_eval_kernels(m, 1, 0, m->npast_dev, split_attn);
             const hipError_t e = hipStreamEndCapture(st, &g);
             if (rc != FL_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
             if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
-            M_HIP(hipGraphInstantiate(&m->graph_exec, g, nullptr, nullptr, 0));
+            M_HIP(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
         }
-        M_HIP(hipGraphLaunch(m->graph_exec, st));
+        M_HIP(hipGraphLaunch(exec, st));
     } else {
         M_HIP(hipMemcpyAsync(m->tok_dev, tokens, (size_t)N * 4, hipMemcpyHostToDevice, st));
-        const int rc = run_eval_kernels(m, N, n_past, nullptr);
+        const int rc = run_eval_kernels(m, N, n_past, nullptr, split_attn);
         if (rc != FL_OK) return rc;
     }
     if (logits_host) {
@@ -579,15 +590,20 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
 }
 
 /* bit 0 (default 1): decode evals replay a captured hipGraph, else plain launches; bit 1 (default 0): decode uses the
- * generic per-op kernels instead of the fused single-token ones (debugging / A-B timing) */
+ * generic per-op kernels instead of the fused single-token ones; bit 2: prefill attention as three kernels; bit 3: decode
+ * attention always in one launch per layer; bit 4: always the two-launch split form (default: split from position 256 on).
+ * Debugging / A-B timing; results do not depend on bits 0, 2, 3, 4. */
 int fl_model_set_graph(fl_model *m, int mode) {
     if (!m) return set_error(FL_EINVAL, "null model");
     m->graph_enabled = (mode & 1) != 0;
     const bool fuse = (mode & 2) == 0;
     m->fuse_prefill_attn = (mode & 4) == 0;
-    if (fuse != m->fuse_decode && m->graph_exec) {
-        (void)hipGraphExecDestroy(m->graph_exec);
-        m->graph_exec = nullptr;
+    m->split_past = (mode & 8) ? INT_MAX : (mode & 16) ? 0 : 256;
+    if (fuse != m->fuse_decode) {
+        if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    if (m->graph_exec_long) (void)hipGraphExecDestroy(m->graph_exec_long);
+        if (m->graph_exec_long) (void)hipGraphExecDestroy(m->graph_exec_long);
+        m->graph_exec = m->graph_exec_long = nullptr;
     }
     m->fuse_decode = fuse;
     return FL_OK;
@@ -806,6 +822,7 @@ void fl_model_free(fl_model *m) {
     for (auto &bk : m->lora_backups) { fr(bk.qs); fr(bk.d); fr(bk.mm); }
     for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
     if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    if (m->graph_exec_long) (void)hipGraphExecDestroy(m->graph_exec_long);
     if (m->pinned) (void)hipHostFree(m->pinned);
     fr(m->npast_dev);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -882,6 +899,13 @@ int fl_debug_gemv_quant(const fl_qtensor *W, const float *x, float *y, const flo
 int fl_debug_decode_attention(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab_dev,
                               float *kc, float *vc, const uint16_t *exp_tab_dev, float scale, fl_qact *out, void *stream) {
     M_HIP(decode_attention(qkv, E, D, H, n_past, n_ctx, rope_tab_dev, kc, vc, exp_tab_dev, scale, out, (hipStream_t)stream));
+    return FL_OK;
+}
+int fl_debug_decode_attention_split(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab_dev,
+                                    float *kc, float *vc, const uint16_t *exp_tab_dev, float scale, float *scores,
+                                    fl_qact *out, const int *dyn_past, void *stream) {
+    M_HIP(decode_attention_split(qkv, E, D, H, n_past, n_ctx, rope_tab_dev, kc, vc, exp_tab_dev, scale, scores, out,
+                                 (hipStream_t)stream, dyn_past));
     return FL_OK;
 }
 int fl_debug_silu_mul_quant(const float *h13, int ld, int N, int F, const uint16_t *silu_tab_dev, fl_qact *out, int layout,

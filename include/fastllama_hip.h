@@ -173,7 +173,8 @@ int fl_model_eval(fl_model *m, const int32_t *tokens_host, int N, int n_past, fl
  * accumulated totals so far are returned through the two pointers (either may be NULL). */
 int fl_model_profile(fl_model *m, int enable, double *mm_ms_total, long *mm_launches);
 /* decode (N = 1) evals replay a captured hipGraph by default; 0 switches to plain launches */
-int fl_model_set_graph(fl_model *m, int mode); /* bit0: hipGraph replay for decode (default on); bit1: generic per-op decode kernels; bit2: three-kernel prefill attention */
+int fl_model_set_graph(fl_model *m, int mode); /* bit0: hipGraph replay for decode (default on); bit1: generic per-op decode kernels; bit2: three-kernel prefill attention;
+                                                * bit3: decode attention never split; bit4: always split (default: two launches from position 256 on) */
 /* LoRA on the resident Q4 weights -- replaces Model::attach_lora / detach_lora (lib/llama.cpp:697-944) and its
  * ggml_compute_forward_add_q_f32 (lib/ggml.c:6414-6520): W <- quantize_row_q(dequantize_row_q(W) + sign * BA), with the
  * reference's SIMD quantizer arithmetic.  base_name is the base tensor ("layers.3.attention.wq.weight"); pass either
@@ -212,6 +213,11 @@ int fl_debug_prefill_attention(const float *qkv_dev, int ldq, int D, int H, int 
                                /* KQ*scale + mask + soft_max + KQV (+ quantize_row_q8_0), one launch (prefill) */
 int fl_debug_decode_attention(const float *qkv_dev, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab_dev,
                               float *kc, float *vc, const uint16_t *exp_tab_dev, float scale, fl_qact *out, void *stream);
+int fl_debug_decode_attention_split(const float *qkv_dev, int E, int D, int H, int n_past, int n_ctx,
+                                    const float *rope_tab_dev, float *kc, float *vc, const uint16_t *exp_tab_dev, float scale,
+                                    float *scores_dev /* [H][n_ctx] workspace */, fl_qact *out,
+                                    const int *dyn_past_dev /* NULL, or the position in device memory (grid sized for n_ctx) */,
+                                    void *stream);  /* the long-context form of the above: two launches, same bits */
 int fl_debug_silu_mul_quant(const float *h13_dev, int ld, int N, int F, const uint16_t *silu_tab_dev, fl_qact *out,
                             int layout, void *stream);
 int fl_debug_rope_kv(float *qkv_dev, int ld, int N, int E, int D, int n_past, int n_ctx, const float *rope_tab_dev,

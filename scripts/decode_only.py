@@ -1,4 +1,4 @@
-"""Decode-only run for profiling: python scripts/decode_only.py [steps] [graph 0/1]"""
+"""Decode-only run for profiling: python scripts/decode_only.py [steps] [graph 0/1] [gemv waves, 0 = auto] [n_past] [model]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -7,21 +7,28 @@ from harness import synth
 from harness.flmodel import FlModel
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 graph = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-cfg = dict(synth.MODELS["7B"])
-m = FlModel(cfg, 2, synth.synth_model_tensors(cfg, 2), n_ctx=1024, max_batch=512)
+waves = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+pasts = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [128]
+name = sys.argv[5] if len(sys.argv) > 5 else "7B"
+cfg = dict(synth.MODELS[name])
+n_ctx = max(1024, (max(pasts) + steps + 8 + 511) // 512 * 512)
+m = FlModel(cfg, 2, synth.synth_model_tensors(cfg, 2), n_ctx=n_ctx, max_batch=512)
 hip.load().fl_model_set_graph(m.h, graph)
-if len(sys.argv) > 3:
-    hip.load().fl_debug_set(1, int(sys.argv[3]))      # force GEMV waves per row group
+if waves:
+    hip.load().fl_debug_set(1, waves)                 # force GEMV waves per row group
 toks = np.random.default_rng(0).integers(3, 259, 512).astype(np.int32)
-m.eval_nocopy(toks, 0)
+m.eval_nocopy(toks, 0)                                # positions beyond 512 hold zeros: fine for timing
 t1 = toks[:1].copy()
-for i in range(3):
-    m.eval_nocopy(t1, 128 + i)
-t0 = time.perf_counter()
-for i in range(steps):
-    m.eval_nocopy(t1, 131 + i)
-dt = (time.perf_counter() - t0) / steps
-print(f"decode {dt*1e3:.3f} ms/token  {1/dt:.1f} tok/s (graph={graph})")
+for past in pasts:
+    for i in range(3):
+        m.eval_nocopy(t1, past + i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        m.eval_nocopy(t1, past + 3 + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print(f"{name} n_ctx={n_ctx} n_past={past}: decode {dt*1e3:.3f} ms/token  {1/dt:.1f} tok/s (graph={graph})")
 
 L = hip.load()
 if hasattr(L, "fl_debug_da_timing"):

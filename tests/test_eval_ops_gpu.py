@@ -224,6 +224,52 @@ def test_decode_attention_fused(env, D, H, n_past):
     assert np.array_equal(s_field, (d * qs.reshape(-1, 32).sum(1).astype(np.float32)).astype(np.float32))
 
 
+@pytest.mark.parametrize("dyn", [False, True])
+@pytest.mark.parametrize("D,H,n_past,n_ctx", [(32, 4, 0, 512), (64, 5, 37, 512), (128, 32, 255, 1024), (128, 32, 256, 1024),
+                                              (128, 8, 700, 1024), (128, 4, 2046, 2048), (128, 3, 1023, 1024), (96, 2, 515, 1024)])
+def test_decode_attention_split_equals_fused(env, D, H, n_past, n_ctx, dyn):
+    """long-context decode attention (scores over (head, 128-position slice) workgroups, then soft_max + KQV + Q8_0 over
+    (head, 32 features)) == the one-launch kernel, bit for bit: caches, and the Q8_0 operand of the wo matmul; with the
+    position as an argument and read from device memory (the hipGraph form, grid sized for n_ctx)."""
+    torch, hip, ops, L, port = env
+    E = H * D
+    rng = np.random.default_rng(D + H + n_past)
+    qkv = rng.standard_normal((1, 3 * E)).astype(np.float32)
+    kc = np.zeros((n_ctx, E), np.float32)
+    vc = np.zeros((E, n_ctx), np.float32)
+    kc[:n_past] = rng.standard_normal((n_past, E))
+    vc[:, :n_past] = rng.standard_normal((E, n_past))
+    vc[:, n_past:] = 7.0                                     # stale values beyond the position must not leak in
+    e = np.empty(1 << 16, np.uint16)
+    L.fl_debug_tables(e.ctypes.data_as(C.c_void_p), None)
+    rt = np.empty((n_ctx, D // 2, 2), np.float32)
+    L.fl_debug_rope_table(rt.ctypes.data_as(C.c_void_p), n_ctx, D)
+    ed, rd, qd = dev(torch, e.view(np.int16)), dev(torch, rt), dev(torch, qkv)
+    scale = float(np.float32(1.0) / np.sqrt(np.float32(D)))
+    res = []
+    for split in (False, True):
+        kd, vd = dev(torch, kc), dev(torch, vc)
+        a = ops.QAct(1, E)
+        hip.check(L.fl_quantize_q8_layout(a.handle, qd.data_ptr(), 3 * E, 1, E, 1, None))
+        a.N, a.K = 1, E
+        if split:
+            sc = torch.full((H, n_ctx), float("nan"), device="cuda")
+            pd = torch.tensor([n_past], dtype=torch.int32, device="cuda")
+            hip.check(L.fl_debug_decode_attention_split(qd.data_ptr(), E, D, H, 0 if dyn else n_past, n_ctx, rd.data_ptr(),
+                                                        kd.data_ptr(), vd.data_ptr(), ed.data_ptr(), scale, sc.data_ptr(),
+                                                        a.handle, pd.data_ptr() if dyn else None, None))
+        else:
+            hip.check(L.fl_debug_decode_attention(qd.data_ptr(), E, D, H, n_past, n_ctx, rd.data_ptr(), kd.data_ptr(),
+                                                  vd.data_ptr(), ed.data_ptr(), scale, a.handle, None))
+        torch.cuda.synchronize()
+        res.append((kd.cpu().numpy(), vd.cpu().numpy(), a.export().cpu().numpy().copy()))
+    (k0, v0, q0), (k1, v1, q1) = res
+    assert np.array_equal(k0.view(np.uint32), k1.view(np.uint32))
+    assert np.array_equal(v0.view(np.uint32), v1.view(np.uint32))
+    assert np.array_equal(q0, q1)
+    assert np.any(q0.reshape(-1, 40)[:, 8:] != 0)
+
+
 @pytest.mark.parametrize("qtype", [2, 3])
 @pytest.mark.parametrize("M,F", [(48, 64), (256, 704), (4096, 11008), (5120, 13824)])
 def test_gemv_silu_fused_equals_unfused(env, qtype, M, F):

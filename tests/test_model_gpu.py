@@ -285,3 +285,30 @@ def test_long_context_path_switches_agree(tmp_path_factory, port, qtype):
     # deeper layers: same values up to the rounding-flip noise of the algorithm
     d = np.abs(ka[:, :1400] - kb[:, :1400]).max() / np.abs(ka[:, :1400]).max()
     assert d <= 5e-2, d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [0, 1])
+def test_decode_attention_split_switch_is_invisible(tmp_path_factory, port, graph):
+    """Decode switches to the two-launch attention at position 256 (second hipGraph capture).  Tokens decoded across the
+    switch give bit-identical logits with the split forced on from the start, forced off, and in the default mode --
+    as hipGraph replays and as plain launches."""
+    from fastllama_amd import hip
+    from harness.flmodel import FlModel
+    L = hip.load()
+    cfg = ggjt.SMALL
+    tensors, _ = build(tmp_path_factory, port, cfg, 2, "split")
+    toks = np.random.default_rng(11).integers(3, 259, 270).astype(np.int32)
+
+    def run(mode):
+        m = FlModel(cfg, 2, tensors, n_ctx=512, max_batch=256)
+        hip.check(L.fl_model_set_graph(m.h, graph | mode))
+        m.eval(toks[:250], n_past=0)
+        out = [m.eval(toks[p:p + 1], n_past=p)[0].copy() for p in range(250, 270)]
+        m.free()
+        return np.stack(out)
+
+    default, never, always = run(0), run(8), run(16)
+    assert np.array_equal(default.view(np.uint32), never.view(np.uint32))
+    assert np.array_equal(default.view(np.uint32), always.view(np.uint32))
+    assert np.isfinite(default).all() and np.ptp(default) > 0
