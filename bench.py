@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--qtype", default="q4_0", choices=["q4_0", "q4_1"])
     ap.add_argument("--n-batch", type=int, default=512)
     ap.add_argument("--decode-steps", type=int, default=64)
+    ap.add_argument("--n-ctx", type=int, default=0, help="context size (default max(1024, 2*n_batch)); the long-context "
+                    "decode leg runs at its end")
     ap.add_argument("--parallel", default="dp", choices=["dp", "tp"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -131,7 +133,7 @@ def main():
     qtype = synth.Q4_0 if args.qtype == "q4_0" else synth.Q4_1
     cfg = dict(synth.MODELS[args.model])
     N = args.n_batch
-    n_ctx = max(1024, 2 * N)
+    n_ctx = max(args.n_ctx, 1024, 2 * N)
     L = hip.load()
     hip.require_device(local)
     tp = args.parallel == "tp" and world > 1
@@ -191,6 +193,14 @@ def main():
     ddt = timed(dec, args.decode_steps)
     decode_ms = ddt / args.decode_steps * 1e3
 
+    # ---------------- the same at the end of the context (K/V stream of n_past positions per layer; two-launch attention) ----
+    long_steps = min(32, args.decode_steps)
+    long_past = n_ctx - long_steps - 4
+    decl = lambda i: model.eval_nocopy(tok1, long_past + i)
+    for i in range(3):
+        decl(i)
+    decode_long_ms = timed(decl, long_steps) / long_steps * 1e3
+
     # ---------------- roofline of the dominant kernels: HIP events around every matmul launch -----
     def pmc_traffic(kernel):
         """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3 --pmc
@@ -249,6 +259,8 @@ def main():
         },
         "prefill_tokens_per_s": value,
         "decode_tokens_per_s": seqs / (decode_ms * 1e-3), "decode_ms_per_token": decode_ms,
+        "decode_long_context": {"n_past": long_past, "tokens_per_s": seqs / (decode_long_ms * 1e-3),
+                                "ms_per_token": decode_long_ms},
         "roofline": roofline, "roofline_decode": roofline_decode,
         "model_device_bytes": hip.load().fl_model_device_bytes(model.h),
     }
