@@ -1032,23 +1032,45 @@ __global__ __launch_bounds__(DP_T) void decode_pv_kernel(const float *__restrict
     load(va, 0);                                           // V does not depend on the scores: in flight under the soft_max
 
     // ---- soft_max of the head's row: fp16 exp table, f64 sum (ggml_compute_forward_soft_max_f32) ----
+    // (8 entries per thread and pass, their loads / table gathers issued together: with one entry per loop iteration
+    //  every 256 positions cost a dependent memory round trip)
     const float *srow = scores + (int64_t)h * n_ctx;
+    constexpr int SM_U = 8;
     float mx = -INFINITY;
-    for (int p = tid; p < P; p += DP_T) {
-        const float x = srow[p];
-        sc[p] = x;
-        mx = fmaxf(mx, x);
+    for (int p0 = tid; p0 < P; p0 += DP_T * SM_U) {
+        float x[SM_U];
+#pragma unroll
+        for (int i = 0; i < SM_U; ++i) x[i] = srow[p0 + i * DP_T < P ? p0 + i * DP_T : 0];
+#pragma unroll
+        for (int i = 0; i < SM_U; ++i) {
+            const int p = p0 + i * DP_T;
+            if (p < P) {
+                sc[p] = x[i];
+                mx = fmaxf(mx, x[i]);
+            }
+        }
     }
     mx = wave_max_f32(mx);
     if ((tid & 63) == 0) redf[tid >> 6] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
     double sum = 0.0;
-    for (int p = tid; p < P; p += DP_T) {                  // each thread revisits its own entries
-        const uint16_t hb = __half_as_ushort(__float2half_rn(sc[p] - mx));
-        const float val = __half2float(__ushort_as_half(exp_tab[hb]));
-        sum += (double)val;
-        sc[p] = val;
+    for (int p0 = tid; p0 < P; p0 += DP_T * SM_U) {        // each thread revisits its own entries
+        float val[SM_U];
+#pragma unroll
+        for (int i = 0; i < SM_U; ++i) {                   // past the row: exp_tab[half(-inf)] = 0, never stored
+            const int p = p0 + i * DP_T;
+            const float x = p < P ? sc[p] : -INFINITY;
+            val[i] = __half2float(__ushort_as_half(exp_tab[__half_as_ushort(__float2half_rn(x - mx))]));
+        }
+#pragma unroll
+        for (int i = 0; i < SM_U; ++i) {
+            const int p = p0 + i * DP_T;
+            if (p < P) {
+                sum += (double)val[i];
+                sc[p] = val[i];
+            }
+        }
     }
     sum = block_sum_f64(sum, red);
     const float inv = (float)(1.0 / sum);
