@@ -86,6 +86,29 @@ def test_ingest_then_greedy_generate_streams_same_tokens(libs, model_file):
     assert common >= 6, (a, b)
 
 
+@pytest.mark.parametrize("with_system", [False, True])
+def test_context_recycling_follows_the_reference(libs, model_file, with_system):
+    """Generating past n_ctx makes FastLlama::recycle_embed_if_exceeds_context (lib/bridge.cpp:161-180) restart at
+    n_past = n_keep with the system prompt and half of the recent tokens re-staged.  The greedy streams of the reference
+    and of this library must still agree well beyond the recycle point (a wrong restart position or a wrong re-staged
+    window changes every token after it)."""
+    path, cfg = model_file
+    res = []
+    for lib in libs:
+        s = llama_capi.Session(lib, path, n_ctx=48, n_batch=8, n_keep=8, last_n_tokens=24)
+        if with_system:
+            assert s.ingest("Sys", system=True)
+        assert s.ingest(" abcdefghijklmnopqrstuvwxyz")
+        ok, text = s.generate(40, temp=0.0)             # 1 + 28 (+ 5) prompt tokens: the context overflows after ~12-18 tokens
+        assert ok
+        res.append(text)
+        s.close()
+    a, b = res
+    assert len(a) >= 36 and len(b) >= 36, (a, b)
+    common = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b)))
+    assert common >= 30, (common, a, b)
+
+
 def test_sampling_is_seeded_and_reset_restores_it(libs, model_file):
     path, cfg = model_file
     ours = libs[1]
