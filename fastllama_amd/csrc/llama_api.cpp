@@ -312,6 +312,13 @@ struct Session {
             log.err("read_hyperparams", "failed to read hyper parameters\n");
             return false;
         }
+        // sizes derived from these fields are allocated before any tensor is seen: refuse what no LLaMA file holds
+        // (a vocabulary entry takes at least 4 bytes of the file)
+        if (h.n_embd > (1 << 16) || h.n_head > h.n_embd || h.n_layer > 1024 || h.n_mult > (1 << 16) ||
+            (size_t)h.n_vocab > (r.n - r.off) / 4) {
+            log.err("read_hyperparams", "implausible hyper parameters (corrupt file?)\n");
+            return false;
+        }
         if (want_vocab) {
             vocab.tok.resize((size_t)h.n_vocab);
             vocab.score.assign((size_t)h.n_vocab, 0.f);
@@ -336,6 +343,7 @@ struct Session {
             if (t.n_dims < 1 || t.n_dims > 2) { log.err("read_tensor_metadata", "tensor has a bad number of dimensions\n"); return false; }
             for (uint32_t d = 0; d < t.n_dims; ++d) t.ne[d] = r.get<uint32_t>();
             t.name = r.str(name_len);
+            if (!r.ok || t.ne[0] == 0 || t.ne[1] == 0) { log.err("read_tensor_metadata", "tensor '" + t.name + "' has an empty or truncated shape\n"); return false; }
             if (mf.version >= 2) r.off += (size_t)(-(int64_t)r.off & 31);
             const size_t nel = (size_t)t.ne[0] * t.ne[1];
             if (t.type == 0) t.bytes = nel * 4;

@@ -543,6 +543,8 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
     if (n_past < 0 || n_past + N > m->n_ctx) return set_error(FL_EINVAL, "n_past+N=%d exceeds n_ctx=%d", n_past + N, m->n_ctx);
     const int E = m->E, V = m->V;
     hipStream_t st = m->stream;
+    for (int i = 0; i < N; ++i)     // ggml_get_rows would read outside tok_embeddings (lib/ggml.c:8353); refuse instead
+        if (tokens[i] < 0 || tokens[i] >= V) return set_error(FL_EINVAL, "token %d at position %d is outside the vocabulary (%d)", tokens[i], i, V);
 
     // Decode (N = 1) is launch-bound (~160 short kernels per token): the whole sequence is captured ONCE into a
     // hipGraph whose kernels read the position from device memory, and replayed per token.  Two captures: past

@@ -92,3 +92,43 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(import|from)\s+oracle\b|liboracle|orc_|oracle/_ref", src, flags=re.M):
                     bad.append(fn)
     assert not bad, bad
+
+
+def test_malformed_model_files_do_not_crash_the_loader(tmp_path):
+    """The file reader runs before any device work: truncated / corrupted GGJT files must come back as `false` with a
+    logged reason, never as a read outside the mapping or a giant allocation (no GPU needed; on the GPU box the same
+    cases run in tests/test_llama_api_gpu.py next to an intact load)."""
+    import oracle
+    from harness import ggjt, llama_capi
+    cfg = ggjt.TINY
+    tensors = ggjt.synth_tensors(cfg, ggjt.Q4_0, oracle.Port().quantize_q4, seed=77)
+    path = str(tmp_path / "t.bin")
+    ggjt.write_ggjt(path, cfg, ggjt.Q4_0, tensors)
+    blob = open(path, "rb").read()
+    cases = {"cut%d" % n: blob[:n] for n in (0, 3, 8, 20, 36, 40, 1000, len(blob) // 2, len(blob) - 1)}
+    off = 8 + 7 * 4
+    for _ in range(cfg["n_vocab"]):
+        off += 4 + int.from_bytes(blob[off:off + 4], "little") + 4
+    for name, (a, b, v) in {"zero_dim": (12, 16, 0), "name_len": (4, 8, 0x7FFFFFFF), "n_dims": (0, 4, 9), "type": (8, 12, 77)}.items():
+        rec = bytearray(blob)
+        rec[off + a:off + b] = v.to_bytes(4, "little")
+        cases[name] = bytes(rec)
+    for name, at in {"n_vocab": 8, "n_embd": 12, "n_layer": 24}.items():
+        rec = bytearray(blob)
+        rec[at:at + 4] = (0x7FFFFFFF).to_bytes(4, "little")
+        cases[name] = bytes(rec)
+    L = llama_capi.LlamaLib(LIB).lib
+    for name, data in cases.items():
+        f = tmp_path / (name + ".bin")
+        f.write_bytes(data)
+        msgs = []
+        cbs = [llama_capi.LOG_FN(lambda f_, fl, m, ml: msgs.append(m[:ml])) for _ in range(3)]
+        cbs += [llama_capi.RESET_FN(lambda: None), llama_capi.PROGRESS_FN(lambda t, d, tot: None)]
+        args = L.llama_create_default_context_args()
+        args.n_ctx, args.n_batch = 32, 8
+        args.logger = llama_capi.Logger(*cbs)
+        ctx = L.llama_create_context(args)
+        assert ctx
+        assert not L.llama_load_model(ctx, os.fsencode(str(f))), name
+        assert msgs, name
+        L.llama_free_context(ctx)

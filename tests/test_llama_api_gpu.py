@@ -174,6 +174,53 @@ def test_error_paths(libs, tmp_path):
     L.llama_free_context(ctx)
 
 
+def test_malformed_model_files_are_refused(libs, model_file, tmp_path):
+    """Truncations at every structural boundary and corrupted directory fields: llama_load_model returns false (and says
+    why through the logger) instead of reading outside the mapping; the intact file still loads afterwards."""
+    path, cfg = model_file
+    ours = libs[1]
+    blob = open(path, "rb").read()
+    cases = {"cut%d" % n: blob[:n] for n in (0, 3, 8, 20, 36, 40, 1000, len(blob) // 2, len(blob) - 1)}
+    hdr = 8 + 7 * 4
+    off = hdr
+    for _ in range(cfg["n_vocab"]):                      # walk the vocabulary to the first tensor record
+        ln = int.from_bytes(blob[off:off + 4], "little")
+        off += 4 + ln + 4
+    rec = bytearray(blob)
+    rec[off + 12:off + 16] = (0).to_bytes(4, "little")   # ne[0] = 0
+    cases["zero_dim"] = bytes(rec)
+    rec = bytearray(blob)
+    rec[off + 4:off + 8] = (0x7FFFFFFF).to_bytes(4, "little")   # name_len far beyond the file
+    cases["name_len"] = bytes(rec)
+    rec = bytearray(blob)
+    rec[off:off + 4] = (9).to_bytes(4, "little")         # n_dims = 9
+    cases["n_dims"] = bytes(rec)
+    rec = bytearray(blob)
+    rec[off + 8:off + 12] = (77).to_bytes(4, "little")   # unknown ggml type
+    cases["type"] = bytes(rec)
+    rec = bytearray(blob)
+    rec[8:12] = (0x7FFFFFFF).to_bytes(4, "little")       # n_vocab
+    cases["n_vocab"] = bytes(rec)
+    L = ours.lib
+    for name, data in cases.items():
+        f = tmp_path / (name + ".bin")
+        f.write_bytes(data)
+        s_args = L.llama_create_default_context_args()
+        s_args.n_ctx, s_args.n_batch = 32, 8
+        msgs = []
+        cbs = [llama_capi.LOG_FN(lambda f_, fl, m, ml: msgs.append(m[:ml])) for _ in range(3)]
+        cbs += [llama_capi.RESET_FN(lambda: None), llama_capi.PROGRESS_FN(lambda t, d, tot: None)]
+        s_args.logger = llama_capi.Logger(*cbs)
+        ctx = L.llama_create_context(s_args)
+        assert ctx
+        assert not L.llama_load_model(ctx, os.fsencode(str(f))), name
+        assert msgs, name                                # ... and the logger was told why
+        L.llama_free_context(ctx)
+    s = llama_capi.Session(ours, path, n_ctx=32, n_batch=8)
+    assert s.ingest("ok")
+    s.close()
+
+
 @pytest.mark.parametrize("n_parts", [2, 4])
 def test_multi_part_checkpoint_merges_to_the_same_model(tmp_path_factory, n_parts):
     """<path>, <path>.1, ... (tok_embeddings / wo / w2 split by columns, the other matrices by rows) load to exactly the

@@ -134,6 +134,12 @@ def test_eval_argument_errors(port):
         m.eval(list(range(3, 20)), n_past=0)           # N > max_batch
     with pytest.raises(hip.FastLlamaHipError):
         m.eval([5] * 8, n_past=30)                     # beyond n_ctx
+    for bad in (-1, cfg["n_vocab"]):
+        with pytest.raises(hip.FastLlamaHipError):
+            m.eval([5, bad, 7], n_past=0)              # token outside the vocabulary
+        with pytest.raises(hip.FastLlamaHipError):
+            m.eval([bad], n_past=3)                    # ... on the single-token (hipGraph) path too
+    assert np.isfinite(m.eval([5, 6, 7], n_past=0)).all()       # the model is still usable afterwards
     t2 = dict(tensors)
     del t2["layers.1.attention.wo.weight"]
     with pytest.raises(hip.FastLlamaHipError):
