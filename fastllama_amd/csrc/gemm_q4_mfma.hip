@@ -53,7 +53,10 @@ __device__ const uint4 fl_zero_chunk[1] = {{0u, 0u, 0u, 0u}};  // source of out-
 // bytes and the same prefetch distance in blocks): half as many barriers and fill bookkeeping per MFMA.
 template <int TYPE, int WM, int WN, int TM, int TN, int KS>
 struct GemmCfg {
-    static constexpr int NSTAGE = KS == 2 ? 3 : 2;            // LDS ring depth
+#ifndef FL_KS4_STAGES
+#define FL_KS4_STAGES 2
+#endif
+    static constexpr int NSTAGE = KS == 2 ? 3 : FL_KS4_STAGES;   // LDS ring depth
     static constexpr int NW = WM * WN;                        // waves per workgroup
     static constexpr int MG = WM * TM;                        // W row groups (16 rows) per workgroup tile
     static constexpr int NG = WN * TN;                        // activation column groups per workgroup tile

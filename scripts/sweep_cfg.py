@@ -16,7 +16,7 @@ for (M, K) in shapes:
     a = ops.QAct(N, K).quantize(x)
     y = torch.empty(N, (M + 3) // 4 * 4, device="cuda")[:, :M]
     res = []
-    for cfg in [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13]:
+    for cfg in ([int(v) for v in os.environ['FL_SWEEP_CFGS'].split(',')] if 'FL_SWEEP_CFGS' in os.environ else [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13]):
         L.fl_debug_set(0, cfg)
         for _ in range(3):
             ops.mul_mat_q(W, a, out=y)
