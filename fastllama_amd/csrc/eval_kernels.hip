@@ -710,11 +710,61 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float *__restrict__ S
     for (int i = lane; i < P; i += 64) p[i] = i < L ? __fmul_rn(p[i], inv) : 0.f;
 }
 
+// The same row held in registers (P <= 64 * IT): every load of the row and every table gather is issued before the first
+// is waited for.  The loop form above pays a dependent memory round trip per 64 columns, three times over -- at 2048
+// keys that is most of the three-kernel attention path.  Same arithmetic; the f64 sum of fp16 terms is exact in any order.
+template <int IT>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(float *__restrict__ S, int ld, int64_t sz, int N, int P,
+                                                               int n_past, const uint16_t *__restrict__ exp_tab,
+                                                               int rows_total) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows_total) return;
+    const int lane = threadIdx.x & 63;
+    const int z = row / N, n = row % N;
+    float *p = S + z * sz + (int64_t)n * ld;
+    const int L = min(P, n_past + n + 1);
+    float x[IT];
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+        const int i = lane + 64 * u;
+        const float v = p[min(i, L - 1)];                  // always inside the valid part of the row
+        x[u] = i < L ? v : -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < IT; ++u) mx = fmaxf(mx, x[u]);
+    mx = wave_max_f32(mx);
+    double sum = 0.0;
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {                         // (-inf - mx rounds to fp16 -inf: a valid table index, entry 0)
+        const float t = __half2float(__ushort_as_half(exp_tab[__half_as_ushort(__float2half_rn(x[u] - mx))]));
+        x[u] = x[u] != -INFINITY ? t : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < IT; ++u) sum += (double)x[u];
+    sum = wave_sum_f64(sum);
+    const float inv = (float)(1.0 / sum);
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+        const int i = lane + 64 * u;
+        if (i < P) p[i] = i < L ? __fmul_rn(x[u], inv) : 0.f;
+    }
+}
+
 hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab,
                         hipStream_t st, const int *dyn_past) {
     const int rows = N * batch;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, S, ld, sz, N, P, n_past, exp_tab, rows,
-                       dyn_past);
+    const dim3 grid((rows + 3) / 4), block(256);
+    if (!dyn_past && P <= 64 * 32) {
+#define FL_SM(IT) hipLaunchKernelGGL(softmax_rows_reg_kernel<IT>, grid, block, 0, st, S, ld, sz, N, P, n_past, exp_tab, rows)
+        if (P <= 64 * 4) FL_SM(4);
+        else if (P <= 64 * 8) FL_SM(8);
+        else if (P <= 64 * 16) FL_SM(16);
+        else FL_SM(32);
+#undef FL_SM
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(softmax_rows_kernel, grid, block, 0, st, S, ld, sz, N, P, n_past, exp_tab, rows, dyn_past);
     return hipGetLastError();
 }
 
