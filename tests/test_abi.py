@@ -132,3 +132,54 @@ def test_malformed_model_files_do_not_crash_the_loader(tmp_path):
         assert not L.llama_load_model(ctx, os.fsencode(str(f))), name
         assert msgs, name
         L.llama_free_context(ctx)
+
+
+def test_unmodified_reference_python_binding_drives_this_library(tmp_path):
+    """The reference's own interfaces/python/fastllama.py (imported from /root/reference, unmodified) is pointed at
+    libfastllama_hip.so through its `library_path=` parameter: default args, context creation, the logger struct and
+    llama_load_model all go through the real ctypes declarations.  Without a GPU the load must fail the way the
+    reference reports failures (RuntimeError from the constructor) with this library's reason in the reference's
+    Logger; on a GPU box the constructor succeeds."""
+    ref_py = "/root/reference/interfaces/python"
+    if not os.path.isfile(os.path.join(ref_py, "fastllama.py")):
+        pytest.skip("reference tree not present")
+    import importlib.util
+    import signal
+    import torch
+    import oracle
+    from harness import ggjt
+    spec = importlib.util.spec_from_file_location("ref_fastllama", os.path.join(ref_py, "fastllama.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    cfg = ggjt.TINY
+    path = str(tmp_path / "t.bin")
+    ggjt.write_ggjt(path, cfg, ggjt.Q4_0, ggjt.synth_tensors(cfg, ggjt.Q4_0, oracle.Port().quantize_q4, seed=5))
+
+    class Capture(ref.Logger):
+        def __init__(self):
+            self.lines = []
+
+        def log_info(self, func_name, message):
+            self.lines.append(("I", func_name, message))
+
+        def log_err(self, func_name, message):
+            self.lines.append(("E", func_name, message))
+
+        def log_warn(self, func_name, message):
+            self.lines.append(("W", func_name, message))
+
+        def progress(self, tag, done_size, total_size):
+            pass
+
+    log = Capture()
+    old = signal.getsignal(signal.SIGINT)
+    try:
+        if torch.cuda.is_available():
+            m = ref.Model(path, num_threads=1, n_ctx=64, n_batch=8, logger=log, library_path=LIB)
+            assert m.ingest("hello")
+        else:
+            with pytest.raises(RuntimeError, match="Unable to load model"):
+                ref.Model(path, num_threads=1, n_ctx=64, n_batch=8, logger=log, library_path=LIB)
+            assert any(k == "E" and "no CPU fallback" in msg for k, _, msg in log.lines), log.lines
+    finally:
+        signal.signal(signal.SIGINT, old)
