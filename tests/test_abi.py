@@ -183,3 +183,22 @@ def test_unmodified_reference_python_binding_drives_this_library(tmp_path):
             assert any(k == "E" and "no CPU fallback" in msg for k, _, msg in log.lines), log.lines
     finally:
         signal.signal(signal.SIGINT, old)
+
+
+@pytest.mark.parametrize("example", ["perplexity.c", "example.c", "example-alpaca.c"])
+def test_reference_c_examples_compile_and_link_against_this_library(tmp_path, example):
+    """The reference's C programs (examples/c/*.c, compiled from where they lie, unmodified) build against
+    include/fastllama.h and link against libfastllama_hip.so: the header is source-compatible and every symbol they
+    use is exported.  Run without a GPU, the program ends at the reference's own `if (!llama_load_model(...)) return 1`."""
+    src = os.path.join("/root/reference/examples/c", example)
+    if not os.path.isfile(src):
+        pytest.skip("reference tree not present")
+    exe = str(tmp_path / "prog")
+    cc = subprocess.run(["gcc", "-std=gnu11", "-I", os.path.join(ROOT, "include"), src, "-o", exe, "-L", os.path.dirname(LIB),
+                         "-l:libfastllama_hip.so", "-Wl,-rpath," + os.path.dirname(LIB), "-Wl,-rpath,/opt/rocm/lib"],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    import torch
+    if not torch.cuda.is_available():
+        run = subprocess.run([exe], cwd=str(tmp_path), capture_output=True, text=True, timeout=60)
+        assert run.returncode == 1, (run.returncode, run.stdout, run.stderr)     # model file absent / no device: load fails
