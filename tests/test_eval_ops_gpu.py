@@ -226,7 +226,8 @@ def test_decode_attention_fused(env, D, H, n_past):
 
 @pytest.mark.parametrize("dyn", [False, True])
 @pytest.mark.parametrize("D,H,n_past,n_ctx", [(32, 4, 0, 512), (64, 5, 37, 512), (128, 32, 255, 1024), (128, 32, 256, 1024),
-                                              (128, 8, 700, 1024), (128, 4, 2046, 2048), (128, 3, 1023, 1024), (96, 2, 515, 1024)])
+                                              (128, 8, 700, 1024), (128, 4, 2046, 2048), (128, 3, 1023, 1024), (96, 2, 515, 1024),
+                                              (64, 3, 97, 100), (128, 2, 290, 292), (32, 2, 99, 100)])
 def test_decode_attention_split_equals_fused(env, D, H, n_past, n_ctx, dyn):
     """long-context decode attention (scores over (head, 128-position slice) workgroups, then soft_max + KQV + Q8_0 over
     (head, 32 features)) == the one-launch kernel, bit for bit: caches, and the Q8_0 operand of the wo matmul; with the
