@@ -30,6 +30,7 @@
 #include <sstream>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -659,20 +660,38 @@ struct Session {
         log.info("perplexity", "calculating perplexity over " + std::to_string(blocks) + " chunk(s)\n");
         double nll = 0.0, res = 0.0;
         size_t count = 0, idx = 1;
-        std::vector<float> probs;
         for (size_t i = 0; i < toks.size(); i += bs, ++idx) {
             const size_t block = std::min(bs, toks.size() - i);
             const std::vector<token_t> in(toks.begin() + (std::ptrdiff_t)i, toks.begin() + (std::ptrdiff_t)(i + block));
             if (!eval(0, in)) { all_logits = old; return -1.f; }
-            for (size_t j = block >> 1; j + 1 < block; ++j) {
-                const float *l = logits.data() + j * V;
-                const float mx = *std::max_element(l, l + V);
-                probs.resize(V);
-                float sum = 0.f;
-                for (size_t k = 0; k < V; ++k) { probs[k] = std::exp(l[k] - mx); sum += probs[k]; }
-                const float p = probs[(size_t)toks[i + j + 1]] / sum;
-                nll += (double)(-std::log(p));
-                ++count;
+            // softmax(logits[j])[next token] over the second half of the block (lib/bridge.cpp:397-407).  With the eval on
+            // the GPU this host loop (n_batch/2 x n_vocab expf) is what a perplexity run waits for: the rows are spread
+            // over n_threads host threads; every row keeps the serial arithmetic and the rows are summed in order, so the
+            // result does not depend on the thread count.
+            const size_t j0 = block >> 1, j1 = block > 0 ? block - 1 : 0;
+            if (j1 > j0) {
+                std::vector<double> row_nll(j1 - j0);
+                auto rows = [&](size_t a, size_t b) {
+                    for (size_t j = a; j < b; ++j) {
+                        const float *l = logits.data() + j * V;
+                        const float mx = *std::max_element(l, l + V);
+                        float sum = 0.f;
+                        for (size_t k = 0; k < V; ++k) sum += std::exp(l[k] - mx);
+                        const float p = std::exp(l[(size_t)toks[i + j + 1]] - mx) / sum;
+                        row_nll[j - j0] = (double)(-std::log(p));
+                    }
+                };
+                const size_t nt = std::min<size_t>(std::max(1, std::min(args.n_threads, 64)), j1 - j0);
+                std::vector<std::thread> pool;
+                const size_t per = (j1 - j0 + nt - 1) / nt;
+                for (size_t t = 1; t < nt; ++t) {
+                    const size_t a = j0 + t * per, b = std::min(j1, a + per);
+                    if (a < b) pool.emplace_back(rows, a, b);
+                }
+                rows(j0, std::min(j1, j0 + per));
+                for (auto &th : pool) th.join();
+                for (double v : row_nll) nll += v;
+                count += j1 - j0;
             }
             res = std::exp(nll / (double)count);
             char line[96];
