@@ -202,3 +202,16 @@ def test_reference_c_examples_compile_and_link_against_this_library(tmp_path, ex
     if not torch.cuda.is_available():
         run = subprocess.run([exe], cwd=str(tmp_path), capture_output=True, text=True, timeout=60)
         assert run.returncode == 1, (run.returncode, run.stdout, run.stderr)     # model file absent / no device: load fails
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """bench.py measures the HIP path only: with no device it exits with a message instead of timing anything else."""
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0
+    assert "no CPU path" in (r.stderr + r.stdout)
+    assert not r.stdout.strip().startswith("{")
