@@ -37,6 +37,7 @@
 #include <stdint.h>
 #include "q4_device.h"
 #include "q4_kernels.h"
+#include "gemm_epi.h"
 
 namespace fl {
 
@@ -86,23 +87,6 @@ struct GemmCfg {
 #else
 #define FL_NOPK   /* the host pass only needs the launch stub */
 #endif
-
-// Optional epilogue for the fused w1|w3 matrix (rows interleaved by 16-row groups: even groups w1, odd groups w3, see
-// model.cpp): instead of storing y, the workgroup computes silu(w1 x) * (w3 x) for its features, and writes it
-// re-quantized to Q8_0 in the QA16 layout the w2 matmul reads -- ggml_silu + ggml_mul (lib/llama.cpp:428-431) and the
-// INIT phase of the next mul_mat (quantize_row_q8_0) without the [N][2 n_ff] f32 round trip through HBM.
-struct GemmSiluEpi {
-    const uint16_t *silu_tab;   // fp16 SiLU table (null: plain store)
-    int8_t *oq;
-    float *od, *os;
-    int KBo;                    // n_ff / 32
-    // second optional epilogue, for the fused wq|wk|wv matrix: rope on Q (stored to y) and on K (stored to the K cache
-    // row of the token's position), V stored transposed into the V cache -- ggml_rope + the two ggml_cpy into memory_k /
-    // memory_v (lib/llama.cpp:328-347) without a pass over the [N][3 n_embd] result.  Arithmetic of rope_kv_kernel.
-    const float2 *rope_tab;     // [n_ctx][D/2] {cos, sin} (null: off)
-    float *kc, *vc;             // [n_ctx][El], [El][n_ctx]
-    int El, D, n_past, n_ctx;
-};
 
 template <int TYPE, int WM, int WN, int TM, int TN, int MINW, int KS>
 __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ? 3 : MINW) FL_NOPK void gemm_q4_mfma_kernel(
@@ -509,7 +493,12 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
     X(12, 2, 2, 2, 2, 4, 4) /*  64x64    4 waves of 32x32, 4-block K-steps   */ \
     X(13, 2, 4, 2, 2, 2, 4) /*  64x128   8 waves of 32x32, 4-block K-steps   */
 
-int g_gemm_force_cfg = -1;  // debug / autotune hook: >= 0 forces one configuration
+int g_gemm_force_cfg = -1;  // debug / autotune hook: >= 0 forces one configuration (>= 100: the 32x32x32 kernel)
+
+// gemm_q4_mfma32.hip
+bool gemm32_supports(const fl_qtensor &W, int cfg, bool silu);
+hipError_t gemm32_launch(int cfg, const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
+                         const float *resid, int ldr, const GemmSiluEpi &epi);
 
 template <int TYPE, int WM, int WN, int TM, int TN, int MINW, int KS>
 static hipError_t launch_gemm(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
@@ -561,6 +550,10 @@ static hipError_t gemm_dispatch(const fl_qtensor &W, const fl_qact &xq, int N, f
     if ((ldy & 3) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return hipErrorInvalidValue;
     const int MGT = W.M16 / 16, NGT = fl_roundup(N, 16) / 16;
     int cfg = pick_config(MGT, NGT, W.type);
+    if (cfg >= 100) {
+        if (gemm32_supports(W, cfg, epi.silu_tab != nullptr)) return gemm32_launch(cfg, W, xq, N, y, ldy, st, resid, ldr, epi);
+        cfg = 12;
+    }
     if (epi.silu_tab && (cfg == 3 || cfg == 8)) cfg = 12;   // the silu epilogue pairs two row groups per wave: TM must be even
 #define X(ID, WM, WN, TM, TN, MINW, KS)                                                                     \
     if (cfg == ID)                                                                                          \

@@ -603,7 +603,6 @@ int fl_model_set_graph(fl_model *m, int mode) {
     m->split_past = (mode & 8) ? INT_MAX : (mode & 16) ? 0 : 256;
     if (fuse != m->fuse_decode) {
         if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
-    if (m->graph_exec_long) (void)hipGraphExecDestroy(m->graph_exec_long);
         if (m->graph_exec_long) (void)hipGraphExecDestroy(m->graph_exec_long);
         m->graph_exec = m->graph_exec_long = nullptr;
     }
