@@ -526,6 +526,12 @@ static hipError_t launch_gemm(const fl_qtensor &W, const fl_qact &xq, int N, flo
 // waves shape when there is little (all 1024 SIMDs busy, latency hidden by occupancy).
 static int pick_config(int MGT, int NGT, int type) {
     if (g_gemm_force_cfg >= 0) return g_gemm_force_cfg;
+    if (g_gemm_force_cfg != -2) {
+        // gemm_q4_mfma32.hip (round 2): 128x64 tiles of four 32x64 waves when that gives every CU at least two workgroups,
+        // else 128x32 tiles of four 32x32 waves (profiles/r02_gemm32_cfg_sweep.txt).  -2 selects the 16x16 kernel below.
+        const int64_t tiles106 = (int64_t)((MGT + 7) / 8) * ((NGT + 3) / 4);
+        return NGT > 2 && tiles106 >= 512 ? 106 : 101;
+    }
     const double tiles16 = (double)MGT * NGT;        // 16x16 output tiles
     const double per_simd = tiles16 / 1024;          // MI355X: 256 CUs x 4 SIMDs
     auto quant = [&](int MG, int NG) {

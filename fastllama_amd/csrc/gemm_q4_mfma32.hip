@@ -71,8 +71,8 @@ struct G32 {
     static constexpr int VM_AT_BOUNDARY = LPW + 3 * L_EVEN + 3 * L_ODD;
 };
 
-template <int TYPE, int WM, int RN, int MINW>
-__global__ __launch_bounds__(64 * WM, MINW) FL_NOPK32 void gemm_q4_mfma32_kernel(
+template <int TYPE, int WM, int RN, int MINW, bool PDB>
+__global__ __launch_bounds__(64 * WM, TYPE == FL_TYPE_Q4_1 ? 2 : MINW) FL_NOPK32 void gemm_q4_mfma32_kernel(
     const uint32_t *qs, const float *dW, const float *mW,   // (no __restrict__: the ring loads must stay where they are issued)
     const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs, int N, int M,
     int MGT /* row groups total */, int NGT /* col groups total */, int KB, float *__restrict__ y, int ldy,
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64 * WM, MINW) FL_NOPK32 void gemm_q4_mfma32_kernel
     __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Q41 ? mW : dW), 0, (int)(wbytes >> 2), 0x00020000);
     const uint32_t rgrp = (uint32_t)(mg0 + 2 * wave + g1);
     const uint32_t voffA = (rgrp * (uint32_t)KB * 16u + (uint32_t)c15) * 16u + (uint32_t)((h ^ (c15 >> 3)) << 3);
-    const uint32_t voffD = (rgrp * (uint32_t)KB * 16u + (uint32_t)c15) * 4u + (RN == 1 ? (uint32_t)h * 64u : 0u);
+    const uint32_t voffD = (rgrp * (uint32_t)KB * 16u + (uint32_t)c15) * 4u;
 
     v2u araw[C::RING];
     float saw[C::RING], maw[C::RING];
@@ -169,10 +169,15 @@ __global__ __launch_bounds__(64 * WM, MINW) FL_NOPK32 void gemm_q4_mfma32_kernel
         constexpr int slot = decltype(SLOT)::value;
         const int kba = kb < KB ? kb : KB - 1;
         araw[slot] = __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(rA, voffA, kba * 256, 0));
-        if (RN == 2 || (slot & 1) == 0) {
-            const int kbd = RN == 2 ? kba : (kb + 1 < KB ? kb : KB - 2);      // RN = 1: lanes h = 1 read block kb + 1
-            saw[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, voffD, kbd * 64, 0));
-            if (Q41) maw[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, voffD, kbd * 64, 0));
+        if (RN == 2) {
+            saw[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, voffD, kba * 64, 0));
+            if (Q41) maw[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, voffD, kba * 64, 0));
+        } else if ((slot & 1) == 0) {
+            // scales of the block PAIR (kb, kb+1): lanes h = 1 read block kb + 1 (KB may be odd under tensor parallelism)
+            const int kb1 = kb + 1 < KB ? kb + 1 : KB - 1;
+            const uint32_t vo = voffD + (uint32_t)(h ? kb1 : kba) * 64u;
+            saw[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, vo, 0, 0));
+            if (Q41) maw[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, vo, 0, 0));
         }
     };
 
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(64 * WM, MINW) FL_NOPK32 void gemm_q4_mfma32_kernel
         unpack(IC(nb), IC(ns));
         load_w(SS, kb + C::RING);
         __builtin_amdgcn_sched_barrier(0);
-        if (RN == 2) {
+        if (RN == 2 && PDB) {
             scale_acc(acc[0], D[0], P[cb], IC(0));
             __builtin_amdgcn_sched_barrier(0);
             P[nb] = __builtin_amdgcn_mfma_f32_32x32x1f32(saw[ns], sbw[nb], zero32, 0, 0, 0);
@@ -296,6 +301,17 @@ __global__ __launch_bounds__(64 * WM, MINW) FL_NOPK32 void gemm_q4_mfma32_kernel
             D[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[nb], bfr[nb][0], magic, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             scale_acc(acc[RN - 1], D[1], P[cb], IC(1));
+        } else if (RN == 2) {
+            // one P buffer (32 VGPRs less: a third wave per SIMD): the scale product of block b+1 is issued after the last
+            // use of block b's, and has the operand reads of the next block to complete under
+            scale_acc(acc[0], D[0], P[0], IC(0));
+            __builtin_amdgcn_sched_barrier(0);
+            D[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[nb], bfr[nb][0], magic, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            scale_acc(acc[RN - 1], D[1], P[0], IC(1));
+            __builtin_amdgcn_sched_barrier(0);
+            P[0] = __builtin_amdgcn_mfma_f32_32x32x1f32(saw[ns], sbw[nb], zero32, 0, 0, 0);
+            if (Q41) ms2 = __builtin_amdgcn_mfma_f32_32x32x1f32(maw[ns], mbw[nb], ms2, 0, 0, 0);
         } else {
             if ((ns & 1) == 0) {                           // b+1 opens a block pair
                 constexpr int pb = (ns >> 1) & 1;
@@ -438,23 +454,25 @@ __global__ __launch_bounds__(64 * WM, MINW) FL_NOPK32 void gemm_q4_mfma32_kernel
 // ------------------------------------------------------------------------------------------------
 // configurations (ids 100...) and launch
 // ------------------------------------------------------------------------------------------------
-//                        id  WM RN minwaves/SIMD     tile      waves
-#define FL_GEMM32_CONFIGS(X)                                                  \
-    X(100, 4, 2, 2)  /* 128 x 64   4 waves of 32x64                        */ \
-    X(101, 4, 1, 2)  /* 128 x 32   4 waves of 32x32                        */ \
-    X(102, 2, 2, 2)  /*  64 x 64   2 waves of 32x64                        */ \
-    X(103, 8, 2, 2)  /* 256 x 64   8 waves of 32x64                        */ \
-    X(104, 8, 1, 2)  /* 256 x 32   8 waves of 32x32                        */ \
-    X(105, 2, 1, 2)  /*  64 x 32   2 waves of 32x32                        */
+//                        id  WM RN minwaves/SIMD  P double-buffered     tile      waves
+#define FL_GEMM32_CONFIGS(X)                                                           \
+    X(100, 4, 2, 2, true)   /* 128 x 64   4 waves of 32x64                          */ \
+    X(101, 4, 1, 3, true)   /* 128 x 32   4 waves of 32x32                          */ \
+    X(102, 2, 2, 2, true)   /*  64 x 64   2 waves of 32x64                          */ \
+    X(103, 8, 2, 2, true)   /* 256 x 64   8 waves of 32x64                          */ \
+    X(104, 8, 1, 3, true)   /* 256 x 32   8 waves of 32x32                          */ \
+    X(105, 2, 1, 3, true)   /*  64 x 32   2 waves of 32x32                          */ \
+    X(106, 4, 2, 3, false)  /* 128 x 64   4 waves of 32x64, three waves per SIMD    */ \
+    X(108, 8, 2, 3, false)  /* 256 x 64   8 waves of 32x64, three waves per SIMD    */
 
-template <int TYPE, int WM, int RN, int MINW>
+template <int TYPE, int WM, int RN, int MINW, bool PDB>
 static hipError_t launch_gemm32(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                                 const float *resid, int ldr, const GemmSiluEpi &epi) {
     using C = G32<TYPE, WM, RN>;
     const int MGT = W.M16 / 16, NGT = fl_roundup(N, 16) / 16;
     const int tiles = ((MGT + 2 * WM - 1) / (2 * WM)) * ((NGT + C::NG - 1) / C::NG);
     static_assert(C::LDS_BYTES <= 65536, "no dynamic-LDS attribute needed");
-    hipLaunchKernelGGL((gemm_q4_mfma32_kernel<TYPE, WM, RN, MINW>), dim3(tiles), dim3(64 * WM), C::LDS_BYTES, st, W.qs, W.d,
+    hipLaunchKernelGGL((gemm_q4_mfma32_kernel<TYPE, WM, RN, MINW, PDB>), dim3(tiles), dim3(64 * WM), C::LDS_BYTES, st, W.qs, W.d,
                        W.m, xq.q, xq.d, xq.s, N, W.M, MGT, NGT, W.KB, y, ldy, resid, ldr, epi);
     return hipGetLastError();
 }
@@ -462,15 +480,15 @@ static hipError_t launch_gemm32(const fl_qtensor &W, const fl_qact &xq, int N, f
 bool gemm32_supports(const fl_qtensor &W, int cfg, bool silu) {
     if ((uint64_t)(W.M16 / 16 + 16) * (uint64_t)W.KB * 256u >= (1ull << 31)) return false;   // 32-bit buffer offsets
     (void)cfg; (void)silu;
-    return W.KB >= 2;
+    return W.KB >= 1;
 }
 
 hipError_t gemm32_launch(int cfg, const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                          const float *resid, int ldr, const GemmSiluEpi &epi) {
-#define X(ID, WM, RN, MINW)                                                                                          \
-    if (cfg == ID)                                                                                                   \
-        return W.type == FL_TYPE_Q4_0 ? launch_gemm32<FL_TYPE_Q4_0, WM, RN, MINW>(W, xq, N, y, ldy, st, resid, ldr, epi) \
-                                      : launch_gemm32<FL_TYPE_Q4_1, WM, RN, MINW>(W, xq, N, y, ldy, st, resid, ldr, epi);
+#define X(ID, WM, RN, MINW, PDB)                                                                                          \
+    if (cfg == ID)                                                                                                        \
+        return W.type == FL_TYPE_Q4_0 ? launch_gemm32<FL_TYPE_Q4_0, WM, RN, MINW, PDB>(W, xq, N, y, ldy, st, resid, ldr, epi) \
+                                      : launch_gemm32<FL_TYPE_Q4_1, WM, RN, MINW, PDB>(W, xq, N, y, ldy, st, resid, ldr, epi);
     FL_GEMM32_CONFIGS(X)
 #undef X
     return hipErrorInvalidValue;

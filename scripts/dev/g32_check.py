@@ -7,11 +7,11 @@ from fastllama_amd import hip, ops
 from harness import synth
 L = hip.load(); hip.require_device(0)
 mode = sys.argv[1] if len(sys.argv) > 1 else "all"
-CFGS = [100, 101, 102, 103, 104, 105]
+CFGS = [100, 101, 102, 103, 104, 105, 106, 108]
 bad = 0
 if mode in ("check", "all"):
     shapes = [(32, 128, 32), (48, 192, 17), (200, 1408, 9), (130, 256, 70), (4096, 4096, 512), (1000, 4096, 100), (4096, 11008, 64),
-              (264, 320, 33)]
+              (264, 320, 33), (256, 352, 33), (40, 96, 20), (33, 32, 16), (4096, 5504, 48)]
     for qt in (2, 3):
         for (M, K, N) in shapes:
             W = ops.QTensor(qt, synth.synth_q4(M, K, qt, 1), M, K)
