@@ -10,6 +10,7 @@
 
 #include "../../include/fastllama_hip.h"
 #include "q4_kernels.h"
+#include "eval_kernels.h"
 #include "runtime.h"
 
 namespace fl {
@@ -284,6 +285,16 @@ int fl_dequantize_row_q4_1(const void *x, float *y, int k, void *st) {
     FL_HIP(dequantize_aos(FL_TYPE_Q4_1, x, y, k, S(st)));
     return FL_OK;
 }
+static int quant_q4(int type, bool reference, const float *x, void *y, int k, void *st) {
+    int rc = check_row(x, y, k);
+    if (rc != FL_OK) return rc;
+    FL_HIP(quantize_row_q4_aos(type, reference, x, y, k, S(st)));
+    return FL_OK;
+}
+int fl_quantize_row_q4_0(const float *x, void *y, int k, void *st) { return quant_q4(FL_TYPE_Q4_0, false, x, y, k, st); }
+int fl_quantize_row_q4_1(const float *x, void *y, int k, void *st) { return quant_q4(FL_TYPE_Q4_1, false, x, y, k, st); }
+int fl_quantize_row_q4_0_reference(const float *x, void *y, int k, void *st) { return quant_q4(FL_TYPE_Q4_0, true, x, y, k, st); }
+int fl_quantize_row_q4_1_reference(const float *x, void *y, int k, void *st) { return quant_q4(FL_TYPE_Q4_1, true, x, y, k, st); }
 static int vec_dot(int type, int n, float *s, const void *x, const void *y, void *st) {
     int rc = check_row(x, y, n);
     if (rc != FL_OK) return rc;
@@ -310,6 +321,10 @@ static void tbl_check(int rc, const char *fn) {
 }
 static void tbl_deq_q4_0(const void *x, float *y, int k) { tbl_check(fl_dequantize_row_q4_0(x, y, k, nullptr), __func__); }
 static void tbl_deq_q4_1(const void *x, float *y, int k) { tbl_check(fl_dequantize_row_q4_1(x, y, k, nullptr), __func__); }
+static void tbl_q4_0(const float *x, void *y, int k) { tbl_check(fl_quantize_row_q4_0(x, y, k, nullptr), __func__); }
+static void tbl_q4_1(const float *x, void *y, int k) { tbl_check(fl_quantize_row_q4_1(x, y, k, nullptr), __func__); }
+static void tbl_q4_0_ref(const float *x, void *y, int k) { tbl_check(fl_quantize_row_q4_0_reference(x, y, k, nullptr), __func__); }
+static void tbl_q4_1_ref(const float *x, void *y, int k) { tbl_check(fl_quantize_row_q4_1_reference(x, y, k, nullptr), __func__); }
 static void tbl_q8_0(const float *x, void *y, int k) { tbl_check(fl_quantize_row_q8_0(x, y, k, nullptr), __func__); }
 static void tbl_dot_q4_0(const int n, float *s, const void *x, const void *y) {
     tbl_check(fl_vec_dot_q4_0_q8_0(n, s, x, y, nullptr), __func__);
@@ -323,10 +338,14 @@ fl_quantize_fns_t fl_get_quantize_fn(size_t type) {
     memset(&t, 0, sizeof t);
     if (type == FL_TYPE_Q4_0) {
         t.dequantize_row_q = tbl_deq_q4_0;
+        t.quantize_row_q = tbl_q4_0;
+        t.quantize_row_q_reference = tbl_q4_0_ref;
         t.quantize_row_q_dot = tbl_q8_0;
         t.vec_dot_q = tbl_dot_q4_0;
     } else if (type == FL_TYPE_Q4_1) {
         t.dequantize_row_q = tbl_deq_q4_1;
+        t.quantize_row_q = tbl_q4_1;
+        t.quantize_row_q_reference = tbl_q4_1_ref;
         t.quantize_row_q_dot = tbl_q8_0;
         t.vec_dot_q = tbl_dot_q4_1;
     }
@@ -438,6 +457,35 @@ int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy
         if (which == 1) FL_HIP(gemm_q4_mfma(*W, *a, a->N, y, ldy, S(st)));
         else FL_HIP(gemm_q4_naive(*W, *a, a->N, y, ldy, S(st)));
     }
+    return FL_OK;
+}
+
+/* test hooks: the fused forms of the prefill GEMM (model.cpp run_eval_kernels) on caller-provided buffers */
+int fl_debug_mul_mat_q_resid(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy, const float *resid, int ldr, void *st) {
+    const fl_qact_impl *a = static_cast<const fl_qact_impl *>(a_);
+    int rc = check_mm(W, a, y, ldy);
+    if (rc != FL_OK) return rc;
+    if (a->layout != 16) return set_error(FL_EINVAL, "gemm needs the QA16 layout");
+    FL_HIP(gemm_q4_mfma(*W, *a, a->N, y, ldy, S(st), resid, ldr));
+    return FL_OK;
+}
+int fl_debug_gemm_qkv(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy, const float *rope_tab_dev, float *kc, float *vc,
+                      int El, int D, int n_past, int n_ctx, void *st) {
+    const fl_qact_impl *a = static_cast<const fl_qact_impl *>(a_);
+    int rc = check_mm(W, a, y, ldy);
+    if (rc != FL_OK) return rc;
+    if (a->layout != 16) return set_error(FL_EINVAL, "gemm needs the QA16 layout");
+    FL_HIP(gemm_q4_mfma_qkv(*W, *a, a->N, y, ldy, rope_tab_dev, kc, vc, El, D, n_past, n_ctx, S(st)));
+    return FL_OK;
+}
+int fl_debug_gemm_silu(const fl_qtensor *W, const fl_qact *a_, const uint16_t *silu_tab_dev, fl_qact *out_, void *st) {
+    const fl_qact_impl *a = static_cast<const fl_qact_impl *>(a_);
+    fl_qact_impl *out = static_cast<fl_qact_impl *>(out_);
+    if (!W || !a || !out || !silu_tab_dev) return set_error(FL_EINVAL, "null argument");
+    if (a->layout != 16 || a->KB != W->KB) return set_error(FL_EINVAL, "gemm_silu: bad activation workspace");
+    if ((size_t)a->N16 * (size_t)(W->M / 2) > out->q_bytes) return set_error(FL_EINVAL, "gemm_silu: output workspace too small");
+    out->N = a->N; out->N16 = a->N16; out->KB = W->M / 64; out->layout = 16;
+    FL_HIP(gemm_q4_mfma_silu(*W, *a, a->N, silu_tab_dev, *out, S(st)));
     return FL_OK;
 }
 

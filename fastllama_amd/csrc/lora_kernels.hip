@@ -132,4 +132,64 @@ hipError_t lora_add_aos(int type, void *aos, int KB, int row0, int rows, int il_
     return hipGetLastError();
 }
 
+// quantize_row_q4_0 / quantize_row_q4_1 and their *_reference twins (the `quantize_row_q` / `quantize_row_q_reference` slots
+// of quantize_fns_t, /root/reference/lib/ggml.c:1731-1745), one thread per 32-element block, on the reference's AoS blocks.
+//   reference flavour (:630-664, :917-956):  id = d ? 1/d : 0, roundf (halves away from zero)
+//   SIMD flavour as built for AVX2 (:757-803, :965-1037): Q4_0 id = 7/amax; both round halves to even
+template <int TYPE, bool SIMD>
+__global__ __launch_bounds__(256) void quantize_row_q4_kernel(const float *__restrict__ x, unsigned char *__restrict__ y, int nb) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nb) return;
+    constexpr int BS = TYPE == FL_TYPE_Q4_0 ? 20 : 24;
+    const float *xb = x + (int64_t)b * 32;
+    unsigned char *blk = y + (int64_t)b * BS;
+    unsigned char *qs = blk + (TYPE == FL_TYPE_Q4_0 ? 4 : 8);
+    float w[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) w[i] = xb[i];
+    if (TYPE == FL_TYPE_Q4_0) {
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) amax = fmaxf(amax, fabsf(w[i]));
+        const float d = __fdiv_rn(amax, 7.0f);
+        const float id = SIMD ? (amax != 0.0f ? __fdiv_rn(7.0f, amax) : 0.0f) : (d != 0.0f ? __fdiv_rn(1.0f, d) : 0.0f);
+        *reinterpret_cast<float *>(blk) = d;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float v0 = ((w[2 * j]) * (id)), v1 = ((w[2 * j + 1]) * (id));
+            const int q0 = (int)(SIMD ? rintf(v0) : roundf(v0)) + 8, q1 = (int)(SIMD ? rintf(v1) : roundf(v1)) + 8;
+            qs[j] = (unsigned char)((q0 & 0xF) | ((q1 & 0xF) << 4));
+        }
+    } else {
+        float mn = w[0], mx = w[0];
+#pragma unroll
+        for (int i = 1; i < 32; ++i) {
+            mn = fminf(mn, w[i]);
+            mx = fmaxf(mx, w[i]);
+        }
+        const float d = __fdiv_rn(((mx) - (mn)), 15.0f);
+        const float id = d != 0.0f ? __fdiv_rn(1.0f, d) : 0.0f;
+        *reinterpret_cast<float *>(blk) = d;
+        *reinterpret_cast<float *>(blk + 4) = mn;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float v0 = ((((w[2 * j]) - (mn))) * (id)), v1 = ((((w[2 * j + 1]) - (mn))) * (id));
+            const int q0 = (int)(SIMD ? rintf(v0) : roundf(v0)), q1 = (int)(SIMD ? rintf(v1) : roundf(v1));
+            qs[j] = (unsigned char)((q0 & 0xF) | ((q1 & 0xF) << 4));
+        }
+    }
+}
+
+hipError_t quantize_row_q4_aos(int type, bool reference, const float *x, void *y, int64_t k, hipStream_t st) {
+    if (k <= 0 || k % 32 != 0) return hipErrorInvalidValue;
+    const int nb = (int)(k / 32);
+    const dim3 grid((unsigned)((nb + 255) / 256));
+    unsigned char *p = static_cast<unsigned char *>(y);
+    if (type == FL_TYPE_Q4_0 && reference) hipLaunchKernelGGL((quantize_row_q4_kernel<FL_TYPE_Q4_0, false>), grid, dim3(256), 0, st, x, p, nb);
+    else if (type == FL_TYPE_Q4_0) hipLaunchKernelGGL((quantize_row_q4_kernel<FL_TYPE_Q4_0, true>), grid, dim3(256), 0, st, x, p, nb);
+    else if (reference) hipLaunchKernelGGL((quantize_row_q4_kernel<FL_TYPE_Q4_1, false>), grid, dim3(256), 0, st, x, p, nb);
+    else hipLaunchKernelGGL((quantize_row_q4_kernel<FL_TYPE_Q4_1, true>), grid, dim3(256), 0, st, x, p, nb);
+    return hipGetLastError();
+}
+
 }  // namespace fl

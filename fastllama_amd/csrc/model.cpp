@@ -914,6 +914,11 @@ int fl_debug_silu_mul_quant(const float *h13, int ld, int N, int F, const uint16
     M_HIP(silu_mul_quant(h13, ld, N, F, silu_tab_dev, out, layout, (hipStream_t)stream, false));
     return FL_OK;
 }
+int fl_debug_silu_mul_quant_woven(const float *h13, int ld, int N, int F, const uint16_t *silu_tab_dev, fl_qact *out, int layout,
+                                  void *stream) {   /* h13 = [w1 x 16 | w3 x 16 | ...]: the woven w1|w3 matmul's output */
+    M_HIP(silu_mul_quant(h13, ld, N, F, silu_tab_dev, out, layout, (hipStream_t)stream, true));
+    return FL_OK;
+}
 int fl_debug_rope_kv(float *qkv, int ld, int N, int E, int D, int n_past, int n_ctx, const float *rope_tab_dev, float *kc,
                      float *vc, void *stream) {
     M_HIP(rope_kv(qkv, ld, N, E, D, n_past, n_ctx, rope_tab_dev, kc, vc, (hipStream_t)stream));

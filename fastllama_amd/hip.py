@@ -120,6 +120,7 @@ _PROTOS = {
                                                   C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                                   C.c_void_p]),
     "fl_debug_silu_mul_quant": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "fl_debug_silu_mul_quant_woven": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "fl_debug_rope_kv": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
     "fl_debug_gemm_f32_abt": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_int,
@@ -127,6 +128,14 @@ _PROTOS = {
     "fl_debug_softmax_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                         C.c_void_p]),
     "fl_debug_mul_mat_q": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "fl_debug_mul_mat_q_resid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "fl_debug_gemm_qkv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_void_p]),
+    "fl_debug_gemm_silu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fl_quantize_row_q4_0": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "fl_quantize_row_q4_1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "fl_quantize_row_q4_0_reference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "fl_quantize_row_q4_1_reference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "fl_debug_qact_layout": (C.c_int, [C.c_void_p]),
     "fl_debug_set": (C.c_int, [C.c_int, C.c_int]),
     "fl_quantize_q8_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

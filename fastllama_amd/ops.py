@@ -127,6 +127,16 @@ def quantize_row_q8_0(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def quantize_row_q(qtype: int, x: torch.Tensor, reference: bool = False) -> torch.Tensor:
+    """quantize_row_q(x, y, k) / quantize_row_q_reference: f32 [k] -> block_q4_0 / block_q4_1 bytes on the device."""
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    k = x.numel()
+    y = torch.empty(k // QK * BLOCK_BYTES[qtype], dtype=torch.uint8, device=x.device)
+    name = "fl_quantize_row_q4_%d%s" % (0 if qtype == Q4_0 else 1, "_reference" if reference else "")
+    check(getattr(hip.load(), name)(_dev(x), _dev(y), k, _stream()), name)
+    return y
+
+
 def dequantize_row_q(qtype: int, blocks: torch.Tensor, k: int) -> torch.Tensor:
     """dequantize_row_q(x, y, k): AoS Q4 block bytes -> f32 [k]."""
     y = torch.empty(k, dtype=torch.float32, device=blocks.device)

@@ -42,32 +42,15 @@ def algorithmic_work(cfg, N, qtype=Q4_0):
     return dict(weight_bytes=wbytes, act_bytes=abytes, bytes=wbytes + abytes, flops=flops, n_matmuls=len(mats))
 
 
-def _roundf(x):
-    """C roundf: half away from zero."""
-    return torch.sign(x) * torch.floor(torch.abs(x) + 0.5)
-
-
 @torch.no_grad()
 def quantize_q4_torch(w: torch.Tensor, qtype: int) -> torch.Tensor:
-    """f32 [M, K] (device) -> uint8 [M, K/32*block_bytes] AoS blocks (device)."""
+    """f32 [M, K] (device) -> uint8 [M, K/32*block_bytes] AoS blocks (device), through the library's
+    quantize_row_q_reference -- the arithmetic of the reference's ggml_quantize_q4_0/1 (lib/ggml.c:12122-12166),
+    bit for bit (tests/test_kernels_gpu.py::test_quantize_row_q4_slots_match_reference): a synthetic model written
+    from these blocks is the file the CPU reference would have quantized itself."""
+    from fastllama_amd import ops
     M, K = w.shape
-    b = w.view(M, K // 32, 32)
-    if qtype == Q4_0:
-        amax = b.abs().amax(-1, keepdim=True)
-        d = amax / 7.0
-        inv = torch.where(d != 0, 1.0 / d, torch.zeros_like(d))
-        q = (_roundf(b * inv).to(torch.int32) + 8).clamp_(0, 15).to(torch.uint8)
-        head = d.contiguous().view(torch.uint8).view(M, K // 32, 4)
-    else:
-        mn = b.amin(-1, keepdim=True)
-        mx = b.amax(-1, keepdim=True)
-        d = (mx - mn) / 15.0
-        inv = torch.where(d != 0, 1.0 / d, torch.zeros_like(d))
-        q = _roundf((b - mn) * inv).to(torch.int32).clamp_(0, 15).to(torch.uint8)
-        head = torch.cat([d.contiguous().view(torch.uint8).view(M, K // 32, 4),
-                          mn.contiguous().view(torch.uint8).view(M, K // 32, 4)], dim=-1)
-    packed = q[..., 0::2] | (q[..., 1::2] << 4)
-    return torch.cat([head, packed], dim=-1).reshape(M, -1).contiguous()
+    return ops.quantize_row_q(qtype, w.contiguous().view(-1), reference=True).view(M, -1)
 
 
 @torch.no_grad()

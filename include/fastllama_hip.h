@@ -85,8 +85,14 @@ void fl_qtensor_free(fl_qtensor *W);
  *   quantize_row_q_dot(x, y, k) replaces quantize_row_q8_0             lib/ggml.c:1299
  *   vec_dot_q(n, s, x, y)       replaces ggml_vec_dot_q4_0_q8_0 / _q4_1_q8_0  lib/ggml.c:2368,2561
  *
- * quantize_row_q / quantize_row_q_reference (f32 -> Q4 weights) are offline tooling in the
- * reference (quantize CLI, LoRA requant) and are not on the eval path: they are NULL in the table. */
+ *   quantize_row_q(x, y, k)            replaces quantize_row_q4_0 / _q4_1 (the SIMD flavour the reference's x86 build
+ *                                      runs: id = 7/amax for Q4_0, halves to even)            lib/ggml.c:666,958
+ *   quantize_row_q_reference(x, y, k)  replaces quantize_row_q4_0_reference / _q4_1_reference (id = 1/d, roundf), the
+ *                                      ones ggml_quantize_q4_0/1 build model files with      lib/ggml.c:630,917 */
+int fl_quantize_row_q4_0(const float *x_dev, void *y_dev /* block_q4_0[k/32] */, int k, void *stream);
+int fl_quantize_row_q4_1(const float *x_dev, void *y_dev /* block_q4_1[k/32] */, int k, void *stream);
+int fl_quantize_row_q4_0_reference(const float *x_dev, void *y_dev, int k, void *stream);
+int fl_quantize_row_q4_1_reference(const float *x_dev, void *y_dev, int k, void *stream);
 int fl_quantize_row_q8_0(const float *x_dev, void *y_dev /* block_q8_0[k/32] */, int k, void *stream);
 int fl_dequantize_row_q4_0(const void *x_dev /* block_q4_0[k/32] */, float *y_dev, int k, void *stream);
 int fl_dequantize_row_q4_1(const void *x_dev /* block_q4_1[k/32] */, float *y_dev, int k, void *stream);
@@ -98,8 +104,8 @@ typedef void (*fl_quantize_row_q_t)(const float *x_dev, void *y_dev, int k);
 typedef void (*fl_vec_dot_q_t)(const int n, float *s_dev, const void *x_dev, const void *y_dev);
 typedef struct {
     fl_dequantize_row_q_t dequantize_row_q;
-    fl_quantize_row_q_t quantize_row_q;            /* NULL */
-    fl_quantize_row_q_t quantize_row_q_reference;  /* NULL */
+    fl_quantize_row_q_t quantize_row_q;
+    fl_quantize_row_q_t quantize_row_q_reference;
     fl_quantize_row_q_t quantize_row_q_dot;
     fl_vec_dot_q_t vec_dot_q;
 } fl_quantize_fns_t;
@@ -220,6 +226,8 @@ int fl_debug_decode_attention_split(const float *qkv_dev, int E, int D, int H, i
                                     void *stream);  /* the long-context form of the above: two launches, same bits */
 int fl_debug_silu_mul_quant(const float *h13_dev, int ld, int N, int F, const uint16_t *silu_tab_dev, fl_qact *out,
                             int layout, void *stream);
+int fl_debug_silu_mul_quant_woven(const float *h13_dev, int ld, int N, int F, const uint16_t *silu_tab_dev, fl_qact *out,
+                                  int layout, void *stream);
 int fl_debug_rope_kv(float *qkv_dev, int ld, int N, int E, int D, int n_past, int n_ctx, const float *rope_tab_dev,
                      float *kc_dev, float *vc_dev, void *stream);
 int fl_debug_gemm_f32_abt(const float *A, int lda, long sAz, const float *B, int ldb, long sBz, float *C, int ldc, long sCz,
@@ -228,6 +236,11 @@ int fl_debug_softmax_rows(float *S_dev, int ld, long sz, int N, int P, int n_pas
                           void *stream);
 
 /* test hooks: force one kernel family regardless of N (N must suit the layout of `a`) */
+/* the fused forms of the prefill GEMM: + residual; wq|wk|wv with rope + KV-cache stores; woven w1|w3 with silu*mul -> Q8_0 */
+int fl_debug_mul_mat_q_resid(const fl_qtensor *W, const fl_qact *a, float *y_dev, int ldy, const float *resid_dev, int ldr, void *stream);
+int fl_debug_gemm_qkv(const fl_qtensor *W, const fl_qact *a, float *y_dev, int ldy, const float *rope_tab_dev, float *kc_dev,
+                      float *vc_dev, int El, int D, int n_past, int n_ctx, void *stream);
+int fl_debug_gemm_silu(const fl_qtensor *W, const fl_qact *a, const uint16_t *silu_tab_dev, fl_qact *out, void *stream);
 int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a, float *y_dev, int ldy, int which /*0 naive,1 mfma,2 gemv*/,
                        void *stream);
 int fl_debug_qact_layout(const fl_qact *a); /* 16 = QA16, 1 = QA1 */

@@ -51,7 +51,8 @@ class Port:
             build()
         self.lib = C.CDLL(path)
         L = self.lib
-        for name in ("orc_quantize_row_q4_0", "orc_quantize_row_q4_1", "orc_quantize_row_q8_0"):
+        for name in ("orc_quantize_row_q4_0", "orc_quantize_row_q4_1", "orc_quantize_row_q8_0", "orc_quantize_row_q4_0_simd",
+                     "orc_quantize_row_q4_1_simd"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int]
             getattr(L, name).restype = None
         for name in ("orc_dequantize_row_q4_0", "orc_dequantize_row_q4_1"):
@@ -79,6 +80,14 @@ class Port:
         M, K = w.shape
         out = np.empty((M, K // QK * BLOCK_BYTES[qtype]), dtype=np.uint8)
         self.lib.orc_quantize_q4(qtype, _ptr(w), _ptr(out), w.size, K)
+        return out
+
+    def quantize_row_q4(self, qtype: int, x: np.ndarray, reference: bool) -> np.ndarray:
+        """quantize_fns[type].quantize_row_q_reference (reference=True) / .quantize_row_q as built for AVX2."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty(x.size // QK * BLOCK_BYTES[qtype], dtype=np.uint8)
+        name = "orc_quantize_row_q4_%d%s" % (0 if qtype == Q4_0 else 1, "" if reference else "_simd")
+        getattr(self.lib, name)(_ptr(x), _ptr(out), x.size)
         return out
 
     def dequantize_row(self, qtype: int, row: np.ndarray, K: int) -> np.ndarray:
@@ -198,6 +207,13 @@ class Ref:
         for r0 in range(0, M, rows_per):
             r1 = min(M, r0 + rows_per)
             fn(_ptr(w[r0:r1]), _ptr(out[r0:r1]), (r1 - r0) * K, K, _ptr(hist))
+        return out
+
+    def quantize_row_q4(self, qtype: int, x: np.ndarray, reference: bool) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty(x.size // QK * BLOCK_BYTES[qtype], dtype=np.uint8)
+        f = self.fns[qtype]
+        (f.quantize_row_q_reference if reference else f.quantize_row_q)(_ptr(x), _ptr(out), x.size)
         return out
 
     def dequantize_row(self, qtype: int, row: np.ndarray, K: int) -> np.ndarray:

@@ -165,8 +165,11 @@ def test_quantize_fns_table_mirrors_reference_vtable(torch, ops, port):
     x = make_x(1, K, 9)[0]
     for qt in (oracle.Q4_0, oracle.Q4_1):
         f = L.fl_get_quantize_fn(qt)
-        assert not f.quantize_row_q and not f.quantize_row_q_reference   # offline tooling: NULL
         xd = dev(torch, x)
+        for slot, reference in ((f.quantize_row_q, False), (f.quantize_row_q_reference, True)):
+            wb = torch.empty(K // 32 * oracle.BLOCK_BYTES[qt], dtype=torch.uint8, device="cuda")
+            slot(xd.data_ptr(), wb.data_ptr(), K)
+            assert np.array_equal(wb.cpu().numpy(), port.quantize_row_q4(qt, x, reference))
         yq = torch.empty(K // 32 * 40, dtype=torch.uint8, device="cuda")
         f.quantize_row_q_dot(xd.data_ptr(), yq.data_ptr(), K)
         assert np.array_equal(yq.cpu().numpy(), port.quantize_row_q8_0(x))
@@ -180,6 +183,32 @@ def test_quantize_fns_table_mirrors_reference_vtable(torch, ops, port):
         want = port.vec_dot(qt, K, wq, port.quantize_row_q8_0(x))
         assert abs(s.item() - want) <= TOL * max(1.0, abs(want))
     assert not L.fl_get_quantize_fn(0).vec_dot_q     # F32 has no entry, like quantize_fns[GGML_TYPE_F32]
+
+
+@pytest.mark.parametrize("nm,qt", Q4)
+@pytest.mark.parametrize("reference", [False, True])
+def test_quantize_row_q4_slots_match_reference(torch, ops, port, nm, qt, reference):
+    """quantize_row_q (the SIMD flavour of the reference's x86 build) and quantize_row_q_reference, bit for bit against
+    the oracle restatement (itself pinned to the compiled reference, tests/test_oracle_pinning.py) -- incl. exact .5
+    ties, where the two flavours differ (rint vs roundf), all-zero and constant blocks, tiny and huge magnitudes."""
+    rng = np.random.default_rng(77)
+    K = 32 * 64
+    x = rng.standard_normal(K).astype(np.float32)
+    x[32:64] = 0.0                                           # all-zero block: d = 0, id = 0
+    x[64:96] = 3.25                                          # constant block (Q4_1: max == min)
+    x[96:128] = np.arange(32, dtype=np.float32) * 0.5 - 7.0  # amax 8.5... exact halves after scaling by 7/amax? no: next
+    x[128:160] = np.concatenate([[7.0, -7.0], (np.arange(30) % 14 - 7) + 0.5]).astype(np.float32)   # id = 1: x.5 ties
+    x[160:192] *= 1e-30
+    x[192:224] *= 1e30
+    x[224:256] = np.concatenate([[0.0, 15.0], np.arange(30) % 15 + 0.5]).astype(np.float32)         # Q4_1 ties: d = 1
+    got = ops.quantize_row_q(qt, dev(torch, x), reference=reference).cpu().numpy()
+    assert np.array_equal(got, port.quantize_row_q4(qt, x, reference))
+    if oracle.have_ref():
+        assert np.array_equal(got, oracle.Ref().quantize_row_q4(qt, x, reference))
+    # what synthetic models are made of (harness/synth.py) is the reference's own file quantizer
+    w = rng.standard_normal((5, 256)).astype(np.float32) * 0.02
+    got = ops.quantize_row_q(qt, dev(torch, w).view(-1), reference=True).cpu().numpy().reshape(5, -1)
+    assert np.array_equal(got, port.quantize_q4(qt, w))
 
 
 # ------------------------------------------------------------------ a9 mul_mat_q_f32 ---------------
@@ -260,8 +289,6 @@ FULL = [(4096, 4096), (11008, 4096), (4096, 11008), (32000, 4096)]
 @pytest.mark.parametrize("M,K", FULL)
 @pytest.mark.parametrize("N", [1, 512])
 def test_llama7b_shapes_sampled_rows_vs_oracle(torch, ops, port, nm, qt, M, K, N):
-    if (N == 512 and qt == oracle.Q4_1 and M > 11008):
-        pytest.skip("covered by Q4_0 at this size")
     rng = np.random.default_rng(M + K + N)
     wq = make_weights(port, qt, M, K, 31 + M % 97)
     x = make_x(N, K, 41)
@@ -298,6 +325,156 @@ def test_exact_properties_at_full_size(torch, ops, port, N):
     if N >= 16:
         ysub = ops.mul_mat(W, x[100:132].contiguous())
         assert torch.equal(ysub, y[100:132])
+
+
+# ---- every tile configuration of both MFMA kernels returns the same bits (7B, 13B and 65B shapes) ------------
+OLD_CFGS = list(range(14))                    # gemm_q4_mfma.hip FL_GEMM_CONFIGS (round 1, 16x16x32 MFMA)
+NEW_CFGS = [100, 101, 102, 103, 104, 105, 106, 108]   # gemm_q4_mfma32.hip FL_GEMM32_CONFIGS (32x32x32 MFMA)
+LLAMA_SHAPES = [(4096, 4096), (11008, 4096), (4096, 11008), (32000, 4096),        # 7B
+                (5120, 5120), (13824, 5120), (5120, 13824),                       # 13B
+                (8192, 8192), (22016, 8192), (8192, 22016)]                       # 65B
+
+
+@pytest.mark.parametrize("nm,qt", Q4)
+@pytest.mark.parametrize("M,K", LLAMA_SHAPES)
+def test_tile_configurations_are_bit_identical_and_match_oracle(torch, ops, port, nm, qt, M, K):
+    """N = 512 (BASELINE.json's n_batch) at every LLaMA matrix shape: each output accumulates its per-block terms in K
+    order whatever the tile shape and whichever MFMA computes the block dots, so all 22 configurations -- and the one
+    pick_config chooses -- must agree BIT FOR BIT; sampled rows are checked against the oracle."""
+    from fastllama_amd import hip
+    from harness import synth
+    L = hip.load()
+    N = 512
+    blocks = synth.synth_q4(M, K, qt, 11 + M % 13)
+    W = ops.QTensor(qt, blocks, M, K)
+    x = dev(torch, make_x(N, K, 17))
+    a = ops.QAct(N, K).quantize(x)
+    try:
+        L.fl_debug_set(0, 12)
+        ref = ops.mul_mat_q(W, a).clone()
+        for cfg in [-1, -2] + OLD_CFGS + NEW_CFGS:
+            L.fl_debug_set(0, cfg)
+            y = ops.mul_mat_q(W, a)
+            assert torch.equal(y, ref), (M, K, cfg, int((y != ref).sum()))
+    finally:
+        L.fl_debug_set(0, -1)
+    rng = np.random.default_rng(M + K)
+    rows = np.sort(rng.choice(M, size=16, replace=False))
+    cols = np.sort(rng.choice(N, size=12, replace=False))
+    want = port.mul_mat_q(qt, blocks[torch.from_numpy(rows).cuda()].cpu().numpy(), x.cpu().numpy()[cols])
+    assert rel_max_err(ref.cpu().numpy()[np.ix_(cols, rows)], want) <= TOL
+    W.free()
+
+
+@pytest.mark.parametrize("nm,qt", Q4)
+@pytest.mark.parametrize("M,K,N", [(48, 192, 17), (200, 1408, 9), (130, 256, 70), (264, 320, 33), (256, 352, 33), (40, 96, 20),
+                                   (33, 32, 16), (1000, 4096, 100)])
+def test_tile_configurations_ragged_shapes(torch, ops, port, nm, qt, M, K, N):
+    """Row / column / K tails (M % 32, N % 32, K/32 odd or not a multiple of the 8-block loop body) in every configuration."""
+    from fastllama_amd import hip
+    L = hip.load()
+    wq = make_weights(port, qt, M, K, 5 + M)
+    W = ops.QTensor(qt, wq, M, K)
+    x = make_x(N, K, 6 + N)
+    a = ops.QAct(N, K).quantize(dev(torch, x))
+    want = port.mul_mat_q(qt, wq, x, strict=False)
+    try:
+        L.fl_debug_set(0, 12)
+        ref = ops.mul_mat_q(W, a).clone()
+        assert rel_max_err(ref.cpu().numpy(), want) <= TOL
+        for cfg in OLD_CFGS + NEW_CFGS:
+            L.fl_debug_set(0, cfg)
+            y = torch.full((N, (M + 3) // 4 * 4), 7.0, device="cuda")[:, :M]
+            ops.mul_mat_q(W, a, out=y)
+            assert torch.equal(y, ref), (M, K, N, cfg)
+    finally:
+        L.fl_debug_set(0, -1)
+
+
+# ---- the fused forms of the prefill GEMM against GEMM + the separate op kernel --------------------------------
+@pytest.mark.parametrize("nm,qt", Q4)
+@pytest.mark.parametrize("E,D,N,n_past", [(256, 32, 40, 9), (4096, 128, 512, 0), (4096, 128, 96, 160), (5120, 128, 512, 512)])
+def test_gemm_qkv_rope_epilogue_equals_gemm_plus_rope_kv(torch, ops, port, nm, qt, E, D, N, n_past):
+    """wq|wk|wv matmul with rope on Q / K and the K / V cache stores as its epilogue == the plain matmul followed by
+    rope_kv_kernel, bit for bit, at n_past > 0 (position 0 has the identity rotation) in both kernels' configurations."""
+    from fastllama_amd import hip
+    from harness import synth
+    L = hip.load()
+    n_ctx = 1024
+    W = ops.QTensor(qt, synth.synth_q4(3 * E, E, qt, 3), 3 * E, E)
+    x = dev(torch, make_x(N, E, 4))
+    a = ops.QAct(N, E).quantize(x)
+    rt = np.empty((n_ctx, D // 2, 2), np.float32)
+    L.fl_debug_rope_table(rt.ctypes.data_as(C.c_void_p), n_ctx, D)
+    rd = dev(torch, rt)
+    qkv = ops.mul_mat_q(W, a).contiguous()
+    kc0, vc0 = torch.zeros((n_ctx, E), device="cuda"), torch.zeros((E, n_ctx), device="cuda")
+    hip.check(L.fl_debug_rope_kv(qkv.data_ptr(), 3 * E, N, E, D, n_past, n_ctx, rd.data_ptr(), kc0.data_ptr(), vc0.data_ptr(), None))
+    try:
+        for cfg in (-1, -2, 10, 12, 100, 101, 106):
+            L.fl_debug_set(0, cfg)
+            y = torch.zeros((N, 3 * E), device="cuda")
+            kc, vc = torch.zeros_like(kc0), torch.zeros_like(vc0)
+            hip.check(L.fl_debug_gemm_qkv(W.handle, a.handle, y.data_ptr(), 3 * E, rd.data_ptr(), kc.data_ptr(), vc.data_ptr(), E, D,
+                                          n_past, n_ctx, None))
+            assert torch.equal(y[:, :E], qkv[:, :E]), cfg                 # roped Q
+            assert torch.equal(kc, kc0) and torch.equal(vc, vc0), cfg     # roped K rows, transposed V columns
+            assert not y[:, E:].any()                                     # K / V never land in y
+    finally:
+        L.fl_debug_set(0, -1)
+
+
+@pytest.mark.parametrize("nm,qt", Q4)
+@pytest.mark.parametrize("F,K,N", [(704, 256, 40), (11008, 4096, 512), (13824, 5120, 100), (352, 256, 33)])
+def test_gemm_silu_epilogue_equals_gemm_plus_silu_mul_quant(torch, ops, port, nm, qt, F, K, N):
+    """woven w1|w3 matmul whose epilogue writes Q8_0(silu(w1 x) * (w3 x)) == plain matmul + silu_mul_quant_kernel:
+    the exported Q8_0 bytes (quants, d, s) are identical."""
+    from fastllama_amd import hip
+    from harness import synth
+    L = hip.load()
+    W = ops.QTensor(qt, synth.synth_q4(2 * F, K, qt, 8), 2 * F, K)     # rows woven by 16: group 2p = w1, 2p+1 = w3
+    x = dev(torch, make_x(N, K, 9))
+    a = ops.QAct(N, K).quantize(x)
+    s = np.empty(1 << 16, np.uint16)
+    L.fl_debug_tables(None, s.ctypes.data_as(C.c_void_p))
+    sd = dev(torch, s.view(np.int16))
+    h13 = ops.mul_mat_q(W, a).contiguous()
+    want = ops.QAct(N, F)
+    hip.check(L.fl_quantize_q8_layout(want.handle, h13.data_ptr(), 2 * F, N, F, 16, None))    # bookkeeping (N, layout)
+    want.N, want.K = N, F
+    # woven = True: h13 = [w1 x 16 | w3 x 16 | ...]
+    hip.check(L.fl_debug_silu_mul_quant_woven(h13.data_ptr(), 2 * F, N, F, sd.data_ptr(), want.handle, 16, None))
+    wb = want.export().cpu().numpy()
+    try:
+        for cfg in (-1, -2, 10, 12, 100, 101, 106):
+            L.fl_debug_set(0, cfg)
+            out = ops.QAct(N, F)
+            hip.check(L.fl_debug_gemm_silu(W.handle, a.handle, sd.data_ptr(), out.handle, None))
+            out.N, out.K = N, F
+            assert np.array_equal(out.export().cpu().numpy(), wb), cfg
+    finally:
+        L.fl_debug_set(0, -1)
+
+
+@pytest.mark.parametrize("nm,qt", Q4)
+def test_gemm_residual_epilogue(torch, ops, port, nm, qt):
+    """y = mul_mat + resid (the ggml_add after wo / w2) fused into the store == matmul then add."""
+    from fastllama_amd import hip
+    from harness import synth
+    L = hip.load()
+    M, K, N = 4096, 4096, 200
+    W = ops.QTensor(qt, synth.synth_q4(M, K, qt, 2), M, K)
+    a = ops.QAct(N, K).quantize(dev(torch, make_x(N, K, 3)))
+    r = dev(torch, make_x(N, M, 4))
+    base = ops.mul_mat_q(W, a)
+    try:
+        for cfg in (-1, -2, 12, 100, 101, 106):
+            L.fl_debug_set(0, cfg)
+            y = torch.empty((N, M), device="cuda")
+            hip.check(L.fl_debug_mul_mat_q_resid(W.handle, a.handle, y.data_ptr(), M, r.data_ptr(), M, None))
+            assert torch.equal(y, base + r), cfg
+    finally:
+        L.fl_debug_set(0, -1)
 
 
 def test_mul_mat_argument_errors(torch, ops, port):

@@ -88,6 +88,24 @@ def test_port_matches_live_reference(port, ref, qt, seed):
     assert np.array_equal(bits(ya), bits(yb))
 
 
+@pytest.mark.parametrize("qt", [oracle.Q4_0, oracle.Q4_1])
+@pytest.mark.parametrize("reference", [False, True])
+def test_row_quantizer_flavours_pinned_to_reference_table(port, ref, qt, reference):
+    """quantize_fns[type].quantize_row_q (the SIMD flavour of this x86 build) and .quantize_row_q_reference
+    (lib/ggml.c:1731-1745) against the restatements the GPU kernels are tested with -- incl. x.5 ties, where rint and
+    roundf part ways."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(32 * 40).astype(np.float32)
+    x[32:64] = 0.0
+    x[64:96] = np.concatenate([[7.0, -7.0], (np.arange(30) % 14 - 7) + 0.5]).astype(np.float32)
+    x[96:128] = np.concatenate([[0.0, 15.0], np.arange(30) % 15 + 0.5]).astype(np.float32)
+    x[128:160] *= 1e-30
+    x[160:192] *= 1e30
+    assert np.array_equal(port.quantize_row_q4(qt, x, reference), ref.quantize_row_q4(qt, x, reference))
+    if qt == oracle.Q4_0:   # the two flavours do differ on ties (this is what the two table slots are for)
+        assert not np.array_equal(port.quantize_row_q4(qt, x, True), port.quantize_row_q4(qt, x, False))
+
+
 def test_reference_result_independent_of_thread_count(ref, port):
     # each output element is computed by exactly one thread in a fixed order (lib/ggml.c:8127-8163)
     wq = port.quantize_q4(oracle.Q4_0, np.random.default_rng(5).normal(0, .02, (37, 512)).astype(np.float32))
