@@ -27,7 +27,8 @@ struct LocalGroup {
     unsigned long gen = 0;
     float *bufs[FL_COMM_MAX_LOCAL] = {nullptr};
     size_t count = 0;
-    int status = FL_OK;
+    int status = FL_OK;        // of the round being collected
+    int done_status = FL_OK;   // of the round that just completed
 };
 
 struct fl_comm {
@@ -79,7 +80,11 @@ int fl_comm_create_local(int world, fl_comm **out) {
     g->refs = world;
     for (int r = 0; r < world; ++r) {
         fl_comm *c = new (std::nothrow) fl_comm();
-        if (!c) return set_error(FL_ENOMEM, "out of host memory");
+        if (!c) {
+            for (int q = 0; q < r; ++q) { delete out[q]; out[q] = nullptr; }
+            delete g;
+            return set_error(FL_ENOMEM, "out of host memory");
+        }
         c->rank = r;
         c->world = world;
         c->lg = g;
@@ -95,7 +100,7 @@ static int local_allreduce(fl_comm *c, float *buf, size_t count, hipStream_t st)
     std::unique_lock<std::mutex> lk(g->mu);
     const unsigned long my_gen = g->gen;
     g->bufs[c->rank] = buf;
-    if (g->arrived == 0) g->count = count;
+    if (g->arrived == 0) { g->count = count; g->status = FL_OK; }     // a new round starts clean: an earlier failure is not sticky
     else if (g->count != count) g->status = FL_EINVAL;
     if (++g->arrived == g->world) {
         if (g->status == FL_OK) {
@@ -103,13 +108,14 @@ static int local_allreduce(fl_comm *c, float *buf, size_t count, hipStream_t st)
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) g->status = FL_EHIP;
         }
+        g->done_status = g->status;      // the verdict of THIS round, read by every member after the wake-up
         g->arrived = 0;
         ++g->gen;
         g->cv.notify_all();
     } else {
         g->cv.wait(lk, [&] { return g->gen != my_gen; });
     }
-    const int rc = g->status;
+    const int rc = g->done_status;
     return rc == FL_OK ? FL_OK : set_error(rc, "local all-reduce failed (mismatched counts or a device error)");
 }
 

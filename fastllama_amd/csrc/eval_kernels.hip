@@ -1214,4 +1214,38 @@ hipError_t add_rows(const float *a, int lda, const float *b, int ldb, float *o, 
     return hipGetLastError();
 }
 
+
+// -log softmax(logits[j])[next token of j] for rows j0 + blockIdx.x -- the inner loop of FastLlama::perplexity
+// (/root/reference/lib/bridge.cpp:397-407: max, sum of expf(l - max), p = expf(l[t] - max) / sum, -log p) on the device,
+// so that a perplexity run copies one double per row to the host instead of n_vocab floats.
+__global__ __launch_bounds__(256) void logits_nll_kernel(const float *__restrict__ logits, int ld, int V, const int *__restrict__ next_tok,
+                                                         int j0, double *__restrict__ out) {
+    __shared__ float smx[4];
+    __shared__ double ssum[4];
+    const int j = j0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float *l = logits + (int64_t)j * ld;
+    float mx = -INFINITY;
+    for (int k = tid; k < V; k += 256) mx = fmaxf(mx, l[k]);
+    mx = wave_max_f32(mx);
+    if (lane == 0) smx[w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    double sum = 0.0;
+    for (int k = tid; k < V; k += 256) sum += (double)expf(l[k] - mx);
+    sum = wave_sum_f64(sum);
+    if (lane == 0) ssum[w] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        const float tot = (float)((ssum[0] + ssum[1]) + (ssum[2] + ssum[3]));
+        const float pr = expf(l[next_tok[blockIdx.x]] - mx) / tot;
+        out[blockIdx.x] = (double)(-logf(pr));
+    }
+}
+
+hipError_t logits_nll(const float *logits, int ld, int V, const int *next_tok_dev, int j0, int rows, double *out_dev, hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(logits_nll_kernel, dim3(rows), dim3(256), 0, st, logits, ld, V, next_tok_dev, j0, out_dev);
+    return hipGetLastError();
+}
+
 }  // namespace fl

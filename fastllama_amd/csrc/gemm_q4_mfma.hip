@@ -507,12 +507,16 @@ static hipError_t launch_gemm(const fl_qtensor &W, const fl_qact &xq, int N, flo
     const int MGT = W.M16 / 16, NGT = fl_roundup(N, 16) / 16;
     const int tiles = ((MGT + Cfg::MG - 1) / Cfg::MG) * ((NGT + Cfg::NG - 1) / Cfg::NG);
     auto kern = gemm_q4_mfma_kernel<TYPE, WM, WN, TM, TN, MINW, KS>;
-    static bool attr_set = false;
-    if (!attr_set && Cfg::LDS_BYTES > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           Cfg::LDS_BYTES);
+    if (Cfg::LDS_BYTES > 65536) {        // the attribute is per device: remember which devices have it (several GPUs in one process)
+        static bool attr_set[64] = {false};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
     }
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), Cfg::LDS_BYTES, st, reinterpret_cast<const uint4 *>(W.qs), W.d,
                        W.m, xq.q, xq.d, xq.s, N, W.M, MGT, NGT, W.KB, y, ldy, resid, ldr, epi);

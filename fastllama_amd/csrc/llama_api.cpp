@@ -276,6 +276,7 @@ struct Session {
     std::deque<token_t> last_n;      // RingBuffer<token_id_t>, include/ring_buffer.hpp:26-40
     size_t last_n_cap = 64;
     std::vector<float> logits, embeddings;
+    int logits_on_device = 0;   // > 0: the host copy of that many logits rows is still owed (perplexity keeps them in HBM)
     std::vector<token_t> system_prompt;
     TokenBufferState tb_state;
     bool all_logits = false;
@@ -551,9 +552,27 @@ struct Session {
     }
 
     // Model::eval(n_past, tokens, logits, ...) -- lib/llama.cpp:272; batches larger than max_batch are split
-    bool eval(int past, const std::vector<token_t> &toks) {
+    // the logits of the last eval on the host (llama_get_logits, save_state): perplexity() leaves them in HBM
+    void sync_logits() {
+        if (logits_on_device <= 0) return;
+        logits.resize((size_t)hp.n_vocab * (size_t)logits_on_device);
+        if (fl_model_logits_read(model, 0, logits_on_device, logits.data()) != FL_OK) logits.clear();
+        logits_on_device = 0;
+    }
+
+    bool eval(int past, const std::vector<token_t> &toks, bool keep_on_device = false) {
         const int V = hp.n_vocab, N = (int)toks.size();
         if (N == 0) return true;
+        logits_on_device = 0;
+        if (keep_on_device && all_logits && N <= max_batch) {      // one device eval, no host copy yet
+            if (fl_model_eval(model, toks.data(), N, past, nullptr, 0, args.embedding_eval_enabled ? (embeddings.resize((size_t)hp.n_embd), embeddings.data()) : nullptr) != FL_OK) {
+                log.err("Model::eval", std::string(fl_last_error()) + "\n");
+                return false;
+            }
+            logits_on_device = N;
+            if (mem_per_token == 0) mem_per_token = 1;
+            return true;
+        }
         logits.resize((size_t)V * (all_logits ? N : 1));
         if (args.embedding_eval_enabled) embeddings.resize((size_t)hp.n_embd);
         for (int i = 0; i < N; i += max_batch) {
@@ -663,33 +682,29 @@ struct Session {
         for (size_t i = 0; i < toks.size(); i += bs, ++idx) {
             const size_t block = std::min(bs, toks.size() - i);
             const std::vector<token_t> in(toks.begin() + (std::ptrdiff_t)i, toks.begin() + (std::ptrdiff_t)(i + block));
-            if (!eval(0, in)) { all_logits = old; return -1.f; }
-            // softmax(logits[j])[next token] over the second half of the block (lib/bridge.cpp:397-407).  With the eval on
-            // the GPU this host loop (n_batch/2 x n_vocab expf) is what a perplexity run waits for: the rows are spread
-            // over n_threads host threads; every row keeps the serial arithmetic and the rows are summed in order, so the
-            // result does not depend on the thread count.
+            if (!eval(0, in, true)) { all_logits = old; return -1.f; }
+            // softmax(logits[j])[next token] over the second half of the block (lib/bridge.cpp:397-407) -- on the device
+            // (fl_model_logits_nll): one double per row comes back instead of n_batch x n_vocab floats (64 MB at 512 x 32000);
+            // the rows are summed in order.  llama_get_logits() fetches the block's logits if a caller asks for them.
             const size_t j0 = block >> 1, j1 = block > 0 ? block - 1 : 0;
             if (j1 > j0) {
                 std::vector<double> row_nll(j1 - j0);
-                auto rows = [&](size_t a, size_t b) {
-                    for (size_t j = a; j < b; ++j) {
+                std::vector<int32_t> next(j1 - j0);
+                for (size_t j = j0; j < j1; ++j) next[j - j0] = toks[i + j + 1];
+                bool ok;
+                if (logits_on_device > 0) {
+                    ok = fl_model_logits_nll(model, (int)j0, (int)(j1 - j0), next.data(), row_nll.data()) == FL_OK;
+                } else {                                   // (a block larger than the device batch was evaluated in pieces)
+                    ok = true;
+                    for (size_t j = j0; j < j1; ++j) {
                         const float *l = logits.data() + j * V;
                         const float mx = *std::max_element(l, l + V);
                         float sum = 0.f;
                         for (size_t k = 0; k < V; ++k) sum += std::exp(l[k] - mx);
-                        const float p = std::exp(l[(size_t)toks[i + j + 1]] - mx) / sum;
-                        row_nll[j - j0] = (double)(-std::log(p));
+                        row_nll[j - j0] = (double)(-std::log(std::exp(l[(size_t)next[j - j0]] - mx) / sum));
                     }
-                };
-                const size_t nt = std::min<size_t>(std::max(1, std::min(args.n_threads, 64)), j1 - j0);
-                std::vector<std::thread> pool;
-                const size_t per = (j1 - j0 + nt - 1) / nt;
-                for (size_t t = 1; t < nt; ++t) {
-                    const size_t a = j0 + t * per, b = std::min(j1, a + per);
-                    if (a < b) pool.emplace_back(rows, a, b);
                 }
-                rows(j0, std::min(j1, j0 + per));
-                for (auto &th : pool) th.join();
+                if (!ok) { log.err("perplexity", std::string(fl_last_error()) + "\n"); all_logits = old; return -1.f; }
                 for (double v : row_nll) nll += v;
                 count += j1 - j0;
             }
@@ -704,6 +719,7 @@ struct Session {
 
     // session state file: byte-compatible with the reference's (lib/bridge.cpp:424-525 + KV dump lib/llama.cpp:57-78)
     bool save_state(const char *path) {
+        sync_logits();
         FILE *f = fopen(path, "wb");
         if (!f) { log.err("save_state", "unable to open the file saving the model state"); return false; }
         auto W = [&](const void *p, size_t n) { return fwrite(p, 1, n, f) == n; };
@@ -733,31 +749,55 @@ struct Session {
     }
 
     bool load_state(const char *path) {
+        // Every size field is checked against what is left of the file and against the model's own limits, everything is
+        // read into temporaries, and the session is touched only once the whole file (KV cache included) has been read.
         FILE *f = fopen(path, "rb");
         if (!f) { log.err("load_state", "unable to open the file loading the model state"); return false; }
-        auto R = [&](void *p, size_t n) { return fread(p, 1, n, f) == n; };
-        bool ok = R(&n_past, sizeof n_past);
-        size_t n = 0;
-        ok = ok && R(&n, sizeof n);
-        std::string rs(ok ? n : 0, '\0');
-        ok = ok && R(rs.data(), n);
-        if (ok) { std::stringstream ss; ss << rs; ss >> rng; }
-        ok = ok && R(&mem_per_token, sizeof mem_per_token) && R(&n, sizeof n);
-        if (ok) { embd.resize(n); ok = R(embd.data(), n * sizeof(token_t)); }
-        ok = ok && R(&n, sizeof n);
-        if (ok) { last_n.clear(); for (size_t i = 0; i < n && ok; ++i) { token_t t; ok = R(&t, sizeof t); if (ok) push_last(t); } }
-        ok = ok && R(&n, sizeof n);
-        if (ok) { logits.resize(n); ok = R(logits.data(), n * sizeof(float)); }
-        ok = ok && R(&n, sizeof n);
-        if (ok) { system_prompt.resize(n); ok = R(system_prompt.data(), n * sizeof(token_t)); }
+        fseek(f, 0, SEEK_END);
+        const long fsize = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        auto left = [&]() -> size_t { const long p = ftell(f); return p < 0 || p > fsize ? 0 : (size_t)(fsize - p); };
+        auto R = [&](void *p, size_t n) { return n <= left() && fread(p, 1, n, f) == n; };
+        auto Rn = [&](size_t *n, size_t elem, size_t limit) { return R(n, sizeof *n) && *n <= limit && *n * elem <= left(); };
+        int t_past = 0;
+        size_t t_mem = 0, n = 0;
+        std::string rs;
+        std::vector<token_t> t_embd, t_last, t_sys;
+        std::vector<float> t_logits;
+        const size_t ctx = (size_t)args.n_ctx, V = (size_t)hp.n_vocab;
+        bool ok = R(&t_past, sizeof t_past) && t_past >= 0 && (size_t)t_past <= ctx;
+        ok = ok && Rn(&n, 1, 1 << 20);
+        if (ok) { rs.resize(n); ok = R(rs.data(), n); }
+        std::mt19937 t_rng;
+        if (ok) { std::stringstream ss; ss << rs; ss >> t_rng; ok = !ss.fail(); }
+        ok = ok && R(&t_mem, sizeof t_mem) && Rn(&n, sizeof(token_t), ctx + (size_t)max_batch);
+        if (ok) { t_embd.resize(n); ok = R(t_embd.data(), n * sizeof(token_t)); }
+        ok = ok && Rn(&n, sizeof(token_t), 1 << 20);
+        if (ok) { t_last.resize(n); ok = R(t_last.data(), n * sizeof(token_t)); }
+        ok = ok && Rn(&n, sizeof(float), V * std::max<size_t>(ctx, (size_t)max_batch));
+        if (ok) { t_logits.resize(n); ok = R(t_logits.data(), n * sizeof(float)); }
+        ok = ok && Rn(&n, sizeof(token_t), ctx);
+        if (ok) { t_sys.resize(n); ok = R(t_sys.data(), n * sizeof(token_t)); }
         int32_t memory_type = 0;
         ok = ok && R(&memory_type, sizeof memory_type) && memory_type == 0;
         const size_t kv = (size_t)hp.n_layer * args.n_ctx * hp.n_embd;
-        std::vector<float> k(ok ? kv : 0), v(ok ? kv : 0);
-        ok = ok && R(k.data(), kv * 4) && R(v.data(), kv * 4) && fl_model_kv_write(model, k.data(), v.data()) == FL_OK;
+        std::vector<float> k, v;
+        if (ok && 2 * kv * 4 <= left()) { k.resize(kv); v.resize(kv); } else ok = false;
+        ok = ok && R(k.data(), kv * 4) && R(v.data(), kv * 4);
         fclose(f);
-        if (!ok) log.err("load_state", "failed to read the model state (was it saved with the same model and n_ctx?)\n");
-        return ok;
+        for (token_t t : t_embd) ok = ok && t >= 0 && (size_t)t < V;
+        ok = ok && fl_model_kv_write(model, k.data(), v.data()) == FL_OK;
+        if (!ok) { log.err("load_state", "failed to read the model state (was it saved with the same model and n_ctx?)\n"); return false; }
+        n_past = t_past;
+        rng = t_rng;
+        mem_per_token = t_mem;
+        embd = std::move(t_embd);
+        last_n.clear();
+        for (token_t t : t_last) push_last(t);
+        logits = std::move(t_logits);
+        logits_on_device = 0;
+        system_prompt = std::move(t_sys);
+        return true;
     }
 
     bool reset() {
@@ -765,6 +805,7 @@ struct Session {
         n_past = 0;
         last_n.clear();
         logits.clear();
+        logits_on_device = 0;
         system_prompt.clear();
         embd.clear();
         rng = std::mt19937((uint32_t)seed);
@@ -785,6 +826,20 @@ static bool valid(const llama_model_context *c) {
     if (!c) { fprintf(stderr, "model context is not initalized. Please use `llama_create_context` to create a context.\n"); return false; }
     if (!c->inner) { fprintf(stderr, "model is not loaded. Please use `llama_load_model` to load a model.\n"); return false; }
     return true;
+}
+
+// No exception crosses the C ABI (the reference is built -fno-exceptions and returns false; SURVEY.md 8b "Errors"):
+// a std::bad_alloc / length_error from a corrupt file or an out-of-memory host becomes `false` (-1 for perplexity).
+template <class F, class R>
+static R guarded(R fail, F &&f) noexcept {
+    try {
+        return f();
+    } catch (const std::exception &e) {
+        fprintf(stderr, "fastllama_hip: %s\n", e.what());
+    } catch (...) {
+        fprintf(stderr, "fastllama_hip: unknown exception\n");
+    }
+    return fail;
 }
 
 extern "C" {
@@ -818,6 +873,7 @@ bool llama_load_model(struct llama_model_context *c, char const *filepath) {
     if (!c) { fprintf(stderr, "model context is not initalized. Please use `llama_create_context` to create a context.\n"); return false; }
     if (c->inner) { fprintf(stderr, "model is already loaded.\n"); return false; }
     if (!filepath) return false;
+    return guarded(false, [&]() -> bool {
     auto s = std::make_unique<Session>();
     s->args = c->args;
     s->log.cb = c->args.logger;
@@ -835,6 +891,7 @@ bool llama_load_model(struct llama_model_context *c, char const *filepath) {
     }
     c->inner = std::move(s);
     return true;
+    });
 }
 
 bool llama_set_stop_words(struct llama_model_context *c, char const **words, size_t len) {
@@ -844,19 +901,25 @@ bool llama_set_stop_words(struct llama_model_context *c, char const **words, siz
     return true;
 }
 
-bool llama_ingest(struct llama_model_context *c, char const *prompt) { return valid(c) && prompt && c->inner->ingest(prompt, false); }
-bool llama_ingest_system_prompt(struct llama_model_context *c, char const *prompt) { return valid(c) && prompt && c->inner->ingest(prompt, true); }
+bool llama_ingest(struct llama_model_context *c, char const *prompt) {
+    return guarded(false, [&] { return valid(c) && prompt && c->inner->ingest(prompt, false); });
+}
+bool llama_ingest_system_prompt(struct llama_model_context *c, char const *prompt) {
+    return guarded(false, [&] { return valid(c) && prompt && c->inner->ingest(prompt, true); });
+}
 
 bool llama_generate(struct llama_model_context *c, LLAMA_STREAM_FUNC stream_fn, size_t number_of_tokens, float top_k, float top_p,
                     float temp, float repeat_penalty) {
     if (!valid(c)) return false;
-    return c->inner->generate([stream_fn](const std::string &s) { if (stream_fn) stream_fn(s.data(), (int)s.size()); },
-                              number_of_tokens, top_k, top_p, temp, repeat_penalty, c->stop_words);
+    return guarded(false, [&] {
+        return c->inner->generate([stream_fn](const std::string &s) { if (stream_fn) stream_fn(s.data(), (int)s.size()); },
+                                  number_of_tokens, top_k, top_p, temp, repeat_penalty, c->stop_words);
+    });
 }
 
 float llama_perplexity(struct llama_model_context *c, char const *prompt) {
     if (!valid(c) || !prompt) return -1.f;
-    return c->inner->perplexity(prompt);
+    return guarded(-1.f, [&] { return c->inner->perplexity(prompt); });
 }
 
 struct llama_array_view_f llama_get_embeddings(struct llama_model_context const *c) {
@@ -868,16 +931,23 @@ struct llama_array_view_f llama_get_embeddings(struct llama_model_context const 
 
 struct llama_array_view_f llama_get_logits(struct llama_model_context const *c) {
     if (!valid(c)) return {nullptr, 0};
+    guarded(0, [&] { c->inner->sync_logits(); return 0; });
     return {c->inner->logits.data(), c->inner->logits.size()};
 }
 
-bool llama_save_state(struct llama_model_context *c, char const *path) { return valid(c) && path && c->inner->save_state(path); }
-bool llama_load_state(struct llama_model_context *c, char const *path) { return valid(c) && path && c->inner->load_state(path); }
+bool llama_save_state(struct llama_model_context *c, char const *path) {
+    return guarded(false, [&] { return valid(c) && path && c->inner->save_state(path); });
+}
+bool llama_load_state(struct llama_model_context *c, char const *path) {
+    return guarded(false, [&] { return valid(c) && path && c->inner->load_state(path); });
+}
 
-bool llama_attach_lora(struct llama_model_context *c, char const *path) { return valid(c) && path && c->inner->attach_lora(path); }
-bool llama_detach_lora(struct llama_model_context *c) { return valid(c) && c->inner->detach_lora(); }
+bool llama_attach_lora(struct llama_model_context *c, char const *path) {
+    return guarded(false, [&] { return valid(c) && path && c->inner->attach_lora(path); });
+}
+bool llama_detach_lora(struct llama_model_context *c) { return guarded(false, [&] { return valid(c) && c->inner->detach_lora(); }); }
 
-bool llama_reset_model(struct llama_model_context *c) { return valid(c) && c->inner->reset(); }
+bool llama_reset_model(struct llama_model_context *c) { return guarded(false, [&] { return valid(c) && c->inner->reset(); }); }
 void llama_free_context(struct llama_model_context *c) { delete c; }
 
 void llama_handle_signal(int) {

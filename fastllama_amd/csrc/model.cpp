@@ -36,7 +36,8 @@ namespace {
 
 struct StagedFuse {            // device AoS staging of a row-stacked tensor (wq|wk|wv or w1|w3)
     void *aos = nullptr;
-    int parts_needed = 0, parts_have = 0;
+    int parts_needed = 0;
+    unsigned parts_mask = 0;   // which parts have arrived (a file listing one part twice must not complete the tensor)
     int rows_per_part = 0, K = 0;
 };
 
@@ -51,6 +52,7 @@ struct Layer {
 struct fl_model {
     fl_model_params hp{};
     int E = 0, H = 0, D = 0, F = 0, V = 0, L = 0, n_ctx = 0, B = 0, qtype = 0;
+    int ldl = 0;                // row stride of `logits` (n_vocab rounded up to 4: 16-byte rows for the GEMM's vector stores)
     int G = 1, rank = 0;        // tensor parallel
     int El = 0, Hl = 0, Fl = 0; // local (per rank) widths
     fl_qtensor *tok_emb = nullptr, *output = nullptr;
@@ -181,6 +183,8 @@ static int make_qtensor(fl_model *m, fl_qtensor **out, const void *aos_dev, int 
 // the layout the silu epilogue of the w1|w3 matmul needs (gemm_q4_mfma.hip, GemmSiluEpi)
 static int stage_part(fl_model *m, StagedFuse &sf, fl_qtensor **out, int nparts, int part, const void *host, int bs,
                       int KB_full, int row0, int rows, int K, bool interleave16 = false) {
+    if (*out) return set_error(FL_EINVAL, "a part of an already complete fused tensor was set again");
+    if (sf.parts_mask & (1u << part)) return set_error(FL_EINVAL, "part %d of a fused tensor was set twice", part);
     if (!sf.aos) {
         sf.parts_needed = nparts;
         sf.rows_per_part = rows;
@@ -199,7 +203,8 @@ static int stage_part(fl_model *m, StagedFuse &sf, fl_qtensor **out, int nparts,
         rc = stage_rows(host, bs, KB_full, row0, rows, 0, K / FL_QK, dst);
     }
     if (rc != FL_OK) return rc;
-    if (++sf.parts_have == sf.parts_needed) {
+    sf.parts_mask |= 1u << part;
+    if (sf.parts_mask == (1u << sf.parts_needed) - 1u) {
         rc = make_qtensor(m, out, sf.aos, nparts * rows, K);
         (void)hipFree(sf.aos);
         sf.aos = nullptr;
@@ -227,6 +232,7 @@ int fl_model_set_tensor(fl_model *m, const char *name, int type, const void *hos
     if (nm == "tok_embeddings.weight" || nm == "output.weight") {
         if ((rc = want_q(E, V)) != FL_OK) return rc;
         fl_qtensor **dst = nm[0] == 't' ? &m->tok_emb : &m->output;
+        if (*dst) return set_error(FL_EINVAL, "%s was set twice", name);
         void *tmp = nullptr;
         M_HIP(hipMalloc(&tmp, (size_t)V * (E / FL_QK) * bs));
         rc = stage_rows(host, bs, E / FL_QK, 0, V, 0, E / FL_QK, tmp);
@@ -236,6 +242,7 @@ int fl_model_set_tensor(fl_model *m, const char *name, int type, const void *hos
     }
     if (nm == "norm.weight") {
         if ((rc = want_f(E)) != FL_OK) return rc;
+        if (m->norm_w) return set_error(FL_EINVAL, "%s was set twice", name);
         return upload_f32(m, &m->norm_w, host, E);
     }
     int il = -1, off = 0;
@@ -243,8 +250,12 @@ int fl_model_set_tensor(fl_model *m, const char *name, int type, const void *hos
         return set_error(FL_EINVAL, "unknown tensor name '%s'", name);
     Layer &ly = m->layers[il];
     const std::string sub(name + off);
-    if (sub == "attention_norm.weight") { if ((rc = want_f(E)) != FL_OK) return rc; return upload_f32(m, &ly.attn_norm, host, E); }
-    if (sub == "ffn_norm.weight") { if ((rc = want_f(E)) != FL_OK) return rc; return upload_f32(m, &ly.ffn_norm, host, E); }
+    if (sub == "attention_norm.weight" || sub == "ffn_norm.weight") {
+        float **dstv = sub[0] == 'a' ? &ly.attn_norm : &ly.ffn_norm;
+        if ((rc = want_f(E)) != FL_OK) return rc;
+        if (*dstv) return set_error(FL_EINVAL, "%s was set twice", name);
+        return upload_f32(m, dstv, host, E);
+    }
     if (sub == "attention.wq.weight" || sub == "attention.wk.weight" || sub == "attention.wv.weight") {
         if ((rc = want_q(E, E)) != FL_OK) return rc;
         const int part = sub[11] == 'q' ? 0 : sub[11] == 'k' ? 1 : 2;
@@ -259,6 +270,7 @@ int fl_model_set_tensor(fl_model *m, const char *name, int type, const void *hos
         const bool is_wo = sub[0] == 'a';
         const int K = is_wo ? E : F, Kl = K / G;
         if ((rc = want_q(K, E)) != FL_OK) return rc;
+        if (is_wo ? ly.wo : ly.w2) return set_error(FL_EINVAL, "%s was set twice", name);
         void *tmp = nullptr;
         M_HIP(hipMalloc(&tmp, (size_t)E * (Kl / FL_QK) * bs));
         rc = stage_rows(host, bs, K / FL_QK, 0, E, r * (Kl / FL_QK), (r + 1) * (Kl / FL_QK), tmp);   // K blocks of rank r
@@ -331,7 +343,8 @@ int fl_model_finalize(fl_model *m) {
     if ((rc = dev_alloc(m, (void **)&m->att, (size_t)m->Hl * B * n_ctx * 4)) != FL_OK) return rc;
     if ((rc = dev_alloc(m, (void **)&m->ao, (size_t)B * El * 4)) != FL_OK) return rc;
     if ((rc = dev_alloc(m, (void **)&m->h13, (size_t)B * 2 * Fl * 4)) != FL_OK) return rc;
-    if ((rc = dev_alloc(m, (void **)&m->logits, (size_t)B * V * 4)) != FL_OK) return rc;
+    m->ldl = fl_roundup(V, 4);   // e.g. the 32001-token vocabularies of Alpaca / Vicuna style checkpoints
+    if ((rc = dev_alloc(m, (void **)&m->logits, (size_t)B * m->ldl * 4)) != FL_OK) return rc;
     if ((rc = qact_alloc(m, &m->qE, B, E)) != FL_OK) return rc;
     if ((rc = qact_alloc(m, &m->qEl, B, El)) != FL_OK) return rc;
     if ((rc = qact_alloc(m, &m->qF, B, Fl)) != FL_OK) return rc;
@@ -442,16 +455,20 @@ static int allreduce_if_tp(fl_model *m, float *buf, size_t count) {
 
 // The fixed kernel sequence of one eval (what ggml_graph_compute walks node by node in the reference).  `dyn` != null:
 // positions are read from device memory (m->npast_dev) instead of the n_past argument -- the decode hipGraph.
-static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool split_attn = false) {
+// [l0, l1): the layers to run; body_only: neither the token-embedding lookup before nor the final norm + lm-head after
+// (fl_model_debug_layers: the teacher-forced per-layer parity tests feed m->x themselves).
+static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool split_attn = false, int l0 = 0, int l1 = -1,
+                            bool body_only = false) {
     const int E = m->E, El = m->El, Fl = m->Fl, D = m->D, Hl = m->Hl, V = m->V, n_ctx = m->n_ctx;
     const int layout = N <= 8 ? 1 : 16;
     const int P = n_past + N;
     hipStream_t st = m->stream;
     const bool tp = m->G > 1;
     const bool fused = N == 1 && D <= 128 && D % 32 == 0 && E <= 8192 && Fl <= 32768 && m->fuse_decode;   // single-token kernels
-    M_HIP(get_rows_qw16(*m->tok_emb, m->tok_dev, N, m->x, E, st));                       // inpL = get_rows  llama.cpp:304
+    if (!body_only) M_HIP(get_rows_qw16(*m->tok_emb, m->tok_dev, N, m->x, E, st));      // inpL = get_rows  llama.cpp:304
     float *inp = m->x, *mid = m->x2;
-    for (int l = 0; l < m->L; ++l) {
+    if (l1 < 0) l1 = m->L;
+    for (int l = l0; l < l1; ++l) {
         const Layer &ly = m->layers[l];
         float *kc = m->kc + (size_t)l * n_ctx * El, *vc = m->vc + (size_t)l * n_ctx * El;
         if (fused) {
@@ -525,12 +542,13 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
             M_HIP(add_rows(m->part, E, mid, E, inp, E, N, E, st));
         }
     }
+    if (body_only) return FL_OK;
     // final norm (kept in f32 for the embeddings) + lm head                                        :452-465
     if (fused) {
         M_HIP(mm_norm(m, m->output, inp, m->norm_w, m->xn, m->logits));
     } else {
         M_HIP(rmsnorm_quant(inp, E, m->norm_w, N, E, m->xn, E, &m->qE, layout, st));
-        M_HIP(mm(m, m->output, m->qE, N, m->logits, V, nullptr, 0));
+        M_HIP(mm(m, m->output, m->qE, N, m->logits, m->ldl, nullptr, 0));
     }
     return FL_OK;
 }
@@ -574,8 +592,8 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
         if (rc != FL_OK) return rc;
     }
     if (logits_host) {
-        if (all_logits) M_HIP(hipMemcpyAsync(logits_host, m->logits, (size_t)N * V * 4, hipMemcpyDeviceToHost, st));
-        else M_HIP(hipMemcpyAsync(logits_host, m->logits + (size_t)(N - 1) * V, (size_t)V * 4, hipMemcpyDeviceToHost, st));
+        if (all_logits) M_HIP(hipMemcpy2DAsync(logits_host, (size_t)V * 4, m->logits, (size_t)m->ldl * 4, (size_t)V * 4, N, hipMemcpyDeviceToHost, st));
+        else M_HIP(hipMemcpyAsync(logits_host, m->logits + (size_t)(N - 1) * m->ldl, (size_t)V * 4, hipMemcpyDeviceToHost, st));
     }
     if (embeddings_host)
         M_HIP(hipMemcpyAsync(embeddings_host, m->xn + (size_t)(N - 1) * E, (size_t)E * 4, hipMemcpyDeviceToHost, st));
@@ -620,7 +638,61 @@ int fl_model_profile(fl_model *m, int enable, double *mm_ms_total, long *mm_laun
     return FL_OK;
 }
 
+/* test hook: layers [l0, l1) of Model::eval on a caller-provided layer input x_host [N][n_embd] (teacher forcing) at n_past;
+ * x_out_host receives the output of layer l1-1.  Afterwards the Q8_0 operands the last layer fed to its wo / w1|w3 / w2
+ * matmuls can be exported (which = 0 / 1 / 2) as block_q8_0 rows -- the discrete intermediates a rounding flip shows up in. */
+int fl_model_debug_layers(fl_model *m, int l0, int l1, const float *x_host, int N, int n_past, float *x_out_host) {
+    if (!m || !m->finalized || !x_host || !x_out_host) return set_error(FL_EINVAL, "fl_model_debug_layers: bad argument");
+    if (m->G != 1 || N < 9 || N > m->B || l0 < 0 || l1 > m->L || l0 >= l1 || n_past < 0 || n_past + N > m->n_ctx)
+        return set_error(FL_EINVAL, "fl_model_debug_layers: single-GPU prefill shapes only");
+    M_HIP(hipMemcpyAsync(m->x, x_host, (size_t)N * m->E * 4, hipMemcpyHostToDevice, m->stream));
+    const int rc = run_eval_kernels(m, N, n_past, nullptr, false, l0, l1, true);
+    if (rc != FL_OK) return rc;
+    M_HIP(hipMemcpyAsync(x_out_host, m->x, (size_t)N * m->E * 4, hipMemcpyDeviceToHost, m->stream));
+    M_HIP(hipStreamSynchronize(m->stream));
+    return FL_OK;
+}
+int fl_model_debug_export_q8(fl_model *m, int which, int N, void *blocks_host /* [N][K/32] block_q8_0 */) {
+    if (!m || !m->finalized || !blocks_host || which < 0 || which > 2 || N < 9) return set_error(FL_EINVAL, "bad argument");
+    const fl_qact &a = which == 0 ? m->qEl : which == 1 ? m->qE : m->qF;
+    const int K = a.KB * FL_QK;
+    void *tmp = nullptr;
+    M_HIP(hipMalloc(&tmp, (size_t)N * a.KB * 40));
+    hipError_t e = export_qa16_to_aos(a, N, K, tmp, m->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(blocks_host, tmp, (size_t)N * a.KB * 40, hipMemcpyDeviceToHost, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    (void)hipFree(tmp);
+    return e == hipSuccess ? FL_OK : hip_fail(e, "fl_model_debug_export_q8");
+}
+
 const float *fl_model_logits_dev(const fl_model *m) { return m ? m->logits : nullptr; }
+int fl_model_logits_ld(const fl_model *m) { return m ? m->ldl : 0; }
+
+/* rows [row0, row0 + rows) of the logits the last eval left in HBM -> host ([rows][n_vocab], dense) */
+int fl_model_logits_read(fl_model *m, int row0, int rows, float *logits_host) {
+    if (!m || !m->finalized || !logits_host || row0 < 0 || rows < 1 || row0 + rows > m->B) return set_error(FL_EINVAL, "fl_model_logits_read: bad argument");
+    M_HIP(hipMemcpy2DAsync(logits_host, (size_t)m->V * 4, m->logits + (size_t)row0 * m->ldl, (size_t)m->ldl * 4, (size_t)m->V * 4, rows,
+                           hipMemcpyDeviceToHost, m->stream));
+    M_HIP(hipStreamSynchronize(m->stream));
+    return FL_OK;
+}
+
+/* nll_host[i] = -log softmax(logits[row0 + i])[next_tokens_host[i]] of the last eval's logits, computed on the device:
+ * the per-row loop of FastLlama::perplexity (lib/bridge.cpp:397-407) without shipping rows x n_vocab floats to the host */
+int fl_model_logits_nll(fl_model *m, int row0, int rows, const int32_t *next_tokens_host, double *nll_host) {
+    if (!m || !m->finalized || !next_tokens_host || !nll_host || row0 < 0 || rows < 1 || row0 + rows > m->B)
+        return set_error(FL_EINVAL, "fl_model_logits_nll: bad argument");
+    for (int i = 0; i < rows; ++i)
+        if (next_tokens_host[i] < 0 || next_tokens_host[i] >= m->V) return set_error(FL_EINVAL, "fl_model_logits_nll: token outside the vocabulary");
+    double *out = nullptr;
+    M_HIP(hipMalloc((void **)&out, (size_t)rows * 8));
+    hipError_t e = hipMemcpyAsync(m->tok_dev, next_tokens_host, (size_t)rows * 4, hipMemcpyHostToDevice, m->stream);
+    if (e == hipSuccess) e = logits_nll(m->logits, m->ldl, m->V, m->tok_dev, row0, rows, out, m->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(nll_host, out, (size_t)rows * 8, hipMemcpyDeviceToHost, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    (void)hipFree(out);
+    return e == hipSuccess ? FL_OK : hip_fail(e, "fl_model_logits_nll");
+}
 void *fl_model_stream(const fl_model *m) { return m ? (void *)m->stream : nullptr; }
 size_t fl_model_device_bytes(const fl_model *m) { return m ? m->dev_bytes : 0; }
 

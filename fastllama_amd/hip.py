@@ -98,7 +98,12 @@ _PROTOS = {
     "fl_model_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "fl_model_profile": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "fl_model_set_graph": (C.c_int, [C.c_void_p, C.c_int]),
+    "fl_model_debug_layers": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "fl_model_debug_export_q8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "fl_model_logits_dev": (C.c_void_p, [C.c_void_p]),
+    "fl_model_logits_ld": (C.c_int, [C.c_void_p]),
+    "fl_model_logits_read": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "fl_model_logits_nll": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "fl_model_stream": (C.c_void_p, [C.c_void_p]),
     "fl_model_device_bytes": (C.c_size_t, [C.c_void_p]),
     "fl_model_kv_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

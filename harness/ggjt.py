@@ -75,20 +75,46 @@ def synth_tensors(cfg: dict, qtype: int, quantize, seed: int = 1234, scale: floa
     return out
 
 
-def write_ggjt(path: str, cfg: dict, qtype: int, tensors: dict):
+def write_ggjt(path: str, cfg: dict, qtype: int, tensors: dict, container: str = "ggjt"):
+    """container: "ggjt" (v1: scores in the vocabulary, tensor data aligned to 32 bytes), "ggmf" (v1: scores, no alignment) or
+    "ggml" (the unversioned original: no version word, no scores, no alignment) -- the three layouts the reference's loader
+    accepts (include/file_loader.hpp:94-250: read_magic_number :94-150, read_vocab :183-205, tensor alignment :236-240)."""
+    E, H, L = cfg["n_embd"], cfg["n_head"], cfg["n_layer"]
+    magic = {"ggjt": 0x67676A74, "ggmf": 0x67676D66, "ggml": 0x67676D6C}[container]
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", magic))
+        if container != "ggml":
+            f.write(struct.pack("<I", 1))
+        f.write(struct.pack("<7I", cfg["n_vocab"], E, cfg["n_mult"], H, L, E // H, qtype))
+        for t in vocab_tokens(cfg["n_vocab"]):
+            f.write(struct.pack("<I", len(t)) + t + (struct.pack("<f", 0.0) if container != "ggml" else b""))
+        for name, (gtype, shape, data) in tensors.items():
+            nb = name.encode()
+            f.write(struct.pack("<III", len(shape), len(nb), gtype))
+            f.write(struct.pack("<%dI" % len(shape), *shape))
+            f.write(nb)
+            if container == "ggjt":
+                f.write(b"\0" * ((-f.tell()) & 31))
+            f.write(np.ascontiguousarray(data).tobytes())
+
+
+def write_ggjt_stream(path: str, cfg: dict, qtype: int, tensor_iter):
+    """write_ggjt for models that do not fit in host memory twice: `tensor_iter` yields (name, (gtype, shape, data)) one at a
+    time (data: numpy array or torch tensor on any device), e.g. harness.synth.synth_model_tensors."""
     E, H, L = cfg["n_embd"], cfg["n_head"], cfg["n_layer"]
     with open(path, "wb") as f:
         f.write(struct.pack("<II", 0x67676A74, 1))
         f.write(struct.pack("<7I", cfg["n_vocab"], E, cfg["n_mult"], H, L, E // H, qtype))
         for t in vocab_tokens(cfg["n_vocab"]):
             f.write(struct.pack("<I", len(t)) + t + struct.pack("<f", 0.0))
-        for name, (gtype, shape, data) in tensors.items():
+        for name, (gtype, shape, data) in tensor_iter:
             nb = name.encode()
             f.write(struct.pack("<III", len(shape), len(nb), gtype))
             f.write(struct.pack("<%dI" % len(shape), *shape))
             f.write(nb)
             f.write(b"\0" * ((-f.tell()) & 31))
-            f.write(np.ascontiguousarray(data).tobytes())
+            arr = data.cpu().numpy() if hasattr(data, "cpu") else np.ascontiguousarray(data)
+            f.write(memoryview(np.ascontiguousarray(arr)).cast("B"))
 
 
 def write_ggjt_parts(path: str, cfg: dict, qtype: int, tensors: dict, n_parts: int):

@@ -66,9 +66,10 @@ def synth_q4(M: int, K: int, qtype: int, seed: int, device="cuda", scale: float 
     return out
 
 
-def synth_model_tensors(cfg, qtype, seed=1234, device="cuda"):
+def synth_model_tensors(cfg, qtype, seed=1234, device="cuda", scale=0.02):
     """Generator of (name, (gtype, shape, device tensor)) for a whole LLaMA-shaped model, in GGJT tensor order.
-    2-D weights ~ N(0, 0.02^2) quantized on the GPU (SURVEY.md 8d recipe); norm vectors 1 + 0.1 N(0,1)."""
+    2-D weights ~ N(0, 0.02^2) quantized on the GPU (SURVEY.md 8d recipe); norm vectors 1 + 0.1 N(0,1).
+    scale: a float, or a callable K -> sigma (e.g. lambda K: 0.5 / K ** 0.5 for a non-expansive network)."""
     from . import ggjt
     E, L, V = cfg["n_embd"], cfg["n_layer"], cfg["n_vocab"]
     F = cfg["n_ff"]
@@ -80,4 +81,4 @@ def synth_model_tensors(cfg, qtype, seed=1234, device="cuda"):
             yield name, (0, shape, v)
         else:
             K, M = shape
-            yield name, (qtype, shape, synth_q4(M, K, qtype, seed + t, device=device))
+            yield name, (qtype, shape, synth_q4(M, K, qtype, seed + t, device=device, scale=scale(K) if callable(scale) else scale))

@@ -194,7 +194,15 @@ int fl_model_lora_apply(fl_model *m, const char *base_name, const float *ba, con
 int fl_model_lora_restore(fl_model *m);
 /* this rank's rows of a base tensor as reference AoS blocks (block_q4_0 / block_q4_1), for tests and tooling */
 int fl_model_tensor_download(fl_model *m, const char *base_name, void *aos_host);
-const float *fl_model_logits_dev(const fl_model *m);
+/* test hooks (teacher-forced per-layer parity): layers [l0, l1) on a caller-provided layer input; then the Q8_0 operand the
+ * last layer fed to wo (which = 0), w1|w3 (1) or w2 (2), as block_q8_0 rows */
+int fl_model_debug_layers(fl_model *m, int l0, int l1, const float *x_host, int N, int n_past, float *x_out_host);
+int fl_model_debug_export_q8(fl_model *m, int which, int N, void *blocks_host);
+const float *fl_model_logits_dev(const fl_model *m); /* rows of fl_model_logits_ld() floats (n_vocab rounded up to 4) */
+int fl_model_logits_ld(const fl_model *m);
+int fl_model_logits_read(fl_model *m, int row0, int rows, float *logits_host);
+/* -log softmax(logits[row0 + i])[next_tokens_host[i]] on the device (FastLlama::perplexity's row loop, lib/bridge.cpp:397-407) */
+int fl_model_logits_nll(fl_model *m, int row0, int rows, const int32_t *next_tokens_host, double *nll_host);
 void *fl_model_stream(const fl_model *m);
 size_t fl_model_device_bytes(const fl_model *m);
 int fl_model_kv_read(const fl_model *m, float *k_host, float *v_host);

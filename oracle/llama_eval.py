@@ -140,20 +140,18 @@ class KV:
         self.v = np.zeros((n_layer, n_ctx, width), f32)   # (the reference stores V transposed; values are the same)
 
 
-def eval_tokens(w: Weights, kv: KV, tokens, n_past: int, port: Port | None = None, tp_rank: int = 0, tp_size: int = 1,
-                allreduce=None) -> tuple[np.ndarray, np.ndarray]:
-    """Model::eval for N tokens at n_past.  Returns (logits [N, V], embeddings [N, E] = final normed activations).
-    With tp_size > 1 this computes rank `tp_rank`'s shard (heads / ffn rows split, wo / w2 column blocks) and calls
-    allreduce(partial [N, E]) -> summed array after wo and w2 -- the exchange SURVEY.md 8(e) specifies."""
-    port = port or Port()
-    E, H, L = w.E, w.H, w.L
+def layer_forward(w: Weights, kv: KV, il: int, x: np.ndarray, n_past: int, port: Port, tp_rank: int = 0, tp_size: int = 1,
+                  allreduce=None):
+    """One transformer layer of Model::eval (lib/llama.cpp:308-443) on the layer input x [N, E].  Returns the layer output and
+    the f32 tensors whose Q8_0 quantization feeds the wo / w1|w3 / w2 matmuls ("att", "ffn_in", "act") -- the discrete
+    intermediates in which a rounding flip of an implementation that sums in another order becomes visible."""
+    E, H = w.E, w.H
     D = E // H
     G, r = tp_size, tp_rank
     El, Hl = E // G, H // G
     qt = w.qtype
-    N = len(tokens)
-    x = np.stack([port.dequantize_row(qt, w.q("tok_embeddings.weight")[t], E) for t in tokens])   # get_rows_q
-    for il in range(L):
+    N = x.shape[0]
+    if True:
         p = f"layers.{il}."
         cur = rms_norm_mul(x, w.f(p + "attention_norm.weight"))
         rows = slice(r * El, (r + 1) * El)
@@ -192,6 +190,24 @@ def eval_tokens(w: Weights, kv: KV, tokens, n_past: int, port: Port | None = Non
         if G > 1:
             part = allreduce(part)
         x = (part + x2).astype(f32)
+    return x, dict(att=att, ffn_in=cur, act=hh)
+
+
+def eval_tokens(w: Weights, kv: KV, tokens, n_past: int, port: Port | None = None, tp_rank: int = 0, tp_size: int = 1,
+                allreduce=None) -> tuple[np.ndarray, np.ndarray]:
+    """Model::eval for N tokens at n_past.  Returns (logits [N, V], embeddings [N, E] = final normed activations).
+    With tp_size > 1 this computes rank `tp_rank`'s shard (heads / ffn rows split, wo / w2 column blocks) and calls
+    allreduce(partial [N, E]) -> summed array after wo and w2 -- the exchange SURVEY.md 8(e) specifies."""
+    port = port or Port()
+    E, H, L = w.E, w.H, w.L
+    D = E // H
+    G, r = tp_size, tp_rank
+    El, Hl = E // G, H // G
+    qt = w.qtype
+    N = len(tokens)
+    x = np.stack([port.dequantize_row(qt, w.q("tok_embeddings.weight")[t], E) for t in tokens])   # get_rows_q
+    for il in range(L):
+        x, _ = layer_forward(w, kv, il, x, n_past, port, tp_rank, tp_size, allreduce)
     xn = rms_norm_mul(x, w.f("norm.weight"))
     logits = port.mul_mat_q(qt, w.q("output.weight"), xn)
     return logits, xn

@@ -221,6 +221,126 @@ def test_malformed_model_files_are_refused(libs, model_file, tmp_path):
     s.close()
 
 
+def _ref_python_binding():
+    """The reference's own interfaces/python/fastllama.py: from the reference tree when it is present (this container), else
+    its bytecode oracle/_ref/fastllama.pyc (compiled from where it lies by oracle/Makefile; the GPU box has no /root/reference)."""
+    import importlib.machinery
+    import importlib.util
+    src = "/root/reference/interfaces/python/fastllama.py"
+    pyc = os.path.join(oracle.REF_DIR, "fastllama.pyc")
+    if os.path.isfile(src):
+        spec = importlib.util.spec_from_file_location("ref_fastllama", src)
+    elif os.path.isfile(pyc):
+        spec = importlib.util.spec_from_loader("ref_fastllama", importlib.machinery.SourcelessFileLoader("ref_fastllama", pyc))
+    else:
+        pytest.skip("neither the reference tree nor oracle/_ref/fastllama.pyc is present")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_unmodified_reference_python_binding_runs_on_this_library(libs, model_file):
+    """fastllama.Model(path, library_path=libfastllama_hip.so) -- the reference's Python surface, unmodified -- loads, ingests,
+    generates and computes perplexity / logits ON THE GPU, with the values the plain ctypes driver gets from the same
+    library and the same token stream the reference library produces."""
+    import signal
+    ref_py = _ref_python_binding()
+    path, cfg = model_file
+    old = signal.getsignal(signal.SIGINT)
+    try:
+        m = ref_py.Model(path, num_threads=4, n_ctx=128, n_batch=32, should_get_all_logits=True, library_path=OURS)
+        ppl = m.perplexity(TEXT)
+        lg = np.array(m.get_logits(), dtype=np.float32)
+        s = llama_capi.Session(libs[1], path, n_ctx=128, n_batch=32, all_logits=True)
+        assert ppl == pytest.approx(s.perplexity(TEXT), rel=1e-6)
+        assert np.array_equal(lg, s.logits())
+        s.close()
+        m.reset()
+        assert m.ingest("The quick brown fox")
+        out = []
+        assert m.generate(num_tokens=12, temp=0.0, streaming_fn=lambda t: out.append(t))
+        rs = llama_capi.Session(libs[1], path, n_ctx=128, n_batch=32)          # the same library through the plain ctypes driver
+        assert rs.ingest("The quick brown fox")
+        ok, stream = rs.generate(12, temp=0.0)
+        assert ok and len(out) > 0 and "".join(out) == stream.decode("utf-8", "replace")
+    finally:
+        signal.signal(signal.SIGINT, old)
+
+
+@pytest.mark.parametrize("example", ["perplexity", "example"])
+def test_reference_c_examples_run_on_the_gpu(libs, tmp_path, example):
+    """The reference's examples/c programs, compiled unmodified against include/fastllama.h and linked against
+    libfastllama_hip.so (oracle/Makefile `clients`), run to completion on the GPU with a model at the path they hard-code."""
+    import subprocess
+    exe = os.path.join(oracle.REF_DIR, "ex_" + example)
+    if not os.path.isfile(exe):
+        pytest.skip("oracle/_ref/ex_* not built")
+    port = oracle.Port()
+    cfg, qtype = ggjt.TINY, ggjt.Q4_0
+    os.makedirs(tmp_path / "models" / "7B")
+    path = str(tmp_path / "models" / "7B" / "ggml-model-q4_0.bin")
+    ggjt.write_ggjt(path, cfg, qtype, ggjt.synth_tensors(cfg, qtype, port.quantize_q4, seed=77))
+    text = (TEXT + " ") * 12
+    (tmp_path / "test.txt").write_text(text)
+    run = subprocess.run([exe], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, (run.returncode, run.stdout[-500:], run.stderr[-500:])
+    if example == "perplexity":
+        got = float(run.stdout.rsplit("Total Perplexity:", 1)[1].split()[0])
+        s = llama_capi.Session(libs[1], path, n_ctx=512, n_batch=512, n_threads=16, n_keep=200)
+        assert got == pytest.approx(s.perplexity(text), rel=1e-4)
+        s.close()
+    else:
+        assert "Ingestion complete!" in run.stdout
+
+
+@pytest.mark.parametrize("container", ["ggmf", "ggml"])
+def test_older_containers_load_to_the_same_model(libs, tmp_path_factory, container):
+    """GGMF v1 (no tensor alignment) and the unversioned GGML container (no version word, no vocabulary scores) --
+    include/file_loader.hpp:94-250 -- load through llama_load_model to the model the GGJT file gives: identical logits
+    from this library, and the reference itself reads the same files to ITS GGJT logits (so the writer is right)."""
+    port = oracle.Port()
+    cfg, qtype = ggjt.TINY, ggjt.Q4_1
+    tensors = ggjt.synth_tensors(cfg, qtype, port.quantize_q4, seed=31)
+    d = tmp_path_factory.mktemp("cont")
+    paths = {c: str(d / f"tiny_{c}.bin") for c in ("ggjt", container)}
+    for c, pth in paths.items():
+        ggjt.write_ggjt(pth, cfg, qtype, tensors, container=c)
+    assert os.path.getsize(paths[container]) < os.path.getsize(paths["ggjt"])          # no alignment padding (, no scores)
+    for lib in libs:
+        out = {}
+        for c, pth in paths.items():
+            s = llama_capi.Session(lib, pth, n_ctx=64, n_batch=32, all_logits=True)
+            assert s.perplexity(TEXT[:30]) > 0
+            out[c] = s.logits()
+            s.close()
+        assert out["ggjt"].size == 31 * cfg["n_vocab"] and np.array_equal(out[container], out["ggjt"])
+
+
+def test_vocabulary_size_not_a_multiple_of_four(tmp_path_factory):
+    """n_vocab = 323 (e.g. the 32001-token vocabularies of Alpaca / Vicuna style checkpoints): the lm-head GEMM writes rows
+    of 16-byte-aligned stride; prefill (N >= 9), small batches and decode all return n_vocab dense logits that agree
+    with the oracle eval."""
+    from harness.flmodel import FlModel
+    from oracle import llama_eval as le
+    port = oracle.Port()
+    cfg = dict(ggjt.TINY, n_vocab=323)
+    qtype = ggjt.Q4_0
+    tensors = ggjt.synth_tensors(cfg, qtype, port.quantize_q4, seed=5)
+    toks = ggjt.text_tokens(TEXT[:20])
+    want, _ = le.eval_tokens(le.Weights(cfg, qtype, tensors), le.KV(cfg["n_layer"], 64, cfg["n_embd"]), toks, 0, port)
+    m = FlModel(cfg, qtype, tensors, n_ctx=64, max_batch=32)
+    got = m.eval(toks, all_logits=True)                       # MFMA GEMM path
+    assert got.shape == (len(toks), 323) and rel(got, want.astype(np.float64)) <= 5e-2
+    assert rel(got[0], want[0].astype(np.float64)) <= 1e-5
+    last = m.eval(toks, all_logits=False)                     # last row only
+    assert np.array_equal(last[0], got[-1])
+    small = m.eval(toks[:5], all_logits=True)                 # N <= 8: GEMV path
+    assert rel(small, want[:5].astype(np.float64)) <= 5e-2
+    one = m.eval([toks[5]], n_past=5)                         # decode hipGraph
+    assert np.isfinite(one).all() and one.shape == (1, 323)
+    m.free()
+
+
 @pytest.mark.parametrize("n_parts", [2, 4])
 def test_multi_part_checkpoint_merges_to_the_same_model(tmp_path_factory, n_parts):
     """<path>, <path>.1, ... (tok_embeddings / wo / w2 split by columns, the other matrices by rows) load to exactly the

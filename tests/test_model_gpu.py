@@ -1,8 +1,9 @@
 """GPU: the device-resident eval (fl_model_eval) against the reference's Model::eval, end to end.
 
 The reference is run LIVE through its own C-ABI (oracle/_ref/pyfastllama.so ships with the snapshot) on a
-synthetic GGJT model written by harness/ggjt.py; the same tensors are fed to fl_model.  North-star bar:
-logits within 1e-3 (max |diff| / max |ref|); measured headroom is ~100x (see the asserts).
+synthetic GGJT model written by harness/ggjt.py; the same tensors are fed to fl_model.  What is asserted, and why the
+north star's 1e-3 on logits holds only up to the first rounding flip, is in check_logits below; the configuration the
+headline is quoted on (7B, 32 layers, n_batch 512) and the flip accounting live in tests/test_parity_7b_gpu.py.
 """
 import os
 
@@ -13,7 +14,6 @@ import oracle
 from harness import ggjt, llama_capi
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-3          # BASELINE.json north_star: logits within 1e-3 (checked at LLaMA-7B width below)
 
 
 def check_logits(got, want, what=""):
@@ -25,9 +25,9 @@ def check_logits(got, want, what=""):
     occasionally flips one rounding; with a few hundred channels and a dozen keys nothing averages it out, and
     every later position that attends to the affected token moves by ~1e-2.  tests/test_llama_eval_oracle.py
     shows the CPU restatement of the reference behaves identically against the reference itself.  Hence:
-    position 0 (single key, no attention freedom) must agree to round-off, every position is bounded, and the
-    strict 1e-3 max-norm bar of the north star is asserted where it is meaningful -- at LLaMA-7B width
-    (test_llama7b_width_logits_within_1e_3)."""
+    position 0 (single key, no attention freedom; two or three layers) must agree to round-off, every position is
+    bounded.  tests/test_parity_7b_gpu.py measures the same thing stage by stage at 7B width (matmul stages 5e-7, a
+    handful of one-quantum flips per 262144 quants) and end to end on the full 32-layer model."""
     per_pos = np.max(np.abs(got.astype(np.float64) - want), axis=1) / np.max(np.abs(want))
     assert per_pos[0] <= 1e-5, (what, per_pos[0])
     assert per_pos.max() <= 5e-2, (what, per_pos.max())
