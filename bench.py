@@ -12,11 +12,12 @@ everything around it; nothing is skipped or cached.  Token ids and weights are r
 `value` = prefill tokens/s summed over ranks.  Decode (N=1, greedy position stepping, the wave-dot GEMV path) is
 reported beside it.
 
---parallel dp (default): every rank owns a full replica and its own batch -- the path's units (activation
-  columns / sequences) are independent, a 7B Q4 model is 4 GB of a 288 GB HBM, so N GPUs shard sequences with no
-  data-path collective (weak scaling).
---parallel tp: Megatron-style tensor parallel eval of ONE batch (wq/wk/wv/w1/w3 by rows, wo/w2 by
-  K blocks, two RCCL all-reduces of the [N, n_embd] partial sums per layer over xGMI); strong scaling.
+--gpus N > 1 (default --parallel auto): the headline is the TENSOR-PARALLEL eval of ONE batch (wq/wk/wv/w1/w3
+  by rows, wo/w2 by K blocks, lm-head by rows; two RCCL all-reduces of the [N, n_embd] partial sums per layer and one
+  all-gather of the logits over xGMI; decode replays one hipGraph with the collectives inside) -- strong scaling.  A
+  replica leg (every rank a full model and its own batch, no collective; weak scaling) is measured in the same run and
+  reported beside it under "replicas".  --parallel dp measures replicas only.
+  BASELINE.json configs 4 / 5: `bench.py --model 13B --gpus 2|4` and `bench.py --model 65B --gpus 8 --n-ctx 2048`.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, timed live with HIP events on the eval stream) and
 `cpu_baseline` (the reference's own ggml mul_mat path timed on this box's host cores, bounded sample).
@@ -89,18 +90,42 @@ def cpu_baseline(cfg, N, qtype, budget_s=25.0):
     }
 
 
+def cpu_config1(cfg, qtype, budget_s=12.0):
+    """BASELINE.json configs[0]: the reference's CPU path at num_threads = 8, n_ctx = 512, n_batch = 128 -- the
+    same bounded sample as cpu_baseline (one layer's matmuls + lm-head through the reference's ggml_graph_compute, extrapolated
+    to one 128-token eval), at exactly 8 threads."""
+    import oracle
+    from harness import synth
+    if not oracle.have_ref():
+        return None
+    E, F, V = cfg["n_embd"], cfg["n_ff"], cfg["n_vocab"]
+    shapes = {"EE": (E, E, 4), "FE": (F, E, 2), "EF": (E, F, 1), "VE": (V, E, 0)}
+    ref = oracle.Ref()
+    times = {}
+    for k, (M, K, _) in shapes.items():
+        wq = synth.synth_q4(M, K, qtype, 99).cpu().numpy()
+        x = np.random.default_rng(1).standard_normal((128, K), dtype=np.float32)
+        ts, _ = ref.timed_mul_mat(qtype, wq, x, 8, 2)
+        times[k] = float(np.median(ts))
+    per_eval = cfg["n_layer"] * sum(times[k] * shapes[k][2] for k in shapes) + times["VE"]
+    return {"value": 128 / per_eval, "unit": "tokens/s", "cores": 8, "kind": "reference", "n_batch": 128, "n_ctx": 512,
+            "sample": "BASELINE.json configs[0]: one layer's 7 mul_mat_q_f32 + lm-head at N=128, 8 threads, median of 2, extrapolated to one eval"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--model", default="7B")
+    ap.add_argument("--model", default="7B", help="7B | 13B | 30B | 65B (BASELINE.json configs 4/5: --model 13B|65B --gpus N)")
     ap.add_argument("--qtype", default="q4_0", choices=["q4_0", "q4_1"])
     ap.add_argument("--n-batch", type=int, default=512)
     ap.add_argument("--decode-steps", type=int, default=64)
     ap.add_argument("--n-ctx", type=int, default=0, help="context size (default max(1024, 2*n_batch)); the long-context "
                     "decode leg runs at its end")
-    ap.add_argument("--parallel", default="dp", choices=["dp", "tp"])
+    ap.add_argument("--parallel", default="auto", choices=["auto", "dp", "tp"],
+                    help="world > 1: tp = ONE batch, Megatron split + RCCL (the headline, strong scaling; a replica leg is measured "
+                         "and reported beside it), dp = replicas only.  auto = tp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -136,27 +161,8 @@ def main():
     n_ctx = max(args.n_ctx, 1024, 2 * N)
     L = hip.load()
     hip.require_device(local)
-    tp = args.parallel == "tp" and world > 1
-    model = FlModel(cfg, qtype, synth.synth_model_tensors(cfg, qtype), n_ctx=n_ctx, max_batch=N,
-                    tp_rank=rank if tp else 0, tp_size=world if tp else 1, device=local)
-    comm = None
-    if tp:
-        idbuf = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            raw = (ctypes.c_ubyte * 128)()
-            hip.check(L.fl_comm_unique_id(raw))
-            idbuf = torch.tensor(list(raw), dtype=torch.uint8)
-        idbuf = idbuf.cuda()
-        dist.broadcast(idbuf, src=0)
-        raw = (ctypes.c_ubyte * 128)(*idbuf.cpu().tolist())
-        comm = L.fl_comm_create(raw, rank, world)
-        if not comm:
-            raise SystemExit("fl_comm_create failed: " + L.fl_last_error().decode())
-        model.set_comm(ctypes.c_void_p(comm))
-
-    rng = np.random.default_rng(7 + (0 if tp else rank))
-    toks = rng.integers(3, 259, size=N).astype(np.int32)      # uniform ids in [3, 258]
-    tok1 = toks[:1].copy()
+    want_tp = world > 1 and args.parallel in ("auto", "tp") and cfg["n_head"] % world == 0 and backend == "nccl"
+    wk, wk1 = synth.algorithmic_work(cfg, N, qtype), synth.algorithmic_work(cfg, 1, qtype)
 
     def barrier():
         if dist is not None:
@@ -177,105 +183,152 @@ def main():
         barrier()
         return dt
 
-    # ---------------- prefill (the headline): K timed evals after W warm-ups ----------------
-    prefill = lambda i: model.eval_nocopy(toks, 0)
-    for i in range(args.warmup):
-        prefill(i)
-    dt = timed(prefill, args.steps)
-    ms_per_step = dt / args.steps * 1e3
-    seqs = 1 if tp else world
-    value = N * seqs / (dt / args.steps)
-
-    # ---------------- decode leg: N = 1 at n_past = 128.. (KV holds the prefill) ----------------
-    dec = lambda i: model.eval_nocopy(tok1, 128 + i)
-    for i in range(3):
-        dec(i)
-    ddt = timed(dec, args.decode_steps)
-    decode_ms = ddt / args.decode_steps * 1e3
-
-    # ---------------- the same at the end of the context (K/V stream of n_past positions per layer; two-launch attention) ----
-    long_steps = min(32, args.decode_steps)
-    long_past = n_ctx - long_steps - 4
-    decl = lambda i: model.eval_nocopy(tok1, long_past + i)
-    for i in range(3):
-        decl(i)
-    decode_long_ms = timed(decl, long_steps) / long_steps * 1e3
-
-    # ---------------- roofline of the dominant kernels: HIP events around every matmul launch -----
-    def pmc_traffic(kernel):
-        """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3 --pmc
-        FETCH_SIZE / WRITE_SIZE, gfx950 correction applied) -- valid for the default 7B Q4_0 n_batch=512 workload."""
+    def pmc_traffic(kernel, tp):
+        """HBM bytes per launch from the committed PMC passes (profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE /
+        WRITE_SIZE in separate passes, gfx950 correction applied) -- valid for the default 7B Q4_0 n_batch=512 workload."""
         try:
             if args.model != "7B" or qtype != 2 or N != 512 or tp:
                 return None
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
                 return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
         except Exception:
             return None
 
-    wk, wk1 = synth.algorithmic_work(cfg, N, qtype), synth.algorithmic_work(cfg, 1, qtype)
-    shard = world if tp else 1
-    model.profile(1)
-    for i in range(max(2, args.steps // 3)):
-        prefill(i)
-    mm_ms, n_launch = model.profile(0)
-    evals = max(2, args.steps // 3)
-    tops = wk["flops"] / shard * evals / (mm_ms * 1e-3) / 1e12
-    roofline = {
-        "kernel": "gemm_q4_mfma_kernel<Q4_%d,...>" % (qtype - 2), "bound": "mfma",
-        "achieved": tops, "peak": PEAK_I8_TOPS, "unit": "TOP/s", "frac": tops / PEAK_I8_TOPS,
-        "traffic": pmc_traffic("gemm_q4_mfma_kernel"),
-        "launches_per_step": n_launch // evals, "avg_launch_us": mm_ms * 1e3 / max(1, n_launch),
-        "algorithmic_flops_per_launch": wk["flops"] / shard / (n_launch / evals),
-        "note": ("ALGORITHMIC 2*M*K*N of the 225 mul_mat_q_f32 (fused into %d launches) / event-timed launch durations; "
-                 "the exact per-32-block scaling forces the K=32 i8 MFMA (2.5 PTOP/s peak) plus 8 scalar VALU ops per "
-                 "16x16x32 tile that do not overlap the MFMA on gfx950 -> measured instruction-mix floor ~0.9 PTOP/s "
-                 "(DESIGN.md, scripts/ubench/coexec2.hip); traffic = HBM bytes per launch from profiles/r01_pmc_traffic.json") % (n_launch // evals),
-    }
-    model.profile(1)
-    for i in range(8):
-        dec(i)
-    mm1_ms, n1 = model.profile(0)
-    gbs = wk1["bytes"] / shard * 8 / (mm1_ms * 1e-3) / 1e9
-    roofline_decode = {
-        "kernel": "gemv_q4_kernel<Q4_%d,1>" % (qtype - 2), "bound": "hbm",
-        "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-        "traffic": pmc_traffic("gemv_q4_kernel"),
-        "launches_per_step": n1 // 8, "avg_launch_us": mm1_ms * 1e3 / max(1, n1),
-        "algorithmic_bytes_per_launch": wk1["bytes"] / shard / (n1 / 8),
-    }
+    def run_leg(tp):
+        """One model (a replica per rank, or this rank's tensor-parallel shard) through the prefill / decode / roofline legs."""
+        model = FlModel(cfg, qtype, synth.synth_model_tensors(cfg, qtype), n_ctx=n_ctx, max_batch=N,
+                        tp_rank=rank if tp else 0, tp_size=world if tp else 1, device=local)
+        comm = None
+        if tp:
+            idbuf = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                raw = (ctypes.c_ubyte * 128)()
+                hip.check(L.fl_comm_unique_id(raw))
+                idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+            idbuf = idbuf.cuda()
+            dist.broadcast(idbuf, src=0)
+            raw = (ctypes.c_ubyte * 128)(*idbuf.cpu().tolist())
+            comm = L.fl_comm_create(raw, rank, world)
+            if not comm:
+                raise SystemExit("fl_comm_create failed: " + L.fl_last_error().decode())
+            model.set_comm(ctypes.c_void_p(comm))
+        rng = np.random.default_rng(7 + (0 if tp else rank))
+        toks = rng.integers(3, 259, size=N).astype(np.int32)      # SURVEY.md 8d: uniform ids in [3, 258]
+        tok1 = toks[:1].copy()
+        seqs = 1 if tp else world
+        shard = world if tp else 1
+        r = {"seqs": seqs}
+        # ---- prefill (the headline): K timed evals after W warm-ups
+        prefill = lambda i: model.eval_nocopy(toks, 0)
+        for i in range(args.warmup):
+            prefill(i)
+        dt = timed(prefill, args.steps)
+        r["ms_per_step"] = dt / args.steps * 1e3
+        r["prefill_tokens_per_s"] = N * seqs / (dt / args.steps)
+        # ---- decode: N = 1 at n_past = 128.. (KV holds the prefill)
+        dec = lambda i: model.eval_nocopy(tok1, 128 + i)
+        for i in range(3):
+            dec(i)
+        r["decode_ms"] = timed(dec, args.decode_steps) / args.decode_steps * 1e3
+        # ---- the same at the end of the context (K/V stream of n_past positions per layer; two-launch attention)
+        long_steps = min(32, args.decode_steps)
+        r["long_past"] = n_ctx - long_steps - 4
+        decl = lambda i: model.eval_nocopy(tok1, r["long_past"] + i)
+        for i in range(3):
+            decl(i)
+        r["decode_long_ms"] = timed(decl, long_steps) / long_steps * 1e3
+        # ---- roofline of the dominant kernels: HIP events around every matmul launch on the eval stream
+        model.profile(1)
+        evals = max(2, args.steps // 3)
+        for i in range(evals):
+            prefill(i)
+        mm_ms, n_launch = model.profile(0)
+        tops = wk["flops"] / shard * evals / (mm_ms * 1e-3) / 1e12
+        r["roofline"] = {
+            "kernel": "gemm_q4_mfma32_kernel<Q4_%d,...>" % (qtype - 2), "bound": "mfma",
+            "achieved": tops, "peak": PEAK_I8_TOPS, "unit": "TOP/s", "frac": tops / PEAK_I8_TOPS,
+            "traffic": pmc_traffic("gemm_q4_mfma32_kernel", tp),
+            "launches_per_step": n_launch // evals, "avg_launch_us": mm_ms * 1e3 / max(1, n_launch),
+            "algorithmic_flops_per_launch": wk["flops"] / shard / (n_launch / evals),
+            "note": ("ALGORITHMIC 2*M*K*N of the %d mul_mat_q_f32 (fused into %d launches) / event-timed launch durations.  peak = "
+                     "the 5 POP/s dense int8 MFMA rate, which v_mfma_i32_32x32x32_i8 (K = 32 = one quant block) runs at; the exact "
+                     "per-block scaling adds 32 VALU ops + half an f32 outer-product MFMA per 32x32 tile and block, and on gfx950 the "
+                     "VALU and the matrix pipe of a SIMD do not overlap: measured instruction-mix ceiling ~1.0 POP/s (DESIGN.md 3.1, "
+                     "profiles/r02_ubench_coexec3.txt)") % (wk["n_matmuls"], n_launch // evals),
+        }
+        model.profile(1)
+        for i in range(8):
+            dec(i)
+        mm1_ms, n1 = model.profile(0)
+        gbs = wk1["bytes"] / shard * 8 / (mm1_ms * 1e-3) / 1e9
+        r["roofline_decode"] = {
+            "kernel": "gemv_q4_kernel<Q4_%d,1>" % (qtype - 2), "bound": "hbm",
+            "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+            "traffic": pmc_traffic("gemv_q4_kernel", tp),
+            "launches_per_step": n1 // 8, "avg_launch_us": mm1_ms * 1e3 / max(1, n1),
+            "algorithmic_bytes_per_launch": wk1["bytes"] / shard / (n1 / 8),
+        }
+        r["model_device_bytes"] = hip.load().fl_model_device_bytes(model.h)
+        barrier()
+        model.free()
+        if comm:
+            L.fl_comm_destroy(ctypes.c_void_p(comm))
+        torch.cuda.empty_cache()
+        return r
 
+    legs = {}
+    if world == 1 or not want_tp or args.parallel == "auto":
+        legs["dp"] = run_leg(False)          # replicas (world == 1: the single-GPU measurement)
+    if want_tp:
+        legs["tp"] = run_leg(True)
+    head = legs["tp"] if "tp" in legs else legs["dp"]
+    tp = "tp" in legs
+    # fraction of the HBM roofline BASELINE.json's target is written in: time to move the ALGORITHMIC bytes of one step
+    # (SURVEY.md 8d: Q4 weights once + f32 activations in and out of the 225 matmuls) at 8 TB/s / measured time per step
+    shard = world if tp else 1
+    t_hbm_prefill_ms = wk["bytes"] / shard / (PEAK_HBM_GBS * 1e9) * 1e3
+    t_hbm_decode_ms = wk1["bytes"] / shard / (PEAK_HBM_GBS * 1e9) * 1e3
     out = {
         "metric": "tokens/sec (prefill n_batch=512 + decode) LLaMA-7B Q4_0",
-        "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if tp else "weak", "vs_baseline": None,
+        "value": head["prefill_tokens_per_s"], "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong" if tp else "weak", "vs_baseline": None,
         "dtype": "i8", "data": "synthetic",
         "config": {
             "workload": (f"LLaMA-{args.model} {args.qtype.upper()} n_batch={N} prefill; step = one full device-resident "
                          f"Model::eval (n_past=0, {wk['n_matmuls']} mul_mat_q_f32 + attention/norm/rope ops), synthetic weights"),
-            "n_batch": N, "n_ctx": n_ctx, "global_batch_tokens": N * seqs,
-            "parallelism": (f"tp{world} (one batch, Megatron split, 2 RCCL all-reduces per layer)" if tp else
+            "n_batch": N, "n_ctx": n_ctx, "global_batch_tokens": N * head["seqs"],
+            "parallelism": (f"tp{world} (ONE batch: wq/wk/wv/w1/w3 by rows, wo/w2 by K blocks, lm-head by rows; 2 RCCL all-reduces per layer "
+                            f"+ 1 all-gather of the logits over xGMI)" if tp else
                             f"dp{world} (one model replica and one batch per GPU, no data-path collective)"),
         },
-        "prefill_tokens_per_s": value,
-        "decode_tokens_per_s": seqs / (decode_ms * 1e-3), "decode_ms_per_token": decode_ms,
-        "decode_long_context": {"n_past": long_past, "tokens_per_s": seqs / (decode_long_ms * 1e-3),
-                                "ms_per_token": decode_long_ms},
-        "roofline": roofline, "roofline_decode": roofline_decode,
-        "model_device_bytes": hip.load().fl_model_device_bytes(model.h),
+        "prefill_tokens_per_s": head["prefill_tokens_per_s"],
+        "decode_tokens_per_s": head["seqs"] / (head["decode_ms"] * 1e-3), "decode_ms_per_token": head["decode_ms"],
+        "decode_long_context": {"n_past": head["long_past"], "tokens_per_s": head["seqs"] / (head["decode_long_ms"] * 1e-3),
+                                "ms_per_token": head["decode_long_ms"]},
+        "hbm_roofline": {"peak_GBs": PEAK_HBM_GBS,
+                         "prefill": {"algorithmic_bytes_per_step": wk["bytes"] / shard, "t_hbm_ms": t_hbm_prefill_ms,
+                                     "frac": t_hbm_prefill_ms / head["ms_per_step"]},
+                         "decode": {"algorithmic_bytes_per_token": wk1["bytes"] / shard, "t_hbm_ms": t_hbm_decode_ms,
+                                    "frac": t_hbm_decode_ms / head["decode_ms"]},
+                         "note": "whole-step fractions (every kernel of the eval, not only the matmuls); BASELINE.json's target is 0.40 for prefill"},
+        "roofline": head["roofline"], "roofline_decode": head["roofline_decode"],
+        "model_device_bytes": head["model_device_bytes"],
     }
+    if tp and "dp" in legs:
+        d = legs["dp"]
+        out["replicas"] = {"scaling": "weak", "parallelism": f"dp{world}: a full replica and its own batch per GPU, no collective",
+                           "prefill_tokens_per_s": d["prefill_tokens_per_s"], "ms_per_step": d["ms_per_step"],
+                           "decode_tokens_per_s": d["seqs"] / (d["decode_ms"] * 1e-3)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(cfg, N, qtype)
+            out["cpu_baseline"]["config1"] = cpu_config1(cfg, qtype)
         except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "unavailable",
                                    "sample": f"failed: {e!r}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     barrier()
-    model.free()
-    if comm:
-        L.fl_comm_destroy(ctypes.c_void_p(comm))
     if dist is not None:
         dist.destroy_process_group()
 

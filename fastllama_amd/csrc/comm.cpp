@@ -26,6 +26,7 @@ struct LocalGroup {
     int world = 1, arrived = 0, refs = 0;
     unsigned long gen = 0;
     float *bufs[FL_COMM_MAX_LOCAL] = {nullptr};
+    float *recvs[FL_COMM_MAX_LOCAL] = {nullptr};   // all-gather destinations
     size_t count = 0;
     int status = FL_OK;        // of the round being collected
     int done_status = FL_OK;   // of the round that just completed
@@ -125,6 +126,65 @@ int fl_comm_allreduce_sum_f32(fl_comm *c, float *buf_dev, size_t count, void *st
     ncclResult_t r = ncclAllReduce(buf_dev, buf_dev, count, ncclFloat32, ncclSum, c->comm, reinterpret_cast<hipStream_t>(stream));
     if (r != ncclSuccess) return set_error(FL_EHIP, "ncclAllReduce: %s", ncclGetErrorString(r));
     return FL_OK;
+}
+
+// recv[r * count + i] <- rank r's send[i]: the logits slices of the row-split lm-head
+static int local_allgather(fl_comm *c, const float *send, size_t count, float *recv, hipStream_t st) {
+    LocalGroup *g = c->lg;
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return set_error(FL_EHIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
+    std::unique_lock<std::mutex> lk(g->mu);
+    const unsigned long my_gen = g->gen;
+    g->bufs[c->rank] = const_cast<float *>(send);
+    g->recvs[c->rank] = recv;
+    if (g->arrived == 0) { g->count = count; g->status = FL_OK; }
+    else if (g->count != count) g->status = FL_EINVAL;
+    if (++g->arrived == g->world) {
+        if (g->status == FL_OK) {
+            for (int d = 0; d < g->world && e == hipSuccess; ++d)
+                for (int r = 0; r < g->world && e == hipSuccess; ++r)
+                    e = hipMemcpyAsync(g->recvs[d] + (size_t)r * count, g->bufs[r], count * 4, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) g->status = FL_EHIP;
+        }
+        g->done_status = g->status;
+        g->arrived = 0;
+        ++g->gen;
+        g->cv.notify_all();
+    } else {
+        g->cv.wait(lk, [&] { return g->gen != my_gen; });
+    }
+    const int rc = g->done_status;
+    return rc == FL_OK ? FL_OK : set_error(rc, "local all-gather failed (mismatched counts or a device error)");
+}
+
+int fl_comm_allgather_f32(fl_comm *c, const float *send_dev, size_t count, float *recv_dev, void *stream) {
+    if (!c || !send_dev || !recv_dev) return set_error(FL_EINVAL, "fl_comm_allgather: null argument");
+    if (c->lg) return local_allgather(c, send_dev, count, recv_dev, reinterpret_cast<hipStream_t>(stream));
+    ncclResult_t r = ncclAllGather(send_dev, recv_dev, count, ncclFloat32, c->comm, reinterpret_cast<hipStream_t>(stream));
+    if (r != ncclSuccess) return set_error(FL_EHIP, "ncclAllGather: %s", ncclGetErrorString(r));
+    return FL_OK;
+}
+
+int fl_comm_is_local(const fl_comm *c) { return c && c->lg ? 1 : 0; }
+
+/* test hook: one all-reduce captured into a hipGraph and replayed `replays` times (RCCL collectives inside the decode graph) */
+int fl_comm_debug_graph_allreduce(fl_comm *c, float *buf_dev, size_t count, int replays, void *stream) {
+    if (!c || c->lg || !buf_dev || !stream) return set_error(FL_EINVAL, "fl_comm_debug_graph_allreduce: needs an RCCL communicator and a stream");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ex = nullptr;
+    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) return set_error(FL_EHIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+    const int rc = fl_comm_allreduce_sum_f32(c, buf_dev, count, stream);
+    e = hipStreamEndCapture(st, &g);
+    if (rc != FL_OK || e != hipSuccess) { if (g) (void)hipGraphDestroy(g); return set_error(FL_EHIP, "capture of ncclAllReduce failed"); }
+    e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    for (int i = 0; i < replays && e == hipSuccess; ++i) e = hipGraphLaunch(ex, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (ex) (void)hipGraphExecDestroy(ex);
+    return e == hipSuccess ? FL_OK : set_error(FL_EHIP, "graph replay of ncclAllReduce: %s", hipGetErrorString(e));
 }
 
 int fl_comm_rank(const fl_comm *c) { return c ? c->rank : -1; }

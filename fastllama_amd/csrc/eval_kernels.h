@@ -43,6 +43,7 @@ hipError_t lora_add_aos(int type, void *aos, int KB, int row0, int rows, int il_
 // quantize_row_q4_{0,1} (SIMD flavour) / *_reference on AoS blocks: f32 [k] -> block_q4_x [k/32]
 hipError_t quantize_row_q4_aos(int type, bool reference, const float *x, void *y, int64_t k, hipStream_t st);
 hipError_t logits_nll(const float *logits, int ld, int V, const int *next_tok_dev, int j0, int rows, double *out_dev, hipStream_t st);
+hipError_t gather_cols(const float *tmp, int G, int N, int Vl, int ldp, float *out, int ldo, hipStream_t st);
 hipError_t add_rows(const float *a, int lda, const float *b, int ldb, float *o, int ldo, int N, int E, hipStream_t st);
 
 }  // namespace fl

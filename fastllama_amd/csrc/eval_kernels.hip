@@ -1248,4 +1248,18 @@ hipError_t logits_nll(const float *logits, int ld, int V, const int *next_tok_de
     return hipGetLastError();
 }
 
+
+// out[n][r * Vl + j] = tmp[r][n][j]: the all-gathered logits slices of the row-split lm-head back into [N][n_vocab] rows
+__global__ void gather_cols_kernel(const float *__restrict__ tmp, int G, int N, int Vl, int ldp, float *__restrict__ out, int ldo) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)G * N * Vl) return;
+    const int j = (int)(gid % Vl), n = (int)((gid / Vl) % N), r = (int)(gid / ((int64_t)Vl * N));
+    out[(int64_t)n * ldo + (int64_t)r * Vl + j] = tmp[((int64_t)r * N + n) * ldp + j];
+}
+hipError_t gather_cols(const float *tmp, int G, int N, int Vl, int ldp, float *out, int ldo, hipStream_t st) {
+    const int64_t total = (int64_t)G * N * Vl;
+    hipLaunchKernelGGL(gather_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, tmp, G, N, Vl, ldp, out, ldo);
+    return hipGetLastError();
+}
+
 }  // namespace fl

@@ -52,6 +52,10 @@ struct Layer {
 struct fl_model {
     fl_model_params hp{};
     int E = 0, H = 0, D = 0, F = 0, V = 0, L = 0, n_ctx = 0, B = 0, qtype = 0;
+    int Vl = 0, ldp = 0;        // tensor parallel with n_vocab % tp_size == 0: the lm-head is split by rows (V/G logits per rank,
+                                // all-gathered): local rows, row stride of `logits_part`.  Vl == 0: lm-head replicated
+    float *logits_part = nullptr, *gather_tmp = nullptr;
+    bool tp_graph_failed = false;   // capturing the RCCL collectives into the decode hipGraph failed once: plain launches from then on
     int ldl = 0;                // row stride of `logits` (n_vocab rounded up to 4: 16-byte rows for the GEMM's vector stores)
     int G = 1, rank = 0;        // tensor parallel
     int El = 0, Hl = 0, Fl = 0; // local (per rank) widths
@@ -148,6 +152,7 @@ fl_model *fl_model_create(const fl_model_params *p) {
     m->G = G; m->rank = p->tp_rank;
     m->El = m->E / G; m->Hl = m->H / G; m->Fl = m->F / G;
     m->w13_il = m->Fl % 32 == 0;
+    if (G > 1 && m->V % G == 0) { m->Vl = m->V / G; m->ldp = fl_roundup(m->Vl, 4); }
     m->layers.resize(m->L);
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
         set_error(FL_EHIP, "hipStreamCreate failed");
@@ -233,10 +238,12 @@ int fl_model_set_tensor(fl_model *m, const char *name, int type, const void *hos
         if ((rc = want_q(E, V)) != FL_OK) return rc;
         fl_qtensor **dst = nm[0] == 't' ? &m->tok_emb : &m->output;
         if (*dst) return set_error(FL_EINVAL, "%s was set twice", name);
+        const bool split = nm[0] == 'o' && m->Vl > 0;      // lm-head: rows [r Vl, (r+1) Vl) of rank r
+        const int rows = split ? m->Vl : V, row0 = split ? r * m->Vl : 0;
         void *tmp = nullptr;
-        M_HIP(hipMalloc(&tmp, (size_t)V * (E / FL_QK) * bs));
-        rc = stage_rows(host, bs, E / FL_QK, 0, V, 0, E / FL_QK, tmp);
-        if (rc == FL_OK) rc = make_qtensor(m, dst, tmp, V, E);
+        M_HIP(hipMalloc(&tmp, (size_t)rows * (E / FL_QK) * bs));
+        rc = stage_rows(host, bs, E / FL_QK, row0, rows, 0, E / FL_QK, tmp);
+        if (rc == FL_OK) rc = make_qtensor(m, dst, tmp, rows, E);
         (void)hipFree(tmp);
         return rc;
     }
@@ -345,6 +352,10 @@ int fl_model_finalize(fl_model *m) {
     if ((rc = dev_alloc(m, (void **)&m->h13, (size_t)B * 2 * Fl * 4)) != FL_OK) return rc;
     m->ldl = fl_roundup(V, 4);   // e.g. the 32001-token vocabularies of Alpaca / Vicuna style checkpoints
     if ((rc = dev_alloc(m, (void **)&m->logits, (size_t)B * m->ldl * 4)) != FL_OK) return rc;
+    if (m->Vl > 0) {
+        if ((rc = dev_alloc(m, (void **)&m->logits_part, (size_t)B * m->ldp * 4)) != FL_OK) return rc;
+        if ((rc = dev_alloc(m, (void **)&m->gather_tmp, (size_t)m->G * B * m->ldp * 4)) != FL_OK) return rc;
+    }
     if ((rc = qact_alloc(m, &m->qE, B, E)) != FL_OK) return rc;
     if ((rc = qact_alloc(m, &m->qEl, B, El)) != FL_OK) return rc;
     if ((rc = qact_alloc(m, &m->qF, B, Fl)) != FL_OK) return rc;
@@ -544,11 +555,19 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
     }
     if (body_only) return FL_OK;
     // final norm (kept in f32 for the embeddings) + lm head                                        :452-465
+    float *lg = m->Vl > 0 ? m->logits_part : m->logits;
+    const int ldlg = m->Vl > 0 ? m->ldp : m->ldl;
     if (fused) {
-        M_HIP(mm_norm(m, m->output, inp, m->norm_w, m->xn, m->logits));
+        M_HIP(mm_norm(m, m->output, inp, m->norm_w, m->xn, lg));
     } else {
         M_HIP(rmsnorm_quant(inp, E, m->norm_w, N, E, m->xn, E, &m->qE, layout, st));
-        M_HIP(mm(m, m->output, m->qE, N, m->logits, m->ldl, nullptr, 0));
+        M_HIP(mm(m, m->output, m->qE, N, lg, ldlg, nullptr, 0));
+    }
+    if (m->Vl > 0) {                                          // rows V/G of the lm-head per rank -> gather the logits slices
+        if (!m->comm) return set_error(FL_EINVAL, "tensor-parallel eval without a communicator");
+        const int rc = fl_comm_allgather_f32(m->comm, m->logits_part, (size_t)N * m->ldp, m->gather_tmp, st);
+        if (rc != FL_OK) return rc;
+        M_HIP(gather_cols(m->gather_tmp, m->G, N, m->Vl, m->ldp, m->logits, m->ldl, st));
     }
     return FL_OK;
 }
@@ -567,7 +586,10 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
     // Decode (N = 1) is launch-bound (~160 short kernels per token): the whole sequence is captured ONCE into a
     // hipGraph whose kernels read the position from device memory, and replayed per token.  Two captures: past
     // split_past positions a single workgroup per head no longer keeps up with the K/V stream (decode_attention_split).
-    const bool use_graph = N == 1 && m->G == 1 && m->graph_enabled && !m->profile;
+    // Under tensor parallelism the RCCL all-reduces / all-gather are captured with the kernels (every rank replays the same
+    // sequence); the single-process group of fl_comm_create_local rendezvouses on the host and cannot be captured.
+    const bool tp_capturable = m->G == 1 || (m->comm && !fl_comm_is_local(m->comm) && !m->tp_graph_failed && !getenv("FL_TP_NO_GRAPH"));
+    const bool use_graph = N == 1 && tp_capturable && m->graph_enabled && !m->profile;
     const bool split_attn = N == 1 && n_past >= m->split_past;
     if (use_graph) {
         hipGraphExec_t &exec = split_attn ? m->graph_exec_long : m->graph_exec;
@@ -580,12 +602,22 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
             M_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             const int rc = run_eval_kernels(m, 1, 0, m->npast_dev, split_attn);
             const hipError_t e = hipStreamEndCapture(st, &g);
-            if (rc != FL_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
-            if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
-            M_HIP(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(g);
+            hipError_t ei = hipSuccess;
+            if (rc == FL_OK && e == hipSuccess) ei = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+            if (g) (void)hipGraphDestroy(g);
+            if (rc != FL_OK || e != hipSuccess || ei != hipSuccess) {
+                exec = nullptr;
+                if (m->G == 1) return rc != FL_OK ? rc : hip_fail(e != hipSuccess ? e : ei, "decode graph capture");
+                (void)hipGetLastError();                   // collectives that cannot be captured here: plain launches
+                m->tp_graph_failed = true;
+            }
         }
-        M_HIP(hipGraphLaunch(exec, st));
+        if (exec) {
+            M_HIP(hipGraphLaunch(exec, st));
+        } else {
+            const int rc = run_eval_kernels(m, 1, n_past, nullptr, split_attn);
+            if (rc != FL_OK) return rc;
+        }
     } else {
         M_HIP(hipMemcpyAsync(m->tok_dev, tokens, (size_t)N * 4, hipMemcpyHostToDevice, st));
         const int rc = run_eval_kernels(m, N, n_past, nullptr, split_attn);
@@ -733,6 +765,7 @@ static int locate_tensor(fl_model *m, const char *name, TensorRef *o) {
     if (nm == "tok_embeddings.weight" || nm == "output.weight") {
         o->t = nm[0] == 't' ? m->tok_emb : m->output;
         o->rows = V; o->Kfull = E; o->Mfull = V;
+        if (nm[0] == 'o' && m->Vl > 0) { o->rows = m->Vl; o->grow0 = r * m->Vl; }
         return FL_OK;
     }
     int il = -1, off = 0;
@@ -890,7 +923,7 @@ void fl_model_free(fl_model *m) {
         fr(ly.s_qkv.aos); fr(ly.s_13.aos);
     }
     fr(m->kc); fr(m->vc); fr(m->exp_tab); fr(m->silu_tab); fr(m->rope_tab); fr(m->tok_dev);
-    fr(m->x); fr(m->x2); fr(m->xn); fr(m->part); fr(m->qkv); fr(m->att); fr(m->ao); fr(m->h13); fr(m->logits);
+    fr(m->x); fr(m->x2); fr(m->xn); fr(m->part); fr(m->qkv); fr(m->att); fr(m->ao); fr(m->h13); fr(m->logits); fr(m->logits_part); fr(m->gather_tmp);
     for (fl_qact *a : {&m->qE, &m->qEl, &m->qF}) { fr(a->q); fr(a->d); fr(a->s); }
     for (auto &bk : m->lora_backups) { fr(bk.qs); fr(bk.d); fr(bk.mm); }
     for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);

@@ -1,0 +1,67 @@
+"""One rank of a tensor-parallel eval over RCCL (one process per GPU).  Used by tests/test_model_gpu.py (2 ranks, skipped on
+a 1-GPU box) and runnable by hand on a multi-GPU node:
+
+    for r in 0 1; do python -m harness.tp_worker $r 2 /tmp/tp_id.bin /tmp/tp_out_$r.npz & done; wait
+
+Rank 0 writes the 128-byte RCCL id to <idfile>; the others wait for it.  Every rank evaluates the same synthetic SMALL model
+(harness/ggjt.py) on its own GPU: a prefill, a decode step through the captured hipGraph (RCCL collectives inside), and a
+plain-launch decode step; rank 0 additionally evaluates the unsharded model.  Results go to <outfile>."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def main():
+    rank, world, idfile, outfile = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import oracle
+    from fastllama_amd import hip
+    from harness import ggjt
+    from harness.flmodel import FlModel
+    torch.cuda.set_device(rank)
+    L = hip.load()
+    hip.require_device(rank)
+    raw = (C.c_ubyte * 128)()
+    if rank == 0:
+        hip.check(L.fl_comm_unique_id(raw), "fl_comm_unique_id")
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(bytes(raw))
+        os.replace(idfile + ".tmp", idfile)
+    else:
+        t0 = time.time()
+        while not os.path.exists(idfile):
+            if time.time() - t0 > 120:
+                raise SystemExit("no RCCL id from rank 0")
+            time.sleep(0.05)
+        raw = (C.c_ubyte * 128)(*open(idfile, "rb").read())
+    comm = L.fl_comm_create(raw, rank, world)
+    if not comm:
+        raise SystemExit("fl_comm_create: " + L.fl_last_error().decode())
+    comm = C.c_void_p(comm)
+    cfg, qtype = ggjt.SMALL, ggjt.Q4_0
+    tensors = ggjt.synth_tensors(cfg, qtype, oracle.Port().quantize_q4, seed=4321)
+    toks = ggjt.text_tokens("The quick brown fox jumps over the lazy dog")
+    m = FlModel(cfg, qtype, tensors, n_ctx=128, max_batch=64, tp_rank=rank, tp_size=world, device=rank)
+    m.set_comm(comm)
+    pre = m.eval(toks, all_logits=True)
+    dec_graph = m.eval([toks[3]], n_past=len(toks))
+    dec_graph2 = m.eval([toks[4]], n_past=len(toks) + 1)            # a replay of the captured graph
+    hip.check(L.fl_model_set_graph(m.h, 0))
+    dec_plain = m.eval([toks[4]], n_past=len(toks) + 1)
+    out = dict(pre=pre, dec_graph=dec_graph, dec_graph2=dec_graph2, dec_plain=dec_plain)
+    if rank == 0:
+        full = FlModel(cfg, qtype, tensors, n_ctx=128, max_batch=64, device=0)
+        out["full_pre"] = full.eval(toks, all_logits=True)
+        out["full_dec"] = full.eval([toks[3]], n_past=len(toks))
+        full.free()
+    np.savez(outfile, **out)
+    m.free()
+    L.fl_comm_destroy(comm)
+
+
+if __name__ == "__main__":
+    main()

@@ -148,6 +148,10 @@ fl_comm *fl_comm_create(const void *id_bytes, int rank, int world); /* on the CU
 #define FL_COMM_MAX_LOCAL 8
 int fl_comm_create_local(int world, fl_comm **out /* [world] */);
 int fl_comm_allreduce_sum_f32(fl_comm *c, float *buf_dev, size_t count, void *stream);
+/* recv_dev[r * count + i] <- rank r's send_dev[i] (the logits slices of the row-split lm-head) */
+int fl_comm_allgather_f32(fl_comm *c, const float *send_dev, size_t count, float *recv_dev, void *stream);
+int fl_comm_is_local(const fl_comm *c);
+int fl_comm_debug_graph_allreduce(fl_comm *c, float *buf_dev, size_t count, int replays, void *stream);
 int fl_comm_rank(const fl_comm *c);
 int fl_comm_size(const fl_comm *c);
 void fl_comm_destroy(fl_comm *c);

@@ -200,6 +200,51 @@ def test_rccl_world_of_one_allreduce():
     L.fl_comm_destroy(c)
 
 
+def test_rccl_allreduce_inside_a_hipgraph():
+    """ncclAllReduce captured into a hipGraph and replayed (what the tensor-parallel decode graph does per layer), on the
+    world of one a 1-GPU box offers: the capture / instantiate / replay path of RCCL itself."""
+    import ctypes as C
+    import torch
+    from fastllama_amd import hip
+    L = hip.load()
+    hip.require_device(0)
+    idb = (C.c_ubyte * 128)()
+    hip.check(L.fl_comm_unique_id(idb), "fl_comm_unique_id")
+    c = C.c_void_p(L.fl_comm_create(idb, 0, 1))
+    assert c, L.fl_last_error().decode()
+    x = torch.randn(4096, device="cuda")
+    want = x.clone()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        hip.check(L.fl_comm_debug_graph_allreduce(c, x.data_ptr(), x.numel(), 3, C.c_void_p(st.cuda_stream)), "graph allreduce")
+    torch.cuda.synchronize()
+    assert torch.equal(x, want)                  # sum over one rank, three times
+    L.fl_comm_destroy(c)
+
+
+def test_rccl_two_ranks_tensor_parallel(tmp_path):
+    """Two processes, two GPUs, RCCL over xGMI: the Megatron split with the row-split lm-head + all-gather, prefill and decode
+    (collectives captured in the decode hipGraph, then plain launches) against the unsharded model.  Needs two devices: the
+    gpurun box has one (skipped there); `harness/tp_worker.py` is the same program for a multi-GPU node."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the tensor-parallel path is covered on one GPU by test_tensor_parallel_shards_on_one_gpu)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    idf = str(tmp_path / "id.bin")
+    procs = [subprocess.Popen([sys.executable, "-m", "harness.tp_worker", str(r), "2", idf, str(tmp_path / f"out{r}.npz")], cwd=root)
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    o = [np.load(str(tmp_path / f"out{r}.npz")) for r in range(2)]
+    for k in ("pre", "dec_graph", "dec_graph2", "dec_plain"):
+        assert np.array_equal(o[0][k], o[1][k]), k                      # every rank ends with the full, identical logits
+    assert np.array_equal(o[0]["dec_graph2"], o[0]["dec_plain"])       # graph replay == plain launches
+    check_logits(o[0]["pre"], o[0]["full_pre"].astype(np.float64), "tp2 (RCCL) prefill vs unsharded")
+    assert relerr(o[0]["dec_graph"], o[0]["full_dec"]) <= 5e-2
+
+
 @pytest.mark.parametrize("cfgname,G", [("SMALL", 2), ("TINY", 4)])
 @pytest.mark.parametrize("qtype", [ggjt.Q4_0, ggjt.Q4_1])
 def test_tensor_parallel_shards_on_one_gpu(tmp_path_factory, port, qtype, cfgname, G):
