@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64 * WM, TYPE == FL_TYPE_Q4_1 ? 2 : MINW) FL_NOPK32
                 const float *pr = resid ? resid + (int64_t)n * ldr + row0 : nullptr;
                 if (row0 + 3 < M) {
                     if (pr) o += *reinterpret_cast<const v4f *>(pr);   // ggml_add(cur, inp) fused into the store
-                    *reinterpret_cast<v4f *>(p) = o;
+                    *reinterpret_cast<v4f *>(p) = o;     // (nontemporal stores here: 5-10 % slower, profiles/r02_gemm32_notes.md)
                 } else {
                     for (int r = 0; r < 4 && row0 + r < M; ++r) p[r] = o[r] + (pr ? pr[r] : 0.f);
                 }
