@@ -24,10 +24,16 @@ hipError_t gemm_f32_abt(const float *A, int lda, int64_t sAz, const float *B, in
 hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab,
                         hipStream_t st, const int *dyn_past = nullptr);
 // prefill: KQ*scale + mask + soft_max + KQV per (head, 32 query rows), score rows in LDS; q = roped Q rows of qkv,
-// kc / vc already hold the new positions.  hipErrorInvalidValue: shape does not fit -> use the three-kernel path.
+// kc / vc already hold the new positions.  When the rows do not fit LDS (deep contexts) the key-tiled form runs instead:
+// same launch count, the scores take one trip through `scratch` ([H] x s_head floats, rows of ld_s >= n_past + N floats,
+// ld_s % 32 == 0).  hipErrorInvalidValue: shape fits neither form -> use the three-kernel path.
 hipError_t prefill_attention(const float *qkv, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc,
                              const float *vc, const uint16_t *exp_tab, int tab_n, float scale, float *ao, int ldo,
-                             hipStream_t st, const fl_qact *qout = nullptr);   // qout: write Q8_0 (QA16) instead of ao
+                             hipStream_t st, const fl_qact *qout = nullptr,   // qout: write Q8_0 (QA16) instead of ao
+                             float *scratch = nullptr, int ld_s = 0, int64_t s_head = 0, int force_deep = 0);
+hipError_t prefill_attention_deep(const float *qkv, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc,
+                                  const float *vc, const uint16_t *exp_tab, int tab_n, float scale, float *scratch, int ld_s,
+                                  int64_t s_head, float *ao, int ldo, hipStream_t st, const fl_qact *qout);
 // decode (N = 1): rope + KV store + KQ + soft_max + KQV + Q8_0 of the result, one workgroup per head
 hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab, float *kc,
                             float *vc, const uint16_t *exp_tab, float scale, const fl_qact *out, hipStream_t st,

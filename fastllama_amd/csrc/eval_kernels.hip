@@ -633,32 +633,393 @@ extern "C" int fl_debug_pa_timing(long long *out) { return (int)hipMemcpyFromSym
 
 #undef PA_SEL
 
+// ------------------------------------------------------------------------------------------------
+// prefill attention at depth: the same function when a block's score rows no longer fit LDS (a second 512-token chunk
+// of a long prompt: 32 rows x 1024+ keys).  Key-tiled, one launch; the score rows take ONE trip through a scratch
+// buffer that only this workgroup touches (L2 / MALL resident) instead of four trips through HBM between three kernels.
+//
+// One 256-thread workgroup per (head, 32-row query block), heaviest blocks first, two workgroups per CU.
+//   phase 0  exp table and the block's roped Q rows -> LDS
+//   phase A  score tiles dealt round-robin to the 4 waves (the MFMA sequence of gemm_f32_abt_kernel), scaled, written
+//            to the scratch rows; every lane keeps the running max of its 16 rows -> row max over lanes and waves
+//   phase B  per row: f64 sum of the fp16 exp-table values of (score - max) -> 1 / sum        (softmax_rows_kernel)
+//   phase C  per chunk of 256 keys: probabilities p = rn(val * inv) of the 32 rows -> LDS, then wave w accumulates
+//            output columns [32w, 32w + 32) over the chunk's keys: A = p (LDS), B = transposed V cache
+//   phase D  Q8_0 of the result (or the f32 rows)
+// Scores, max, the exact f64 sum, p and the k order of the KQV accumulation (8-key steps pairing k with k + 4, then
+// (k, k+1) pairs for the tail: chunk boundaries are multiples of 8) are those of the three-kernel path: bit-identical.
+// ------------------------------------------------------------------------------------------------
+constexpr int PD_T = 256, PD_NW = PD_T / 64, PD_CH = 256, PD_LD = PD_CH + 4;
+#ifndef PD_ABL
+#define PD_ABL 0   // timing experiments only (scripts/attn_deep.py), never defined in the product
+#endif
+
+// fp16 exp-table values of x[j] - mx (masked x = -inf -> 0), NV lookups in flight together.  The table index is taken
+// from mx - x >= 0: rounding is sign-symmetric, so half(mx - x) is half(x - mx) without its sign bit, and the cases
+// softmax_rows_kernel tells apart collapse into one compare: +0 -> entry 0 = exp(-0) = 1; [0, tab_n) the table; up to +inf
+// (0x7C00; masked columns) exp underflows to 0 in fp16 (host-checked bound); NaNs and impossible negative differences -> NaN.
+// The empty asm pins every LDS read as unconditional: left alone the compiler turns the selects into one branch per
+// element around its lookup, which serialises the LDS round trips.
+template <int NV>
+__device__ __forceinline__ void pa_exp_vals(const float (&x)[NV], float mx, const uint16_t *tab, int tab_n, float (&out)[NV]) {
+    uint32_t t[NV], idx[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        idx[j] = __half_as_ushort(__float2half_rn(mx - x[j]));
+        t[j] = tab[min(idx[j], (uint32_t)(tab_n - 1))];
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) asm volatile("" : "+v"(t[j]));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const uint32_t e = idx[j] < (uint32_t)tab_n ? t[j] : idx[j] <= 0x7C00u ? 0u : 0x7E00u;
+        out[j] = __half2float(__ushort_as_half((uint16_t)e));
+    }
+}
+
+template <int NSTEP>   // head_dim / 8
+__global__ __launch_bounds__(PD_T, 2) void prefill_attention_deep_kernel(const float *__restrict__ qkv, int ldq, int N, int n_past,
+                                                                         int n_ctx, int E, const float *__restrict__ kc,
+                                                                         const float *__restrict__ vc,
+                                                                         const uint16_t *__restrict__ exp_tab, int tab_n,
+                                                                         float scale, float *S, int lds_, int64_t s_head,
+                                                                         float *__restrict__ ao, int ldo,
+                                                                         int8_t *__restrict__ oq, float *__restrict__ od,
+                                                                         float *__restrict__ os) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    constexpr int D = NSTEP * 8, QLD = D + 4, NT = D / 32;
+    const int h = blockIdx.x, nb = (N + 31) >> 5, mb = nb - 1 - (int)blockIdx.y;   // heavy blocks first
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, kk = lane >> 5;
+    const int P = n_past + N, m0 = mb * 32;
+    const int ke = min(P, n_past + m0 + 32);                          // keys any row of the block can see
+    const int ntl = (ke + 31) >> 5;
+    uint16_t *tab = reinterpret_cast<uint16_t *>(psm);
+    float *const U = reinterpret_cast<float *>(tab + ((tab_n + 7) & ~7));        // Q rows | p chunk | output tile
+    constexpr int U_FLOATS = 32 * QLD > 32 * PD_LD ? 32 * QLD : 32 * PD_LD;
+    static_assert(NT * 32 * 33 <= U_FLOATS, "output staging fits the union area");
+    float *const wmax = U + U_FLOATS;                                 // [PD_NW][32]
+    float *const rmax = wmax + PD_NW * 32;                            // [32]
+    float *const rinv = rmax + 32;                                    // [32]
+    float *const Srow = S + h * s_head;                               // scratch rows of this head: [N][lds_]
+    auto row_len = [&](int row) { return min(P, n_past + m0 + row + 1); };   // rows >= N: duplicates of row N - 1 (L = P)
+    // the head's scratch rows as a buffer: rows >= N and columns >= ld fall outside and are dropped / read as 0 by the range check
+    __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(Srow, 0, (int)((int64_t)N * lds_ * 4), 0x00020000);
+
+    // ---- phase 0 ----
+    float4 kf[NSTEP];
+    {
+        const float *pb = kc + (int64_t)min(min(wave, ntl - 1) * 32 + r, P - 1) * E + h * D + 4 * kk;
+#pragma unroll
+        for (int j = 0; j < NSTEP; ++j) kf[j] = *reinterpret_cast<const float4 *>(pb + 8 * j);
+    }
+    for (int i = threadIdx.x; i < 32 * (D / 4); i += PD_T) {
+        const int row = i / (D / 4), c4 = i % (D / 4);
+        const float4 v = *reinterpret_cast<const float4 *>(qkv + (int64_t)min(m0 + row, N - 1) * ldq + h * D + c4 * 4);
+        *reinterpret_cast<float4 *>(U + row * QLD + c4 * 4) = v;
+    }
+    for (int i = threadIdx.x; i * 8 < tab_n; i += PD_T)
+        reinterpret_cast<uint4 *>(tab)[i] = reinterpret_cast<const uint4 *>(exp_tab + 0x8000)[i];
+    __syncthreads();
+
+    // ---- phase A: scores -> scratch, running row max ----
+    {
+        float mx[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx[i] = -INFINITY;
+        const uint32_t voffS = (uint32_t)(((m0 + 4 * kk) * lds_ + r) * 4);
+        const int full_end = (n_past + m0 + 1) >> 5;                  // tiles below: every column visible to every row
+        for (int kt = wave; kt < ntl; kt += PD_NW) {
+            // fragment j of the NEXT tile is requested as soon as this tile's MFMAs have read fragment j: one K tile of
+            // registers, a full tile of MFMAs (4096 cycles) to cover the latency.  Past the end: the last tile again.
+            const float *pbn = kc + (int64_t)min(min(kt + PD_NW, ntl - 1) * 32 + r, P - 1) * E + h * D + 4 * kk;
+            const float *qa = U + r * QLD + 4 * kk;
+            v16f acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NSTEP; ++j) {
+                const float4 qf = *reinterpret_cast<const float4 *>(qa + 8 * j);
+#if !(PD_ABL & 1)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.x, kf[j].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.y, kf[j].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.z, kf[j].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.w, kf[j].w, acc, 0, 0, 0);
+#else
+                acc[j & 15] += qf.x * kf[j].x;
+#endif
+                kf[j] = *reinterpret_cast<const float4 *>(pbn + 8 * j);
+            }
+            const int sbase = __builtin_amdgcn_readfirstlane(kt * 128);
+            float sc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                sc[i] = __fmul_rn(acc[i], scale);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc[i]), rS, voffS, sbase + ((i & 3) + 8 * (i >> 2)) * lds_ * 4, 0);
+            }
+            if (kt >= full_end) {                                     // a tile the diagonal crosses: masked columns do not count
+                const int col = kt * 32 + r;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sc[i] = col < row_len((i & 3) + 8 * (i >> 2) + 4 * kk) ? sc[i] : -INFINITY;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm("v_max_f32 %0, %1, %2" : "=v"(mx[i]) : "v"(sc[i]), "v"(mx[i]));   // no NaN quieting moves
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                                // max over the 32 columns a half-wave holds
+            float m = mx[i];
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                const float t = __shfl_xor(m, o, 64);
+                m = t > m ? t : m;
+            }
+            if (r == 0) wmax[wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * kk] = m;
+        }
+    }
+    __syncthreads();   // scratch rows and wave maxima are complete (workgroup-scope release / acquire)
+
+    // ---- phase B: 1 / sum of the row's exp values; wave w owns rows w, w + 4, ... (8 rows), all in flight together ----
+    constexpr int RPW = 32 / PD_NW;
+    int Lq[RPW];
+    float mq[RPW], iq[RPW];
+    uint32_t vrow[RPW];                                               // byte offset of the row inside the head's scratch
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+        const int row = wave + PD_NW * u;
+        Lq[u] = row_len(row);
+        vrow[u] = (uint32_t)(min(m0 + row, N - 1) * lds_) * 4u;
+        float m = wmax[row];
+#pragma unroll
+        for (int w = 1; w < PD_NW; ++w) m = fmaxf(m, wmax[w * 32 + row]);
+        mq[u] = m;
+    }
+    float x[RPW][4], xn[RPW][4];
+    auto load_x = [&](float (&dst)[RPW][4], int c0) __attribute__((always_inline)) {   // scores of columns c0 + lane + 64 j; masked: -inf
+#pragma unroll
+        for (int u = 0; u < RPW; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = c0 + lane + 64 * j;
+                const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rS, vrow[u] + (uint32_t)min(i, Lq[u] - 1) * 4u, 0, 0));
+                dst[u][j] = i < Lq[u] ? v : -INFINITY;
+            }
+    };
+    {
+        double sum[RPW];
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) sum[u] = 0.0;
+        load_x(x, 0);
+        for (int c0 = 0; c0 < ((PD_ABL & 2) ? 1 : ke); c0 += PD_CH) {
+            if (c0 + PD_CH < ke) load_x(xn, c0 + PD_CH);
+#pragma unroll
+            for (int u = 0; u < RPW; ++u) {
+                float v[4];
+                pa_exp_vals<4>(x[u], mq[u], tab, tab_n, v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum[u] += (double)v[j];
+            }
+#pragma unroll
+            for (int u = 0; u < RPW; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[u][j] = xn[u][j];
+        }
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) iq[u] = (float)(1.0 / wave_sum_f64(sum[u]));
+    }
+    load_x(x, 0);      // chunk 0 again, for phase C (L2 hits; in flight across the barrier)
+    __syncthreads();   // every wave is done with the Q rows: U becomes the p chunk
+
+    // ---- phase C: KQV over chunks of PD_CH keys ----
+    v16f acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int d0 = wave * 32;
+    const bool pv = wave < NT;
+    const float *pb = vc + (int64_t)(h * D + (pv ? d0 : 0) + r) * n_ctx;   // transposed V cache row (d0 + r)
+    float4 b0 = {0, 0, 0, 0}, b1 = b0, b2 = b0, b3 = b0;
+    auto load_v = [&](int kb) {
+        b0 = *reinterpret_cast<const float4 *>(pb + kb + 4 * kk);
+        b1 = *reinterpret_cast<const float4 *>(pb + kb + 8 + 4 * kk);
+        b2 = *reinterpret_cast<const float4 *>(pb + kb + 16 + 4 * kk);
+        b3 = *reinterpret_cast<const float4 *>(pb + kb + 24 + 4 * kk);
+    };
+    if (pv && 32 <= ke) load_v(0);
+    for (int c0 = 0; c0 < ke; c0 += PD_CH) {
+        // p = rn(val * inv) of the chunk's columns, rows wave + 4u (masked: val = 0)
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {
+            float v[4];
+#if !(PD_ABL & 4)
+            pa_exp_vals<4>(x[u], mq[u], tab, tab_n, v);
+#else
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = x[u][j];
+#endif
+#pragma unroll
+            for (int j = 0; j < 4; ++j) U[(wave + PD_NW * u) * PD_LD + lane + 64 * j] = __fmul_rn(v[j], iq[u]);
+        }
+        if (c0 + PD_CH < ke) load_x(x, c0 + PD_CH);                   // next chunk's scores under this chunk's MFMAs
+        __syncthreads();
+        if (pv) {
+            const float *pa = U + r * PD_LD - c0;                     // pa[k]: probability of key k for query row r
+            const int kc_end = min(ke, c0 + PD_CH);
+            int k = c0;
+            for (; k + 32 <= kc_end; k += 32) {
+                const float4 c0v = b0, c1v = b1, c2v = b2, c3v = b3;
+                if (k + 64 <= ke) load_v(k + 32);                     // runs ahead across the chunk boundary
+                const float4 a0 = *reinterpret_cast<const float4 *>(pa + k + 4 * kk);
+                const float4 a1 = *reinterpret_cast<const float4 *>(pa + k + 8 + 4 * kk);
+                const float4 a2 = *reinterpret_cast<const float4 *>(pa + k + 16 + 4 * kk);
+                const float4 a3 = *reinterpret_cast<const float4 *>(pa + k + 24 + 4 * kk);
+#if !(PD_ABL & 8)
+#define FL_PV4(a, b)                                                      \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);   \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);   \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);   \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+#else
+#define FL_PV4(a, b) acc[0] += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+#endif
+                FL_PV4(a0, c0v) FL_PV4(a1, c1v) FL_PV4(a2, c2v) FL_PV4(a3, c3v)
+            }
+            if (kc_end == ke) {                                       // last chunk: the tail of gemm_f32_abt_kernel
+                for (; k + 8 <= ke; k += 8) {
+                    const float4 a0 = *reinterpret_cast<const float4 *>(pa + k + 4 * kk);
+                    const float4 c0v = *reinterpret_cast<const float4 *>(pb + k + 4 * kk);
+                    FL_PV4(a0, c0v)
+                }
+#undef FL_PV4
+                for (; k < ke; k += 2) {
+                    const float a = (k + kk < ke) ? pa[k + kk] : 0.f;
+                    const float b = (k + kk < ke) ? pb[k + kk] : 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- phase D ----
+    if (!oq) {
+        if (pv) {
+            const int col = h * D + d0 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * kk;
+                if (row < N) ao[(int64_t)row * ldo + col] = acc[i];
+            }
+        }
+        return;
+    }
+    if (pv) {
+        float *T = U + wave * (32 * 33);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T[((i & 3) + 8 * (i >> 2) + 4 * kk) * 33 + r] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 * NT) {                                      // quantize_row_q8_0 per (token, 32 columns), lib/ggml.c:1341-1440
+        const int w = threadIdx.x >> 5, rr = threadIdx.x & 31;
+        const int n = m0 + rr, KBo = E >> 5, N16 = (N + 15) & ~15;
+        if (n < N16) {
+            const float *T = U + w * (32 * 33) + rr * 33;
+            float v[32], amax = 0.f;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                v[e] = n < N ? T[e] : 0.f;
+                amax = fmaxf(amax, fabsf(v[e]));
+            }
+            const float dd = __fdiv_rn(amax, 127.0f);
+            const float id = amax != 0.0f ? __fdiv_rn(127.0f, amax) : 0.0f;
+            int qi[32], sum = 0;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                qi[e] = (int)rintf(__fmul_rn(v[e], id));
+                sum += qi[e];
+            }
+            const int c = n & 15;
+            const int64_t cb = ((int64_t)(n >> 4) * KBo + ((h * D + w * 32) >> 5)) * 16 + c;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                auto pk = [](int a, int b, int cc, int d) -> uint32_t {
+                    return (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(cc & 0xFF) << 16) | ((uint32_t)(d & 0xFF) << 24);
+                };
+                *reinterpret_cast<uint2 *>(oq + cb * 32 + qw16_pos(c, g) * 8) =
+                    make_uint2(pk(qi[8 * g], qi[8 * g + 2], qi[8 * g + 4], qi[8 * g + 6]), pk(qi[8 * g + 1], qi[8 * g + 3], qi[8 * g + 5], qi[8 * g + 7]));
+            }
+            od[cb] = dd;
+            os[cb] = __fmul_rn(dd, (float)sum);
+        }
+    }
+}
+
+hipError_t prefill_attention_deep(const float *qkv, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc,
+                                  const float *vc, const uint16_t *exp_tab, int tab_n, float scale, float *scratch, int ld_s,
+                                  int64_t s_head, float *ao, int ldo, hipStream_t st, const fl_qact *qout) {
+    const int P = n_past + N, nb = (N + 31) / 32;
+    if (!scratch || (qout && (E % 32 != 0))) return hipErrorInvalidValue;
+    // rows of the scratch must not share a cache line with another workgroup's rows; ld_s >= the keys a row can see
+    if (D % 32 != 0 || D > 128 || (n_ctx & 3) != 0 || (ld_s & 31) != 0 || ld_s < P || tab_n < 0 || tab_n > 24576 || (tab_n & 7)) return hipErrorInvalidValue;
+    const int qld = D + 4, uf = 32 * qld > 32 * PD_LD ? 32 * qld : 32 * PD_LD;
+    const size_t lds = (size_t)tab_n * 2 + (size_t)uf * 4 + (PD_NW * 32 + 64) * 4;
+    const dim3 grid(H, nb);
+#define FL_PD(NS)                                                                                                       \
+    do {                                                                                                                \
+        static bool attr_set[64] = {};                                                                                  \
+        int dev = 0;                                                                                                    \
+        (void)hipGetDevice(&dev);                                                                                       \
+        if (!attr_set[dev & 63]) {                                                                                      \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(prefill_attention_deep_kernel<NS>),       \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                  \
+            if (e != hipSuccess) return e;                                                                              \
+            attr_set[dev & 63] = true;                                                                                  \
+        }                                                                                                               \
+        hipLaunchKernelGGL(prefill_attention_deep_kernel<NS>, grid, dim3(PD_T), lds, st, qkv, ldq, N, n_past, n_ctx, E, kc, vc, \
+                           exp_tab, tab_n, scale, scratch, ld_s, s_head, ao, ldo, qout ? qout->q : nullptr,             \
+                           qout ? qout->d : nullptr, qout ? qout->s : nullptr);                                         \
+    } while (0)
+    if (D == 128) FL_PD(16);
+    else if (D == 96) FL_PD(12);
+    else if (D == 64) FL_PD(8);
+    else FL_PD(4);
+#undef FL_PD
+    return hipGetLastError();
+}
+
 // tab_n: number of fp16 exp-table entries after 0x8000 that are kept in LDS; every entry in (0x8000 + tab_n, 0xFC00] must
 // be 0 (the caller checks that on the host table).  Returns hipErrorInvalidValue when the shape does not fit
 // (caller falls back to the three-kernel path).
 hipError_t prefill_attention(const float *qkv, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc,
                              const float *vc, const uint16_t *exp_tab, int tab_n, float scale, float *ao, int ldo,
-                             hipStream_t st, const fl_qact *qout) {
+                             hipStream_t st, const fl_qact *qout, float *scratch, int ld_s, int64_t s_head, int force_deep) {
     const int P = n_past + N, nb = (N + 31) / 32;
     if (qout && (E % 32 != 0)) return hipErrorInvalidValue;
-    if (D % 32 != 0 || D > 128 || (n_ctx & 3) != 0 || P > 64 * PA_SM_IT || tab_n < 0 || tab_n > 24576 || (tab_n & 7)) return hipErrorInvalidValue;
+    // score rows in LDS when they fit; else the key-tiled form with one trip through `scratch` ([H][>= N rows][ld_s] floats)
+    auto deep = [&]() {
+        return prefill_attention_deep(qkv, ldq, D, H, N, n_past, n_ctx, E, kc, vc, exp_tab, tab_n, scale, scratch, ld_s, s_head, ao,
+                                      ldo, st, qout);
+    };
+    if (force_deep) return deep();
+    if (D % 32 != 0 || D > 128 || (n_ctx & 3) != 0 || tab_n < 0 || tab_n > 24576 || (tab_n & 7)) return hipErrorInvalidValue;
+    if (P > 64 * PA_SM_IT) return deep();
     const size_t tab_bytes = (size_t)tab_n * 2, qblk = (size_t)32 * (D + 4) * 4;   // exp table; Q rows of one block
     // pair mode: score rows of block x and of block nb-1-x: 32 * (2 n_past + 32 (nb + 1) + 8) floats (+64: round-ups)
     const size_t lds_pair = (size_t)32 * (2 * (size_t)n_past + 32 * (size_t)(nb + 1) + 8 + 64) * 4 + tab_bytes + 2 * qblk;
     const size_t lds_single = (size_t)32 * (((size_t)P + 31) / 32 * 32 + 4 + 4) * 4 + tab_bytes + qblk;
     const size_t cap = 160 * 1024;
     int pair = nb >= 2 && lds_pair <= cap ? 1 : 0;
-    if (!pair && lds_single > cap) return hipErrorInvalidValue;
+    if (!pair && lds_single > cap) return deep();
     const size_t lds = pair ? lds_pair : lds_single;
     const dim3 grid(H, pair ? (nb + 1) / 2 : nb);
 #define FL_PA(NS)                                                                                                       \
     do {                                                                                                                \
-        static bool attr_set = false;                                                                                   \
-        if (!attr_set) {                                                                                                \
+        static bool attr_set[64] = {};                                                                                  \
+        int dev = 0;                                                                                                    \
+        (void)hipGetDevice(&dev);                                                                                       \
+        if (!attr_set[dev & 63]) {                                                                                      \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(prefill_attention_kernel<NS>),            \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);                   \
             if (e != hipSuccess) return e;                                                                              \
-            attr_set = true;                                                                                            \
+            attr_set[dev & 63] = true;                                                                                  \
         }                                                                                                               \
         hipLaunchKernelGGL(prefill_attention_kernel<NS>, grid, dim3(PA_T), lds, st, qkv, ldq, N, n_past, n_ctx, E, kc, vc, \
                            exp_tab, tab_n, scale, ao, ldo, pair, qout ? qout->q : nullptr, qout ? qout->d : nullptr,    \

@@ -78,6 +78,7 @@ struct fl_model {
     bool graph_enabled = true;
     bool fuse_decode = true;     // N == 1: norm-in-GEMV + one attention kernel per layer
     bool fuse_prefill_attn = true;   // N >= 9: KQ + soft_max + KQV in one launch
+    int force_deep_attn = 0;         // debugging: always the key-tiled form of that launch
     bool w13_il = false;             // w1|w3 woven by 16-row groups (n_ff/tp a multiple of 32): silu epilogue in the matmul
     int exp_tab_n = 0;               // fp16 exp-table entries after 0x8000 that are non-zero (rounded up to 8): the LDS copy
     // LoRA: originals of the tensors an adapter touched (the reference's use_mmap path keeps them too, llama.cpp:868-874)
@@ -504,7 +505,8 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
             const float kq_scale = 1.0f / sqrtf((float)E / (float)m->H);
             // KQ, scale, mask, soft_max, KQV in one launch with the score rows in LDS when they fit       :364-398
             hipError_t pe = (N >= 9 && !dyn && m->fuse_prefill_attn)
-                                ? prefill_attention(m->qkv, 3 * El, D, Hl, N, n_past, n_ctx, El, kc, vc, m->exp_tab, m->exp_tab_n, kq_scale, m->ao, El, st, &m->qEl)
+                                ? prefill_attention(m->qkv, 3 * El, D, Hl, N, n_past, n_ctx, El, kc, vc, m->exp_tab, m->exp_tab_n, kq_scale, m->ao, El, st, &m->qEl,
+                                                    m->att, n_ctx, (int64_t)N * n_ctx, m->force_deep_attn)
                                 : hipErrorInvalidValue;
             if (pe != hipSuccess) {
                 (void)hipGetLastError();
@@ -643,13 +645,15 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
 
 /* bit 0 (default 1): decode evals replay a captured hipGraph, else plain launches; bit 1 (default 0): decode uses the
  * generic per-op kernels instead of the fused single-token ones; bit 2: prefill attention as three kernels; bit 3: decode
- * attention always in one launch per layer; bit 4: always the two-launch split form (default: split from position 256 on).
- * Debugging / A-B timing; results do not depend on bits 0, 2, 3, 4. */
+ * attention always in one launch per layer; bit 4: always the two-launch split form (default: split from position 256 on);
+ * bit 5: prefill attention always in its key-tiled (deep-context) form.
+ * Debugging / A-B timing; results do not depend on bits 0, 2, 3, 4, 5. */
 int fl_model_set_graph(fl_model *m, int mode) {
     if (!m) return set_error(FL_EINVAL, "null model");
     m->graph_enabled = (mode & 1) != 0;
     const bool fuse = (mode & 2) == 0;
     m->fuse_prefill_attn = (mode & 4) == 0;
+    m->force_deep_attn = (mode & 32) ? 1 : 0;
     m->split_past = (mode & 8) ? INT_MAX : (mode & 16) ? 0 : 256;
     if (fuse != m->fuse_decode) {
         if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
@@ -980,6 +984,9 @@ int fl_debug_gemv_silu(const fl_qtensor *W, const float *h13, const uint16_t *si
     M_HIP(gemv_q4_silu(*W, h13, silu_tab, y, resid, (hipStream_t)stream, false));
     return FL_OK;
 }
+static float *g_pa_scratch = nullptr;
+static int g_pa_ld = 0;
+static long g_pa_head = 0;
 int fl_debug_prefill_attention(const float *qkv, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc,
                                const float *vc, const uint16_t *exp_tab_dev, float scale, float *ao, int ldo, fl_qact *qout,
                                void *stream) {
@@ -990,7 +997,13 @@ int fl_debug_prefill_attention(const float *qkv, int ldq, int D, int H, int N, i
             if (f32_to_f16_bits(expf(f16_bits_to_f32((uint16_t)i))) != 0) last_nz = i - 0x8000;
         tab_n = (last_nz + 1 + 7) & ~7;
     }
-    M_HIP(prefill_attention(qkv, ldq, D, H, N, n_past, n_ctx, E, kc, vc, exp_tab_dev, tab_n, scale, ao, ldo, (hipStream_t)stream, qout));
+    M_HIP(prefill_attention(qkv, ldq, D, H, N, n_past, n_ctx, E, kc, vc, exp_tab_dev, tab_n, scale, ao, ldo, (hipStream_t)stream, qout,
+                            g_pa_scratch, g_pa_ld, g_pa_head, g_pa_scratch ? 1 : 0));
+    return FL_OK;
+}
+// the next fl_debug_prefill_attention calls run the key-tiled (deep-context) form with this scratch ([H][N][ld] floats); NULL: back
+int fl_debug_prefill_attention_scratch(float *scratch, int ld, long head_stride) {
+    g_pa_scratch = scratch; g_pa_ld = ld; g_pa_head = head_stride;
     return FL_OK;
 }
 int fl_debug_gemv_norm_silu(const fl_qtensor *W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act,

@@ -122,6 +122,7 @@ _PROTOS = {
     "fl_debug_gemv_quant": (C.c_int, [C.c_void_p] * 5),
     "fl_debug_prefill_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "fl_debug_prefill_attention_scratch": (C.c_int, [C.c_void_p, C.c_int, C.c_long]),
     "fl_debug_decode_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "fl_debug_decode_attention_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

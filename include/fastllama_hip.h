@@ -229,6 +229,9 @@ int fl_debug_prefill_attention(const float *qkv_dev, int ldq, int D, int H, int 
                                const float *kc, const float *vc, const uint16_t *exp_tab_dev, float scale, float *ao_dev,
                                int ldo, fl_qact *qout /* NULL: f32 result to ao; else Q8_0 (QA16) of it */, void *stream);
                                /* KQ*scale + mask + soft_max + KQV (+ quantize_row_q8_0), one launch (prefill) */
+int fl_debug_prefill_attention_scratch(float *scratch_dev, int ld, long head_stride);
+                               /* non-NULL: the following fl_debug_prefill_attention calls run the key-tiled (deep-context) form,
+                                  scores staged in scratch [H][head_stride], rows of ld floats (ld % 32 == 0, ld >= n_past + N) */
 int fl_debug_decode_attention(const float *qkv_dev, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab_dev,
                               float *kc, float *vc, const uint16_t *exp_tab_dev, float scale, fl_qact *out, void *stream);
 int fl_debug_decode_attention_split(const float *qkv_dev, int E, int D, int H, int n_past, int n_ctx,

@@ -12,7 +12,7 @@ qkv = torch.randn(N, 3 * E, device="cuda"); kc = torch.randn(n_ctx, E, device="c
 e = np.empty(1 << 16, np.uint16); L.fl_debug_tables(e.ctypes.data_as(C.c_void_p), None)
 ed = torch.from_numpy(e.view(np.int16)).cuda(); ao = torch.empty(N, E, device="cuda")
 def run():
-    hip.check(L.fl_debug_prefill_attention(qkv.data_ptr(), 3 * E, D, H, N, P0, n_ctx, E, kc.data_ptr(), vc.data_ptr(), ed.data_ptr(), 0.0883883, ao.data_ptr(), E, None))
+    hip.check(L.fl_debug_prefill_attention(qkv.data_ptr(), 3 * E, D, H, N, P0, n_ctx, E, kc.data_ptr(), vc.data_ptr(), ed.data_ptr(), 0.0883883, ao.data_ptr(), E, None, None))
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -352,6 +352,56 @@ def test_prefill_attention_fused_equals_three_kernels(env, N, P0, D, H, n_ctx):
             assert np.max(np.abs(got - want)) <= 2e-5 * max(1.0, np.max(np.abs(want)))
 
 
+@pytest.mark.parametrize("N,P0,D,H,n_ctx", [(512, 512, 128, 8, 1024), (512, 1536, 128, 4, 2048), (100, 1900, 128, 2, 2048),
+                                            (33, 7, 64, 3, 64), (300, 203, 128, 2, 512), (9, 0, 96, 2, 64), (77, 530, 32, 5, 640),
+                                            (512, 0, 128, 4, 512), (256, 3000, 128, 2, 4096)])
+def test_prefill_attention_deep_equals_three_kernels(env, N, P0, D, H, n_ctx):
+    """The key-tiled form of the prefill attention launch (deep contexts: a block's score rows do not fit LDS, they take one
+    trip through a scratch buffer) == gemm_f32_abt -> softmax_rows -> gemm_f32_abt bit for bit, f32 rows and the Q8_0 operand,
+    for chunk-boundary cases (n_past not a multiple of 8 / 32 / 256, N not a multiple of 32, head_dim 32..128, 4096 keys)."""
+    torch, hip, ops, L, port = env
+    E, P = H * D, P0 + N
+    rng = np.random.default_rng(N + D + H + P0)
+    qkv = rng.standard_normal((N, 3 * E)).astype(np.float32)
+    kc = np.zeros((n_ctx, E), np.float32)
+    vc = np.zeros((E, n_ctx), np.float32)
+    kc[:P] = rng.standard_normal((P, E))
+    vc[:, :P] = rng.standard_normal((E, P))
+    e = np.empty(1 << 16, np.uint16)
+    L.fl_debug_tables(e.ctypes.data_as(C.c_void_p), None)
+    ed, qd, kd, vd = dev(torch, e.view(np.int16)), dev(torch, qkv), dev(torch, kc), dev(torch, vc)
+    scale = float(np.float32(1.0) / np.sqrt(np.float32(D)))
+    att = torch.full((H, N, n_ctx), 7.0, device="cuda")
+    ao0 = torch.zeros((N, E), device="cuda")
+    hip.check(L.fl_debug_gemm_f32_abt(qd.data_ptr(), 3 * E, D, kd.data_ptr(), E, D, att.data_ptr(), n_ctx, N * n_ctx, N, P, D, H,
+                                      scale, 1, P0, None))
+    hip.check(L.fl_debug_softmax_rows(att.data_ptr(), n_ctx, N * n_ctx, N, P, P0, H, ed.data_ptr(), None))
+    hip.check(L.fl_debug_gemm_f32_abt(att.data_ptr(), n_ctx, N * n_ctx, vd.data_ptr(), n_ctx, D * n_ctx, ao0.data_ptr(), E, D,
+                                      N, D, P, H, 1.0, 2, P0, None))
+    scratch = torch.full((H, N, n_ctx), float("nan"), device="cuda")
+    guard = scratch.clone()
+    ao1 = torch.full((N, E), -3.0, device="cuda")
+    hip.check(L.fl_debug_prefill_attention_scratch(scratch.data_ptr(), n_ctx, N * n_ctx))
+    try:
+        hip.check(L.fl_debug_prefill_attention(qd.data_ptr(), 3 * E, D, H, N, P0, n_ctx, E, kd.data_ptr(), vd.data_ptr(), ed.data_ptr(),
+                                               scale, ao1.data_ptr(), E, None, None))
+        torch.cuda.synchronize()
+        assert torch.equal(ao1, ao0)
+        del guard
+        if N >= 9:
+            a = ops.QAct(N, E)
+            junk = torch.full((N, E), 5.0, device="cuda")
+            hip.check(L.fl_quantize_q8_layout(a.handle, junk.data_ptr(), E, N, E, 16, None))     # sizes, layout; poison
+            a.N, a.K = N, E
+            hip.check(L.fl_debug_prefill_attention(qd.data_ptr(), 3 * E, D, H, N, P0, n_ctx, E, kd.data_ptr(), vd.data_ptr(),
+                                                   ed.data_ptr(), scale, ao1.data_ptr(), E, a.handle, None))
+            got_q8 = a.export().cpu().numpy()
+            want_q8 = np.stack([port.quantize_row_q8_0(r_) for r_ in ao0.cpu().numpy()])
+            assert np.array_equal(got_q8, want_q8)
+    finally:
+        hip.check(L.fl_debug_prefill_attention_scratch(None, 0, 0))
+
+
 @pytest.mark.parametrize("qtype", [2, 3])
 @pytest.mark.parametrize("F,K", [(64, 64), (704, 256), (11008, 4096)])
 def test_gemv_pair_silu_epilogue_and_quant_prologue(env, qtype, F, K):

@@ -296,7 +296,7 @@ def test_tensor_parallel_shards_on_one_gpu(tmp_path_factory, port, qtype, cfgnam
 @pytest.mark.parametrize("qtype", [ggjt.Q4_0])
 def test_long_context_path_switches_agree(tmp_path_factory, port, qtype):
     """A 1400-token context evaluated in different chunkings walks through every attention path: the one-launch prefill
-    kernel in pair mode (n_past = 0), in single-block mode (n_past > 0), the three-kernel fallback once n_past + N no
+    kernel in pair mode (n_past = 0), in single-block mode (n_past > 0), the key-tiled form once n_past + N no
     longer fits LDS (> 960 keys), the N <= 8 path and the single-token decode kernel.  The KV cache they leave behind
     must be interchangeable: a fixed probe token evaluated after each chunking gives logits that agree to the usual
     cross-path bound, and the K/V state agrees bit for bit where the producing kernels are bit-identical by design."""
@@ -325,7 +325,7 @@ def test_long_context_path_switches_agree(tmp_path_factory, port, qtype):
         m.free()
         return k, v, lg
 
-    ka, va, la = run([512, 448, 440])                    # pair mode; single-block mode (P = 960); three-kernel fallback
+    ka, va, la = run([512, 448, 440])                    # pair mode; single-block mode (P = 960); key-tiled form
     kb, vb, lb = run([500, 300, 300, 300])               # odd block counts, other switch points
     kc_, vc_, lc = run([512, 512, 368, 8])               # ... and an N <= 8 tail
     # layer 0 K/V depend only on the token embeddings and the (bit-identical) wqkv + rope epilogue vs kernel pair
@@ -336,6 +336,44 @@ def test_long_context_path_switches_agree(tmp_path_factory, port, qtype):
     # deeper layers: same values up to the rounding-flip noise of the algorithm
     d = np.abs(ka[:, :1400] - kb[:, :1400]).max() / np.abs(ka[:, :1400]).max()
     assert d <= 5e-2, d
+
+
+@pytest.mark.gpu
+def test_prefill_attention_forms_are_interchangeable(tmp_path_factory, port):
+    """The three forms of prefill attention -- score rows in LDS, key-tiled through a scratch buffer (what deep contexts
+    get), three kernels -- are bit-identical per output, so a 1400-token prompt ingested in 512-token chunks leaves the same
+    K/V cache and the same logits whichever form runs: default (LDS form, then the key-tiled one from the second chunk
+    on), key-tiled forced everywhere (set_graph bit 5), three kernels everywhere (bit 2)."""
+    import ctypes as C
+    from fastllama_amd import hip
+    from harness.flmodel import FlModel
+    L = hip.load()
+    cfg = ggjt.SMALL
+    tensors, _ = build(tmp_path_factory, port, cfg, ggjt.Q4_0, "forms")
+    toks = np.random.default_rng(6).integers(3, 259, 1400).astype(np.int32)
+    n_ctx = 1536
+    E, Ln = cfg["n_embd"], cfg["n_layer"]
+
+    def run(mode):
+        m = FlModel(cfg, ggjt.Q4_0, tensors, n_ctx=n_ctx, max_batch=512)
+        hip.check(L.fl_model_set_graph(m.h, 1 | mode))
+        n_past, last = 0, None
+        for c in (512, 448, 431, 9):
+            last = m.eval(toks[n_past:n_past + c], n_past=n_past, all_logits=True).copy()
+            n_past += c
+        k = np.empty((Ln, n_ctx, E), np.float32)
+        v = np.empty((Ln, E, n_ctx), np.float32)
+        hip.check(L.fl_model_kv_read(m.h, k.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)), "kv_read")
+        m.free()
+        return k[:, :1400], v[:, :, :1400], last
+
+    k0, v0, l0 = run(0)
+    for mode in (32, 4):
+        k1, v1, l1 = run(mode)
+        assert np.array_equal(k0.view(np.uint32), k1.view(np.uint32)), mode
+        assert np.array_equal(v0.view(np.uint32), v1.view(np.uint32)), mode
+        assert np.array_equal(l0.view(np.uint32), l1.view(np.uint32)), mode
+    assert np.isfinite(l0).all() and np.ptp(l0) > 0
 
 
 @pytest.mark.gpu
