@@ -6,7 +6,7 @@ from fastllama_amd import hip
 from harness import synth
 from harness.flmodel import FlModel
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-graph = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+graph = int(sys.argv[2]) if len(sys.argv) > 2 else 1   # fl_model_set_graph mode bits (1 = hipGraph replay, 64 = f32 w1|w3 product, ...)
 waves = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 pasts = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [128]
 name = sys.argv[5] if len(sys.argv) > 5 else "7B"
