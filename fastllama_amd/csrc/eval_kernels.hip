@@ -379,17 +379,23 @@ __device__ __forceinline__ void pa_softmax4(float *const (&rowp)[4], const int (
     }
 #pragma unroll
     for (int u4 = 0; u4 < 4; ++u4) {
+        // table index from mx - x >= 0 (rounding is sign-symmetric: half(mx - x) is half(x - mx) without the sign bit):
+        // +0 -> entry 0 = exp(-0) = 1; [0, tab_n): the table; up to +inf (0x7C00; masked columns, x = -inf): exp underflows
+        // to 0 in fp16 (host-checked bound); NaNs and (impossible) negative differences: NaN like the full table.
+        // The empty asm keeps the LDS reads unconditional (else: one branch per element around its lookup).
         double sum = 0.0;
+        uint32_t idx[IT], t[IT];
 #pragma unroll
         for (int u = 0; u < IT; ++u) {
-            const float xv = x[u4][u];
-            const uint16_t hb = __half_as_ushort(__float2half_rn(xv - mx[u4]));
-            const int idx = (int)hb - 0x8000;
-            const uint16_t t = tab[min(max(idx, 0), tab_n - 1)];
-            // hb == 0: exp(+0) = 1; [0x8000, 0x8000+tab_n): the table; up to -inf (0xFC00): underflows to 0 in fp16
-            // (host-checked bound); anything else is a NaN (or a positive difference, impossible): NaN like the table
-            const uint16_t e = hb == 0 ? (uint16_t)0x3C00 : idx < 0 ? (uint16_t)0x7E00 : idx < tab_n ? t : hb <= 0xFC00 ? (uint16_t)0 : (uint16_t)0x7E00;
-            const float v = (xv != -INFINITY) ? __half2float(__ushort_as_half(e)) : 0.f;   // masked / beyond the row: nothing
+            idx[u] = __half_as_ushort(__float2half_rn(mx[u4] - x[u4][u]));
+            t[u] = tab[min(idx[u], (uint32_t)(tab_n - 1))];
+        }
+#pragma unroll
+        for (int u = 0; u < IT; ++u) asm volatile("" : "+v"(t[u]));
+#pragma unroll
+        for (int u = 0; u < IT; ++u) {
+            const uint32_t e = idx[u] < (uint32_t)tab_n ? t[u] : idx[u] <= 0x7C00u ? 0u : 0x7E00u;
+            const float v = __half2float(__ushort_as_half((uint16_t)e));
             x[u4][u] = v;
             sum += (double)v;
         }
@@ -538,27 +544,41 @@ __global__ __launch_bounds__(PA_T) void prefill_attention_kernel(const float *__
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
             int k = 0;
-            float4 b0 = {0, 0, 0, 0}, b1 = b0, b2 = b0, b3 = b0;
-            auto load_v = [&](int kb) {                                   // 32 k: four float4 per lane
-                b0 = *reinterpret_cast<const float4 *>(pb + kb + 4 * kk);
-                b1 = *reinterpret_cast<const float4 *>(pb + kb + 8 + 4 * kk);
-                b2 = *reinterpret_cast<const float4 *>(pb + kb + 16 + 4 * kk);
-                b3 = *reinterpret_cast<const float4 *>(pb + kb + 24 + 4 * kk);
-            };
-            if (k + 32 <= ke) load_v(0);
-            for (; k + 32 <= ke; k += 32) {
-                const float4 c0 = b0, c1 = b1, c2 = b2, c3 = b3;
-                if (k + 64 <= ke) load_v(k + 32);
-                const float4 a0 = *reinterpret_cast<const float4 *>(pa + k + 4 * kk);
-                const float4 a1 = *reinterpret_cast<const float4 *>(pa + k + 8 + 4 * kk);
-                const float4 a2 = *reinterpret_cast<const float4 *>(pa + k + 16 + 4 * kk);
-                const float4 a3 = *reinterpret_cast<const float4 *>(pa + k + 24 + 4 * kk);
 #define FL_PV4(a, b)                                                      \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);   \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);   \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);   \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-                FL_PV4(a0, c0) FL_PV4(a1, c1) FL_PV4(a2, c2) FL_PV4(a3, c3)
+            // V (L2) is requested TWO 32-key steps ahead of its MFMAs: three register sets in rotation
+            float4 vb[3][4];
+            auto load_v = [&](float4 (&d)[4], int kb) __attribute__((always_inline)) {   // 32 k: four float4 per lane
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[j] = *reinterpret_cast<const float4 *>(pb + kb + 8 * j + 4 * kk);
+            };
+            auto mm32 = [&](const float4 (&bv)[4], int kb) __attribute__((always_inline)) {
+                const float4 a0 = *reinterpret_cast<const float4 *>(pa + kb + 4 * kk);
+                const float4 a1 = *reinterpret_cast<const float4 *>(pa + kb + 8 + 4 * kk);
+                const float4 a2 = *reinterpret_cast<const float4 *>(pa + kb + 16 + 4 * kk);
+                const float4 a3 = *reinterpret_cast<const float4 *>(pa + kb + 24 + 4 * kk);
+                FL_PV4(a0, bv[0]) FL_PV4(a1, bv[1]) FL_PV4(a2, bv[2]) FL_PV4(a3, bv[3])
+            };
+            if (32 <= ke) load_v(vb[0], 0);
+            if (64 <= ke) load_v(vb[1], 32);
+            for (; k + 96 <= ke; k += 96) {
+                load_v(vb[2], k + 64);
+                mm32(vb[0], k);
+                if (k + 128 <= ke) load_v(vb[0], k + 96);
+                mm32(vb[1], k + 32);
+                if (k + 160 <= ke) load_v(vb[1], k + 128);
+                mm32(vb[2], k + 64);
+            }
+            if (k + 32 <= ke) {
+                mm32(vb[0], k);
+                k += 32;
+                if (k + 32 <= ke) {
+                    mm32(vb[1], k);
+                    k += 32;
+                }
             }
             for (; k + 8 <= ke; k += 8) {
                 const float4 a0 = *reinterpret_cast<const float4 *>(pa + k + 4 * kk);

@@ -91,6 +91,26 @@ for t in range(2):
     valu += "".join(add(120 + i, 16 * t + i) for i in range(16)) + "".join(fmac(64 + 16 * t + i, 120 + i, 32 + 16 * t + i) for i in range(16))
 mode("VALU-P i8-32: 2 x (mfma32 + 16 mul + 16 sub + 16 fmac)", valu)
 
+# --- packed f32 VALU: does v_pk_* retire two lanes' worth per issue slot? -------------------------------------------
+def pkadd(d, a):
+    return f"v_pk_add_f32 v[{d}:{d+1}], v[{a}:{a+1}], v[138:139]\n"
+
+
+def pkfma(acc, a, b):
+    return f"v_pk_fma_f32 v[{acc}:{acc+1}], v[{a}:{a+1}], v[{b}:{b+1}], v[{acc}:{acc+1}]\n"
+
+
+mode("64 v_add_f32", "".join(add(64 + i % 32) for i in range(64)))
+mode("32 v_pk_add_f32 (same 64 results)", "".join(pkadd(64 + 2 * (i % 16), 64 + 2 * (i % 16)) for i in range(32)))
+mode("64 v_fmac_f32", "".join(fmac(64 + i % 32, 136, 137) for i in range(64)))
+mode("32 v_pk_fma_f32 (same 64 results)", "".join(pkfma(64 + 2 * (i % 16), 32 + 2 * (i % 16), 0 + 2 * (i % 8)) for i in range(32)))
+realpk = pm32() + mf32(0) + mf32(16)
+realpk += "".join(pkadd(120 + 2 * i, 2 * i) for i in range(8)) + "".join(pkfma(64 + 2 * i, 120 + 2 * i, 32 + 2 * i) for i in range(8))
+realpk += "s_nop 7\ns_nop 7\n"
+realpk += "".join(pkadd(120 + 2 * i, 16 + 2 * i) for i in range(8)) + "".join(pkfma(80 + 2 * i, 120 + 2 * i, 48 + 2 * i) for i in range(8))
+mode("realistic i8-32, PACKED: P2b + 2 x (mfma32 + 8 pk_add + 8 pk_fma)", realpk)
+mode("realistic i8-32, PACKED + 6 unpack ops", unpack(6) + realpk)
+
 # --- i8 16x16 forms (reference points) -----------------------------------------------------------------
 mode("8 mfma_i32_16x16x32_i8", "".join(mf16(4 * i) for i in range(8)))
 mode("8 mfma_i32_16x16x64_i8 (two blocks each: rate check only)", "".join(mf16x16x64(4 * i) for i in range(8)))
@@ -125,7 +145,7 @@ template <int MODE>
 __global__ __launch_bounds__(768) void k(float *out, int n) {{
     asm volatile("v_mov_b32 v96, 0x01010101\\n v_mov_b32 v97, 0x01010101\\n v_mov_b32 v98, 0x01010101\\n v_mov_b32 v99, 0x01010101\\n"
                  "v_mov_b32 v100, 0x01010101\\n v_mov_b32 v101, 0x01010101\\n v_mov_b32 v102, 0x01010101\\n v_mov_b32 v103, 0x01010101\\n"
-                 "v_mov_b32 v136, 1.0\\n v_mov_b32 v137, 0\\n"
+                 "v_mov_b32 v136, 1.0\\n v_mov_b32 v137, 0\\n v_mov_b32 v138, 1.0\\n v_mov_b32 v139, 1.0\\n"
                  "v_mov_b32 v140, 0\\n v_mov_b32 v141, 0\\n v_mov_b32 v142, 0\\n v_mov_b32 v143, 0\\n"
                  "v_mov_b32 v144, 0\\n v_mov_b32 v145, 0\\n v_mov_b32 v146, 0\\n v_mov_b32 v147, 0\\n" ::: CLOB);
 '''
