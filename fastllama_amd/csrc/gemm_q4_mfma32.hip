@@ -71,6 +71,12 @@ struct G32 {
     static constexpr int VM_AT_BOUNDARY = LPW + 3 * L_EVEN + 3 * L_ODD;
 };
 
+#ifdef G32_TIMING   // development build only: per-workgroup clocks of the launch phases (scripts/dev/g32_timeline.py)
+__device__ long long g32_dbg[4096 * 8];
+#define G32_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g32_dbg[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define G32_STAMP(k) do {} while (0)
+#endif
 template <int TYPE, int WM, int RN, int MINW, bool PDB>
 __global__ __launch_bounds__(64 * WM, TYPE == FL_TYPE_Q4_1 ? 2 : MINW) FL_NOPK32 void gemm_q4_mfma32_kernel(
     const uint32_t *qs, const float *dW, const float *mW,   // (no __restrict__: the ring loads must stay where they are issued)
@@ -79,6 +85,10 @@ __global__ __launch_bounds__(64 * WM, TYPE == FL_TYPE_Q4_1 ? 2 : MINW) FL_NOPK32
     const float *__restrict__ resid, int ldr, GemmSiluEpi epi) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (and loses it if it has to instantiate the
                                       // generic lambdas below, whose bodies use gfx950 builtins)
+    G32_STAMP(0);
+#ifdef G32_TIMING
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 128 && blockIdx.x < 4096) g32_dbg[blockIdx.x * 8 + 5 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg((15 << 11) | 4);
+#endif
     using C = G32<TYPE, WM, RN>;
     constexpr int KS = C::KS;
     constexpr bool Q41 = TYPE == FL_TYPE_Q4_1;
@@ -247,12 +257,14 @@ __global__ __launch_bounds__(64 * WM, TYPE == FL_TYPE_Q4_1 ? 2 : MINW) FL_NOPK32
     load_w(IC(0), 0); load_w(IC(1), 1); load_w(IC(2), 2); load_w(IC(3), 3);
     fill(1, KS);
     load_w(IC(4), 4); load_w(IC(5), 5); load_w(IC(6), 6); load_w(IC(7), 7);
+    G32_STAMP(1);
 #ifdef FL_G32_SAFE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::LPW + 2 * C::L_EVEN + 2 * C::L_ODD) : "memory");   // stage 0 and blocks 0..3 landed
 #endif
     __builtin_amdgcn_s_barrier();
+    G32_STAMP(2);
     fill(2, 2 * KS);
     int cur = 0;
     const unsigned char *base = smem;
@@ -330,6 +342,7 @@ __global__ __launch_bounds__(64 * WM, TYPE == FL_TYPE_Q4_1 ? 2 : MINW) FL_NOPK32
         block(IC(0), kb + 0, t); block(IC(1), kb + 1, t); block(IC(2), kb + 2, t); block(IC(3), kb + 3, t);
         block(IC(4), kb + 4, t + 1); block(IC(5), kb + 5, t + 1); block(IC(6), kb + 6, t + 1); block(IC(7), kb + 7, t + 1);
     }
+    G32_STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the (zero / repeated) tail fills and ring loads
 #undef IC
 
@@ -448,6 +461,7 @@ __global__ __launch_bounds__(64 * WM, TYPE == FL_TYPE_Q4_1 ? 2 : MINW) FL_NOPK32
             }
         }
     }
+    G32_STAMP(4);
 #endif
 }
 
@@ -495,3 +509,6 @@ hipError_t gemm32_launch(int cfg, const fl_qtensor &W, const fl_qact &xq, int N,
 }
 
 }  // namespace fl
+#ifdef G32_TIMING
+extern "C" int fl_debug_g32_timing(long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fl::g32_dbg), sizeof(long long) * (size_t)n * 8); }
+#endif
