@@ -588,6 +588,45 @@ struct Session {
         return true;
     }
 
+    // The evals of one ingest() call, collected instead of run one by one: the bookkeeping between them (n_past, the context
+    // recycling) never looks at an eval's results, so a run of consecutive blocks can go to the device as ONE pipelined ingest
+    // (fl_model_ingest: two blocks in flight, lm-head for the last one only) -- the same evals, the same K/V cache and logits.
+    struct PendingEval { int past; std::vector<token_t> toks; };
+    std::vector<PendingEval> pending;
+    bool flush_pending() {
+        bool ok = true;
+        size_t i = 0;
+        while (ok && i < pending.size()) {
+            size_t j = i + 1;                                       // [i, j): consecutive positions, sizes the device accepts
+            int end = pending[i].past + (int)pending[i].toks.size();
+            const bool plain = !all_logits && !args.embedding_eval_enabled && (int)pending[i].toks.size() <= max_batch;
+            while (plain && j < pending.size() && pending[j].past == end && (int)pending[j].toks.size() <= max_batch) {
+                end += (int)pending[j].toks.size();
+                ++j;
+            }
+            if (j - i >= 2) {
+                std::vector<token_t> all;
+                std::vector<int> lens;
+                for (size_t k = i; k < j; ++k) {
+                    all.insert(all.end(), pending[k].toks.begin(), pending[k].toks.end());
+                    lens.push_back((int)pending[k].toks.size());
+                }
+                logits_on_device = 0;
+                logits.resize((size_t)hp.n_vocab);
+                if (fl_model_ingest(model, all.data(), lens.data(), (int)lens.size(), pending[i].past, logits.data()) != FL_OK) {
+                    log.err("Model::eval", std::string(fl_last_error()) + "\n");
+                    ok = false;
+                }
+                if (mem_per_token == 0) mem_per_token = 1;
+            } else {
+                ok = eval(pending[i].past, pending[i].toks);
+            }
+            i = j;
+        }
+        pending.clear();
+        return ok;
+    }
+
     // lib/bridge.cpp:161-180
     bool recycle_if_exceeds_context() {
         const size_t len = embd.size();
@@ -627,11 +666,12 @@ struct Session {
             log.progress(PROGRESS_TAG_INGEST, i, in.size());
             const size_t block = std::min(nb, in.size() - i);
             recycle_if_exceeds_context();
-            if (!embd.empty() && !eval(n_past, embd)) return false;
+            if (!embd.empty()) pending.push_back({n_past, embd});   // (the reference evaluates here; see flush_pending)
             n_past += (int)embd.size();
             embd.assign(in.begin() + (std::ptrdiff_t)i, in.begin() + (std::ptrdiff_t)(i + block));
             for (size_t j = 0; j < block; ++j) push_last(in[i + j]);
         }
+        if (!flush_pending()) return false;
         log.progress(PROGRESS_TAG_INGEST, in.size(), in.size());
         last_n.clear();
         return true;

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/fastllama_hip.h"
@@ -49,7 +50,18 @@ struct Layer {
 
 }  // namespace
 
-struct fl_model {
+// Everything ONE eval in flight owns: its token ids, activations, Q8_0 operands and the stream its kernels run on.  The model
+// has a second set (fl_model::alt, allocated on first use) so that two consecutive chunks of a long prompt can be in flight at
+// once (fl_model_ingest).
+struct Act {
+    int *tok_dev = nullptr;
+    float *x = nullptr, *x2 = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *ao = nullptr, *h13 = nullptr,
+          *part = nullptr, *logits = nullptr;
+    fl_qact qE{}, qEl{}, qF{};                      // K = E, K = E/G (input of wo), K = F/G (input of w2)
+    hipStream_t stream = nullptr;
+};
+
+struct fl_model : Act {
     fl_model_params hp{};
     int E = 0, H = 0, D = 0, F = 0, V = 0, L = 0, n_ctx = 0, B = 0, qtype = 0;
     int Vl = 0, ldp = 0;        // tensor parallel with n_vocab % tp_size == 0: the lm-head is split by rows (V/G logits per rank,
@@ -65,12 +77,11 @@ struct fl_model {
     float *kc = nullptr, *vc = nullptr;            // [L][n_ctx][El], [L][El][n_ctx]
     uint16_t *exp_tab = nullptr, *silu_tab = nullptr;
     float *rope_tab = nullptr;                      // [n_ctx][D/2][2]
-    // work buffers
-    int *tok_dev = nullptr;
-    float *x = nullptr, *x2 = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *ao = nullptr, *h13 = nullptr,
-          *part = nullptr, *logits = nullptr;
-    fl_qact qE{}, qEl{}, qF{};                      // K = E, K = E/G (input of wo), K = F/G (input of w2)
-    hipStream_t stream = nullptr;
+    // work buffers: the Act base (primary set) and, for pipelined ingests, a second one
+    Act alt;
+    bool alt_ready = false;
+    std::vector<hipEvent_t> kv_ev[2];               // [set][layer]: that set's chunk has stored its K/V rows of the layer
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     fl_comm *comm = nullptr;
     bool finalized = false;
     size_t dev_bytes = 0;
@@ -117,6 +128,31 @@ static int qact_alloc(fl_model *m, fl_qact *a, int maxN, int K) {
     if (rc == FL_OK) rc = dev_alloc(m, (void **)&a->s, qact_bytes_scale(maxN, K));
     a->KB = K / FL_QK;
     return rc;
+}
+
+static int act_alloc(fl_model *m, Act &a) {      // the work buffers of one eval in flight (a.stream is the caller's business)
+    const size_t B = (size_t)m->B, E = (size_t)m->E, El = (size_t)m->El, Fl = (size_t)m->Fl;
+    int rc;
+    if ((rc = dev_alloc(m, (void **)&a.tok_dev, B * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&a.x, B * E * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&a.x2, B * E * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&a.xn, B * E * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&a.part, B * E * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&a.qkv, B * 3 * El * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&a.att, (size_t)m->Hl * B * (size_t)m->n_ctx * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&a.ao, B * El * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&a.h13, B * 2 * Fl * 4)) != FL_OK) return rc;
+    if ((rc = dev_alloc(m, (void **)&a.logits, B * (size_t)m->ldl * 4)) != FL_OK) return rc;
+    if ((rc = qact_alloc(m, &a.qE, m->B, m->E)) != FL_OK) return rc;
+    if ((rc = qact_alloc(m, &a.qEl, m->B, m->El)) != FL_OK) return rc;
+    if ((rc = qact_alloc(m, &a.qF, m->B, m->Fl)) != FL_OK) return rc;
+    return FL_OK;
+}
+static void act_free(Act &a) {
+    auto fr = [](void *p) { if (p) (void)hipFree(p); };
+    fr(a.tok_dev); fr(a.x); fr(a.x2); fr(a.xn); fr(a.part); fr(a.qkv); fr(a.att); fr(a.ao); fr(a.h13); fr(a.logits);
+    for (fl_qact *q : {&a.qE, &a.qEl, &a.qF}) { fr(q->q); fr(q->d); fr(q->s); }
+    a = Act{};
 }
 
 static uint16_t f32_to_f16_bits(float f) {  // round-to-nearest-even, as _cvtss_sh(x, 0) (GGML_FP32_TO_FP16 with F16C)
@@ -340,26 +376,14 @@ int fl_model_finalize(fl_model *m) {
         if ((rc = dev_alloc(m, (void **)&m->rope_tab, rt.size() * 4)) != FL_OK) return rc;
         M_HIP(hipMemcpy(m->rope_tab, rt.data(), rt.size() * 4, hipMemcpyHostToDevice));
     }
-    if ((rc = dev_alloc(m, (void **)&m->tok_dev, (size_t)B * 4)) != FL_OK) return rc;
     if ((rc = dev_alloc(m, (void **)&m->npast_dev, 16)) != FL_OK) return rc;
     M_HIP(hipHostMalloc((void **)&m->pinned, 16, hipHostMallocDefault));
-    if ((rc = dev_alloc(m, (void **)&m->x, (size_t)B * E * 4)) != FL_OK) return rc;
-    if ((rc = dev_alloc(m, (void **)&m->x2, (size_t)B * E * 4)) != FL_OK) return rc;
-    if ((rc = dev_alloc(m, (void **)&m->xn, (size_t)B * E * 4)) != FL_OK) return rc;
-    if ((rc = dev_alloc(m, (void **)&m->part, (size_t)B * E * 4)) != FL_OK) return rc;
-    if ((rc = dev_alloc(m, (void **)&m->qkv, (size_t)B * 3 * El * 4)) != FL_OK) return rc;
-    if ((rc = dev_alloc(m, (void **)&m->att, (size_t)m->Hl * B * n_ctx * 4)) != FL_OK) return rc;
-    if ((rc = dev_alloc(m, (void **)&m->ao, (size_t)B * El * 4)) != FL_OK) return rc;
-    if ((rc = dev_alloc(m, (void **)&m->h13, (size_t)B * 2 * Fl * 4)) != FL_OK) return rc;
     m->ldl = fl_roundup(V, 4);   // e.g. the 32001-token vocabularies of Alpaca / Vicuna style checkpoints
-    if ((rc = dev_alloc(m, (void **)&m->logits, (size_t)B * m->ldl * 4)) != FL_OK) return rc;
+    if ((rc = act_alloc(m, *m)) != FL_OK) return rc;
     if (m->Vl > 0) {
         if ((rc = dev_alloc(m, (void **)&m->logits_part, (size_t)B * m->ldp * 4)) != FL_OK) return rc;
         if ((rc = dev_alloc(m, (void **)&m->gather_tmp, (size_t)m->G * B * m->ldp * 4)) != FL_OK) return rc;
     }
-    if ((rc = qact_alloc(m, &m->qE, B, E)) != FL_OK) return rc;
-    if ((rc = qact_alloc(m, &m->qEl, B, El)) != FL_OK) return rc;
-    if ((rc = qact_alloc(m, &m->qF, B, Fl)) != FL_OK) return rc;
     M_HIP(hipDeviceSynchronize());
     m->finalized = true;
     return FL_OK;
@@ -469,8 +493,11 @@ static int allreduce_if_tp(fl_model *m, float *buf, size_t count) {
 // positions are read from device memory (m->npast_dev) instead of the n_past argument -- the decode hipGraph.
 // [l0, l1): the layers to run; body_only: neither the token-embedding lookup before nor the final norm + lm-head after
 // (fl_model_debug_layers: the teacher-forced per-layer parity tests feed m->x themselves).
+// kv_wait / kv_rec (pipelined ingest, per layer): the stream waits for kv_wait[l] before the layer's attention reads the K/V cache
+// (the previous chunk, running on the other stream, has stored its rows), and records kv_rec[l] once this chunk's rows are stored.
 static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool split_attn = false, int l0 = 0, int l1 = -1,
-                            bool body_only = false) {
+                            bool body_only = false, bool skip_head = false, const hipEvent_t *kv_wait = nullptr,
+                            const hipEvent_t *kv_rec = nullptr) {
     const int E = m->E, El = m->El, Fl = m->Fl, D = m->D, Hl = m->Hl, V = m->V, n_ctx = m->n_ctx;
     const int layout = N <= 8 ? 1 : 16;
     const int P = n_past + N;
@@ -487,12 +514,14 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
             // decode: norm folded into the matmul, attention in one launch per layer (rope .. KQV .. Q8_0)
             M_HIP(mm_norm(m, ly.wqkv, inp, ly.attn_norm, nullptr, m->qkv));
             const float kq_scale = 1.0f / sqrtf((float)E / (float)m->H);
+            if (kv_wait) M_HIP(hipStreamWaitEvent(st, kv_wait[l], 0));        // (a one-token chunk of a pipelined ingest)
             if (split_attn)
                 M_HIP(decode_attention_split(m->qkv, El, D, Hl, n_past, n_ctx, m->rope_tab, kc, vc, m->exp_tab, kq_scale,
                                              m->att, &m->qEl, st, dyn));
             else
                 M_HIP(decode_attention(m->qkv, El, D, Hl, n_past, n_ctx, m->rope_tab, kc, vc, m->exp_tab, kq_scale,
                                        &m->qEl, st, dyn));
+            if (kv_rec) M_HIP(hipEventRecord(kv_rec[l], st));
         } else {
             // norm + attention_norm*cur -> Q8_0                                                        llama.cpp:311-319
             M_HIP(rmsnorm_quant(inp, E, ly.attn_norm, N, E, nullptr, 0, &m->qE, layout, st));
@@ -502,6 +531,8 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
                 M_HIP(mm(m, ly.wqkv, m->qE, N, m->qkv, 3 * El, nullptr, 0));                           // wq, wk, wv  :328-334
                 M_HIP(rope_kv(m->qkv, 3 * El, N, El, D, n_past, n_ctx, m->rope_tab, kc, vc, st, dyn)); // rope, store :328-347
             }
+            if (kv_rec) M_HIP(hipEventRecord(kv_rec[l], st));
+            if (kv_wait) M_HIP(hipStreamWaitEvent(st, kv_wait[l], 0));
             const float kq_scale = 1.0f / sqrtf((float)E / (float)m->H);
             // KQ, scale, mask, soft_max, KQV in one launch with the score rows in LDS when they fit       :364-398
             hipError_t pe = (N >= 9 && !dyn && m->fuse_prefill_attn)
@@ -555,7 +586,7 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
             M_HIP(add_rows(m->part, E, mid, E, inp, E, N, E, st));
         }
     }
-    if (body_only) return FL_OK;
+    if (body_only || skip_head) return FL_OK;
     // final norm (kept in f32 for the embeddings) + lm head                                        :452-465
     float *lg = m->Vl > 0 ? m->logits_part : m->logits;
     const int ldlg = m->Vl > 0 ? m->ldp : m->ldl;
@@ -640,6 +671,80 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
         }
         m->ev_used = 0;
     }
+    return FL_OK;
+}
+
+/* A long prompt as consecutive chunks -- what the session's ingest loop (lib/bridge.cpp:186-238) evaluates one llama_eval at a
+ * time: chunk c is tokens[sum(len[0..c-1]) ...] at position n_past + that sum.  The chunks are the same evals, bit for bit, but
+ * two of them are in flight at once on two streams: chunk c+1 needs chunk c only where its attention reads the K/V cache, layer
+ * by layer, so its kernels fill the launch ramps and tails of chunk c's (every launch of a 512-token eval is a single round of
+ * workgroups; two independent evals overlap to 1.14x the throughput, profiles/r02_two_stream_probe.txt).  The lm-head runs for
+ * the LAST chunk only (the reference computes and discards the others' logits).  logits_host: n_vocab floats of the last token,
+ * or NULL.  Tensor-parallel models and profiling runs take the chunks one after the other. */
+int fl_model_ingest(fl_model *m, const int32_t *tokens, const int *chunk_len, int n_chunks, int n_past, float *logits_host) {
+    if (!m || !tokens || !chunk_len) return set_error(FL_EINVAL, "fl_model_ingest: null argument");
+    if (!m->finalized) return set_error(FL_EINVAL, "fl_model_ingest: model not finalized");
+    if (n_chunks < 1) return set_error(FL_EINVAL, "fl_model_ingest: no chunks");
+    long total = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        if (chunk_len[c] < 1 || chunk_len[c] > m->B) return set_error(FL_EINVAL, "chunk %d: %d tokens (1..%d)", c, chunk_len[c], m->B);
+        total += chunk_len[c];
+    }
+    if (n_past < 0 || n_past + total > m->n_ctx) return set_error(FL_EINVAL, "n_past %d + %ld tokens exceed n_ctx %d", n_past, total, m->n_ctx);
+    for (long i = 0; i < total; ++i)
+        if (tokens[i] < 0 || tokens[i] >= m->V) return set_error(FL_EINVAL, "token %d at position %ld is outside the vocabulary (%d)", tokens[i], i, m->V);
+    if (n_chunks == 1 || m->G > 1 || m->profile) {
+        long off = 0;
+        for (int c = 0; c < n_chunks; ++c) {
+            const int rc = fl_model_eval(m, tokens + off, chunk_len[c], n_past + (int)off, c == n_chunks - 1 ? logits_host : nullptr, 0, nullptr);
+            if (rc != FL_OK) return rc;
+            off += chunk_len[c];
+        }
+        return FL_OK;
+    }
+    if (!m->alt_ready) {                                  // the second set of work buffers, its stream, the per-layer events
+        if (!m->alt.stream) M_HIP(hipStreamCreateWithFlags(&m->alt.stream, hipStreamNonBlocking));
+        hipStream_t st1 = m->alt.stream;
+        const int rc = act_alloc(m, m->alt);
+        m->alt.stream = st1;
+        if (rc != FL_OK) return rc;
+        for (auto &v : m->kv_ev)
+            while ((int)v.size() < m->L) {
+                hipEvent_t e;
+                M_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                v.push_back(e);
+            }
+        if (!m->ev_fork) M_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+        if (!m->ev_join) M_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+        m->alt_ready = true;
+    }
+    Act &prim = *m;
+    // the second stream starts behind whatever the primary stream still has queued (an earlier eval's K/V stores)
+    M_HIP(hipEventRecord(m->ev_fork, prim.stream));
+    M_HIP(hipStreamWaitEvent(m->alt.stream, m->ev_fork, 0));
+    long off = 0;
+    int rc = FL_OK;
+    for (int c = 0; c < n_chunks && rc == FL_OK; ++c) {
+        const int set = (n_chunks - 1 - c) & 1;           // the last chunk runs on the primary set: its logits / embeddings stay there
+        if (set) std::swap(prim, m->alt);
+        hipError_t e = hipMemcpyAsync(m->tok_dev, tokens + off, (size_t)chunk_len[c] * 4, hipMemcpyHostToDevice, m->stream);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(tokens)");
+        if (rc == FL_OK)
+            rc = run_eval_kernels(m, chunk_len[c], n_past + (int)off, nullptr, false, 0, -1, false, c != n_chunks - 1,
+                                  c > 0 ? m->kv_ev[set ^ 1].data() : nullptr, m->kv_ev[set].data());
+        if (set) std::swap(prim, m->alt);
+        off += chunk_len[c];
+    }
+    // join: everything the second stream did happens-before whatever follows on the primary one
+    hipError_t e = hipEventRecord(m->ev_join, m->alt.stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(prim.stream, m->ev_join, 0);
+    if (e == hipSuccess && rc == FL_OK && logits_host)
+        e = hipMemcpyAsync(logits_host, m->logits + (size_t)(chunk_len[n_chunks - 1] - 1) * m->ldl, (size_t)m->V * 4, hipMemcpyDeviceToHost, prim.stream);
+    const hipError_t es = hipStreamSynchronize(prim.stream);
+    (void)hipStreamSynchronize(m->alt.stream);
+    if (rc != FL_OK) return rc;
+    if (e != hipSuccess) return hip_fail(e, "fl_model_ingest: join");
+    if (es != hipSuccess) return hip_fail(es, "fl_model_ingest: synchronize");
     return FL_OK;
 }
 
@@ -926,9 +1031,18 @@ void fl_model_free(fl_model *m) {
         fl_qtensor_free(ly.wqkv); fl_qtensor_free(ly.wo); fl_qtensor_free(ly.w13); fl_qtensor_free(ly.w2);
         fr(ly.s_qkv.aos); fr(ly.s_13.aos);
     }
-    fr(m->kc); fr(m->vc); fr(m->exp_tab); fr(m->silu_tab); fr(m->rope_tab); fr(m->tok_dev);
-    fr(m->x); fr(m->x2); fr(m->xn); fr(m->part); fr(m->qkv); fr(m->att); fr(m->ao); fr(m->h13); fr(m->logits); fr(m->logits_part); fr(m->gather_tmp);
-    for (fl_qact *a : {&m->qE, &m->qEl, &m->qF}) { fr(a->q); fr(a->d); fr(a->s); }
+    fr(m->kc); fr(m->vc); fr(m->exp_tab); fr(m->silu_tab); fr(m->rope_tab);
+    fr(m->logits_part); fr(m->gather_tmp);
+    {
+        hipStream_t st0 = m->stream, st1 = m->alt.stream;
+        act_free(*m);
+        act_free(m->alt);
+        m->stream = st0;
+        if (st1) (void)hipStreamDestroy(st1);
+    }
+    for (auto &v : m->kv_ev) for (hipEvent_t e : v) (void)hipEventDestroy(e);
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     for (auto &bk : m->lora_backups) { fr(bk.qs); fr(bk.d); fr(bk.mm); }
     for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
     if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);

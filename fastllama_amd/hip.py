@@ -99,6 +99,7 @@ _PROTOS = {
     "fl_model_finalize": (C.c_int, [C.c_void_p]),
     "fl_model_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fl_model_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "fl_model_ingest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "fl_model_profile": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "fl_model_set_graph": (C.c_int, [C.c_void_p, C.c_int]),
     "fl_model_debug_layers": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

@@ -59,6 +59,16 @@ class FlModel:
                   "fl_model_eval")
         return (lg, emb) if embeddings else lg
 
+    def ingest(self, tokens, chunk, n_past=0, want_logits=True):
+        """The consecutive evals of a long prompt, `chunk` tokens at a time, pipelined on two streams (fl_model_ingest).
+        Returns the last token's logits."""
+        toks = np.ascontiguousarray(tokens, dtype=np.int32)
+        lens = np.array([min(chunk, toks.size - i) for i in range(0, toks.size, chunk)], dtype=np.int32)
+        lg = np.empty((1, self.V), dtype=np.float32) if want_logits else None
+        hip.check(self.L.fl_model_ingest(self.h, toks.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), lens.size, n_past,
+                                         lg.ctypes.data_as(C.c_void_p) if want_logits else None), "fl_model_ingest")
+        return lg
+
     def free(self):
         if getattr(self, "h", None):
             self.L.fl_model_free(self.h)

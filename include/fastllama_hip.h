@@ -179,6 +179,12 @@ int fl_model_set_comm(fl_model *m, fl_comm *c);
  * N*n_vocab (all_logits != 0, `should_put_all_logits`); embeddings_host (optional) n_embd floats of the last token. */
 int fl_model_eval(fl_model *m, const int32_t *tokens_host, int N, int n_past, float *logits_host, int all_logits,
                   float *embeddings_host);
+/* The consecutive evals of a long prompt (the session's ingest loop, lib/bridge.cpp:186-238, one llama_eval per n_batch
+ * chunk): chunk c = the next chunk_len[c] tokens, evaluated at n_past + (tokens before it).  Same results as fl_model_eval
+ * chunk by chunk, bit for bit; two chunks are in flight at once on two streams (chunk c+1 waits for chunk c layer by layer,
+ * only where its attention reads the K/V cache) and only the last chunk runs the lm-head.  logits_host: n_vocab floats of the
+ * last token, or NULL. */
+int fl_model_ingest(fl_model *m, const int32_t *tokens_host, const int *chunk_len, int n_chunks, int n_past, float *logits_host);
 /* enable: 1 = reset + start timing every quantized-matmul launch (HIP events on the eval stream), 0 = stop; the
  * accumulated totals so far are returned through the two pointers (either may be NULL). */
 int fl_model_profile(fl_model *m, int enable, double *mm_ms_total, long *mm_launches);

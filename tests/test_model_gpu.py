@@ -377,6 +377,53 @@ def test_prefill_attention_forms_are_interchangeable(tmp_path_factory, port):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("chunk,total", [(512, 1400), (100, 731), (37, 75), (512, 512), (64, 65)])
+def test_pipelined_ingest_equals_chunk_by_chunk_evals(tmp_path_factory, port, chunk, total):
+    """fl_model_ingest keeps two consecutive chunks of a prompt in flight on two streams (chunk c+1 waits for chunk c layer by
+    layer, where its attention reads the K/V cache) and runs the lm-head for the last chunk only.  The evals are the same: K/V
+    cache and final logits are bit-identical to fl_model_eval chunk by chunk, from n_past = 0 and behind an existing context,
+    twice in a row (the second set of work buffers and its events are reused), and a decode step afterwards sees the same state."""
+    import ctypes as C
+    from fastllama_amd import hip
+    from harness.flmodel import FlModel
+    L = hip.load()
+    cfg = ggjt.SMALL
+    tensors, _ = build(tmp_path_factory, port, cfg, ggjt.Q4_0, "pipe")
+    toks = np.random.default_rng(chunk + total).integers(3, 259, total + 40).astype(np.int32)
+    n_ctx = 1536
+    E, Ln = cfg["n_embd"], cfg["n_layer"]
+
+    def kv(m, upto):
+        k = np.empty((Ln, n_ctx, E), np.float32)
+        v = np.empty((Ln, E, n_ctx), np.float32)
+        hip.check(L.fl_model_kv_read(m.h, k.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)), "kv_read")
+        return k[:, :upto].copy(), v[:, :, :upto].copy()
+
+    def run(pipelined):
+        m = FlModel(cfg, ggjt.Q4_0, tensors, n_ctx=n_ctx, max_batch=512)
+        out = []
+        past = 0
+        for lo, hi in ((0, 40), (40, 40 + total)):                     # a short context first, then the long prompt behind it
+            if pipelined:
+                lg = m.ingest(toks[lo:hi], chunk, n_past=past)
+            else:
+                for i in range(lo, hi, chunk):
+                    lg = m.eval(toks[i:min(i + chunk, hi)], n_past=past + i - lo)
+            past += hi - lo
+            out.append(lg.copy())
+        out.append(m.eval(toks[:1], n_past=past).copy())                # decode step on top
+        k, v = kv(m, past + 1)
+        m.free()
+        return out, k, v
+
+    (a, ka, va), (b, kb, vb) = run(False), run(True)
+    assert np.array_equal(ka.view(np.uint32), kb.view(np.uint32)) and np.array_equal(va.view(np.uint32), vb.view(np.uint32))
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert np.isfinite(a[-1]).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("graph", [0, 1])
 def test_decode_attention_split_switch_is_invisible(tmp_path_factory, port, graph):
     """Decode switches to the two-launch attention at position 256 (second hipGraph capture).  Tokens decoded across the
