@@ -979,6 +979,7 @@ hipError_t prefill_attention_deep(const float *qkv, int ldq, int D, int H, int N
     if (!scratch || (qout && (E % 32 != 0))) return hipErrorInvalidValue;
     // rows of the scratch must not share a cache line with another workgroup's rows; ld_s >= the keys a row can see
     if (D % 32 != 0 || D > 128 || (n_ctx & 3) != 0 || (ld_s & 31) != 0 || ld_s < P || tab_n < 0 || tab_n > 24576 || (tab_n & 7)) return hipErrorInvalidValue;
+    if ((int64_t)N * ld_s * 4 >= (int64_t)1 << 31) return hipErrorInvalidValue;          // 32-bit offsets into a head's scratch rows
     const int qld = D + 4, uf = 32 * qld > 32 * PD_LD ? 32 * qld : 32 * PD_LD;
     const size_t lds = (size_t)tab_n * 2 + (size_t)uf * 4 + (PD_NW * 32 + 64) * 4;
     const dim3 grid(H, nb);
