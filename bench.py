@@ -282,7 +282,7 @@ def main():
             t_seq, t_pipe = timed(one_by_one, lsteps) / lsteps, timed(pipelined, lsteps) / lsteps
             r["long_prompt"] = {"tokens": n_long, "n_batch": N, "tokens_per_s": n_long * seqs / t_pipe, "ms": t_pipe * 1e3,
                                 "chunk_by_chunk_tokens_per_s": n_long * seqs / t_seq,
-                                "note": "consecutive n_batch evals of one prompt, two in flight on two streams (fl_model_ingest); bit-identical to chunk by chunk"}
+                                "note": "fl_model_ingest: the consecutive n_batch evals of one prompt, two in flight on two streams (one stream from 65B width on); bit-identical to chunk by chunk"}
         barrier()
         model.free()
         if comm:

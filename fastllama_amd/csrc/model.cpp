@@ -90,6 +90,7 @@ struct fl_model : Act {
     bool fuse_decode = true;     // N == 1: norm-in-GEMV + one attention kernel per layer
     bool fuse_prefill_attn = true;   // N >= 9: KQ + soft_max + KQV in one launch
     int force_deep_attn = 0;         // debugging: always the key-tiled form of that launch
+    bool ingest_one_stream = false;  // debugging: fl_model_ingest takes its chunks one after the other
     bool w13_il = false;             // w1|w3 woven by 16-row groups (n_ff/tp a multiple of 32): silu epilogue in the matmul
     int exp_tab_n = 0;               // fp16 exp-table entries after 0x8000 that are non-zero (rounded up to 8): the LDS copy
     // LoRA: originals of the tensors an adapter touched (the reference's use_mmap path keeps them too, llama.cpp:868-874)
@@ -693,13 +694,30 @@ int fl_model_ingest(fl_model *m, const int32_t *tokens, const int *chunk_len, in
     if (n_past < 0 || n_past + total > m->n_ctx) return set_error(FL_EINVAL, "n_past %d + %ld tokens exceed n_ctx %d", n_past, total, m->n_ctx);
     for (long i = 0; i < total; ++i)
         if (tokens[i] < 0 || tokens[i] >= m->V) return set_error(FL_EINVAL, "token %d at position %ld is outside the vocabulary (%d)", tokens[i], i, m->V);
-    if (n_chunks == 1 || m->G > 1 || m->profile) {
+    if (n_chunks == 1 || m->profile) {
         long off = 0;
         for (int c = 0; c < n_chunks; ++c) {
             const int rc = fl_model_eval(m, tokens + off, chunk_len[c], n_past + (int)off, c == n_chunks - 1 ? logits_host : nullptr, 0, nullptr);
             if (rc != FL_OK) return rc;
             off += chunk_len[c];
         }
+        return FL_OK;
+    }
+    // Two chunks in flight pay where a launch is one short round of workgroups (7B: +10 %, 13B: +15 %); at 65B width the launches are
+    // four times longer, their ramps and tails are 3 % of them, and two evals sharing the L2 cost more than that (4.59 k vs 4.66 k
+    // tok/s, profiles/r02_bench_configs.jsonl).  Tensor-parallel models have one communicator: one stream.
+    const bool two = m->G == 1 && m->E < 8192 && !m->ingest_one_stream;
+    if (!two) {
+        long off = 0;
+        for (int c = 0; c < n_chunks; ++c) {
+            M_HIP(hipMemcpyAsync(m->tok_dev, tokens + off, (size_t)chunk_len[c] * 4, hipMemcpyHostToDevice, m->stream));
+            const int rc = run_eval_kernels(m, chunk_len[c], n_past + (int)off, nullptr, false, 0, -1, false, c != n_chunks - 1);
+            if (rc != FL_OK) return rc;
+            off += chunk_len[c];
+        }
+        if (logits_host)
+            M_HIP(hipMemcpyAsync(logits_host, m->logits + (size_t)(chunk_len[n_chunks - 1] - 1) * m->ldl, (size_t)m->V * 4, hipMemcpyDeviceToHost, m->stream));
+        M_HIP(hipStreamSynchronize(m->stream));
         return FL_OK;
     }
     if (!m->alt_ready) {                                  // the second set of work buffers, its stream, the per-layer events
@@ -751,14 +769,15 @@ int fl_model_ingest(fl_model *m, const int32_t *tokens, const int *chunk_len, in
 /* bit 0 (default 1): decode evals replay a captured hipGraph, else plain launches; bit 1 (default 0): decode uses the
  * generic per-op kernels instead of the fused single-token ones; bit 2: prefill attention as three kernels; bit 3: decode
  * attention always in one launch per layer; bit 4: always the two-launch split form (default: split from position 256 on);
- * bit 5: prefill attention always in its key-tiled (deep-context) form.
- * Debugging / A-B timing; results do not depend on bits 0, 2, 3, 4, 5. */
+ * bit 5: prefill attention always in its key-tiled (deep-context) form; bit 7: fl_model_ingest on one stream.
+ * Debugging / A-B timing; results do not depend on bits 0, 2, 3, 4, 5, 7. */
 int fl_model_set_graph(fl_model *m, int mode) {
     if (!m) return set_error(FL_EINVAL, "null model");
     m->graph_enabled = (mode & 1) != 0;
     const bool fuse = (mode & 2) == 0;
     m->fuse_prefill_attn = (mode & 4) == 0;
     m->force_deep_attn = (mode & 32) ? 1 : 0;
+    m->ingest_one_stream = (mode & 128) != 0;
     m->split_past = (mode & 8) ? INT_MAX : (mode & 16) ? 0 : 256;
     if (fuse != m->fuse_decode) {
         if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);

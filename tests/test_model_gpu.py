@@ -399,8 +399,9 @@ def test_pipelined_ingest_equals_chunk_by_chunk_evals(tmp_path_factory, port, ch
         hip.check(L.fl_model_kv_read(m.h, k.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)), "kv_read")
         return k[:, :upto].copy(), v[:, :, :upto].copy()
 
-    def run(pipelined):
+    def run(pipelined, mode=1):
         m = FlModel(cfg, ggjt.Q4_0, tensors, n_ctx=n_ctx, max_batch=512)
+        hip.check(L.fl_model_set_graph(m.h, mode))
         out = []
         past = 0
         for lo, hi in ((0, 40), (40, 40 + total)):                     # a short context first, then the long prompt behind it
@@ -416,10 +417,12 @@ def test_pipelined_ingest_equals_chunk_by_chunk_evals(tmp_path_factory, port, ch
         m.free()
         return out, k, v
 
-    (a, ka, va), (b, kb, vb) = run(False), run(True)
-    assert np.array_equal(ka.view(np.uint32), kb.view(np.uint32)) and np.array_equal(va.view(np.uint32), vb.view(np.uint32))
-    for x, y in zip(a, b):
-        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    a, ka, va = run(False)
+    for mode in (1, 1 | 128):                                           # two streams; the one-stream form wide / sharded models take
+        b, kb, vb = run(True, mode)
+        assert np.array_equal(ka.view(np.uint32), kb.view(np.uint32)) and np.array_equal(va.view(np.uint32), vb.view(np.uint32))
+        for x, y in zip(a, b):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
     assert np.isfinite(a[-1]).all()
 
 
