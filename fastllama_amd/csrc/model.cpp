@@ -724,6 +724,7 @@ int fl_model_ingest(fl_model *m, const int32_t *tokens, const int *chunk_len, in
         if (!m->alt.stream) M_HIP(hipStreamCreateWithFlags(&m->alt.stream, hipStreamNonBlocking));
         hipStream_t st1 = m->alt.stream;
         const int rc = act_alloc(m, m->alt);
+        if (rc != FL_OK) act_free(m->alt);                // (no half-allocated set left behind)
         m->alt.stream = st1;
         if (rc != FL_OK) return rc;
         for (auto &v : m->kv_ev)
