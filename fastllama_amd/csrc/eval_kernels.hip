@@ -481,6 +481,7 @@ __global__ __launch_bounds__(PA_T) void prefill_attention_kernel(const float *__
     if (!(PA_ABL & 1)) {
         for (int u = wave; u < nunits; u += PA_T / 64) {
             if (u + PA_T / 64 < nunits) load_k(kn, u + PA_T / 64);    // next tile's K under this tile's MFMAs
+            __builtin_amdgcn_sched_barrier(0);                        // (... and not, as the scheduler would have it, after them)
             const int q = u < ntl0 ? 0 : 1, kt = u < ntl0 ? u : u - ntl0;
             const float *qa = Qs + (q * 32 + r) * QLD + 4 * kk;
             v16f acc;
@@ -649,6 +650,7 @@ __global__ __launch_bounds__(PA_T) void prefill_attention_kernel(const float *__
 }
 #ifdef PA_TIMING
 extern "C" int fl_debug_pa_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pa_dbg), sizeof(long long) * 64 * 8); }
+extern "C" int fl_debug_pd_timing(long long *out);
 #endif
 
 #undef PA_SEL
@@ -670,6 +672,12 @@ extern "C" int fl_debug_pa_timing(long long *out) { return (int)hipMemcpyFromSym
 // (k, k+1) pairs for the tail: chunk boundaries are multiples of 8) are those of the three-kernel path: bit-identical.
 // ------------------------------------------------------------------------------------------------
 constexpr int PD_T = 256, PD_NW = PD_T / 64, PD_CH = 256, PD_LD = PD_CH + 4;
+#ifdef PA_TIMING
+__device__ long long pd_dbg[64 * 8];
+#define PD_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y < 64) pd_dbg[blockIdx.y * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define PD_STAMP(k) do {} while (0)
+#endif
 #ifndef PD_ABL
 #define PD_ABL 0   // timing experiments only (scripts/attn_deep.py), never defined in the product
 #endif
@@ -707,6 +715,7 @@ __global__ __launch_bounds__(PD_T, 2) void prefill_attention_deep_kernel(const f
                                                                          int8_t *__restrict__ oq, float *__restrict__ od,
                                                                          float *__restrict__ os) {
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    PD_STAMP(0);
     constexpr int D = NSTEP * 8, QLD = D + 4, NT = D / 32;
     const int h = blockIdx.x, nb = (N + 31) >> 5, mb = nb - 1 - (int)blockIdx.y;   // heavy blocks first
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -741,6 +750,7 @@ __global__ __launch_bounds__(PD_T, 2) void prefill_attention_deep_kernel(const f
     for (int i = threadIdx.x; i * 8 < tab_n; i += PD_T)
         reinterpret_cast<uint4 *>(tab)[i] = reinterpret_cast<const uint4 *>(exp_tab + 0x8000)[i];
     __syncthreads();
+    PD_STAMP(1);
 
     // ---- phase A: scores -> scratch, running row max ----
     {
@@ -757,9 +767,10 @@ __global__ __launch_bounds__(PD_T, 2) void prefill_attention_deep_kernel(const f
             v16f acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            float4 qf = *reinterpret_cast<const float4 *>(qa);
 #pragma unroll
             for (int j = 0; j < NSTEP; ++j) {
-                const float4 qf = *reinterpret_cast<const float4 *>(qa + 8 * j);
+                const float4 qn = *reinterpret_cast<const float4 *>(qa + 8 * (j + 1 < NSTEP ? j + 1 : j));   // next step's A fragment
 #if !(PD_ABL & 1)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.x, kf[j].x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.y, kf[j].y, acc, 0, 0, 0);
@@ -769,13 +780,17 @@ __global__ __launch_bounds__(PD_T, 2) void prefill_attention_deep_kernel(const f
                 acc[j & 15] += qf.x * kf[j].x;
 #endif
                 kf[j] = *reinterpret_cast<const float4 *>(pbn + 8 * j);
-            }
+                qf = qn;
+                __builtin_amdgcn_sched_barrier(0);                     // (left alone the scheduler gathers the 16 loads at the end of the tile:
+            }                                                          //  no prefetch distance, an exposed L2 round trip per tile)
             const int sbase = __builtin_amdgcn_readfirstlane(kt * 128);
             float sc[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 sc[i] = __fmul_rn(acc[i], scale);
+#if !(PD_ABL & 16)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc[i]), rS, voffS, sbase + ((i & 3) + 8 * (i >> 2)) * lds_ * 4, 0);
+#endif
             }
             if (kt >= full_end) {                                     // a tile the diagonal crosses: masked columns do not count
                 const int col = kt * 32 + r;
@@ -796,7 +811,9 @@ __global__ __launch_bounds__(PD_T, 2) void prefill_attention_deep_kernel(const f
             if (r == 0) wmax[wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * kk] = m;
         }
     }
+    PD_STAMP(2);
     __syncthreads();   // scratch rows and wave maxima are complete (workgroup-scope release / acquire)
+    PD_STAMP(3);
 
     // ---- phase B: 1 / sum of the row's exp values; wave w owns rows w, w + 4, ... (8 rows), all in flight together ----
     constexpr int RPW = 32 / PD_NW;
@@ -847,6 +864,7 @@ __global__ __launch_bounds__(PD_T, 2) void prefill_attention_deep_kernel(const f
         for (int u = 0; u < RPW; ++u) iq[u] = (float)(1.0 / wave_sum_f64(sum[u]));
     }
     load_x(x, 0);      // chunk 0 again, for phase C (L2 hits; in flight across the barrier)
+    PD_STAMP(4);
     __syncthreads();   // every wave is done with the Q rows: U becomes the p chunk
 
     // ---- phase C: KQV over chunks of PD_CH keys ----
@@ -919,6 +937,7 @@ __global__ __launch_bounds__(PD_T, 2) void prefill_attention_deep_kernel(const f
         __syncthreads();
     }
 
+    PD_STAMP(5);
     // ---- phase D ----
     if (!oq) {
         if (pv) {
@@ -970,8 +989,12 @@ __global__ __launch_bounds__(PD_T, 2) void prefill_attention_deep_kernel(const f
             os[cb] = __fmul_rn(dd, (float)sum);
         }
     }
+    PD_STAMP(6);
 }
 
+#ifdef PA_TIMING
+extern "C" int fl_debug_pd_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pd_dbg), sizeof(long long) * 64 * 8); }
+#endif
 hipError_t prefill_attention_deep(const float *qkv, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc,
                                   const float *vc, const uint16_t *exp_tab, int tab_n, float scale, float *scratch, int ld_s,
                                   int64_t s_head, float *ao, int ldo, hipStream_t st, const fl_qact *qout) {
