@@ -213,12 +213,15 @@ def main():
             if not comm:
                 raise SystemExit("fl_comm_create failed: " + L.fl_last_error().decode())
             model.set_comm(ctypes.c_void_p(comm))
+            peer_exchange = bool(L.fl_comm_has_p2p(ctypes.c_void_p(comm)))
         rng = np.random.default_rng(7 + (0 if tp else rank))
         toks = rng.integers(3, 259, size=N).astype(np.int32)      # uniform ids in [3, 258]
         tok1 = toks[:1].copy()
         seqs = 1 if tp else world
         shard = world if tp else 1
         r = {"seqs": seqs}
+        if tp:
+            r["peer_exchange"] = peer_exchange      # decode-size messages go through peer-mapped buffers instead of a ring collective
         # ---- prefill (the headline): K timed evals after W warm-ups
         prefill = lambda i: model.eval_nocopy(toks, 0)
         for i in range(args.warmup):
@@ -337,6 +340,8 @@ def main():
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "unavailable",
                                        "sample": f"failed: {e!r}"}
+        if tp:
+            out["tp_small_message_path"] = "peer-mapped buffers (hipIpc), one kernel per rank" if head.get("peer_exchange") else "RCCL"
         if tp_error:
             out["tp_error"] = tp_error + " -- the headline above is the replica leg"
         if rank == 0:

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -32,11 +33,56 @@ struct LocalGroup {
     int done_status = FL_OK;   // of the round that just completed
 };
 
+// One-shot exchange of small messages through peer-mapped buffers (hipIpc; p2p_exchange_kernel, eval_kernels.hip): what a decode
+// token's 16-32 KB all-reduces and its logits all-gather take instead of a ring collective.  Set up next to the RCCL
+// communicator when every step of the handle exchange succeeds; otherwise the communicator simply stays RCCL-only.
+constexpr size_t P2P_CAP = 64 * 1024;          // floats per slot (256 KB): the exchange buffer of a rank is two slots
+constexpr size_t P2P_MAX_COUNT = 16 * 1024;    // messages up to 64 KB go this way (one workgroup moves them)
+struct P2PState {
+    P2PPeers peers{};
+    void *own_buf = nullptr, *own_flag = nullptr;
+    void *mapped[2 * FL_COMM_MAX_LOCAL] = {nullptr};
+    int n_mapped = 0;
+    bool ready = false;
+};
+
 struct fl_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     LocalGroup *lg = nullptr;
+    P2PState p2p;
 };
+
+static int p2p_alloc(fl_comm *c) {
+    P2PState &p = c->p2p;
+    if (p.own_buf) return FL_OK;
+    if (c->world < 2 || c->world > FL_COMM_MAX_LOCAL) return set_error(FL_EINVAL, "peer exchange needs 2..%d ranks", FL_COMM_MAX_LOCAL);
+    hipError_t e = hipMalloc(&p.own_buf, 2 * P2P_CAP * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&p.own_flag, 4096);           // [0..1] flags (exported), [16] this rank's epoch
+    if (e == hipSuccess) e = hipMemset(p.own_flag, 0, 4096);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        if (p.own_buf) (void)hipFree(p.own_buf);
+        if (p.own_flag) (void)hipFree(p.own_flag);
+        p.own_buf = p.own_flag = nullptr;
+        return set_error(FL_EHIP, "peer exchange buffers: %s", hipGetErrorString(e));
+    }
+    p.peers.world = c->world;
+    p.peers.rank = c->rank;
+    p.peers.cap = P2P_CAP;
+    p.peers.buf[c->rank] = static_cast<float *>(p.own_buf);
+    p.peers.flag[c->rank] = static_cast<unsigned *>(p.own_flag);
+    p.peers.epoch = static_cast<unsigned *>(p.own_flag) + 16;
+    return FL_OK;
+}
+static void p2p_free(fl_comm *c) {
+    P2PState &p = c->p2p;
+    for (int i = 0; i < p.n_mapped; ++i) (void)hipIpcCloseMemHandle(p.mapped[i]);
+    if (p.own_buf) (void)hipFree(p.own_buf);
+    if (p.own_flag) (void)hipFree(p.own_flag);
+    p = P2PState{};
+}
+static_assert(2 * sizeof(hipIpcMemHandle_t) == FL_COMM_P2P_HANDLE_BYTES, "hipIpcMemHandle_t size");
 
 static_assert(sizeof(ncclUniqueId) == FL_COMM_ID_BYTES, "ncclUniqueId size");
 
@@ -69,8 +115,85 @@ fl_comm *fl_comm_create(const void *id_bytes, int rank, int world) {
     }
     c->rank = rank;
     c->world = world;
+    // peer-mapped exchange buffers for the small messages: handles travel through the communicator itself
+    if (world >= 2 && world <= FL_COMM_MAX_LOCAL && !getenv("FL_NO_P2P")) {
+        unsigned char mine[FL_COMM_P2P_HANDLE_BYTES], all[FL_COMM_P2P_HANDLE_BYTES * FL_COMM_MAX_LOCAL];
+        void *stage = nullptr;
+        bool ok = fl_comm_p2p_export(c, mine) == FL_OK && hipMalloc(&stage, sizeof all + sizeof mine) == hipSuccess;
+        if (ok) ok = hipMemcpy(static_cast<unsigned char *>(stage) + sizeof all, mine, sizeof mine, hipMemcpyHostToDevice) == hipSuccess;
+        // (every rank takes part in the collective whatever happened locally: a rank that failed contributes a zero handle)
+        if (!ok && stage) (void)hipMemset(static_cast<unsigned char *>(stage) + sizeof all, 0, sizeof mine);
+        if (stage) {
+            ncclResult_t g = ncclAllGather(static_cast<unsigned char *>(stage) + sizeof all, stage, sizeof mine, ncclUint8, c->comm, nullptr);
+            if (g != ncclSuccess || hipDeviceSynchronize() != hipSuccess ||
+                hipMemcpy(all, stage, sizeof mine * (size_t)world, hipMemcpyDeviceToHost) != hipSuccess)
+                ok = false;
+            (void)hipFree(stage);
+            bool every = ok;
+            for (int r = 0; r < world && every; ++r) {
+                bool nz = false;
+                for (size_t i = 0; i < sizeof mine; ++i) nz = nz || all[(size_t)r * sizeof mine + i] != 0;
+                every = nz;
+            }
+            if (!every || fl_comm_p2p_import(c, all) != FL_OK) p2p_free(c);
+        } else {
+            p2p_free(c);
+        }
+        (void)hipGetLastError();
+    }
     return c;
 }
+
+/* A communicator that has ONLY the peer-mapped exchange (no RCCL): for hosts that move the handles themselves
+ * (fl_comm_p2p_export / fl_comm_p2p_import) -- and for testing the exchange with two processes on one GPU, where RCCL
+ * refuses to start.  Messages beyond the exchange buffers' reach fail. */
+fl_comm *fl_comm_create_p2p(int rank, int world) {
+    if (ensure_device() != FL_OK) return nullptr;
+    if (world < 2 || world > FL_COMM_MAX_LOCAL || rank < 0 || rank >= world) {
+        set_error(FL_EINVAL, "fl_comm_create_p2p: bad arguments");
+        return nullptr;
+    }
+    fl_comm *c = new (std::nothrow) fl_comm();
+    if (!c) return nullptr;
+    c->rank = rank;
+    c->world = world;
+    return c;
+}
+
+int fl_comm_p2p_export(fl_comm *c, void *handles_out) {
+    if (!c || !handles_out || c->lg) return set_error(FL_EINVAL, "fl_comm_p2p_export: bad arguments");
+    int rc = p2p_alloc(c);
+    if (rc != FL_OK) return rc;
+    hipIpcMemHandle_t h[2];
+    hipError_t e = hipIpcGetMemHandle(&h[0], c->p2p.own_buf);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&h[1], c->p2p.own_flag);
+    if (e != hipSuccess) return set_error(FL_EHIP, "hipIpcGetMemHandle: %s", hipGetErrorString(e));
+    memcpy(handles_out, h, sizeof h);
+    return FL_OK;
+}
+
+int fl_comm_p2p_import(fl_comm *c, const void *handles_all) {
+    if (!c || !handles_all || c->lg || !c->p2p.own_buf) return set_error(FL_EINVAL, "fl_comm_p2p_import: export first");
+    P2PState &p = c->p2p;
+    const unsigned char *src = static_cast<const unsigned char *>(handles_all);
+    for (int r = 0; r < c->world; ++r) {
+        if (r == c->rank) continue;
+        hipIpcMemHandle_t h[2];
+        memcpy(h, src + (size_t)r * sizeof h, sizeof h);
+        for (int k = 0; k < 2; ++k) {
+            void *ptr = nullptr;
+            hipError_t e = hipIpcOpenMemHandle(&ptr, h[k], hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) return set_error(FL_EHIP, "hipIpcOpenMemHandle (rank %d): %s", r, hipGetErrorString(e));
+            p.mapped[p.n_mapped++] = ptr;
+            if (k == 0) p.peers.buf[r] = static_cast<float *>(ptr);
+            else p.peers.flag[r] = static_cast<unsigned *>(ptr);
+        }
+    }
+    p.ready = true;
+    return FL_OK;
+}
+
+int fl_comm_has_p2p(const fl_comm *c) { return c && c->p2p.ready ? 1 : 0; }
 
 int fl_comm_create_local(int world, fl_comm **out) {
     if (ensure_device() != FL_OK) return FL_ENODEV;
@@ -123,6 +246,11 @@ static int local_allreduce(fl_comm *c, float *buf, size_t count, hipStream_t st)
 int fl_comm_allreduce_sum_f32(fl_comm *c, float *buf_dev, size_t count, void *stream) {
     if (!c || !buf_dev) return set_error(FL_EINVAL, "fl_comm_allreduce: null argument");
     if (c->lg) return local_allreduce(c, buf_dev, count, reinterpret_cast<hipStream_t>(stream));
+    if (c->p2p.ready && count <= P2P_MAX_COUNT) {
+        hipError_t e = p2p_exchange(c->p2p.peers, buf_dev, count, nullptr, reinterpret_cast<hipStream_t>(stream));
+        return e == hipSuccess ? FL_OK : set_error(FL_EHIP, "peer all-reduce: %s", hipGetErrorString(e));
+    }
+    if (!c->comm) return set_error(FL_EINVAL, "all-reduce of %zu floats needs an RCCL communicator", count);
     ncclResult_t r = ncclAllReduce(buf_dev, buf_dev, count, ncclFloat32, ncclSum, c->comm, reinterpret_cast<hipStream_t>(stream));
     if (r != ncclSuccess) return set_error(FL_EHIP, "ncclAllReduce: %s", ncclGetErrorString(r));
     return FL_OK;
@@ -161,6 +289,11 @@ static int local_allgather(fl_comm *c, const float *send, size_t count, float *r
 int fl_comm_allgather_f32(fl_comm *c, const float *send_dev, size_t count, float *recv_dev, void *stream) {
     if (!c || !send_dev || !recv_dev) return set_error(FL_EINVAL, "fl_comm_allgather: null argument");
     if (c->lg) return local_allgather(c, send_dev, count, recv_dev, reinterpret_cast<hipStream_t>(stream));
+    if (c->p2p.ready && count <= P2P_MAX_COUNT) {
+        hipError_t e = p2p_exchange(c->p2p.peers, const_cast<float *>(send_dev), count, recv_dev, reinterpret_cast<hipStream_t>(stream));
+        return e == hipSuccess ? FL_OK : set_error(FL_EHIP, "peer all-gather: %s", hipGetErrorString(e));
+    }
+    if (!c->comm) return set_error(FL_EINVAL, "all-gather of %zu floats needs an RCCL communicator", count);
     ncclResult_t r = ncclAllGather(send_dev, recv_dev, count, ncclFloat32, c->comm, reinterpret_cast<hipStream_t>(stream));
     if (r != ncclSuccess) return set_error(FL_EHIP, "ncclAllGather: %s", ncclGetErrorString(r));
     return FL_OK;
@@ -170,7 +303,7 @@ int fl_comm_is_local(const fl_comm *c) { return c && c->lg ? 1 : 0; }
 
 /* test hook: one all-reduce captured into a hipGraph and replayed `replays` times (RCCL collectives inside the decode graph) */
 int fl_comm_debug_graph_allreduce(fl_comm *c, float *buf_dev, size_t count, int replays, void *stream) {
-    if (!c || c->lg || !buf_dev || !stream) return set_error(FL_EINVAL, "fl_comm_debug_graph_allreduce: needs an RCCL communicator and a stream");
+    if (!c || c->lg || !buf_dev || !stream) return set_error(FL_EINVAL, "fl_comm_debug_graph_allreduce: needs an RCCL or peer-exchange communicator and a stream");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipGraph_t g = nullptr;
     hipGraphExec_t ex = nullptr;
@@ -192,6 +325,7 @@ int fl_comm_size(const fl_comm *c) { return c ? c->world : 0; }
 
 void fl_comm_destroy(fl_comm *c) {
     if (!c) return;
+    p2p_free(c);
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->lg) {
         bool last;

@@ -6,4 +6,14 @@
 namespace fl {
 // every bufs[r][i] <- bufs[0][i] + bufs[1][i] + ... (rank order) for i < count   (eval_kernels.hip)
 hipError_t sum_buffers_inplace(float *const *bufs, int world, size_t count, hipStream_t st);
+// one-shot exchange of a small message through peer-mapped buffers (eval_kernels.hip): all-reduce in rank order into `data`, or
+// (gather_out != NULL) all-gather of `count` floats per rank into gather_out[rank][count]
+struct P2PPeers {
+    float *buf[FL_COMM_MAX_LOCAL];        // [2 slots][cap] floats of every rank (own + mapped peers')
+    unsigned *flag[FL_COMM_MAX_LOCAL];    // [2] epoch flags of every rank
+    unsigned *epoch;                      // this rank's epoch counter (device memory)
+    size_t cap;
+    int world, rank;
+};
+hipError_t p2p_exchange(const P2PPeers &peers, float *data, size_t count, float *gather_out, hipStream_t st);
 }  // namespace fl

@@ -1601,6 +1601,49 @@ hipError_t sum_buffers_inplace(float *const *bufs, int world, size_t count, hipS
     return hipGetLastError();
 }
 
+// One-shot all-reduce / all-gather of a SMALL message between the tensor-parallel ranks of one node (the 16-32 KB partial
+// sums of a decode token): every rank owns an exchange buffer that its peers have mapped (hipIpc; xGMI between GPUs).
+// Epoch e, slot e & 1: copy the local vector into the own slot (system-scope stores) -> release flag[slot] = e -> wait until
+// every peer's flag says e -> read all slots and add them in RANK ORDER (the order sum_buffers_kernel uses, identical on every
+// rank, so the ranks stay bit-identical).  Two slots: a rank can only start epoch e + 1 after every peer has published e,
+// i.e. after it finished reading epoch e - 1's slot.  One kernel, no host involvement: it can be captured in the decode hipGraph
+// (the epoch counter lives in device memory).  One workgroup: the message is a few pages and the cost is the round trip.
+__global__ __launch_bounds__(1024) void p2p_exchange_kernel(P2PPeers a, float *data, unsigned count, float *gather_out) {
+    __shared__ unsigned ep_s;
+    const unsigned tid = threadIdx.x;
+    if (tid == 0) ep_s = *a.epoch + 1;
+    __syncthreads();
+    const unsigned e = ep_s, slot = e & 1;
+    float *mine = a.buf[a.rank] + (size_t)slot * a.cap;
+    for (unsigned i = tid; i < count; i += 1024) __hip_atomic_store(mine + i, data[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(a.flag[a.rank] + slot, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid < (unsigned)a.world && (int)tid != a.rank) {
+        const unsigned *f = a.flag[tid] + slot;
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    if (!gather_out) {
+        for (unsigned i = tid; i < count; i += 1024) {
+            float s = __hip_atomic_load(a.buf[0] + (size_t)slot * a.cap + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int r = 1; r < a.world; ++r)
+                s += __hip_atomic_load(a.buf[r] + (size_t)slot * a.cap + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            data[i] = s;
+        }
+    } else {
+        for (int r = 0; r < a.world; ++r)
+            for (unsigned i = tid; i < count; i += 1024)
+                gather_out[(size_t)r * count + i] = __hip_atomic_load(a.buf[r] + (size_t)slot * a.cap + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (tid == 0) *a.epoch = e;
+}
+hipError_t p2p_exchange(const P2PPeers &peers, float *data, size_t count, float *gather_out, hipStream_t st) {
+    if (count == 0 || count > peers.cap || peers.world < 2 || peers.world > FL_COMM_MAX_LOCAL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(p2p_exchange_kernel, dim3(1), dim3(1024), 0, st, peers, data, (unsigned)count, gather_out);
+    return hipGetLastError();
+}
+
 // out[n][e] = a[n][e] + b[n][e]   (ggml_add)
 __global__ void add_rows_kernel(const float *__restrict__ a, int lda, const float *__restrict__ b, int ldb,
                                 float *__restrict__ o, int ldo, int N, int E) {

@@ -86,6 +86,10 @@ _PROTOS = {
     "fl_comm_allreduce_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "fl_comm_allgather_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "fl_comm_is_local": (C.c_int, [C.c_void_p]),
+    "fl_comm_create_p2p": (C.c_void_p, [C.c_int, C.c_int]),
+    "fl_comm_p2p_export": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fl_comm_p2p_import": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fl_comm_has_p2p": (C.c_int, [C.c_void_p]),
     "fl_comm_debug_graph_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "fl_comm_rank": (C.c_int, [C.c_void_p]),
     "fl_comm_size": (C.c_int, [C.c_void_p]),

@@ -3,6 +3,9 @@ a 1-GPU box) and runnable by hand on a multi-GPU node:
 
     for r in 0 1; do python -m harness.tp_worker $r 2 /tmp/tp_id.bin /tmp/tp_out_$r.npz & done; wait
 
+With a fifth argument (a directory) every rank runs on device 0 and the communicator is the peer-mapped exchange alone
+(fl_comm_create_p2p; handles through files in that directory): two processes, ONE GPU.
+
 Rank 0 writes the 128-byte RCCL id to <idfile>; the others wait for it.  Every rank evaluates the same synthetic SMALL model
 (harness/ggjt.py) on its own GPU: a prefill, a decode step through the captured hipGraph (RCCL collectives inside), and a
 plain-launch decode step; rank 0 additionally evaluates the unsharded model.  Results go to <outfile>."""
@@ -22,11 +25,34 @@ def main():
     from fastllama_amd import hip
     from harness import ggjt
     from harness.flmodel import FlModel
-    torch.cuda.set_device(rank)
+    p2p_dir = sys.argv[5] if len(sys.argv) > 5 else None         # peer-exchange communicator, every rank on device 0 (see below)
+    dev = 0 if p2p_dir else rank
+    torch.cuda.set_device(dev)
     L = hip.load()
-    hip.require_device(rank)
+    hip.require_device(dev)
     raw = (C.c_ubyte * 128)()
-    if rank == 0:
+    if p2p_dir:
+        # no RCCL (it refuses two ranks on one GPU): the peer-mapped exchange alone carries the collectives of a model whose
+        # messages are small enough for it; the hipIpc handles travel through files
+        comm = L.fl_comm_create_p2p(rank, world)
+        if not comm:
+            raise SystemExit("fl_comm_create_p2p: " + L.fl_last_error().decode())
+        comm = C.c_void_p(comm)
+        mine = (C.c_ubyte * 128)()
+        hip.check(L.fl_comm_p2p_export(comm, mine), "p2p_export")
+        with open(os.path.join(p2p_dir, f"h{rank}.tmp"), "wb") as f:
+            f.write(bytes(mine))
+        os.replace(os.path.join(p2p_dir, f"h{rank}.tmp"), os.path.join(p2p_dir, f"h{rank}.bin"))
+        allh, t0 = b"", time.time()
+        for r in range(world):
+            pth = os.path.join(p2p_dir, f"h{r}.bin")
+            while not os.path.exists(pth):
+                if time.time() - t0 > 120:
+                    raise SystemExit("no handle from rank %d" % r)
+                time.sleep(0.02)
+            allh += open(pth, "rb").read()
+        hip.check(L.fl_comm_p2p_import(comm, (C.c_ubyte * len(allh))(*allh)), "p2p_import")
+    elif rank == 0:
         hip.check(L.fl_comm_unique_id(raw), "fl_comm_unique_id")
         with open(idfile + ".tmp", "wb") as f:
             f.write(bytes(raw))
@@ -38,14 +64,15 @@ def main():
                 raise SystemExit("no RCCL id from rank 0")
             time.sleep(0.05)
         raw = (C.c_ubyte * 128)(*open(idfile, "rb").read())
-    comm = L.fl_comm_create(raw, rank, world)
-    if not comm:
-        raise SystemExit("fl_comm_create: " + L.fl_last_error().decode())
-    comm = C.c_void_p(comm)
+    if not p2p_dir:
+        comm = L.fl_comm_create(raw, rank, world)
+        if not comm:
+            raise SystemExit("fl_comm_create: " + L.fl_last_error().decode())
+        comm = C.c_void_p(comm)
     cfg, qtype = ggjt.SMALL, ggjt.Q4_0
     tensors = ggjt.synth_tensors(cfg, qtype, oracle.Port().quantize_q4, seed=4321)
     toks = ggjt.text_tokens("The quick brown fox jumps over the lazy dog")
-    m = FlModel(cfg, qtype, tensors, n_ctx=128, max_batch=64, tp_rank=rank, tp_size=world, device=rank)
+    m = FlModel(cfg, qtype, tensors, n_ctx=128, max_batch=64, tp_rank=rank, tp_size=world, device=dev)
     m.set_comm(comm)
     pre = m.eval(toks, all_logits=True)
     dec_graph = m.eval([toks[3]], n_past=len(toks))

@@ -151,6 +151,16 @@ int fl_comm_allreduce_sum_f32(fl_comm *c, float *buf_dev, size_t count, void *st
 /* recv_dev[r * count + i] <- rank r's send_dev[i] (the logits slices of the row-split lm-head) */
 int fl_comm_allgather_f32(fl_comm *c, const float *send_dev, size_t count, float *recv_dev, void *stream);
 int fl_comm_is_local(const fl_comm *c);
+/* Small messages (<= 64 KB: the partial sums and logits slices of a decode token) skip the ring collective: every rank owns an
+ * exchange buffer its peers map (hipIpc, xGMI), and ONE kernel per rank publishes, waits for and adds -- in rank order -- the
+ * G vectors.  fl_comm_create sets this up by itself (the handles travel through RCCL; FL_NO_P2P=1 disables it).  A host that
+ * moves the handles itself: fl_comm_create_p2p on every rank, fl_comm_p2p_export -> gather the FL_COMM_P2P_HANDLE_BYTES of all
+ * ranks in rank order -> fl_comm_p2p_import.  Such a communicator has no RCCL behind it: larger messages fail. */
+#define FL_COMM_P2P_HANDLE_BYTES 128
+fl_comm *fl_comm_create_p2p(int rank, int world);
+int fl_comm_p2p_export(fl_comm *c, void *handles_out /* FL_COMM_P2P_HANDLE_BYTES */);
+int fl_comm_p2p_import(fl_comm *c, const void *handles_all /* world * FL_COMM_P2P_HANDLE_BYTES, rank order */);
+int fl_comm_has_p2p(const fl_comm *c);
 int fl_comm_debug_graph_allreduce(fl_comm *c, float *buf_dev, size_t count, int replays, void *stream);
 int fl_comm_rank(const fl_comm *c);
 int fl_comm_size(const fl_comm *c);

@@ -222,6 +222,70 @@ def test_rccl_allreduce_inside_a_hipgraph():
     L.fl_comm_destroy(c)
 
 
+def test_peer_exchange_two_processes_on_one_gpu(tmp_path):
+    """The one-shot small-message exchange (peer-mapped buffers over hipIpc, one kernel per rank: publish, wait, add in rank
+    order) between two PROCESSES -- on one GPU, which is all this box has and which RCCL refuses; the handles travel through
+    files.  All-reduces of several sizes (alternating slots), an all-gather, an all-reduce captured in a hipGraph and replayed:
+    every rank ends with the rank-order f32 sum, bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-m", "harness.p2p_worker", str(r), "2", str(tmp_path), "0"], cwd=root, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=240)[0].decode(errors="replace"))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("peer exchange workers did not finish (a rank spinning on a peer that never ran?)")
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    o = [np.load(str(tmp_path / f"out{r}.npz")) for r in range(2)]
+    for k, n in enumerate((4096, 1, 8192, 16384, 333, 4096)):
+        xs = [np.random.default_rng(100 * k + r).standard_normal(n).astype(np.float32) for r in range(2)]
+        want = (xs[0] + xs[1]).astype(np.float32)
+        for r in range(2):
+            assert np.array_equal(o[r][f"ar{k}"].view(np.uint32), want.view(np.uint32)), (k, r)
+    want = np.concatenate([np.random.default_rng(7 + r).standard_normal(1000).astype(np.float32) for r in range(2)])
+    for r in range(2):
+        assert np.array_equal(o[r]["ag"], want)
+    xs = [np.random.default_rng(55 + r).standard_normal(4096).astype(np.float32) for r in range(2)]
+    s1 = (xs[0] + xs[1]).astype(np.float32)
+    want = ((s1 + s1) + (s1 + s1)).astype(np.float32)            # three replays: S, 2S, 4S (exact doublings)
+    for r in range(2):
+        assert np.array_equal(o[r]["graph"].view(np.uint32), want.view(np.uint32)), r
+    print("peer all-reduce of 4096 floats: %.1f / %.1f us per call" % (float(o[0]["us_per_allreduce"]), float(o[1]["us_per_allreduce"])))
+
+
+def test_two_process_tensor_parallel_over_the_peer_exchange(tmp_path):
+    """The tensor-parallel eval across two real PROCESSES on this box's one GPU: every collective of the (small) model --
+    two all-reduces per layer, the logits all-gather, eager in prefill and captured in the decode hipGraph -- goes through the
+    peer-mapped exchange.  Same checks as the two-GPU RCCL test below."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-m", "harness.tp_worker", str(r), "2", str(tmp_path / "unused"), str(tmp_path / f"out{r}.npz"),
+                               str(tmp_path)], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=300)[0].decode(errors="replace"))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("tensor-parallel workers did not finish")
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    o = [np.load(str(tmp_path / f"out{r}.npz")) for r in range(2)]
+    for k in ("pre", "dec_graph", "dec_graph2", "dec_plain"):
+        assert np.array_equal(o[0][k], o[1][k]), k                      # every rank ends with the full, identical logits
+    assert np.array_equal(o[0]["dec_graph2"], o[0]["dec_plain"])       # graph replay == plain launches
+    check_logits(o[0]["pre"], o[0]["full_pre"].astype(np.float64), "tp2 (peer exchange) prefill vs unsharded")
+    assert relerr(o[0]["dec_graph"], o[0]["full_dec"]) <= 5e-2
+
+
 def test_rccl_two_ranks_tensor_parallel(tmp_path):
     """Two processes, two GPUs, RCCL over xGMI: the Megatron split with the row-split lm-head + all-gather, prefill and decode
     (collectives captured in the decode hipGraph, then plain launches) against the unsharded model.  Needs two devices: the
