@@ -127,7 +127,7 @@ def main():
                     help="world > 1: tp = ONE batch, Megatron split + RCCL (the headline, strong scaling; a replica leg is measured "
                          "and reported beside it), dp = replicas only.  auto = tp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--tp-timeout", type=int, default=420, help="seconds the tensor-parallel leg may take before the replica leg is reported alone")
+    ap.add_argument("--tp-timeout", type=int, default=300, help="seconds the tensor-parallel leg may take before the replica leg is reported alone")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -57,8 +57,15 @@ static int p2p_alloc(fl_comm *c) {
     P2PState &p = c->p2p;
     if (p.own_buf) return FL_OK;
     if (c->world < 2 || c->world > FL_COMM_MAX_LOCAL) return set_error(FL_EINVAL, "peer exchange needs 2..%d ranks", FL_COMM_MAX_LOCAL);
-    hipError_t e = hipMalloc(&p.own_buf, 2 * P2P_CAP * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&p.own_flag, 4096);           // [0..1] flags (exported), [16] this rank's epoch
+    // fine-grained device memory (what RCCL uses for its own peer buffers): coherent for peers while a kernel runs; the kernel
+    // uses system-scope accesses on top of it.  Plain hipMalloc if the runtime refuses the flag.
+    auto alloc = [](void **ptr, size_t bytes) {
+        hipError_t r = hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocFinegrained);
+        if (r != hipSuccess) { (void)hipGetLastError(); r = hipMalloc(ptr, bytes); }
+        return r;
+    };
+    hipError_t e = alloc(&p.own_buf, 2 * P2P_CAP * sizeof(float));
+    if (e == hipSuccess) e = alloc(&p.own_flag, 4096);               // [0..1] flags (exported), [16] this rank's epoch
     if (e == hipSuccess) e = hipMemset(p.own_flag, 0, 4096);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
