@@ -127,11 +127,14 @@ def main():
                     help="world > 1: tp = ONE batch, Megatron split + RCCL (the headline, strong scaling; a replica leg is measured "
                          "and reported beside it), dp = replicas only.  auto = tp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--peer-exchange", action="store_true", help="tensor-parallel leg: decode-size messages through peer-mapped buffers (FL_P2P=1) instead of RCCL; never run over xGMI so far")
     ap.add_argument("--tp-timeout", type=int, default=300, help="seconds the tensor-parallel leg may take before the replica leg is reported alone")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.peer_exchange:
+        os.environ["FL_P2P"] = "1"
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")

@@ -123,7 +123,10 @@ fl_comm *fl_comm_create(const void *id_bytes, int rank, int world) {
     c->rank = rank;
     c->world = world;
     // peer-mapped exchange buffers for the small messages: handles travel through the communicator itself
-    if (world >= 2 && world <= FL_COMM_MAX_LOCAL && !getenv("FL_NO_P2P")) {
+    // (opt-in, FL_P2P=1: the exchange has run between processes on one GPU only -- no multi-GPU node was available to this
+    //  project -- and a communicator that every multi-GPU run depends on should not default to an untried path)
+    const char *want_p2p = getenv("FL_P2P");
+    if (world >= 2 && world <= FL_COMM_MAX_LOCAL && want_p2p && want_p2p[0] == '1') {
         unsigned char mine[FL_COMM_P2P_HANDLE_BYTES], all[FL_COMM_P2P_HANDLE_BYTES * FL_COMM_MAX_LOCAL];
         void *stage = nullptr;
         bool ok = fl_comm_p2p_export(c, mine) == FL_OK && hipMalloc(&stage, sizeof all + sizeof mine) == hipSuccess;

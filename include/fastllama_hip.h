@@ -153,7 +153,8 @@ int fl_comm_allgather_f32(fl_comm *c, const float *send_dev, size_t count, float
 int fl_comm_is_local(const fl_comm *c);
 /* Small messages (<= 64 KB: the partial sums and logits slices of a decode token) skip the ring collective: every rank owns an
  * exchange buffer its peers map (hipIpc, xGMI), and ONE kernel per rank publishes, waits for and adds -- in rank order -- the
- * G vectors.  fl_comm_create sets this up by itself (the handles travel through RCCL; FL_NO_P2P=1 disables it).  A host that
+ * G vectors.  With FL_P2P=1 in the environment fl_comm_create sets this up by itself (the handles travel through RCCL; any
+ * failure leaves a plain RCCL communicator).  Opt-in because it has only ever run between processes on ONE GPU.  A host that
  * moves the handles itself: fl_comm_create_p2p on every rank, fl_comm_p2p_export -> gather the FL_COMM_P2P_HANDLE_BYTES of all
  * ranks in rank order -> fl_comm_p2p_import.  Such a communicator has no RCCL behind it: larger messages fail. */
 #define FL_COMM_P2P_HANDLE_BYTES 128
