@@ -165,7 +165,10 @@ def main():
     n_ctx = max(args.n_ctx, 1024, 2 * N)
     L = hip.load()
     hip.require_device(local)
-    want_tp = world > 1 and args.parallel in ("auto", "tp") and cfg["n_head"] % world == 0 and backend == "nccl"
+    # development: FL_BENCH_P2P_ONLY=1 builds the tensor-parallel communicator from the peer exchange alone (no RCCL), which lets
+    # the tensor-parallel leg of this file run as two processes on ONE GPU -- with a model whose messages fit (--model tiny --n-batch 32)
+    p2p_only = os.environ.get("FL_BENCH_P2P_ONLY") == "1"
+    want_tp = world > 1 and args.parallel in ("auto", "tp") and cfg["n_head"] % world == 0 and (backend == "nccl" or p2p_only)
     wk, wk1 = synth.algorithmic_work(cfg, N, qtype), synth.algorithmic_work(cfg, 1, qtype)
 
     def barrier():
@@ -203,7 +206,19 @@ def main():
         model = FlModel(cfg, qtype, synth.synth_model_tensors(cfg, qtype), n_ctx=n_ctx, max_batch=N,
                         tp_rank=rank if tp else 0, tp_size=world if tp else 1, device=local)
         comm = None
-        if tp:
+        if tp and p2p_only:
+            comm = L.fl_comm_create_p2p(rank, world)
+            if not comm:
+                raise SystemExit("fl_comm_create_p2p failed: " + L.fl_last_error().decode())
+            mine = (ctypes.c_ubyte * 128)()
+            hip.check(L.fl_comm_p2p_export(ctypes.c_void_p(comm), mine), "p2p_export")
+            gathered = [None] * world
+            dist.all_gather_object(gathered, bytes(mine))
+            allh = b"".join(gathered)
+            hip.check(L.fl_comm_p2p_import(ctypes.c_void_p(comm), (ctypes.c_ubyte * len(allh))(*allh)), "p2p_import")
+            model.set_comm(ctypes.c_void_p(comm))
+            peer_exchange = True
+        elif tp:
             idbuf = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
                 raw = (ctypes.c_ubyte * 128)()

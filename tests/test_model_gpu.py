@@ -286,6 +286,27 @@ def test_two_process_tensor_parallel_over_the_peer_exchange(tmp_path):
     assert relerr(o[0]["dec_graph"], o[0]["full_dec"]) <= 5e-2
 
 
+def test_bench_tensor_parallel_leg_as_two_processes_on_one_gpu():
+    """bench.py's world > 1 code -- replica leg, tensor-parallel leg (communicator, sharded model, timing, the JSON line with
+    `replicas` beside the headline) -- run the way the driver launches it, with two ranks on this box's one GPU: gloo for the
+    process group, the peer exchange as the communicator, a model whose messages fit it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FL_BENCH_DEVICE="0", FL_BENCH_BACKEND="gloo", FL_BENCH_P2P_ONLY="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", "bench.py", "--gpus", "2", "--model", "tiny", "--n-batch", "32", "--steps", "3",
+                        "--warmup", "1", "--decode-steps", "8"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "tp_error" not in d
+    assert d["config"]["parallelism"].startswith("tp2") and d["tp_small_message_path"].startswith("peer-mapped")
+    assert d["replicas"]["scaling"] == "weak" and d["replicas"]["prefill_tokens_per_s"] > 0
+    assert d["value"] > 0 and d["decode_tokens_per_s"] > 0 and d["config"]["global_batch_tokens"] == 32
+
+
 def test_rccl_two_ranks_tensor_parallel(tmp_path):
     """Two processes, two GPUs, RCCL over xGMI: the Megatron split with the row-split lm-head + all-gather, prefill and decode
     (collectives captured in the decode hipGraph, then plain launches) against the unsharded model.  Needs two devices: the
