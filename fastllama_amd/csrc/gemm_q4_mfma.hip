@@ -534,7 +534,12 @@ static int pick_config(int MGT, int NGT, int type) {
         // gemm_q4_mfma32.hip (round 2): 128x64 tiles of four 32x64 waves when that gives every CU at least two workgroups,
         // else 128x32 tiles of four 32x32 waves (profiles/r02_gemm32_cfg_sweep.txt).  -2 selects the 16x16 kernel below.
         const int64_t tiles106 = (int64_t)((MGT + 7) / 8) * ((NGT + 3) / 4);
-        return NGT > 2 && tiles106 >= 512 ? 106 : 101;
+        if (!(NGT > 2 && tiles106 >= 512)) return 101;
+        // a launch lasts as long as its busiest SIMD: when the last round of 256 workgroups would be at most half full, its rows
+        // get 128x32 tiles instead (cfg 116, gemm_q4_mfma32_mixed_kernel; LLaMA-7B w1|w3 at n_batch 512: 5.375 rounds).  -3: never.
+        const int64_t part = tiles106 % 256;
+        if (g_gemm_force_cfg != -3 && tiles106 >= 512 && part >= 16 && part <= 128) return 116;
+        return 106;
     }
     const double tiles16 = (double)MGT * NGT;        // 16x16 output tiles
     const double per_simd = tiles16 / 1024;          // MI355X: 256 CUs x 4 SIMDs

@@ -77,14 +77,16 @@ __device__ long long g32_dbg[4096 * 8];
 #else
 #define G32_STAMP(k) do {} while (0)
 #endif
+// The kernel body, for the tiles of row groups [mg_base, mg_base + mg_count) of the matrix; `bid` numbers this region's tiles.
+// (A launch is one region -- gemm_q4_mfma32_kernel -- or two regions with different tile shapes -- gemm_q4_mfma32_mixed_kernel.)
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the kernels' launch stubs (and loses them if it has to instantiate
+                                      // the generic lambdas below, whose bodies use gfx950 builtins)
 template <int TYPE, int WM, int RN, int MINW, bool PDB>
-__global__ __launch_bounds__(64 * WM, TYPE == FL_TYPE_Q4_1 ? 2 : MINW) FL_NOPK32 void gemm_q4_mfma32_kernel(
+__device__ __forceinline__ FL_NOPK32 void gemm32_body(
     const uint32_t *qs, const float *dW, const float *mW,   // (no __restrict__: the ring loads must stay where they are issued)
     const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs, int N, int M,
     int MGT /* row groups total */, int NGT /* col groups total */, int KB, float *__restrict__ y, int ldy,
-    const float *__restrict__ resid, int ldr, GemmSiluEpi epi) {
-#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (and loses it if it has to instantiate the
-                                      // generic lambdas below, whose bodies use gfx950 builtins)
+    const float *__restrict__ resid, int ldr, const GemmSiluEpi &epi, int bid, int mg_base, int mg_count) {
     G32_STAMP(0);
 #ifdef G32_TIMING
     if ((threadIdx.x & 63) == 0 && threadIdx.x < 128 && blockIdx.x < 4096) g32_dbg[blockIdx.x * 8 + 5 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg((15 << 11) | 4);
@@ -93,21 +95,20 @@ __global__ __launch_bounds__(64 * WM, TYPE == FL_TYPE_Q4_1 ? 2 : MINW) FL_NOPK32
     constexpr int KS = C::KS;
     constexpr bool Q41 = TYPE == FL_TYPE_Q4_1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i31 = lane & 31, h = lane >> 5, c15 = lane & 15, g1 = (lane >> 4) & 1;
+    const int tid_k = threadIdx.x, lane_k = tid_k & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid_k >> 6);
+    const int i31_k = lane_k & 31, h_k = lane_k >> 5, c15_k = lane_k & 15, g1 = (lane_k >> 4) & 1;
 
     // ---- XCD-aware bijective remap of the tile id: block b runs on XCD b % 8; the N-tiles that share a W row panel
     //      get consecutive ids on one XCD, so the panel is fetched from HBM once and re-read from that XCD's L2.
-    const int tiles_m = (MGT + 2 * WM - 1) / (2 * WM), tiles_n = (NGT + C::NG - 1) / C::NG;
-    int bid = blockIdx.x;
+    const int tiles_m = (mg_count + 2 * WM - 1) / (2 * WM), tiles_n = (NGT + C::NG - 1) / C::NG;
     {
         const int nwg = tiles_m * tiles_n;
         const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
     }
     const int tn = bid % tiles_n, tm = bid / tiles_n;
-    const int mg0 = tm * 2 * WM, ng0 = tn * C::NG;
+    const int mg0 = mg_base + tm * 2 * WM, ng0 = tn * C::NG;
 
     // ---- LDS fill plan of the activation side: piece ids [0, B_PIECES) int8, then d_x (, s_x).  Wave w owns pieces w, w+NW, ...;
     //      every wave issues exactly LPW LDS-DMA loads per stage (missing ones read out of range into a sink) so that one
@@ -129,14 +130,14 @@ __global__ __launch_bounds__(64 * WM, TYPE == FL_TYPE_Q4_1 ? 2 : MINW) FL_NOPK32
         int fbytes = 0;
         funit[s] = 0; lds_off[s] = C::OFF_SINK; fvoff[s] = 0x80000000u; blk_of_lane[s] = 0;
         if (p < C::B_PIECES) {
-            const int c = p * 64 + lane, gi = c / (KS * 32), e = c % (KS * 32);
+            const int c = p * 64 + lane_k, gi = c / (KS * 32), e = c % (KS * 32);
             fbytes = NGT * KB * 512; funit[s] = 512;
             lds_off[s] = p * 1024;
             blk_of_lane[s] = e / 32;
             fvoff[s] = (uint32_t)(ng0 + gi) * (uint32_t)KB * 512u + (uint32_t)e * 16u;      // group >= NGT: out of range
         } else if (p < C::PIECES) {
             const int pl = p - C::B_PIECES;
-            const int gi = lane / (KS * 4), e = lane % (KS * 4);
+            const int gi = lane_k / (KS * 4), e = lane_k % (KS * 4);
             fbase = pl == 0 ? xd : xs; fbytes = NGT * KB * 64; funit[s] = 64;
             lds_off[s] = C::OFF_PL + pl * 1024;
             blk_of_lane[s] = e / 4;
@@ -168,8 +169,8 @@ __global__ __launch_bounds__(64 * WM, TYPE == FL_TYPE_Q4_1 ? 2 : MINW) FL_NOPK32
     __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dW), 0, (int)(wbytes >> 2), 0x00020000);
     __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Q41 ? mW : dW), 0, (int)(wbytes >> 2), 0x00020000);
     const uint32_t rgrp = (uint32_t)(mg0 + 2 * wave + g1);
-    const uint32_t voffA = (rgrp * (uint32_t)KB * 16u + (uint32_t)c15) * 16u + (uint32_t)((h ^ (c15 >> 3)) << 3);
-    const uint32_t voffD = (rgrp * (uint32_t)KB * 16u + (uint32_t)c15) * 4u;
+    const uint32_t voffA = (rgrp * (uint32_t)KB * 16u + (uint32_t)c15_k) * 16u + (uint32_t)((h_k ^ (c15_k >> 3)) << 3);
+    const uint32_t voffD = (rgrp * (uint32_t)KB * 16u + (uint32_t)c15_k) * 4u;
 
     v2u araw[C::RING];
     float saw[C::RING], maw[C::RING];
@@ -183,17 +184,17 @@ __global__ __launch_bounds__(64 * WM, TYPE == FL_TYPE_Q4_1 ? 2 : MINW) FL_NOPK32
             saw[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, voffD, kba * 64, 0));
             if (Q41) maw[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, voffD, kba * 64, 0));
         } else if ((slot & 1) == 0) {
-            // scales of the block PAIR (kb, kb+1): lanes h = 1 read block kb + 1 (KB may be odd under tensor parallelism)
+            // scales of the block PAIR (kb, kb+1): lanes h_k = 1 read block kb + 1 (KB may be odd under tensor parallelism)
             const int kb1 = kb + 1 < KB ? kb + 1 : KB - 1;
-            const uint32_t vo = voffD + (uint32_t)(h ? kb1 : kba) * 64u;
+            const uint32_t vo = voffD + (uint32_t)(h_k ? kb1 : kba) * 64u;
             saw[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, vo, 0, 0));
             if (Q41) maw[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, vo, 0, 0));
         }
     };
 
-    // ---- per-lane LDS offsets of the B fragments and the activation scales ----
-    const int b_off = (g1 * KS) * 512 + c15 * 32 + ((h ^ (c15 >> 3)) << 4);               // + jt * 2 KS 512 + u * 512
-    const int sb_off = C::OFF_PL + (RN == 2 ? ((2 * h + g1) * KS) * 64 : (g1 * KS + h) * 64) + c15 * 4;   // + u * 64
+    // ---- per-lane_k LDS offsets of the B fragments and the activation scales ----
+    const int b_off = (g1 * KS) * 512 + c15_k * 32 + ((h_k ^ (c15_k >> 3)) << 4);               // + jt * 2 KS 512 + u * 512
+    const int sb_off = C::OFF_PL + (RN == 2 ? ((2 * h_k + g1) * KS) * 64 : (g1 * KS + h_k) * 64) + c15_k * 4;   // + u * 64
 
     v16f acc[RN];
     v32f ms2;        // Q4_1, RN = 2: m_w x s_x of both column tiles
@@ -347,6 +348,11 @@ __global__ __launch_bounds__(64 * WM, TYPE == FL_TYPE_Q4_1 ? 2 : MINW) FL_NOPK32
 #undef IC
 
     // ---- results: lane (i31, h) holds rows 8 g + 4 h + {0..3} (g = 0..3) of column i31 of each of its RN tiles ----
+    // (the lane coordinates are taken afresh: as values that live across the loop they are what the allocator spills when two
+    //  bodies share a kernel -- and a kernel that touches scratch at all starts its waves slower)
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int i31 = lane_e & 31, h = lane_e >> 5, c15 = lane_e & 15, lane = lane_e, tid = lane_e + 64 * wave;
+    (void)c15; (void)lane; (void)tid;
     const int rowbase = (mg0 + 2 * wave) * 16;
     auto out4 = [&](int j, int g) FL_NOPK32 __attribute__((always_inline)) -> v4f {
         v4f o;
@@ -462,6 +468,36 @@ __global__ __launch_bounds__(64 * WM, TYPE == FL_TYPE_Q4_1 ? 2 : MINW) FL_NOPK32
         }
     }
     G32_STAMP(4);
+}
+#endif   // __HIP_DEVICE_COMPILE__
+
+template <int TYPE, int WM, int RN, int MINW, bool PDB>
+__global__ __launch_bounds__(64 * WM, TYPE == FL_TYPE_Q4_1 ? 2 : MINW) FL_NOPK32 void gemm_q4_mfma32_kernel(
+    const uint32_t *qs, const float *dW, const float *mW, const int8_t *__restrict__ xq, const float *__restrict__ xd,
+    const float *__restrict__ xs, int N, int M, int MGT, int NGT, int KB, float *__restrict__ y, int ldy,
+    const float *__restrict__ resid, int ldr, GemmSiluEpi epi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    gemm32_body<TYPE, WM, RN, MINW, PDB>(qs, dW, mW, xq, xd, xs, N, M, MGT, NGT, KB, y, ldy, resid, ldr, epi, (int)blockIdx.x, 0, MGT);
+#endif
+}
+
+// Two tile shapes in one launch.  A launch's duration is set by the SIMD that draws the most wave tiles: with 128 x 64 tiles,
+// LLaMA-7B's w1|w3 matmul at n_batch 512 is 1376 workgroups = 5.375 per CU -- six rounds' worth of time for 5.4 rounds of work
+// (M scan, profiles/r02_gemm32_mscan.txt).  The first n_a workgroups take 128 x 64 tiles of row groups [0, mg_split) -- whole
+// multiples of 256 workgroups -- and the rest covers the remaining row groups with 128 x 32 tiles: twice as many workgroups of
+// half the work each, which fill the slots the last full round frees.  Same arithmetic per output in both regions (every tile
+// configuration returns identical bits), so the result does not depend on where the split falls.
+template <int TYPE>
+__global__ __launch_bounds__(256, TYPE == FL_TYPE_Q4_1 ? 2 : 3) FL_NOPK32 void gemm_q4_mfma32_mixed_kernel(
+    const uint32_t *qs, const float *dW, const float *mW, const int8_t *__restrict__ xq, const float *__restrict__ xd,
+    const float *__restrict__ xs, int N, int M, int MGT, int NGT, int KB, float *__restrict__ y, int ldy,
+    const float *__restrict__ resid, int ldr, GemmSiluEpi epi, int n_a, int mg_split) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if ((int)blockIdx.x < n_a)
+        gemm32_body<TYPE, 4, 2, 3, false>(qs, dW, mW, xq, xd, xs, N, M, MGT, NGT, KB, y, ldy, resid, ldr, epi, (int)blockIdx.x, 0, mg_split);
+    else
+        gemm32_body<TYPE, 4, 1, 3, true>(qs, dW, mW, xq, xd, xs, N, M, MGT, NGT, KB, y, ldy, resid, ldr, epi, (int)blockIdx.x - n_a, mg_split,
+                                         MGT - mg_split);
 #endif
 }
 
@@ -491,6 +527,26 @@ static hipError_t launch_gemm32(const fl_qtensor &W, const fl_qact &xq, int N, f
     return hipGetLastError();
 }
 
+// cfg 116: 128 x 64 tiles for the row groups that fill whole rounds of 256 workgroups, 128 x 32 tiles for the rest
+template <int TYPE>
+static hipError_t launch_gemm32_mixed(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
+                                      const float *resid, int ldr, const GemmSiluEpi &epi) {
+    using CA = G32<TYPE, 4, 2>;
+    using CB = G32<TYPE, 4, 1>;
+    const int MGT = W.M16 / 16, NGT = fl_roundup(N, 16) / 16;
+    const int tn_a = (NGT + CA::NG - 1) / CA::NG, tn_b = (NGT + CB::NG - 1) / CB::NG;
+    const int tm_all = (MGT + 7) / 8;                                  // 128-row tiles
+    int tm_a = (tm_all * tn_a / 256) * 256 / tn_a;                     // row tiles of whole 256-workgroup rounds ...
+    while (tm_a > 0 && (tm_a * tn_a) % 8 != 0) --tm_a;                 // ... and a multiple of the 8 XCDs (the remap of region B)
+    const int mg_split = tm_a * 8 < MGT ? tm_a * 8 : MGT;
+    const int n_a = tm_a * tn_a, n_b = ((MGT - mg_split + 7) / 8) * tn_b;
+    constexpr int lds = CA::LDS_BYTES > CB::LDS_BYTES ? CA::LDS_BYTES : CB::LDS_BYTES;
+    static_assert(lds <= 65536, "no dynamic-LDS attribute needed");
+    hipLaunchKernelGGL((gemm_q4_mfma32_mixed_kernel<TYPE>), dim3(n_a + n_b), dim3(256), lds, st, W.qs, W.d, W.m, xq.q, xq.d, xq.s, N, W.M,
+                       MGT, NGT, W.KB, y, ldy, resid, ldr, epi, n_a, mg_split);
+    return hipGetLastError();
+}
+
 bool gemm32_supports(const fl_qtensor &W, int cfg, bool silu) {
     if ((uint64_t)(W.M16 / 16 + 16) * (uint64_t)W.KB * 256u >= (1ull << 31)) return false;   // 32-bit buffer offsets
     (void)cfg; (void)silu;
@@ -505,6 +561,9 @@ hipError_t gemm32_launch(int cfg, const fl_qtensor &W, const fl_qact &xq, int N,
                                       : launch_gemm32<FL_TYPE_Q4_1, WM, RN, MINW, PDB>(W, xq, N, y, ldy, st, resid, ldr, epi);
     FL_GEMM32_CONFIGS(X)
 #undef X
+    if (cfg == 116)
+        return W.type == FL_TYPE_Q4_0 ? launch_gemm32_mixed<FL_TYPE_Q4_0>(W, xq, N, y, ldy, st, resid, ldr, epi)
+                                      : launch_gemm32_mixed<FL_TYPE_Q4_1>(W, xq, N, y, ldy, st, resid, ldr, epi);
     return hipErrorInvalidValue;
 }
 

@@ -18,7 +18,7 @@ for _ in range(5):
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); ops.mul_mat_q(W, a, out=y); e1.record(); torch.cuda.synchronize()
-nwg = (M // 128) * (N // (64 if cfg in (100, 106, 102, 103, 108) else 32))
+nwg = (M // 128) * (N // (64 if cfg in (100, 106, 102, 103, 108, 116) else 32))
 n = min(nwg, 4096)
 buf = (C.c_longlong * (n * 8))()
 lib = C.CDLL(hip.LIB_PATH)

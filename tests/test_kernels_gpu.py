@@ -329,7 +329,7 @@ def test_exact_properties_at_full_size(torch, ops, port, N):
 
 # ---- every tile configuration of both MFMA kernels returns the same bits (7B, 13B and 65B shapes) ------------
 OLD_CFGS = list(range(14))                    # gemm_q4_mfma.hip FL_GEMM_CONFIGS (round 1, 16x16x32 MFMA)
-NEW_CFGS = [100, 101, 102, 103, 104, 105, 106, 108]   # gemm_q4_mfma32.hip FL_GEMM32_CONFIGS (32x32x32 MFMA)
+NEW_CFGS = [100, 101, 102, 103, 104, 105, 106, 108, 116]   # gemm_q4_mfma32.hip FL_GEMM32_CONFIGS (32x32x32 MFMA); 116 = two tile shapes in one launch
 LLAMA_SHAPES = [(4096, 4096), (11008, 4096), (4096, 11008), (32000, 4096),        # 7B
                 (5120, 5120), (13824, 5120), (5120, 13824),                       # 13B
                 (8192, 8192), (22016, 8192), (8192, 22016)]                       # 65B
@@ -339,7 +339,7 @@ LLAMA_SHAPES = [(4096, 4096), (11008, 4096), (4096, 11008), (32000, 4096),      
 @pytest.mark.parametrize("M,K", LLAMA_SHAPES)
 def test_tile_configurations_are_bit_identical_and_match_oracle(torch, ops, port, nm, qt, M, K):
     """N = 512 (BASELINE.json's n_batch) at every LLaMA matrix shape: each output accumulates its per-block terms in K
-    order whatever the tile shape and whichever MFMA computes the block dots, so all 22 configurations -- and the one
+    order whatever the tile shape and whichever MFMA computes the block dots, so all 23 configurations -- and the one
     pick_config chooses -- must agree BIT FOR BIT; sampled rows are checked against the oracle."""
     from fastllama_amd import hip
     from harness import synth
@@ -411,7 +411,7 @@ def test_gemm_qkv_rope_epilogue_equals_gemm_plus_rope_kv(torch, ops, port, nm, q
     kc0, vc0 = torch.zeros((n_ctx, E), device="cuda"), torch.zeros((E, n_ctx), device="cuda")
     hip.check(L.fl_debug_rope_kv(qkv.data_ptr(), 3 * E, N, E, D, n_past, n_ctx, rd.data_ptr(), kc0.data_ptr(), vc0.data_ptr(), None))
     try:
-        for cfg in (-1, -2, 10, 12, 100, 101, 106):
+        for cfg in (-1, -2, 10, 12, 100, 101, 106, 116):
             L.fl_debug_set(0, cfg)
             y = torch.zeros((N, 3 * E), device="cuda")
             kc, vc = torch.zeros_like(kc0), torch.zeros_like(vc0)
@@ -446,7 +446,7 @@ def test_gemm_silu_epilogue_equals_gemm_plus_silu_mul_quant(torch, ops, port, nm
     hip.check(L.fl_debug_silu_mul_quant_woven(h13.data_ptr(), 2 * F, N, F, sd.data_ptr(), want.handle, 16, None))
     wb = want.export().cpu().numpy()
     try:
-        for cfg in (-1, -2, 10, 12, 100, 101, 106):
+        for cfg in (-1, -2, 10, 12, 100, 101, 106, 116):
             L.fl_debug_set(0, cfg)
             out = ops.QAct(N, F)
             hip.check(L.fl_debug_gemm_silu(W.handle, a.handle, sd.data_ptr(), out.handle, None))
@@ -468,7 +468,7 @@ def test_gemm_residual_epilogue(torch, ops, port, nm, qt):
     r = dev(torch, make_x(N, M, 4))
     base = ops.mul_mat_q(W, a)
     try:
-        for cfg in (-1, -2, 12, 100, 101, 106):
+        for cfg in (-1, -2, 12, 100, 101, 106, 116):
             L.fl_debug_set(0, cfg)
             y = torch.empty((N, M), device="cuda")
             hip.check(L.fl_debug_mul_mat_q_resid(W.handle, a.handle, y.data_ptr(), M, r.data_ptr(), M, None))
