@@ -22,10 +22,10 @@ def agg(leg, c):
 
 
 out, md = {}, []
-for leg, mm in (("pre", "gemm_q4_mfma32_kernel"), ("dec", "gemv_q4_kernel")):
+for leg, mm, pat in (("pre", "gemm_q4_mfma32_kernel", "gemm_q4_mfma32_"), ("dec", "gemv_q4_kernel", "gemv_q4_kernel")):   # (pat: incl. the mixed-tile launch)
     fe, wr = agg(leg, "FETCH_SIZE"), agg(leg, "WRITE_SIZE")
-    nf = sum(len(v) for k, v in fe.items() if mm in k); tf = sum(sum(v) for k, v in fe.items() if mm in k)
-    nw = sum(len(v) for k, v in wr.items() if mm in k); tw = sum(sum(v) for k, v in wr.items() if mm in k)
+    nf = sum(len(v) for k, v in fe.items() if pat in k); tf = sum(sum(v) for k, v in fe.items() if pat in k)
+    nw = sum(len(v) for k, v in wr.items() if pat in k); tw = sum(sum(v) for k, v in wr.items() if pat in k)
     rd, w = tf / nf * 1024 * 2, tw / nw * 1024
     out[mm] = {"launches_sampled": nf, "fetch_bytes_per_launch": rd, "write_bytes_per_launch": w, "hbm_bytes_per_launch": rd + w}
     md.append(f"\n## {'prefill (n_batch 512)' if leg == 'pre' else 'decode'}: per kernel, mean per launch\n\n"
