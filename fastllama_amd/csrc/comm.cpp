@@ -149,6 +149,17 @@ fl_comm *fl_comm_create(const void *id_bytes, int rank, int world) {
         } else {
             p2p_free(c);
         }
+        // every rank must take the same path for a given message: the exchange is used only if it came up on ALL ranks
+        int *agree = nullptr;
+        int mine_ok = c->p2p.ready ? 1 : 0, all_ok = 0;
+        if (hipMalloc(&agree, sizeof(int)) == hipSuccess && hipMemcpy(agree, &mine_ok, sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+            ncclAllReduce(agree, agree, 1, ncclInt32, ncclMin, c->comm, nullptr) == ncclSuccess && hipDeviceSynchronize() == hipSuccess &&
+            hipMemcpy(&all_ok, agree, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && all_ok == 1) {
+            // keep it
+        } else {
+            p2p_free(c);
+        }
+        if (agree) (void)hipFree(agree);
         (void)hipGetLastError();
     }
     return c;
@@ -184,6 +195,7 @@ int fl_comm_p2p_export(fl_comm *c, void *handles_out) {
 
 int fl_comm_p2p_import(fl_comm *c, const void *handles_all) {
     if (!c || !handles_all || c->lg || !c->p2p.own_buf) return set_error(FL_EINVAL, "fl_comm_p2p_import: export first");
+    if (c->p2p.ready || c->p2p.n_mapped) return set_error(FL_EINVAL, "fl_comm_p2p_import: already imported");
     P2PState &p = c->p2p;
     const unsigned char *src = static_cast<const unsigned char *>(handles_all);
     for (int r = 0; r < c->world; ++r) {
