@@ -61,6 +61,8 @@ struct fl_qact_impl : fl_qact {
     size_t q_bytes, s_bytes;
 };
 
+namespace fl { void gemm32_mixed_split(int MGT, int NGT, int *n_a, int *mg_split, int *n_b); }   // gemm_q4_mfma32.hip
+
 extern "C" {
 
 const char *fl_version(void) { return "fastllama_hip 0.1 (gfx950)"; }
@@ -407,6 +409,13 @@ int fl_quantize_q8(fl_qact *a, const float *x, int ldx, int N, int K, void *st) 
     return fl_quantize_q8_layout(a, x, ldx, N, K, N <= 8 ? 1 : 16, st);
 }
 
+/* host logic of the mixed-tile GEMM launch (gemm_q4_mfma32.hip, cfg 116): how M16/16 row groups x ceil(N/16) column groups are
+ * split into workgroups of 128 x 64 tiles (row groups [0, mg_split)) and of 128 x 32 tiles (the rest) */
+int fl_debug_gemm_mixed_split(int row_groups, int col_groups, int *n_a, int *mg_split, int *n_b) {
+    if (row_groups < 1 || col_groups < 1 || !n_a || !mg_split || !n_b) return set_error(FL_EINVAL, "fl_debug_gemm_mixed_split: bad arguments");
+    fl::gemm32_mixed_split(row_groups, col_groups, n_a, mg_split, n_b);
+    return FL_OK;
+}
 int fl_debug_set(int what, int value) {
     if (what == 0) fl::g_gemm_force_cfg = value;
     if (what == 1) fl::g_gemv_force_waves = value;   // 0 = automatic, else 4 / 8 / 16 waves per 16-row group

@@ -527,19 +527,26 @@ static hipError_t launch_gemm32(const fl_qtensor &W, const fl_qact &xq, int N, f
     return hipGetLastError();
 }
 
-// cfg 116: 128 x 64 tiles for the row groups that fill whole rounds of 256 workgroups, 128 x 32 tiles for the rest
+// cfg 116: 128 x 64 tiles for the row groups that fill whole rounds of 256 workgroups, 128 x 32 tiles for the rest.
+// Row groups [0, mg_split) -> n_a workgroups of 128 x 64; [mg_split, MGT) -> n_b workgroups of 128 x 32.
+void gemm32_mixed_split(int MGT, int NGT, int *n_a, int *mg_split, int *n_b) {
+    const int tn_a = (NGT + 3) / 4, tn_b = (NGT + 1) / 2;              // column tiles of 64 / 32
+    const int tm_all = (MGT + 7) / 8;                                  // 128-row tiles
+    int tm_a = (int)((int64_t)tm_all * tn_a / 256 * 256 / tn_a);       // row tiles of whole 256-workgroup rounds ...
+    while (tm_a > 0 && (tm_a * tn_a) % 8 != 0) --tm_a;                 // ... and a multiple of the 8 XCDs (the remap of region B)
+    *mg_split = tm_a * 8 < MGT ? tm_a * 8 : MGT;
+    *n_a = tm_a * tn_a;
+    *n_b = ((MGT - *mg_split + 7) / 8) * tn_b;
+}
+
 template <int TYPE>
 static hipError_t launch_gemm32_mixed(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                                       const float *resid, int ldr, const GemmSiluEpi &epi) {
     using CA = G32<TYPE, 4, 2>;
     using CB = G32<TYPE, 4, 1>;
     const int MGT = W.M16 / 16, NGT = fl_roundup(N, 16) / 16;
-    const int tn_a = (NGT + CA::NG - 1) / CA::NG, tn_b = (NGT + CB::NG - 1) / CB::NG;
-    const int tm_all = (MGT + 7) / 8;                                  // 128-row tiles
-    int tm_a = (tm_all * tn_a / 256) * 256 / tn_a;                     // row tiles of whole 256-workgroup rounds ...
-    while (tm_a > 0 && (tm_a * tn_a) % 8 != 0) --tm_a;                 // ... and a multiple of the 8 XCDs (the remap of region B)
-    const int mg_split = tm_a * 8 < MGT ? tm_a * 8 : MGT;
-    const int n_a = tm_a * tn_a, n_b = ((MGT - mg_split + 7) / 8) * tn_b;
+    int n_a, mg_split, n_b;
+    gemm32_mixed_split(MGT, NGT, &n_a, &mg_split, &n_b);
     constexpr int lds = CA::LDS_BYTES > CB::LDS_BYTES ? CA::LDS_BYTES : CB::LDS_BYTES;
     static_assert(lds <= 65536, "no dynamic-LDS attribute needed");
     hipLaunchKernelGGL((gemm_q4_mfma32_mixed_kernel<TYPE>), dim3(n_a + n_b), dim3(256), lds, st, W.qs, W.d, W.m, xq.q, xq.d, xq.s, N, W.M,

@@ -151,6 +151,7 @@ _PROTOS = {
     "fl_quantize_row_q4_0_reference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "fl_quantize_row_q4_1_reference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "fl_debug_qact_layout": (C.c_int, [C.c_void_p]),
+    "fl_debug_gemm_mixed_split": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "fl_debug_set": (C.c_int, [C.c_int, C.c_int]),
     "fl_quantize_q8_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }

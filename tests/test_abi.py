@@ -215,3 +215,30 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert r.returncode != 0
     assert "no CPU path" in (r.stderr + r.stdout)
     assert not r.stdout.strip().startswith("{")
+
+
+def test_mixed_tile_split_covers_every_row_group_once():
+    """Host logic of the GEMM launch with two tile shapes (gemm_q4_mfma32.hip, cfg 116): row groups [0, mg_split) go to whole
+    rounds of 256 workgroups of 128x64 tiles, the rest to 128x32 tiles.  Whatever the shape: the two regions partition the row
+    groups, region A is a multiple of 128-row tiles and of the 8 XCDs (region B's tile ids are remapped per XCD), and its
+    workgroup count is what its rows need -- at most the whole rounds that fit."""
+    import ctypes as C
+    from fastllama_amd import hip
+    L = hip.load()
+    for M in (16, 128, 4000, 4096, 11008, 12288, 22016, 27648, 32000, 44032, 100000):
+        for N in (9, 16, 48, 64, 100, 128, 256, 500, 512, 1024):
+            mgt, ngt = (M + 15) // 16, (N + 15) // 16
+            na, split, nb = C.c_int(), C.c_int(), C.c_int()
+            assert L.fl_debug_gemm_mixed_split(mgt, ngt, C.byref(na), C.byref(split), C.byref(nb)) == 0
+            na, split, nb = na.value, split.value, nb.value
+            tn_a, tn_b = (ngt + 3) // 4, (ngt + 1) // 2
+            assert 0 <= split <= mgt and (split % 8 == 0 or split == mgt)
+            assert na == ((split + 7) // 8) * tn_a if split < mgt else na >= 0
+            assert na % 8 == 0 and na <= ((mgt + 7) // 8) * tn_a
+            assert nb == ((mgt - split + 7) // 8) * tn_b
+            if na:                                               # whole rounds, up to the XCD rounding
+                assert na <= (((mgt + 7) // 8) * tn_a) // 256 * 256
+    # the case it exists for: LLaMA-7B w1|w3 at n_batch 512 -- 1376 tiles of 128x64 = five whole rounds + 96
+    na, split, nb = C.c_int(), C.c_int(), C.c_int()
+    L.fl_debug_gemm_mixed_split(22016 // 16, 512 // 16, C.byref(na), C.byref(split), C.byref(nb))
+    assert (na.value, split.value * 16, nb.value) == (1280, 20480, 192)
