@@ -72,6 +72,10 @@ class Port:
         L.orc_lora_add.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                    C.c_float, C.c_void_p]
         L.orc_lora_add.restype = C.c_int
+        L.orc_mul_mat_f32.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_mul_mat_f32.restype = None
+        L.orc_vec_dot_f32_mm.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_vec_dot_f32_mm.restype = C.c_float
 
     # ---- weights ----
     def quantize_q4(self, qtype: int, w: np.ndarray) -> np.ndarray:
@@ -100,6 +104,17 @@ class Port:
     def dequantize(self, qtype: int, wq: np.ndarray, K: int) -> np.ndarray:
         return np.stack([self.dequantize_row(qtype, r, K) for r in wq])
 
+
+    def mul_mat_f32(self, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+        """ggml_mul_mat on two f32 matrices (ggml_compute_forward_mul_mat_f32 as the reference's build compiled it):
+        a [M, K], b [N, K] (rows may be strided views with contiguous elements) -> [N, M]."""
+        assert a.dtype == np.float32 and b.dtype == np.float32 and a.shape[1] == b.shape[1]
+        assert a.strides[1] == 4 and b.strides[1] == 4 and a.strides[0] % 4 == 0 and b.strides[0] % 4 == 0
+        M, K = a.shape
+        N = b.shape[0]
+        out = np.empty((N, M), dtype=np.float32)
+        self.lib.orc_mul_mat_f32(_ptr(a), a.strides[0] // 4, _ptr(b), b.strides[0] // 4, _ptr(out), M, M, N, K)
+        return out
 
     def lora_add(self, qtype: int, wq: np.ndarray, K: int, a=None, b=None, ba=None, sign: float = 1.0):
         """LoRA merge on AoS Q4 rows (oracle/q4_oracle.c:orc_lora_add / oracle/ref_driver.c:ref_lora_add).

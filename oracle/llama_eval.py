@@ -168,12 +168,13 @@ def layer_forward(w: Weights, kv: KV, il: int, x: np.ndarray, n_past: int, port:
         scale = f32(1.0) / np.sqrt(f32(E) / f32(H), dtype=f32)
         att = np.empty((N, El), f32)
         for h in range(Hl):
-            s = (Q[:, h, :] @ K[:, h, :].T).astype(f32)                      # ggml_mul_mat f32 (order differs from AVX)
+            s = port.mul_mat_f32(K[:, h, :], Q[:, h, :])                     # ggml_mul_mat(K, Q) f32: [N, P], AVX2 lane order
             s = (s * scale).astype(f32)                                      # ggml_scale
             mask = np.arange(P)[None, :] > (n_past + np.arange(N))[:, None]  # diag_mask_inf
             s[mask] = -np.inf
             pr = soft_max_rows(s)
-            att[:, h * D:(h + 1) * D] = (pr @ Vv[:, h, :]).astype(f32)
+            vt = np.ascontiguousarray(Vv[:, h, :].T)                         # the reference's V view: D rows of P keys
+            att[:, h * D:(h + 1) * D] = port.mul_mat_f32(vt, pr)             # ggml_mul_mat(V_trans, KQ_soft_max): [N, D]
         kb = (El // QK)
         part = port.mul_mat_q(qt, slice_kblocks(w.q(p + "attention.wo.weight"), qt, r * kb, (r + 1) * kb), att, strict=G == 1)
         if G > 1:

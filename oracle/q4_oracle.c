@@ -274,6 +274,50 @@ float orc_vec_dot_f32(int n, const float *x, const float *y) {
     return sumf;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * ggml_vec_dot_f32 AS COMPILED INTO ggml_compute_forward_mul_mat_f32 by the reference's gcc -O3 x86-64-v3 build
+ * (lib/ggml.c:2295-2330 inlined at :7662; oracle/_ref disassembly of ggml_compute_forward, the vfmadd231ps loop
+ * with four ymm accumulators): the 32-wide body and the reduction as above, then the n % 32 leftovers the way gcc
+ * vectorised that loop -- chunks of 8 and then one chunk of 4 elements as rounded products (vmulps) added one by
+ * one in order (vaddss), and only the last n % 4 elements as scalar FMAs (vfmadd231ss).  This is the dot of the
+ * attention matmuls (K.Q over head_dim, V.P over the n_past + N keys), lib/llama.cpp:364,389.
+ * ---------------------------------------------------------------------------------------- */
+float orc_vec_dot_f32_mm(int n, const float *x, const float *y) {
+    float sum[4][8] = {{0}};
+    const int np = n & ~31;
+    for (int i = 0; i < np; i += 32)
+        for (int j = 0; j < 4; ++j)
+            for (int l = 0; l < 8; ++l) sum[j][l] = fmaf(x[i + 8 * j + l], y[i + 8 * j + l], sum[j][l]);
+    float t0[4];
+    for (int l = 0; l < 8; ++l) {
+        sum[0][l] = sum[0][l] + sum[1][l];
+        sum[2][l] = sum[2][l] + sum[3][l];
+        sum[0][l] = sum[0][l] + sum[2][l];
+    }
+    for (int l = 0; l < 4; ++l) t0[l] = sum[0][l] + sum[0][l + 4];
+    float sumf = (t0[0] + t0[1]) + (t0[2] + t0[3]);
+    int i = np;
+    for (; i + 8 <= n; i += 8)
+        for (int l = 0; l < 8; ++l) { const float p = x[i + l] * y[i + l]; sumf = sumf + p; }
+    if (n - i >= 4) {
+        for (int l = 0; l < 4; ++l) { const float p = x[i + l] * y[i + l]; sumf = sumf + p; }
+        i += 4;
+    }
+    for (; i < n; ++i) sumf = fmaf(x[i], y[i], sumf);
+    return sumf;
+}
+
+/* ggml_compute_forward_mul_mat_f32, non-BLAS path (lib/ggml.c:7631-7672): C[n][m] = vec_dot_f32(K, A row m, B row n);
+ * A is M rows (stride lda), B is N rows (stride ldb), C is N rows of M (stride ldc). */
+void orc_mul_mat_f32(const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int m = 0; m < M; ++m)
+        for (int n = 0; n < N; ++n)
+            C[(size_t)n * ldc + m] = orc_vec_dot_f32_mm(K, A + (size_t)m * lda, B + (size_t)n * ldb);
+}
+
 void orc_quantize_row_q4_0_simd(const float *x, void *vy, int k) {
     orc_block_q4_0 *y = (orc_block_q4_0 *)vy;
     for (int b = 0; b < k / QK; ++b) {
