@@ -112,6 +112,21 @@ def cpu_config1(cfg, qtype, budget_s=12.0):
             "sample": "BASELINE.json configs[0]: one layer's 7 mul_mat_q_f32 + lm-head at N=128, 8 threads, median of 2, extrapolated to one eval"}
 
 
+def self_launch(n):
+    """Re-run this command line under torch.distributed.run with n ranks on 127.0.0.1; returns its exit code."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL / peer-mapped buffers across processes
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,7 +144,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--peer-exchange", action="store_true", help="tensor-parallel leg: decode-size messages through peer-mapped buffers (FL_P2P=1) instead of RCCL; never run over xGMI so far")
     ap.add_argument("--tp-timeout", type=int, default=300, help="seconds the tensor-parallel leg may take before the replica leg is reported alone")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-mode (reference-order kernels) timings")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short 7B Q4_1 leg (BASELINE.json config 3)")
+    ap.add_argument("--all-configs", action="store_true", help="also run BASELINE.json configs 4/5 (13B, 65B n_ctx 2048) as short legs "
+                    "on this rank's GPU and report them under other_configs (config 3, 7B Q4_1, always runs at --gpus 1)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (one process per GPU over RCCL,
+        # the command line the docstring names) and pass rank 0's JSON line through.
+        raise SystemExit(self_launch(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -170,6 +194,7 @@ def main():
     p2p_only = os.environ.get("FL_BENCH_P2P_ONLY") == "1"
     want_tp = world > 1 and args.parallel in ("auto", "tp") and cfg["n_head"] % world == 0 and (backend == "nccl" or p2p_only)
     wk, wk1 = synth.algorithmic_work(cfg, N, qtype), synth.algorithmic_work(cfg, 1, qtype)
+    t_begin_all = time.perf_counter()
 
     def barrier():
         if dist is not None:
@@ -201,10 +226,15 @@ def main():
         except Exception:
             return None
 
-    def run_leg(tp):
-        """One model (a replica per rank, or this rank's tensor-parallel shard) through the prefill / decode / roofline legs."""
+    def run_leg(tp, cfg=cfg, qtype=qtype, N=N, n_ctx=n_ctx, short=False):
+        """One model (a replica per rank, or this rank's tensor-parallel shard) through the prefill / decode / roofline legs.
+        short: prefill + decode timings only, fewer steps (the other BASELINE configs reported beside the headline)."""
+        wk, wk1 = synth.algorithmic_work(cfg, N, qtype), synth.algorithmic_work(cfg, 1, qtype)
+        steps = max(2, args.steps // 4) if short else args.steps
+        dsteps = max(8, args.decode_steps // 4) if short else args.decode_steps
         model = FlModel(cfg, qtype, synth.synth_model_tensors(cfg, qtype), n_ctx=n_ctx, max_batch=N,
                         tp_rank=rank if tp else 0, tp_size=world if tp else 1, device=local)
+        model.set_exact(False)
         comm = None
         if tp and p2p_only:
             comm = L.fl_comm_create_p2p(rank, world)
@@ -237,21 +267,42 @@ def main():
         tok1 = toks[:1].copy()
         seqs = 1 if tp else world
         shard = world if tp else 1
-        r = {"seqs": seqs}
+        r = {"seqs": seqs, "wk": wk, "wk1": wk1, "shard": shard}
         if tp:
             r["peer_exchange"] = peer_exchange      # decode-size messages go through peer-mapped buffers instead of a ring collective
+            r["n_ranks_rccl"] = int(L.fl_comm_rccl_ranks(ctypes.c_void_p(comm)))
         # ---- prefill (the headline): K timed evals after W warm-ups
         prefill = lambda i: model.eval_nocopy(toks, 0)
         for i in range(args.warmup):
             prefill(i)
-        dt = timed(prefill, args.steps)
-        r["ms_per_step"] = dt / args.steps * 1e3
-        r["prefill_tokens_per_s"] = N * seqs / (dt / args.steps)
+        dt = timed(prefill, steps)
+        r["ms_per_step"] = dt / steps * 1e3
+        r["prefill_tokens_per_s"] = N * seqs / (dt / steps)
         # ---- decode: N = 1 at n_past = 128.. (KV holds the prefill)
-        dec = lambda i: model.eval_nocopy(tok1, 128 + i)
+        dec = lambda i: model.eval_nocopy(tok1, min(128, N) + i)
         for i in range(3):
             dec(i)
-        r["decode_ms"] = timed(dec, args.decode_steps) / args.decode_steps * 1e3
+        r["decode_ms"] = timed(dec, dsteps) / dsteps * 1e3
+        # ---- the same two timings in EXACT mode (reference-order kernels: logits bit-identical to the reference's x86 build,
+        #      tests/test_parity_7b_gpu.py); the fast mode above computes exact block dots and adds them in its own f32 order
+        if not args.no_exact:
+            model.set_exact(True)
+            xsteps = max(2, steps // 4)
+            prefill(0)
+            xdt = timed(prefill, xsteps) / xsteps
+            for i in range(3):
+                dec(i)
+            xdec = timed(dec, dsteps) / dsteps
+            model.set_exact(False)
+            r["exact"] = {"ms_per_step": xdt * 1e3, "prefill_tokens_per_s": N * seqs / xdt, "decode_ms": xdec * 1e3,
+                          "decode_tokens_per_s": seqs / xdec}
+        if short:
+            barrier()
+            model.free()
+            if comm:
+                L.fl_comm_destroy(ctypes.c_void_p(comm))
+            torch.cuda.empty_cache()
+            return r
         # ---- the same at the end of the context (K/V stream of n_past positions per layer; two-launch attention)
         long_steps = min(32, args.decode_steps)
         r["long_past"] = n_ctx - long_steps - 4
@@ -311,7 +362,19 @@ def main():
         torch.cuda.empty_cache()
         return r
 
-    def emit(legs, tp_error):
+    def summary(leg, name):
+        """the short form of a leg: other_configs entries"""
+        t_hbm = leg["wk"]["bytes"] / leg["shard"] / (PEAK_HBM_GBS * 1e9) * 1e3
+        t_hbm1 = leg["wk1"]["bytes"] / leg["shard"] / (PEAK_HBM_GBS * 1e9) * 1e3
+        o = {"config": name, "prefill_tokens_per_s": leg["prefill_tokens_per_s"], "ms_per_step": leg["ms_per_step"],
+             "decode_tokens_per_s": leg["seqs"] / (leg["decode_ms"] * 1e-3),
+             "hbm_roofline_frac": {"prefill": t_hbm / leg["ms_per_step"], "decode": t_hbm1 / leg["decode_ms"]}}
+        if "exact" in leg:
+            o["exact_mode"] = {"prefill_tokens_per_s": leg["exact"]["prefill_tokens_per_s"],
+                               "decode_tokens_per_s": leg["exact"]["decode_tokens_per_s"]}
+        return o
+
+    def emit(legs, tp_error, others=()):
         head = legs["tp"] if "tp" in legs else legs["dp"]
         tp = "tp" in legs
         # fraction of the HBM roofline BASELINE.json's target is written in: time to move the ALGORITHMIC bytes of one step
@@ -345,7 +408,21 @@ def main():
             "prefill_long_prompt": head.get("long_prompt"),
             "roofline": head["roofline"], "roofline_decode": head["roofline_decode"],
             "model_device_bytes": head["model_device_bytes"],
+            # is the headline the tensor-parallel eval over RCCL, and how many ranks does the RCCL communicator itself count?
+            "tp_ok": bool(tp) if world > 1 else None, "n_ranks_rccl": head.get("n_ranks_rccl", 0) if world > 1 else None,
+            "mode": "fast",
+            "mode_note": ("value = fast mode: exact integer block dots on the MFMA units, per-block f32 terms added in the kernels' own order "
+                          "(1e-7 per matmul; ~1e-2 on 7B logits after 32 layers).  exact_mode = the reference-order kernels (FL_EXACT=1 / "
+                          "fl_model_set_exact): logits bit-identical to the reference's x86 build, tests/test_parity_7b_gpu.py"),
         }
+        if "exact" in head:
+            x = head["exact"]
+            out["exact_mode"] = {"prefill_tokens_per_s": x["prefill_tokens_per_s"], "ms_per_step": x["ms_per_step"],
+                                 "decode_tokens_per_s": x["decode_tokens_per_s"], "decode_ms_per_token": x["decode_ms"],
+                                 "hbm_roofline_frac": {"prefill": t_hbm_prefill_ms / x["ms_per_step"], "decode": t_hbm_decode_ms / x["decode_ms"]},
+                                 "parity": "bit-identical logits vs oracle/_ref on this configuration (tests/test_parity_7b_gpu.py)"}
+        if others:
+            out["other_configs"] = list(others)
         if tp and "dp" in legs:
             d = legs["dp"]
             out["replicas"] = {"scaling": "weak", "parallelism": f"dp{world}: a full replica and its own batch per GPU, no collective",
@@ -368,9 +445,20 @@ def main():
 
 
     legs = {}
+    others = []
     tp_error = None
     if world == 1 or not want_tp or args.parallel == "auto":
         legs["dp"] = run_leg(False)          # replicas (world == 1: the single-GPU measurement)
+    if world == 1 and args.model == "7B" and args.qtype == "q4_0" and not args.no_other_configs:
+        # BASELINE.json config 3 under the same clock as the headline; configs 4 / 5 (single-GPU form) on request
+        try:
+            others.append(summary(run_leg(False, qtype=synth.Q4_1, short=True), f"LLaMA-7B Q4_1 n_batch={N} (BASELINE config 3), 1 GPU"))
+            if args.all_configs:
+                others.append(summary(run_leg(False, cfg=dict(synth.MODELS["13B"]), short=True), f"LLaMA-13B Q4_0 n_batch={N} (BASELINE config 4 on 1 GPU)"))
+                others.append(summary(run_leg(False, cfg=dict(synth.MODELS["65B"]), n_ctx=2048, short=True),
+                                      f"LLaMA-65B Q4_0 n_batch={N} n_ctx=2048 (BASELINE config 5 on 1 GPU)"))
+        except Exception as e:  # noqa: BLE001 -- never lose the headline to a side leg
+            others.append({"config": "other configs", "error": repr(e)})
     if want_tp:
         # The tensor-parallel leg is the one part of this file that no 1-GPU box can rehearse with more than one rank.  It must
         # not cost the run its line: an exception or a hang (watchdog) falls back to the replica leg, measured above, and says so.
@@ -378,7 +466,7 @@ def main():
 
         def on_alarm(signum, frame):
             if rank == 0 and "dp" in legs:
-                emit({"dp": legs["dp"]}, f"tensor-parallel leg did not finish within {args.tp_timeout} s")
+                emit({"dp": legs["dp"]}, f"tensor-parallel leg did not finish within {args.tp_timeout} s", others)
             os._exit(0 if "dp" in legs else 3)
 
         signal.signal(signal.SIGALRM, on_alarm)
@@ -399,7 +487,7 @@ def main():
             legs.pop("tp", None)
             if "dp" not in legs:
                 raise SystemExit("tensor-parallel leg failed and no replica leg was requested: " + tp_error)
-    emit(legs, tp_error)
+    emit(legs, tp_error, others)
     barrier()
     if dist is not None:
         dist.destroy_process_group()

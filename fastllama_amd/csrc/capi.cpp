@@ -458,7 +458,10 @@ int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy
     const fl_qact_impl *a = static_cast<const fl_qact_impl *>(a_);
     int rc = check_mm(W, a, y, ldy);
     if (rc != FL_OK) return rc;
-    if (which == 2) {
+    if (which == 3) {                      // reference-order kernels, whichever the layout says
+        if (a->layout == 1) FL_HIP(gemv_q4_exact(*W, *a, a->N, y, ldy, S(st)));
+        else FL_HIP(gemm_q4_exact(*W, *a, a->N, y, ldy, S(st)));
+    } else if (which == 2) {
         if (a->layout != 1) return set_error(FL_EINVAL, "gemv needs the QA1 layout");
         FL_HIP(gemv_q4(*W, *a, a->N, y, ldy, S(st)));
     } else {

@@ -129,16 +129,26 @@ fl_comm *fl_comm_create(const void *id_bytes, int rank, int world) {
     if (world >= 2 && world <= FL_COMM_MAX_LOCAL && want_p2p && want_p2p[0] == '1') {
         unsigned char mine[FL_COMM_P2P_HANDLE_BYTES], all[FL_COMM_P2P_HANDLE_BYTES * FL_COMM_MAX_LOCAL];
         void *stage = nullptr;
-        bool ok = fl_comm_p2p_export(c, mine) == FL_OK && hipMalloc(&stage, sizeof all + sizeof mine) == hipSuccess;
+        // The staging buffer comes first: a rank that cannot even allocate it cannot take part in the collectives below, and
+        // must not leave its peers waiting inside them -- it aborts the communicator (the peers' calls then fail instead of
+        // hanging) and reports the failure.  Everything after this point is collective-safe: a rank whose local setup failed
+        // still joins the all-gather with a zero handle and the agreement with a 0.
+        if (hipMalloc(&stage, sizeof all + sizeof mine) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error(FL_ENOMEM, "fl_comm_create: no device memory for the peer-exchange handshake; communicator aborted");
+            (void)ncclCommAbort(c->comm);
+            delete c;
+            return nullptr;
+        }
+        bool ok = fl_comm_p2p_export(c, mine) == FL_OK;
         if (ok) ok = hipMemcpy(static_cast<unsigned char *>(stage) + sizeof all, mine, sizeof mine, hipMemcpyHostToDevice) == hipSuccess;
         // (every rank takes part in the collective whatever happened locally: a rank that failed contributes a zero handle)
-        if (!ok && stage) (void)hipMemset(static_cast<unsigned char *>(stage) + sizeof all, 0, sizeof mine);
-        if (stage) {
+        if (!ok) (void)hipMemset(static_cast<unsigned char *>(stage) + sizeof all, 0, sizeof mine);
+        {
             ncclResult_t g = ncclAllGather(static_cast<unsigned char *>(stage) + sizeof all, stage, sizeof mine, ncclUint8, c->comm, nullptr);
             if (g != ncclSuccess || hipDeviceSynchronize() != hipSuccess ||
                 hipMemcpy(all, stage, sizeof mine * (size_t)world, hipMemcpyDeviceToHost) != hipSuccess)
                 ok = false;
-            (void)hipFree(stage);
             bool every = ok;
             for (int r = 0; r < world && every; ++r) {
                 bool nz = false;
@@ -146,20 +156,20 @@ fl_comm *fl_comm_create(const void *id_bytes, int rank, int world) {
                 every = nz;
             }
             if (!every || fl_comm_p2p_import(c, all) != FL_OK) p2p_free(c);
-        } else {
-            p2p_free(c);
         }
         // every rank must take the same path for a given message: the exchange is used only if it came up on ALL ranks
-        int *agree = nullptr;
+        // (the agreement word lives in the staging buffer: no allocation that could fail between the two collectives)
+        int *agree = static_cast<int *>(stage);
         int mine_ok = c->p2p.ready ? 1 : 0, all_ok = 0;
-        if (hipMalloc(&agree, sizeof(int)) == hipSuccess && hipMemcpy(agree, &mine_ok, sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
-            ncclAllReduce(agree, agree, 1, ncclInt32, ncclMin, c->comm, nullptr) == ncclSuccess && hipDeviceSynchronize() == hipSuccess &&
+        const bool sent = hipMemcpy(agree, &mine_ok, sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+        if (!sent) (void)hipMemset(agree, 0, sizeof(int));
+        if (ncclAllReduce(agree, agree, 1, ncclInt32, ncclMin, c->comm, nullptr) == ncclSuccess && hipDeviceSynchronize() == hipSuccess &&
             hipMemcpy(&all_ok, agree, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && all_ok == 1) {
             // keep it
         } else {
             p2p_free(c);
         }
-        if (agree) (void)hipFree(agree);
+        (void)hipFree(stage);
         (void)hipGetLastError();
     }
     return c;
@@ -216,6 +226,13 @@ int fl_comm_p2p_import(fl_comm *c, const void *handles_all) {
 }
 
 int fl_comm_has_p2p(const fl_comm *c) { return c && c->p2p.ready ? 1 : 0; }
+/* exchanges of this rank that gave up waiting for a peer (p2p_exchange_kernel's bounded spin); synchronises the device */
+int fl_comm_p2p_timeouts(const fl_comm *c) {
+    if (!c || !c->p2p.ready) return 0;
+    unsigned n = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&n, c->p2p.peers.epoch + 1, sizeof n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)n;
+}
 
 int fl_comm_create_local(int world, fl_comm **out) {
     if (ensure_device() != FL_OK) return FL_ENODEV;
@@ -344,6 +361,12 @@ int fl_comm_debug_graph_allreduce(fl_comm *c, float *buf_dev, size_t count, int 
 
 int fl_comm_rank(const fl_comm *c) { return c ? c->rank : -1; }
 int fl_comm_size(const fl_comm *c) { return c ? c->world : 0; }
+/* ranks the RCCL communicator itself reports (ncclCommCount); 0 for a communicator without RCCL behind it (local shards, p2p only) */
+int fl_comm_rccl_ranks(const fl_comm *c) {
+    if (!c || !c->comm) return 0;
+    int n = 0;
+    return ncclCommCount(c->comm, &n) == ncclSuccess ? n : -1;
+}
 
 void fl_comm_destroy(fl_comm *c) {
     if (!c) return;

@@ -21,6 +21,10 @@ hipError_t rope_kv(float *qkv, int ld, int N, int E, int D, int n_past, int n_ct
 hipError_t gemm_f32_abt(const float *A, int lda, int64_t sAz, const float *B, int ldb, int64_t sBz, float *C, int ldc,
                         int64_t sCz, int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past,
                         hipStream_t st, const int *dyn_past = nullptr, int nn_max = 0);
+// the same interface in ggml_vec_dot_f32's order (4 x 8 FMA lanes, fixed tree, compiled leftover loop): exact_kernels.hip
+hipError_t dot_f32_abt_exact(const float *A, int lda, int64_t sAz, const float *B, int ldb, int64_t sBz, float *C, int ldc,
+                             int64_t sCz, int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past,
+                             hipStream_t st, const int *dyn_past = nullptr, int nn_max = 0);
 hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab,
                         hipStream_t st, const int *dyn_past = nullptr);
 // prefill: KQ*scale + mask + soft_max + KQV per (head, 32 query rows), score rows in LDS; q = roped Q rows of qkv,

@@ -593,9 +593,10 @@ struct Session {
     // (fl_model_ingest: two blocks in flight, lm-head for the last one only) -- the same evals, the same K/V cache and logits.
     struct PendingEval { int past; std::vector<token_t> toks; };
     std::vector<PendingEval> pending;
-    bool flush_pending() {
+    // returns the index of the first entry that failed (all evals before it are in the K/V cache), or pending.size()
+    size_t flush_pending() {
         bool ok = true;
-        size_t i = 0;
+        size_t i = 0, failed = pending.size();
         while (ok && i < pending.size()) {
             size_t j = i + 1;                                       // [i, j): consecutive positions, sizes the device accepts
             int end = pending[i].past + (int)pending[i].toks.size();
@@ -621,10 +622,10 @@ struct Session {
             } else {
                 ok = eval(pending[i].past, pending[i].toks);
             }
+            if (!ok) failed = i;
             i = j;
         }
-        pending.clear();
-        return ok;
+        return failed;
     }
 
     // lib/bridge.cpp:161-180
@@ -662,6 +663,7 @@ struct Session {
             system_prompt = in;
         }
         const size_t nb = (size_t)args.n_batch;
+        pending.clear();                                            // (nothing survives a call that an exception cut short)
         for (size_t i = 0; i < in.size(); i += nb) {
             log.progress(PROGRESS_TAG_INGEST, i, in.size());
             const size_t block = std::min(nb, in.size() - i);
@@ -671,7 +673,16 @@ struct Session {
             embd.assign(in.begin() + (std::ptrdiff_t)i, in.begin() + (std::ptrdiff_t)(i + block));
             for (size_t j = 0; j < block; ++j) push_last(in[i + j]);
         }
-        if (!flush_pending()) return false;
+        const size_t failed = flush_pending();
+        if (failed < pending.size()) {
+            // the reference returns from inside the loop with n_past and embd as they were when that eval failed
+            // (lib/bridge.cpp:214-219): the K/V cache holds everything before the failing block, the block itself is still staged
+            n_past = pending[failed].past;
+            embd = pending[failed].toks;
+            pending.clear();
+            return false;
+        }
+        pending.clear();
         log.progress(PROGRESS_TAG_INGEST, in.size(), in.size());
         last_n.clear();
         return true;
@@ -697,6 +708,11 @@ struct Session {
             if (!embd.empty() && !eval(n_past, embd)) return false;
             n_past += (int)embd.size();
             embd.clear();
+            sync_logits();                 // (a perplexity() call may have left its block's logits in HBM)
+            if (logits.size() < (size_t)hp.n_vocab) {
+                log.err("generate", "no logits to sample from: ingest a prompt first\n");
+                return false;
+            }
             const float *last = logits.data() + logits.size() - (size_t)hp.n_vocab;
             const token_t id = sample_top_p_top_k(last, hp.n_vocab, last_n, (double)repeat_penalty, (int)top_k, (double)top_p,
                                                   (double)temp, rng);
@@ -739,9 +755,9 @@ struct Session {
                     for (size_t j = j0; j < j1; ++j) {
                         const float *l = logits.data() + j * V;
                         const float mx = *std::max_element(l, l + V);
-                        float sum = 0.f;
-                        for (size_t k = 0; k < V; ++k) sum += std::exp(l[k] - mx);
-                        row_nll[j - j0] = (double)(-std::log(std::exp(l[(size_t)next[j - j0]] - mx) / sum));
+                        double sum = 0.0;                   // as logits_nll_kernel: f64 sum of the f32 exponentials
+                        for (size_t k = 0; k < V; ++k) sum += (double)std::exp(l[k] - mx);
+                        row_nll[j - j0] = -std::log((double)std::exp(l[(size_t)next[j - j0]] - mx) / sum);
                     }
                 }
                 if (!ok) { log.err("perplexity", std::string(fl_last_error()) + "\n"); all_logits = old; return -1.f; }

@@ -33,6 +33,10 @@
 
 using namespace fl;
 
+#ifndef FL_DEFAULT_EXACT
+#define FL_DEFAULT_EXACT 0
+#endif
+
 namespace {
 
 struct StagedFuse {            // device AoS staging of a row-stacked tensor (wq|wk|wv or w1|w3)
@@ -91,6 +95,7 @@ struct fl_model : Act {
     bool fuse_prefill_attn = true;   // N >= 9: KQ + soft_max + KQV in one launch
     int force_deep_attn = 0;         // debugging: always the key-tiled form of that launch
     bool ingest_one_stream = false;  // debugging: fl_model_ingest takes its chunks one after the other
+    bool exact = false;              // reference-order kernels (exact_kernels.hip): logits bit-identical to the reference's x86 build
     bool w13_il = false;             // w1|w3 woven by 16-row groups (n_ff/tp a multiple of 32): silu epilogue in the matmul
     int exp_tab_n = 0;               // fp16 exp-table entries after 0x8000 that are non-zero (rounded up to 8): the LDS copy
     // LoRA: originals of the tensors an adapter touched (the reference's use_mmap path keeps them too, llama.cpp:868-874)
@@ -190,6 +195,7 @@ fl_model *fl_model_create(const fl_model_params *p) {
     m->G = G; m->rank = p->tp_rank;
     m->El = m->E / G; m->Hl = m->H / G; m->Fl = m->F / G;
     m->w13_il = m->Fl % 32 == 0;
+    m->exact = fl_default_exact() != 0;
     if (G > 1 && m->V % G == 0) { m->Vl = m->V / G; m->ldp = fl_roundup(m->Vl, 4); }
     m->layers.resize(m->L);
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -419,7 +425,8 @@ static hipError_t mm(fl_model *m, const fl_qtensor *W, const fl_qact &a, int N, 
     hipEvent_t e1;
     hipError_t r = prof_begin(m, &e1);
     if (r != hipSuccess) return r;
-    r = N <= 8 ? gemv_q4(*W, a, N, y, ldy, m->stream, resid, ldr) : gemm_q4_mfma(*W, a, N, y, ldy, m->stream, resid, ldr);
+    if (m->exact) r = N <= 8 ? gemv_q4_exact(*W, a, N, y, ldy, m->stream, resid, ldr) : gemm_q4_exact(*W, a, N, y, ldy, m->stream, resid, ldr);
+    else r = N <= 8 ? gemv_q4(*W, a, N, y, ldy, m->stream, resid, ldr) : gemm_q4_mfma(*W, a, N, y, ldy, m->stream, resid, ldr);
     prof_end(m, e1);
     return r;
 }
@@ -504,7 +511,9 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
     const int P = n_past + N;
     hipStream_t st = m->stream;
     const bool tp = m->G > 1;
-    const bool fused = N == 1 && D <= 128 && D % 32 == 0 && E <= 8192 && Fl <= 32768 && m->fuse_decode;   // single-token kernels
+    const bool exact = m->exact;        // reference-order matmuls: the per-op sequence, every matmul through exact_kernels.hip
+    const bool fused = N == 1 && D <= 128 && D % 32 == 0 && E <= 8192 && Fl <= 32768 && m->fuse_decode && !exact;   // single-token kernels
+    const bool fuse_pa = m->fuse_prefill_attn && !exact;
     if (!body_only) M_HIP(get_rows_qw16(*m->tok_emb, m->tok_dev, N, m->x, E, st));      // inpL = get_rows  llama.cpp:304
     float *inp = m->x, *mid = m->x2;
     if (l1 < 0) l1 = m->L;
@@ -526,7 +535,7 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
         } else {
             // norm + attention_norm*cur -> Q8_0                                                        llama.cpp:311-319
             M_HIP(rmsnorm_quant(inp, E, ly.attn_norm, N, E, nullptr, 0, &m->qE, layout, st));
-            if (N >= 9 && !dyn && m->fuse_prefill_attn) {
+            if (N >= 9 && !dyn && fuse_pa) {
                 M_HIP(mm_qkv_rope(m, ly.wqkv, m->qE, N, kc, vc, n_past));                              // wq, wk, wv + rope + KV store
             } else {
                 M_HIP(mm(m, ly.wqkv, m->qE, N, m->qkv, 3 * El, nullptr, 0));                           // wq, wk, wv  :328-334
@@ -536,19 +545,19 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
             if (kv_wait) M_HIP(hipStreamWaitEvent(st, kv_wait[l], 0));
             const float kq_scale = 1.0f / sqrtf((float)E / (float)m->H);
             // KQ, scale, mask, soft_max, KQV in one launch with the score rows in LDS when they fit       :364-398
-            hipError_t pe = (N >= 9 && !dyn && m->fuse_prefill_attn)
+            hipError_t pe = (N >= 9 && !dyn && fuse_pa)
                                 ? prefill_attention(m->qkv, 3 * El, D, Hl, N, n_past, n_ctx, El, kc, vc, m->exp_tab, m->exp_tab_n, kq_scale, m->ao, El, st, &m->qEl,
                                                     m->att, n_ctx, (int64_t)N * n_ctx, m->force_deep_attn)
                                 : hipErrorInvalidValue;
             if (pe != hipSuccess) {
                 (void)hipGetLastError();
                 // KQ, scale, mask, soft_max                                                            :364-379
-                M_HIP(gemm_f32_abt(m->qkv, 3 * El, D, kc, El, D, m->att, n_ctx, (int64_t)N * n_ctx, N, P, D, Hl, kq_scale, 1, n_past,
-                                   st, dyn, n_ctx));
+                M_HIP((exact ? dot_f32_abt_exact : gemm_f32_abt)(m->qkv, 3 * El, D, kc, El, D, m->att, n_ctx, (int64_t)N * n_ctx, N, P, D, Hl,
+                                                                 kq_scale, 1, n_past, st, dyn, n_ctx));
                 M_HIP(softmax_rows(m->att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, Hl, m->exp_tab, st, dyn));
                 // KQV, merged back to [N, n_embd]                                                      :389-398
-                M_HIP(gemm_f32_abt(m->att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, m->ao, El, D, N, D, P, Hl,
-                                   1.0f, 2, n_past, st, dyn, n_ctx));
+                M_HIP((exact ? dot_f32_abt_exact : gemm_f32_abt)(m->att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, m->ao, El, D, N,
+                                                                 D, P, Hl, 1.0f, 2, n_past, st, dyn, n_ctx));
                 M_HIP((layout == 16 ? quantize_q8_qa16 : quantize_q8_qa1)(m->ao, El, N, El, m->qEl, st));
             }   // (the one-launch kernel wrote the Q8_0 operand of the wo matmul itself)
         }
@@ -562,7 +571,7 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
             M_HIP(add_rows(m->part, E, inp, E, mid, E, N, E, st));
         }
         // feed-forward                                                                             :412-436
-        const bool silu_in_gemm = N >= 9 && m->w13_il;    // silu * mul -> Q8_0 is the epilogue of the w1|w3 matmul
+        const bool silu_in_gemm = N >= 9 && m->w13_il && !exact;    // silu * mul -> Q8_0 is the epilogue of the w1|w3 matmul
         const bool silu_in_gemv = fused && m->w13_il;         // decode: silu * mul is the epilogue of the w1|w3 GEMV
         if (silu_in_gemv) {
             M_HIP(mm_norm_silu(m, ly.w13, mid, ly.ffn_norm, m->h13));
@@ -723,10 +732,12 @@ int fl_model_ingest(fl_model *m, const int32_t *tokens, const int *chunk_len, in
     if (!m->alt_ready) {                                  // the second set of work buffers, its stream, the per-layer events
         if (!m->alt.stream) M_HIP(hipStreamCreateWithFlags(&m->alt.stream, hipStreamNonBlocking));
         hipStream_t st1 = m->alt.stream;
-        const int rc = act_alloc(m, m->alt);
-        if (rc != FL_OK) act_free(m->alt);                // (no half-allocated set left behind)
-        m->alt.stream = st1;
-        if (rc != FL_OK) return rc;
+        if (!m->alt.x) {                                  // (a previous call may have got this far and failed on an event below)
+            const int rc = act_alloc(m, m->alt);
+            if (rc != FL_OK) act_free(m->alt);            // (no half-allocated set left behind)
+            m->alt.stream = st1;
+            if (rc != FL_OK) return rc;
+        }
         for (auto &v : m->kv_ev)
             while ((int)v.size() < m->L) {
                 hipEvent_t e;
@@ -787,6 +798,26 @@ int fl_model_set_graph(fl_model *m, int mode) {
     }
     m->fuse_decode = fuse;
     return FL_OK;
+}
+
+/* 1: every matmul of the following evals runs in the reference's summation order (exact_kernels.hip) -- logits bit-identical to
+ * the reference's x86 build; 0: the fast kernels (exact block dots, own f32 order).  The decode graphs are re-captured. */
+int fl_model_set_exact(fl_model *m, int on) {
+    if (!m) return set_error(FL_EINVAL, "null model");
+    if ((on != 0) != m->exact) {
+        if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+        if (m->graph_exec_long) (void)hipGraphExecDestroy(m->graph_exec_long);
+        m->graph_exec = m->graph_exec_long = nullptr;
+    }
+    m->exact = on != 0;
+    return FL_OK;
+}
+int fl_model_get_exact(const fl_model *m) { return m && m->exact ? 1 : 0; }
+/* the mode new models start in: FL_EXACT=1 / FL_EXACT=0 in the environment, else the built-in default */
+int fl_default_exact(void) {
+    const char *e = getenv("FL_EXACT");
+    if (e && *e) return atoi(e) != 0;
+    return FL_DEFAULT_EXACT;
 }
 
 /* bench hook: time every quantized-matmul launch of the following evals with HIP events on the eval stream */
@@ -1179,6 +1210,11 @@ int fl_debug_rope_kv(float *qkv, int ld, int N, int E, int D, int n_past, int n_
 int fl_debug_gemm_f32_abt(const float *A, int lda, long sAz, const float *B, int ldb, long sBz, float *Cc, int ldc, long sCz,
                           int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past, void *stream) {
     M_HIP(gemm_f32_abt(A, lda, sAz, B, ldb, sBz, Cc, ldc, sCz, M, Nn, K, batch, alpha, causal_mode, n_past, (hipStream_t)stream));
+    return FL_OK;
+}
+int fl_debug_gemm_f32_abt_exact(const float *A, int lda, long sAz, const float *B, int ldb, long sBz, float *Cc, int ldc, long sCz,
+                                int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past, void *stream) {
+    M_HIP(dot_f32_abt_exact(A, lda, sAz, B, ldb, sBz, Cc, ldc, sCz, M, Nn, K, batch, alpha, causal_mode, n_past, (hipStream_t)stream));
     return FL_OK;
 }
 int fl_debug_softmax_rows(float *S, int ld, long sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab_dev,

@@ -46,6 +46,11 @@ hipError_t gemm_q4_mfma_silu(const fl_qtensor &W, const fl_qact &xq, int N, cons
                              hipStream_t st);
 hipError_t gemm_q4_mfma_qkv(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, const float *rope_tab, float *kc,
                             float *vc, int El, int D, int n_past, int n_ctx, hipStream_t st);
+// reference-order ("exact") forms: 8 lane accumulators per output in block order + the AVX2 hsum (exact_kernels.hip)
+hipError_t gemv_q4_exact(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
+                         const float *resid = nullptr, int ldr = 0);
+hipError_t gemm_q4_exact(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
+                         const float *resid = nullptr, int ldr = 0);
 hipError_t gemm_q4_naive(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st);
 
 size_t qact_bytes_q(int N, int K);      // bytes of the q plane for N columns (padded to 16)

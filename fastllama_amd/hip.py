@@ -90,9 +90,11 @@ _PROTOS = {
     "fl_comm_p2p_export": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fl_comm_p2p_import": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fl_comm_has_p2p": (C.c_int, [C.c_void_p]),
+    "fl_comm_p2p_timeouts": (C.c_int, [C.c_void_p]),
     "fl_comm_debug_graph_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "fl_comm_rank": (C.c_int, [C.c_void_p]),
     "fl_comm_size": (C.c_int, [C.c_void_p]),
+    "fl_comm_rccl_ranks": (C.c_int, [C.c_void_p]),
     "fl_comm_destroy": (None, [C.c_void_p]),
     "fl_model_create": (C.c_void_p, [C.POINTER(ModelParams)]),
     "fl_model_lora_shape": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -139,6 +141,11 @@ _PROTOS = {
                                    C.c_void_p, C.c_void_p]),
     "fl_debug_gemm_f32_abt": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_int,
                                         C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "fl_debug_gemm_f32_abt_exact": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_int,
+                                              C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "fl_model_set_exact": (C.c_int, [C.c_void_p, C.c_int]),
+    "fl_model_get_exact": (C.c_int, [C.c_void_p]),
+    "fl_default_exact": (C.c_int, []),
     "fl_debug_softmax_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                         C.c_void_p]),
     "fl_debug_mul_mat_q": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

@@ -36,6 +36,10 @@ class FlModel:
             del data
         hip.check(L.fl_model_finalize(self.h), "fl_model_finalize")
 
+    def set_exact(self, on: bool):
+        """reference-order matmuls (logits bit-identical to the reference) / the fast kernels"""
+        hip.check(self.L.fl_model_set_exact(self.h, 1 if on else 0), "fl_model_set_exact")
+
     def set_comm(self, comm):
         hip.check(self.L.fl_model_set_comm(self.h, comm), "fl_model_set_comm")
 

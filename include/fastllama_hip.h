@@ -162,9 +162,11 @@ fl_comm *fl_comm_create_p2p(int rank, int world);
 int fl_comm_p2p_export(fl_comm *c, void *handles_out /* FL_COMM_P2P_HANDLE_BYTES */);
 int fl_comm_p2p_import(fl_comm *c, const void *handles_all /* world * FL_COMM_P2P_HANDLE_BYTES, rank order */);
 int fl_comm_has_p2p(const fl_comm *c);
+int fl_comm_p2p_timeouts(const fl_comm *c); /* exchanges that gave up waiting for a peer (~20 s each); 0 on a healthy group */
 int fl_comm_debug_graph_allreduce(fl_comm *c, float *buf_dev, size_t count, int replays, void *stream);
 int fl_comm_rank(const fl_comm *c);
 int fl_comm_size(const fl_comm *c);
+int fl_comm_rccl_ranks(const fl_comm *c); /* ncclCommCount of the RCCL communicator; 0 = none behind this handle */
 void fl_comm_destroy(fl_comm *c);
 
 /* ---------------------------------------------------------------- the model -------------------- */
@@ -202,6 +204,13 @@ int fl_model_profile(fl_model *m, int enable, double *mm_ms_total, long *mm_laun
 /* decode (N = 1) evals replay a captured hipGraph by default; 0 switches to plain launches */
 int fl_model_set_graph(fl_model *m, int mode); /* bit0: hipGraph replay for decode (default on); bit1: generic per-op decode kernels; bit2: three-kernel prefill attention;
                                                 * bit3: decode attention never split; bit4: always split (default: two launches from position 256 on) */
+/* Summation order of the matmuls.  1 ("exact"): the reference's own order -- 8 f32 lane accumulators per Q4 x Q8_0 dot in block
+ * order and the AVX2 horizontal sum (lib/ggml.c:2445-2487, :2639-2689), ggml_vec_dot_f32's 4 x 8 lanes in the attention matmuls
+ * (lib/ggml.c:2295-2330) -- logits bit-identical to the reference's x86 build.  0 ("fast"): exact integer block dots on the MFMA
+ * units, block terms added in the kernels' own f32 order (1e-7 per matmul; ~1e-2 on the logits after 32 layers). */
+int fl_model_set_exact(fl_model *m, int on);
+int fl_model_get_exact(const fl_model *m);
+int fl_default_exact(void); /* the mode new models start in: environment FL_EXACT=1|0, else the library default */
 /* LoRA on the resident Q4 weights -- replaces Model::attach_lora / detach_lora (lib/llama.cpp:697-944) and its
  * ggml_compute_forward_add_q_f32 (lib/ggml.c:6414-6520): W <- quantize_row_q(dequantize_row_q(W) + sign * BA), with the
  * reference's SIMD quantizer arithmetic.  base_name is the base tensor ("layers.3.attention.wq.weight"); pass either
@@ -264,6 +273,9 @@ int fl_debug_rope_kv(float *qkv_dev, int ld, int N, int E, int D, int n_past, in
                      float *kc_dev, float *vc_dev, void *stream);
 int fl_debug_gemm_f32_abt(const float *A, int lda, long sAz, const float *B, int ldb, long sBz, float *C, int ldc, long sCz,
                           int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past, void *stream);
+int fl_debug_gemm_f32_abt_exact(const float *A, int lda, long sAz, const float *B, int ldb, long sBz, float *C, int ldc, long sCz,
+                                int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past, void *stream);
+                                /* the same product in ggml_vec_dot_f32's order (exact mode's attention matmuls) */
 int fl_debug_softmax_rows(float *S_dev, int ld, long sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab_dev,
                           void *stream);
 
@@ -273,7 +285,7 @@ int fl_debug_mul_mat_q_resid(const fl_qtensor *W, const fl_qact *a, float *y_dev
 int fl_debug_gemm_qkv(const fl_qtensor *W, const fl_qact *a, float *y_dev, int ldy, const float *rope_tab_dev, float *kc_dev,
                       float *vc_dev, int El, int D, int n_past, int n_ctx, void *stream);
 int fl_debug_gemm_silu(const fl_qtensor *W, const fl_qact *a, const uint16_t *silu_tab_dev, fl_qact *out, void *stream);
-int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a, float *y_dev, int ldy, int which /*0 naive,1 mfma,2 gemv*/,
+int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a, float *y_dev, int ldy, int which /*0 naive,1 mfma,2 gemv,3 reference-order (exact)*/,
                        void *stream);
 int fl_debug_qact_layout(const fl_qact *a); /* 16 = QA16, 1 = QA1 */
 int fl_debug_gemm_mixed_split(int row_groups, int col_groups, int *n_a, int *mg_split, int *n_b);  /* host logic of the two-tile-shape launch */

@@ -49,3 +49,44 @@ def test_bench_two_ranks_code_path():
     d = _line(r.stdout)                                      # rank 0 only prints
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert "cpu_baseline" not in d                          # reported at N = 1 only
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (the driver's form): bench.py spawns torch.distributed.run itself
+    and rank 0's line says n_gpus = 2.  On this 1-GPU box both ranks sit on device 0 and reduce their timings over gloo
+    (FL_BENCH_* overrides), so the leg is the replica one: tp_ok is False and no RCCL communicator is counted."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--model", "tiny", "--n-batch", "64", "--steps",
+                        "2", "--warmup", "1", "--decode-steps", "4"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=_clean_env(FL_BENCH_DEVICE="0", FL_BENCH_BACKEND="gloo"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    d = _line(r.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["tp_ok"] is False and d["n_ranks_rccl"] == 0
+
+
+def test_bench_self_launched_tensor_parallel_leg():
+    """The same bare command with the tensor-parallel leg rehearsed as two processes on ONE GPU (peer exchange instead of RCCL):
+    the headline is the TP eval (tp_ok, strong scaling) and the line says that no RCCL communicator carried it."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--model", "tiny", "--n-batch", "32", "--steps",
+                        "2", "--warmup", "1", "--decode-steps", "4"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=_clean_env(FL_BENCH_DEVICE="0", FL_BENCH_BACKEND="gloo", FL_BENCH_P2P_ONLY="1"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["tp_ok"] is True and d["scaling"] == "strong" and d["n_ranks_rccl"] == 0 and "tp_error" not in d
+
+
+def test_bench_reports_both_modes_and_config3():
+    """N = 1: the line carries the exact-mode timings beside the fast-mode headline; tp_ok / n_ranks_rccl are null."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "tiny", "--n-batch", "64", "--steps", "2",
+                        "--warmup", "1", "--decode-steps", "4", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                       env=_clean_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    assert d["mode"] == "fast" and d["exact_mode"]["prefill_tokens_per_s"] > 0 and d["exact_mode"]["decode_tokens_per_s"] > 0
+    assert d["tp_ok"] is None and d["n_ranks_rccl"] is None

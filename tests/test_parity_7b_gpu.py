@@ -1,19 +1,22 @@
 """GPU: parity of the device eval with the reference on the configuration the headline number is quoted on
-(BASELINE.json configs 2/3: LLaMA-7B, 32 layers, n_batch = 512, Q4_0 and Q4_1), and a measured account of WHERE the
-deviation comes from.
+(BASELINE.json configs 2/3: LLaMA-7B, 32 layers, n_batch = 512, Q4_0 and Q4_1), in BOTH modes of the library, and a measured
+account of where the fast mode's deviation comes from.
 
 1. test_llama7b_full_model_nbatch512_vs_reference: the same synthetic GGJT file through the reference's own C-ABI
-   (oracle/_ref/pyfastllama.so, CPU) and through fl_model (GPU): all 512 x 32000 logits compared; the numbers go to
-   gpurun_out/parity_7b_<type>.json (committed as profiles/r02_parity_7b.json).
+   (oracle/_ref/pyfastllama.so, CPU) and through fl_model (GPU); all 512 x 32000 logits compared.
+     * exact mode (fl_model_set_exact, reference-order kernels): every logit BIT-IDENTICAL to the reference -- north_star's
+       "within 1e-3" with nothing to spare on either side;
+     * fast mode (MFMA kernels, own f32 order): the measured deviation, asserted with margin.
+   The numbers go to gpurun_out/parity_7b_<type>_<weights>.json (committed under profiles/).
 2. test_teacher_forced_layers_flip_accounting: 7B-width layers fed the ORACLE's layer input (teacher forcing).  Every op
-   of a layer is bit-exact given equal inputs except the summation order inside the matmuls (1e-7); the reference path
+   of a layer is bit-exact given equal inputs except the summation order inside the fast matmuls (1e-7); the reference path
    re-quantizes to int8 before every matmul and rounds to fp16 to index its exp / silu tables, so that 1e-7 either
-   vanishes or flips one rounding.  The test counts the flips in the three Q8_0 operands of a layer and checks that
-   (a) a layer's output agrees to 1e-5 wherever no flip happened upstream, (b) flips are rare and one quantum each.
+   vanishes or flips one rounding.  The test counts the flips in the Q8_0 operands of a layer (5-14 per 262 144 quants, each
+   one quantum), and checks that the exact mode has none: its layer output equals the oracle's bit for bit.
 
-north_star's "logits within 1e-3" holds position by position until the first flip (position 0: 1e-5); after one, on
-RANDOM weights every later layer amplifies it (the reference deviates from itself by the same amount between two batch
-splits: tests/test_llama_eval_oracle.py::test_reference_logits_depend_on_batch_split).
+At this width the reference is bit-identical to itself across batch splits (its f32 dots have no remainder loops; measured
+in test 1); on toy widths it is not (tests/test_llama_eval_oracle.py::test_reference_logits_depend_on_batch_split) -- and the
+exact mode reproduces that too, because it follows the same per-eval order.
 """
 import ctypes as C
 import json
@@ -97,9 +100,17 @@ def test_llama7b_full_model_nbatch512_vs_reference(tmp_path_factory, reflib, qty
     os.remove(path)
     # ---- this library (GPU), same tensors, same tokens ----
     m = FlModel(scfg, qtype, gen(), n_ctx=512, max_batch=512)
+    m.set_exact(False)
     got = m.eval(toks, n_past=0, all_logits=True).astype(np.float64)
+    m.set_exact(True)
+    t0 = time.time()
+    got_exact = m.eval(toks, n_past=0, all_logits=True)
+    t_exact = time.time() - t0
     m.free()
     torch.cuda.empty_cache()
+    want32 = want.astype(np.float32)
+    n_bits_differ = int((got_exact.view(np.uint32) != want32.view(np.uint32)).sum())
+    xp, x_l2, x_greedy = _metrics(got_exact.astype(np.float64), want)
     per_pos, rel_l2, greedy = _metrics(got, want)
     pp2, rel_l2_half, greedy_half = _metrics(got[256:], want[256:])
     sp, self_l2, self_greedy = _metrics(want_split, want[256:])   # the reference against itself
@@ -108,6 +119,9 @@ def test_llama7b_full_model_nbatch512_vs_reference(tmp_path_factory, reflib, qty
                       "quantize_row_q_reference, random printable-ASCII prompt of 512 tokens",
                reference="oracle/_ref/pyfastllama.so (the reference compiled in place): llama_ingest + llama_generate(1) + llama_get_logits",
                metric="per position: max_i |g_i - c_i| / max_i |c_i| over the 32000 logits (SURVEY.md 8c)",
+               exact_mode_vs_reference=dict(logits_with_different_bits=n_bits_differ, of=int(want32.size), max=float(xp.max()), rel_l2=x_l2,
+                                            frac_positions_within_1e3=float(np.mean(xp <= 1e-3)), greedy_token_agreement=x_greedy,
+                                            seconds_eval512_incl_logits_copy=round(t_exact, 3)),
                gpu_vs_reference=dict(position0=float(per_pos[0]), max=float(per_pos.max()), median=float(np.median(per_pos)),
                                      rel_l2=rel_l2, frac_positions_within_1e3=float(np.mean(per_pos <= 1e-3)),
                                      frac_positions_within_1e2=float(np.mean(per_pos <= 1e-2)), greedy_token_agreement=greedy,
@@ -121,7 +135,9 @@ def test_llama7b_full_model_nbatch512_vs_reference(tmp_path_factory, reflib, qty
     with open(os.path.join(OUT, f"parity_7b_{tag}_{wname.split('_')[0]}.json"), "w") as f:
         json.dump(rec, f, indent=1)
     print(json.dumps(rec))
-    # what a user observes agrees in both regimes; the logits bounds are the measured ones with margin (profiles/r02_parity_7b.json):
+    # exact mode: the reference's logits, bit for bit (north_star: within 1e-3 at every position)
+    assert n_bits_differ == 0 and xp.max() == 0.0, (n_bits_differ, float(xp.max()))
+    # fast mode -- what a user observes agrees in both regimes; the logits bounds are the measured ones with margin (profiles/r02_parity_7b.json):
     # ~10 one-quantum flips per position on the way through 32 layers (test_teacher_forced_layers_flip_accounting counts
     # them per stage), each worth ~1e-3 of max|x|, decaying in the non-expansive net and amplified in the expansive one.
     # (At this width the reference is bit-identical to itself across batch splits -- no remainder loops in its f32 dots --
@@ -133,50 +149,53 @@ def test_llama7b_full_model_nbatch512_vs_reference(tmp_path_factory, reflib, qty
         assert per_pos.max() <= 0.2 and rel_l2 <= 0.12 and greedy >= 0.75, (per_pos.max(), rel_l2, greedy)
 
 
-def test_deviation_floor_of_a_reordered_cpu_implementation(tmp_path_factory, reflib):
-    """How far does ANY implementation that sums in another order land from the reference on this model?  The pinned numpy
-    oracle runs the reference's own matmul arithmetic bit for bit (oracle.Port) and differs from it in ONE place only: the
-    order of the f32 dots inside attention (numpy vs the AVX2 loop).  Full 7B Q4_0 (SURVEY recipe weights), 128 tokens:
-    reference vs oracle vs GPU, pairwise.  The GPU path must not be further from the reference than such a CPU re-ordering is
-    (x2 margin): its deviation is the algorithm's sensitivity, not an implementation error."""
+def test_oracle_reference_and_exact_gpu_agree_at_7b_width(tmp_path_factory, reflib):
+    """Three implementations of the same arithmetic on a 7B-WIDTH model (4 layers to bound the numpy oracle's run time, real
+    vocabulary, 96 tokens in one batch): the reference (CPU, its own C-ABI), the pinned numpy oracle (oracle/llama_eval.py -- the
+    teacher of test_teacher_forced_layers_flip_accounting) and this library's exact mode (GPU) return the same bits; the fast
+    mode's distance from them is recorded.  (Round 2 measured here how far a re-ordered CPU implementation lands from the
+    reference -- the oracle then summed its attention dots in numpy's order and sat 6e-2 away on the 32-layer model; with the
+    reference's own order in those dots it is at 0.)"""
     import torch
     from harness import synth
     from harness.flmodel import FlModel
     port = oracle.Port()
-    qtype, N = ggjt.Q4_0, 128
-    cfg = dict(n_vocab=32000, n_embd=4096, n_mult=256, n_head=32, n_layer=32)
-    scfg = dict(synth.MODELS["7B"])
+    qtype, N = ggjt.Q4_0, 96
+    cfg = dict(n_vocab=32000, n_embd=4096, n_mult=256, n_head=32, n_layer=4)
+    scfg = dict(synth.MODELS["7B"], n_layer=4)
     tensors = {name: (g, shape, data.cpu().numpy()) for name, (g, shape, data) in synth.synth_model_tensors(scfg, qtype, seed=1234)}
     torch.cuda.empty_cache()
-    path = str(tmp_path_factory.mktemp("m7b") / "llama7b.bin")
+    path = str(tmp_path_factory.mktemp("m7b") / "llama7b_4l.bin")
     ggjt.write_ggjt(path, cfg, qtype, tensors)
     rng = np.random.default_rng(11)
     text = bytes(rng.integers(33, 127, size=N - 2).astype(np.uint8)).decode()
     toks = [1] + [b + 3 for b in (" " + text).encode()]
-    ref = llama_capi.Session(reflib, path, n_ctx=256, n_batch=N, n_threads=min(32, os.cpu_count() or 8), all_logits=True)
+    ref = llama_capi.Session(reflib, path, n_ctx=128, n_batch=N, n_threads=min(32, os.cpu_count() or 8), all_logits=True)
     assert ref.ingest(text) and ref.generate(1, temp=0.0)[0]
-    want = ref.logits().reshape(N, cfg["n_vocab"]).astype(np.float64)
+    want = ref.logits().reshape(N, cfg["n_vocab"]).copy()
     ref.close()
     os.remove(path)
     t0 = time.time()
     orc, _ = le.eval_tokens(le.Weights(cfg, qtype, tensors), le.KV(cfg["n_layer"], N, cfg["n_embd"]), toks, 0, port)
     t_orc = time.time() - t0
-    m = FlModel(cfg, qtype, tensors, n_ctx=256, max_batch=N)
+    m = FlModel(cfg, qtype, tensors, n_ctx=128, max_batch=N)
+    m.set_exact(True)
+    got_x = m.eval(toks, n_past=0, all_logits=True)
+    m.set_exact(False)
     got = m.eval(toks, n_past=0, all_logits=True).astype(np.float64)
     m.free()
-    pairs = {}
-    for name, (a, b) in dict(gpu_vs_reference=(got, want), oracle_vs_reference=(orc.astype(np.float64), want),
-                             gpu_vs_oracle=(got, orc.astype(np.float64))).items():
-        pp, l2, gr = _metrics(a, b)
-        pairs[name] = dict(max=float(pp.max()), median=float(np.median(pp)), position0=float(pp[0]), rel_l2=l2, greedy=gr)
-    rec = dict(config="LLaMA-7B Q4_0, 32 layers, 128 tokens in one batch, SURVEY 8d recipe weights (sigma 0.02)",
-               oracle="oracle/llama_eval.py: the reference's matmul arithmetic bit for bit, numpy order inside the attention dots",
-               pairs=pairs, oracle_seconds=round(t_orc, 1))
+    pp, l2, gr = _metrics(got, want.astype(np.float64))
+    rec = dict(config="LLaMA-7B width, 4 layers, Q4_0, 96 tokens in one batch, SURVEY 8d recipe weights (sigma 0.02)",
+               oracle_vs_reference_bits_differing=int((orc.view(np.uint32) != want.view(np.uint32)).sum()),
+               exact_gpu_vs_reference_bits_differing=int((got_x.view(np.uint32) != want.view(np.uint32)).sum()),
+               fast_gpu_vs_reference=dict(max=float(pp.max()), median=float(np.median(pp)), position0=float(pp[0]), rel_l2=l2, greedy=gr),
+               oracle_seconds=round(t_orc, 1))
     os.makedirs(OUT, exist_ok=True)
-    with open(os.path.join(OUT, "parity_7b_floor.json"), "w") as f:
+    with open(os.path.join(OUT, "parity_7b_width_three_way.json"), "w") as f:
         json.dump(rec, f, indent=1)
     print(json.dumps(rec))
-    assert pairs["gpu_vs_reference"]["rel_l2"] <= 2.0 * pairs["oracle_vs_reference"]["rel_l2"] + 1e-3, pairs
+    assert rec["oracle_vs_reference_bits_differing"] == 0 and rec["exact_gpu_vs_reference_bits_differing"] == 0, rec
+    assert pp[0] <= 1e-5 and l2 <= 5e-2, rec
 
 
 def _q8_rows(port, x):
@@ -276,7 +295,7 @@ def test_teacher_forced_layers_flip_accounting(qtype, tag):
         a3.N, a3.K = N, E
         nf, step, nd, n = _flips(a3.export().cpu().numpy(), _q8_rows(port, mid["att"]))
         rec["attention_q8"] = dict(quants=n, differing=nf, max_step=step, scales_differing=nd)
-        assert step <= 1 and nf <= 1e-3 * n, rec
+        assert step <= 1 and nf <= 64, rec                 # measured 5-14 of 262 144 (profiles/r02_parity_layers.json)
         # S4: wo + residual on the oracle's attention output
         Wo = ops.QTensor(qtype, w.q(p + "attention.wo.weight"), E, E)
         x2 = torch.empty((N, E), device="cuda")
@@ -299,7 +318,7 @@ def test_teacher_forced_layers_flip_accounting(qtype, tag):
         a6.N, a6.K = N, F
         nf, step, nd, n = _flips(a6.export().cpu().numpy(), _q8_rows(port, mid["act"]))
         rec["silu_q8"] = dict(quants=n, differing=nf, max_step=step, scales_differing=nd)
-        assert step <= 1 and nf <= 1e-3 * n, rec
+        assert step <= 1 and nf <= 64, rec                 # measured 5-11 of 704 512
         # S7: w2 + residual on the oracle's activation
         W2 = ops.QTensor(qtype, w.q(p + "feed_forward.w2.weight"), E, F)
         xo = torch.empty((N, E), device="cuda")
@@ -312,6 +331,13 @@ def test_teacher_forced_layers_flip_accounting(qtype, tag):
                                           out.ctypes.data_as(C.c_void_p)), "fl_model_debug_layers")
         rec["whole_layer_err"] = _relmax(out, x_next)
         assert rec["whole_layer_err"] <= 2e-2
+        # ... and in exact mode: no flips anywhere, the layer output and its three Q8_0 operands are the oracle's, bit for bit
+        m.set_exact(True)
+        hip.check(L.fl_model_debug_layers(m.h, il, il + 1, np.ascontiguousarray(x).ctypes.data_as(C.c_void_p), N, 0,
+                                          out.ctypes.data_as(C.c_void_p)), "fl_model_debug_layers")
+        m.set_exact(False)
+        rec["whole_layer_exact_mode_bits_differing"] = int((out.view(np.uint32) != x_next.view(np.uint32)).sum())
+        assert rec["whole_layer_exact_mode_bits_differing"] == 0, rec
         layers.append(rec)
         for t in (Wqkv, Wo, W13, W2):
             t.free()
