@@ -416,9 +416,11 @@ int fl_debug_gemm_mixed_split(int row_groups, int col_groups, int *n_a, int *mg_
     fl::gemm32_mixed_split(row_groups, col_groups, n_a, mg_split, n_b);
     return FL_OK;
 }
+extern int g_debug_exact;   // model.cpp
 int fl_debug_set(int what, int value) {
     if (what == 0) fl::g_gemm_force_cfg = value;
     if (what == 1) fl::g_gemv_force_waves = value;   // 0 = automatic, else 4 / 8 / 16 waves per 16-row group
+    if (what == 2) g_debug_exact = value;            // the single-token test hooks (fl_debug_gemv_*, fl_debug_decode_attention*) in exact mode
     return FL_OK;
 }
 

@@ -41,12 +41,12 @@ hipError_t prefill_attention_deep(const float *qkv, int ldq, int D, int H, int N
 // decode (N = 1): rope + KV store + KQ + soft_max + KQV + Q8_0 of the result, one workgroup per head
 hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab, float *kc,
                             float *vc, const uint16_t *exp_tab, float scale, const fl_qact *out, hipStream_t st,
-                            const int *dyn_past = nullptr);
+                            const int *dyn_past = nullptr, bool exact = false);   // exact: ggml_vec_dot_f32's order in both dots
 // the same result (bit for bit) from two launches that spread a head over many CUs: (head, 128 positions) scores into
 // `scores` [H][n_ctx], then (head, 32 features) soft_max + KQV + Q8_0.  For long contexts.
 hipError_t decode_attention_split(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab,
                                   float *kc, float *vc, const uint16_t *exp_tab, float scale, float *scores,
-                                  const fl_qact *out, hipStream_t st, const int *dyn_past = nullptr);
+                                  const fl_qact *out, hipStream_t st, const int *dyn_past = nullptr, bool exact = false);
 // LoRA merge on reference AoS blocks (lora_kernels.hip): rows [row0, row0+rows) <- quantize(dequantize + sign * BA)
 hipError_t lora_add_aos(int type, void *aos, int KB, int row0, int rows, int il_part, const float *ba, int64_t ldba, const float *A,
                         const float *B, int r, int ba_row0, int ba_col0, float sign, hipStream_t st);

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <climits>
 #include "eval_kernels.h"
 #include "comm.h"
 #include "q4_device.h"
@@ -1192,8 +1193,65 @@ __device__ long long da_dbg[8];
 #else
 #define DA_STAMP(k) do {} while (0)
 #endif
+// Dots of the decode attention: 8 lanes per row, lane l8 holds the float4 pieces at element offsets 32 j + 4 l8 (+ c).
+// ORD = 0: the fast order -- one accumulator per lane, pieces ascending, group8_sum_f32.
+// ORD = 1: ggml_vec_dot_f32's order (exact mode; lib/ggml.c:2295-2330, reduction :1921-1936): element 32 i + 8 jj + l belongs to
+//   lane l of accumulator sum[jj]; offset 4 l8 + c is jj = l8 >> 1, l = 4 (l8 & 1) + c, so component c of this lane's float4
+//   accumulator IS sum[l8 >> 1][4 (l8 & 1) + c], chained over the 32-element steps in order.  Reduction: sum0 += sum1,
+//   sum2 += sum3 (lanes l8 ^ 2), sum0 += sum2 (lanes l8 ^ 4), lo128 + hi128 (lanes l8 ^ 1), hadd, hadd ((x + y) + (z + w)).
+//   f32 addition is commutative, so all 8 lanes end with the same bits.
+template <int ORD>
+__device__ __forceinline__ void att_fma4(float4 &a, const float4 x, const float4 y) {
+    if (ORD == 0) {
+        a.x = __fmaf_rn(x.x, y.x, a.x);
+        a.x = __fmaf_rn(x.y, y.y, a.x);
+        a.x = __fmaf_rn(x.z, y.z, a.x);
+        a.x = __fmaf_rn(x.w, y.w, a.x);
+    } else {
+        a.x = __fmaf_rn(x.x, y.x, a.x);
+        a.y = __fmaf_rn(x.y, y.y, a.y);
+        a.z = __fmaf_rn(x.z, y.z, a.z);
+        a.w = __fmaf_rn(x.w, y.w, a.w);
+    }
+}
+constexpr int DPP_QUAD_REV = 0x1B;     // quad_perm [3,2,1,0]: lane i <-> i ^ 3
+template <int ORD>
+__device__ __forceinline__ float att_reduce8(float4 a) {
+    if (ORD == 0) return group8_sum_f32(a.x);
+    auto x4 = [](float v) { return dpp_f32<DPP_QUAD_REV>(dpp_f32<DPP_HALF_MIRROR>(v)); };     // lane i ^ 7 ^ 3 = i ^ 4
+    a.x = __fadd_rn(a.x, dpp_f32<DPP_XOR2>(a.x)); a.y = __fadd_rn(a.y, dpp_f32<DPP_XOR2>(a.y));
+    a.z = __fadd_rn(a.z, dpp_f32<DPP_XOR2>(a.z)); a.w = __fadd_rn(a.w, dpp_f32<DPP_XOR2>(a.w));
+    a.x = __fadd_rn(a.x, x4(a.x)); a.y = __fadd_rn(a.y, x4(a.y));
+    a.z = __fadd_rn(a.z, x4(a.z)); a.w = __fadd_rn(a.w, x4(a.w));
+    a.x = __fadd_rn(a.x, dpp_f32<DPP_XOR1>(a.x)); a.y = __fadd_rn(a.y, dpp_f32<DPP_XOR1>(a.y));
+    a.z = __fadd_rn(a.z, dpp_f32<DPP_XOR1>(a.z)); a.w = __fadd_rn(a.w, dpp_f32<DPP_XOR1>(a.w));
+    return __fadd_rn(__fadd_rn(a.x, a.y), __fadd_rn(a.z, a.w));
+}
+// the n % 32 leftovers of that dot as the reference's build compiled them: chunks of 8, then one of 4 elements as rounded
+// products added in order, the last n % 4 as FMAs.  p[i], v(i) for i in [0, n): the elements behind the 32-wide body.
+template <typename VF>
+__device__ __forceinline__ float att_leftovers(float s, const float *__restrict__ p, int n, VF v) {
+#pragma clang fp contract(off)     // plain operators under this pragma: hipcc contracts a * b + c even across __fmul_rn / __fadd_rn
+    int i = 0;
+    for (; i + 8 <= n; i += 8)
+        for (int l = 0; l < 8; ++l) {
+            const float pr = p[i + l] * v(i + l);
+            s = s + pr;
+        }
+    if (n - i >= 4) {
+        for (int l = 0; l < 4; ++l) {
+            const float pr = p[i + l] * v(i + l);
+            s = s + pr;
+        }
+        i += 4;
+    }
+    for (; i < n; ++i) s = __fmaf_rn(p[i], v(i), s);
+    return s;
+}
+
 constexpr int DA_T = 512, DA_KPRE = 4, DA_VPRE = 8;
 
+template <int ORD>
 __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const float *__restrict__ qkv, int E, int D, int n_past,
                                                                 int n_ctx, const float2 *__restrict__ rope_tab,
                                                                 float *__restrict__ kc, float *__restrict__ vc,
@@ -1273,17 +1331,14 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const float *__r
         if (j < J) q4[j] = *reinterpret_cast<const float4 *>(qs + l8 * 4 + j * 32);
     float mx = -INFINITY;
     auto kq = [&](int p, const float4 *kr) {
-        float a = 0.f;
+        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (j >= J) break;
             const float4 k4 = p == pos ? *reinterpret_cast<const float4 *>(ks + l8 * 4 + j * 32) : kr[j];
-            a = __fmaf_rn(q4[j].x, k4.x, a);
-            a = __fmaf_rn(q4[j].y, k4.y, a);
-            a = __fmaf_rn(q4[j].z, k4.z, a);
-            a = __fmaf_rn(q4[j].w, k4.w, a);
+            att_fma4<ORD>(a4, k4, q4[j]);
         }
-        a = group8_sum_f32(a);
+        float a = att_reduce8<ORD>(a4);
         a = __fmul_rn(a, scale);
         if (l8 == 0) sc[p] = a;
         mx = fmaxf(mx, a);
@@ -1323,7 +1378,7 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const float *__r
 
     DA_STAMP(4);
     // ---- KQV ----
-    auto pv = [&](float a, int d, int c, float4 v4) -> float {
+    auto pv = [&](float4 &a, int d, int c, float4 v4) {
         const int p0 = c * 32 + l8 * 4;
         if (p0 + 3 >= pos) {                               // piece holding the fresh position (and what lies beyond)
             const float fresh = vs[d];
@@ -1333,26 +1388,30 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const float *__r
             v4.w = p0 + 3 == pos ? fresh : p0 + 3 > pos ? 0.f : v4.w;
         }
         const float4 p4 = *reinterpret_cast<const float4 *>(sc + p0);
-        a = __fmaf_rn(p4.x, v4.x, a);
-        a = __fmaf_rn(p4.y, v4.y, a);
-        a = __fmaf_rn(p4.z, v4.z, a);
-        a = __fmaf_rn(p4.w, v4.w, a);
-        return a;
+        att_fma4<ORD>(a, p4, v4);
     };
+    // ORD = 1: only whole 32-position steps go through the lanes; the P % 32 positions behind them are the reference's leftover loop
+    const int nlane = ORD ? (P >> 5) : nchunk;
 #pragma unroll
     for (int rp = 0; rp < 2; ++rp) {
         if (rp >= nvr) break;
         const int d = rp * 64 + r64;
-        float a = 0.f;
+        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (d < D) {
 #pragma unroll
             for (int c = 0; c < DA_VPRE; ++c)
-                if (c < nchunk && c * 32 + l8 * 4 < P) a = pv(a, d, c, vreg[rp][c]);
-            for (int c = DA_VPRE; c < nchunk; ++c)
+                if (c < nlane && c * 32 + l8 * 4 < P) pv(a4, d, c, vreg[rp][c]);
+            for (int c = DA_VPRE; c < nlane; ++c)
                 if (c * 32 + l8 * 4 < P)
-                    a = pv(a, d, c, *reinterpret_cast<const float4 *>(vc + (int64_t)(h * D + d) * n_ctx + c * 32 + l8 * 4));
+                    pv(a4, d, c, *reinterpret_cast<const float4 *>(vc + (int64_t)(h * D + d) * n_ctx + c * 32 + l8 * 4));
         }
-        a = group8_sum_f32(a);
+        float a = att_reduce8<ORD>(a4);
+        if (ORD && d < D && l8 == 0 && (P & 31)) {
+            const int np = P & ~31;
+            const float *vr = vc + (int64_t)(h * D + d) * n_ctx + np;
+            const float fresh = vs[d];
+            a = att_leftovers(a, sc + np, P - np, [&](int i) { return np + i == pos ? fresh : vr[i]; });
+        }
         if (d < D && l8 == 0) out[d] = a;
     }
     __syncthreads();
@@ -1372,11 +1431,15 @@ extern "C" int fl_debug_da_timing(long long *out) { return (int)hipMemcpyFromSym
 
 hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab, float *kc,
                             float *vc, const uint16_t *exp_tab, float scale, const fl_qact *out, hipStream_t st,
-                            const int *dyn_past) {
+                            const int *dyn_past, bool exact) {
     if (D % 32 != 0 || D > 128 || n_ctx % 4 != 0 || E % 4 != 0) return hipErrorInvalidValue;
     const size_t lds = (size_t)(4 * D + n_ctx + 4) * 4 + 8 * 8 + 8 * 4;
-    hipLaunchKernelGGL(decode_attention_kernel, dim3(H), dim3(DA_T), lds, st, qkv, E, D, n_past, n_ctx,
-                       reinterpret_cast<const float2 *>(rope_tab), kc, vc, exp_tab, scale, out->q, out->d, out->s, dyn_past);
+    if (exact)
+        hipLaunchKernelGGL(decode_attention_kernel<1>, dim3(H), dim3(DA_T), lds, st, qkv, E, D, n_past, n_ctx,
+                           reinterpret_cast<const float2 *>(rope_tab), kc, vc, exp_tab, scale, out->q, out->d, out->s, dyn_past);
+    else
+        hipLaunchKernelGGL(decode_attention_kernel<0>, dim3(H), dim3(DA_T), lds, st, qkv, E, D, n_past, n_ctx,
+                           reinterpret_cast<const float2 *>(rope_tab), kc, vc, exp_tab, scale, out->q, out->d, out->s, dyn_past);
     return hipGetLastError();
 }
 
@@ -1394,6 +1457,7 @@ hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, i
 // ------------------------------------------------------------------------------------------------
 constexpr int DS_T = 512, DS_POS = 128, DP_T = 256, DP_BATCH = 16;
 
+template <int ORD>
 __global__ __launch_bounds__(DS_T) void decode_scores_kernel(const float *__restrict__ qkv, int E, int D, int n_past,
                                                              int n_ctx, const float2 *__restrict__ rope_tab,
                                                              float *__restrict__ kc, float *__restrict__ vc, float scale,
@@ -1445,21 +1509,19 @@ __global__ __launch_bounds__(DS_T) void decode_scores_kernel(const float *__rest
     for (int u = 0; u < DS_POS / 64; ++u) {
         const int p = p0 + u * 64 + r64;
         if (p >= P) continue;
-        float a = 0.f;
+        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (j >= J) break;
             const float4 k4 = p == pos ? *reinterpret_cast<const float4 *>(ks + l8 * 4 + j * 32) : kreg[u][j];
-            a = __fmaf_rn(q4[j].x, k4.x, a);
-            a = __fmaf_rn(q4[j].y, k4.y, a);
-            a = __fmaf_rn(q4[j].z, k4.z, a);
-            a = __fmaf_rn(q4[j].w, k4.w, a);
+            att_fma4<ORD>(a4, k4, q4[j]);
         }
-        a = group8_sum_f32(a);
+        const float a = att_reduce8<ORD>(a4);
         if (l8 == 0) scores[(int64_t)h * n_ctx + p] = __fmul_rn(a, scale);
     }
 }
 
+template <int ORD>
 __global__ __launch_bounds__(DP_T) void decode_pv_kernel(const float *__restrict__ scores, int E, int D, int n_past,
                                                          int n_ctx, const float *__restrict__ vc,
                                                          const uint16_t *__restrict__ exp_tab, int8_t *__restrict__ oq,
@@ -1536,21 +1598,20 @@ __global__ __launch_bounds__(DP_T) void decode_pv_kernel(const float *__restrict
     __syncthreads();
 
     // ---- KQV for feature d: lane l8 owns positions 32c + 4 l8 .. +3, pieces in ascending order ----
-    float a = 0.f;
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int np = ORD ? (P & ~31) : INT_MAX;              // ORD = 1: positions from np on are the reference's leftover loop
     auto consume = [&](const float4 *r, int b) {
 #pragma unroll
         for (int c = 0; c < DP_BATCH; ++c) {
             const int pp = (b * DP_BATCH + c) * 32 + l8 * 4;
             float4 v4 = r[c];
-            v4.x = pp > pos ? 0.f : v4.x;                  // beyond the fresh position: stale cache / clamped loads
-            v4.y = pp + 1 > pos ? 0.f : v4.y;
-            v4.z = pp + 2 > pos ? 0.f : v4.z;
-            v4.w = pp + 3 > pos ? 0.f : v4.w;
+            const int lim = min(pos, np - 1);
+            v4.x = pp > lim ? 0.f : v4.x;                  // beyond the fresh position: stale cache / clamped loads
+            v4.y = pp + 1 > lim ? 0.f : v4.y;
+            v4.z = pp + 2 > lim ? 0.f : v4.z;
+            v4.w = pp + 3 > lim ? 0.f : v4.w;
             const float4 p4 = *reinterpret_cast<const float4 *>(sc + pp);
-            a = __fmaf_rn(p4.x, v4.x, a);
-            a = __fmaf_rn(p4.y, v4.y, a);
-            a = __fmaf_rn(p4.z, v4.z, a);
-            a = __fmaf_rn(p4.w, v4.w, a);
+            att_fma4<ORD>(a4, p4, v4);
         }
     };
     for (int b = 0; b < nbatch; b += 2) {
@@ -1559,7 +1620,8 @@ __global__ __launch_bounds__(DP_T) void decode_pv_kernel(const float *__restrict
         load(va, b + 2);
         consume(vb, b + 1);
     }
-    a = group8_sum_f32(a);
+    float a = att_reduce8<ORD>(a4);
+    if (ORD && l8 == 0 && (P & 31)) a = att_leftovers(a, sc + np, P - np, [&](int i) { return vrow[np + i]; });
     if (l8 == 0) out[tid >> 3] = a;
     __syncthreads();
     if (tid < 4) {                                         // one Q8_0 block: 4 adjacent lanes x 8 features
@@ -1572,16 +1634,24 @@ __global__ __launch_bounds__(DP_T) void decode_pv_kernel(const float *__restrict
 
 hipError_t decode_attention_split(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab,
                                   float *kc, float *vc, const uint16_t *exp_tab, float scale, float *scores,
-                                  const fl_qact *out, hipStream_t st, const int *dyn_past) {
+                                  const fl_qact *out, hipStream_t st, const int *dyn_past, bool exact) {
     if (D % 32 != 0 || D > 128 || n_ctx % 4 != 0 || E % 4 != 0) return hipErrorInvalidValue;
     const int slices = dyn_past ? (n_ctx + DS_POS - 1) / DS_POS : (n_past + DS_POS) / DS_POS;
-    hipLaunchKernelGGL(decode_scores_kernel, dim3(H, slices), dim3(DS_T), 0, st, qkv, E, D, n_past, n_ctx,
-                       reinterpret_cast<const float2 *>(rope_tab), kc, vc, scale, scores, dyn_past);
+    if (exact)
+        hipLaunchKernelGGL(decode_scores_kernel<1>, dim3(H, slices), dim3(DS_T), 0, st, qkv, E, D, n_past, n_ctx,
+                           reinterpret_cast<const float2 *>(rope_tab), kc, vc, scale, scores, dyn_past);
+    else
+        hipLaunchKernelGGL(decode_scores_kernel<0>, dim3(H, slices), dim3(DS_T), 0, st, qkv, E, D, n_past, n_ctx,
+                           reinterpret_cast<const float2 *>(rope_tab), kc, vc, scale, scores, dyn_past);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t lds = 4 * 8 + 4 * 4 + 32 * 4 + (size_t)((n_ctx + 511) / 512 * 512 + 512) * 4;
-    hipLaunchKernelGGL(decode_pv_kernel, dim3(H, D / 32), dim3(DP_T), lds, st, scores, E, D, n_past, n_ctx, vc, exp_tab,
-                       out->q, out->d, out->s, dyn_past);
+    if (exact)
+        hipLaunchKernelGGL(decode_pv_kernel<1>, dim3(H, D / 32), dim3(DP_T), lds, st, scores, E, D, n_past, n_ctx, vc, exp_tab,
+                           out->q, out->d, out->s, dyn_past);
+    else
+        hipLaunchKernelGGL(decode_pv_kernel<0>, dim3(H, D / 32), dim3(DP_T), lds, st, scores, E, D, n_past, n_ctx, vc, exp_tab,
+                           out->q, out->d, out->s, dyn_past);
     return hipGetLastError();
 }
 

@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include "eval_kernels.h"
 #include "q4_device.h"
+#include "gemv_prologue.h"
 #include "q4_kernels.h"
 
 #pragma clang fp contract(off)
@@ -144,12 +145,292 @@ static hipError_t launch_gemv_exact(const fl_qtensor &W, const fl_qact &xq, int 
     return hipGetLastError();
 }
 
+hipError_t gemv1_q4_exact(const fl_qtensor &W, const fl_qact &xq, float *y, hipStream_t st, const float *resid);
+static inline bool resid_has_ld(int) { return false; }    // N == 1: one row of y / resid, strides do not matter
 hipError_t gemv_q4_exact(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st, const float *resid,
                          int ldr) {
     if (N < 1 || N > 8) return hipErrorInvalidValue;
+    if (N == 1 && !resid_has_ld(ldr)) {
+        const hipError_t e = gemv1_q4_exact(W, xq, y, st, resid);
+        if (e != hipErrorInvalidValue) return e;
+        (void)hipGetLastError();
+    }
     return W.type == FL_TYPE_Q4_0 ? launch_gemv_exact<FL_TYPE_Q4_0>(W, xq, N, y, ldy, st, resid, ldr)
                                   : launch_gemv_exact<FL_TYPE_Q4_1>(W, xq, N, y, ldy, st, resid, ldr);
 }
+
+// ------------------------------------------------------------------------------------------------
+// N = 1, the decode kernel.  A matrix of 4096 rows has only 256 row groups, so one wave per group (above) would have to pull
+// 40-108 KB through its own registers, round trip after round trip.  Here ONE workgroup per CU streams a sequence of row groups
+// (group = blockIdx.x, + gridDim.x, ...) and splits the work by what depends on the running sums and what does not:
+//   * NWG PRODUCER waves stream the blocks (a chunk of KC = 8 * NWG blocks at a time, D chunks in flight -- across the
+//     boundaries between row groups, so the stream never drains) and do everything order-independent -- unpack, v_dot4,
+//     d_w * d_x -- leaving per block and row the 8 integer lane sums and the f32 scale in a double-buffered LDS chunk;
+//   * 2 CHAIN waves (lane = row x lane-sum j, one accumulator each) run  acc_j = fma(dd_b, float(q_bj), acc_j)  block after
+//     block over the chunk the producers finished last, while those fill the next one: the fma chain is hidden under the weight
+//     stream; at the end of a row group they add the 8 lane sums in the reference's order and store.
+// Q4_0 bookkeeping: the unpacked nibbles are 16 * (nib - 8) and the stored scale is d / 16 (q4_layout.h); the producers store
+// 16 isum and rn((d/16) d_x) = rn(d d_x) / 16: fma(dd/16, 16 q, a) and the reference's fma(dd, q, a) round the same real number.
+// The prologue (rms_norm / silu*mul / plain Q8_0 of the f32 activation, built in LDS by all waves, gemv_prologue.h) runs once
+// per workgroup.  PAIR (woven w1|w3 matrix): groups 2u, 2u+1 are the w1 / w3 rows of the same 16 features; the chain lane that
+// finishes row r of both stores silu(w1 x) * (w3 x) -- ggml_silu + ggml_mul of lib/llama.cpp:428-431.
+// ------------------------------------------------------------------------------------------------
+template <int TYPE, int NWG, int PRO, int PAIR>
+__global__ __launch_bounds__(64 * (NWG + 2)) void gemv1_q4_exact_kernel(
+    const uint32_t *__restrict__ qs, const float *__restrict__ dW, const float *__restrict__ mW, const int8_t *__restrict__ xq,
+    const float *__restrict__ xd, const float *__restrict__ xs, int M, int units, int KB, float *__restrict__ y,
+    const float *__restrict__ resid, const float *__restrict__ xf, const void *__restrict__ aux, float *__restrict__ ynorm,
+    int woven, const uint16_t *__restrict__ aux2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    constexpr int G2 = PAIR ? 2 : 1, NT = 64 * (NWG + 2);
+    constexpr int BPW = 8, KC = BPW * NWG, D = 6;                   // blocks per producer wave and chunk; chunk; chunks in flight
+    constexpr int CHUNK_BYTES = KC * (512 + 64 + (TYPE == FL_TYPE_Q4_1 ? 64 + 4 : 0));
+    const int lane = threadIdx.x & 63, wg = threadIdx.x >> 6;
+    const bool producer = wg < NWG;
+    const int nchunks = (KB + KC - 1) / KC;
+    const int my_units = blockIdx.x < units ? (units - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int T = my_units * G2 * nchunks;                          // chunks this workgroup streams
+    auto group_of = [&](int gidx) { return (blockIdx.x + (gidx / G2) * (int)gridDim.x) * G2 + gidx % G2; };
+
+    // LDS: [Q8_0 activation (PRO)] [chunk buffers 0, 1]
+    int8_t *lq = reinterpret_cast<int8_t *>(gsm);                   // [KB][32]
+    float *ld_ = reinterpret_cast<float *>(gsm + (size_t)KB * 32);  // [KB] d
+    float *ls_ = ld_ + KB;                                          // [KB] s
+    unsigned char *cbase = gsm + (size_t)KB * 40;
+    auto P32 = [&](int buf) { return reinterpret_cast<int *>(cbase + (size_t)buf * CHUNK_BYTES); };                // [KC][16][8]
+    auto DDp = [&](int buf) { return reinterpret_cast<float *>(cbase + (size_t)buf * CHUNK_BYTES + KC * 512); };   // [KC][16]
+    auto MWp = [&](int buf) { return DDp(buf) + KC * 16; };                                                          // [KC][16]
+    auto SXp = [&](int buf) { return DDp(buf) + KC * 32; };                                                          // [KC]
+    __shared__ double sh[4];
+
+    GP_DECL(PRO);
+    GemvPrologue<PRO, NT>::issue(pv, pw, psl, psb, xf, aux, KB, woven);
+
+    // producer state.  A chunk gives a producer wave 8 blocks x 16 rows = 128 (block, row) items, two per lane: item i of lane L
+    // is flat = 64 i + L -> block u = flat / 16, row = flat % 16 -- its 16 nibble bytes are one uint4 and a wave-load is one
+    // contiguous KiB.  The scales of the 8 blocks (128 floats, contiguous) are taken two per lane, independently of the items.
+    uint4 w[D][2];
+    float2 dw[D], mw[D];
+    auto load_chunk = [&](int t, int slot) {                       // t >= T: a cache-hot dummy (the tensor's first blocks), never used
+        const bool live = t < T;
+        const int gidx = live ? t / nchunks : 0, c = live ? t - gidx * nchunks : 0;
+        const int64_t gb0 = live ? (int64_t)group_of(gidx) * KB + c * KC + wg * BPW : 0;   // first block of this wave's share
+        const int64_t gbl = live ? (int64_t)group_of(gidx) * KB + KB - 1 : KB - 1;         // last valid block of the row group
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int flat = i * 64 + lane;
+            const int64_t gb = min(gb0 + (flat >> 4), gbl);
+            w[slot][i] = reinterpret_cast<const uint4 *>(qs)[gb * 16 + (flat & 15)];
+        }
+        const int64_t gs = min(gb0 + (lane >> 3), gbl);
+        dw[slot] = *reinterpret_cast<const float2 *>(dW + gs * 16 + 2 * (lane & 7));
+        if (TYPE == FL_TYPE_Q4_1) mw[slot] = *reinterpret_cast<const float2 *>(mW + gs * 16 + 2 * (lane & 7));
+    };
+    if (T == 0) return;                                             // (more workgroups than row groups: never launched that way)
+    // Every load of the stream is issued unconditionally -- past the end of the stream and in the chain waves it reads a
+    // cache-hot dummy: the compiler can then COUNT the loads in flight and wait for exactly the chunk (or the prologue
+    // operands, which were requested before) it needs, s_waitcnt vmcnt(n); under conditions it waits for everything.
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) load_chunk(producer ? dd : T, dd);
+    if constexpr (PRO != 0) {
+        GemvPrologue<PRO, NT>::finish(pv, pw, psl, psb, xf, aux, KB, woven, lq, ld_, ls_, sh, ynorm, blockIdx.x == 0);
+    } else {                                          // the activation is already Q8_0 (QA1 in HBM): copy it next to the chunks
+        for (int i = threadIdx.x; i < KB * 2; i += NT) reinterpret_cast<uint4 *>(lq)[i] = reinterpret_cast<const uint4 *>(xq)[i];
+        for (int i = threadIdx.x; i < KB; i += NT) {
+            ld_[i] = xd[i];
+            ls_[i] = TYPE == FL_TYPE_Q4_1 ? xs[i] : 0.f;
+        }
+        __syncthreads();
+    }
+
+    // The two roles run separate loops (their register sets must not be live together); every wave of the workgroup passes
+    // the same number of barriers -- one per chunk -- and the branch is wave-uniform.
+    if (producer) {
+#pragma unroll 1
+        for (int t0 = 0; t0 < T; t0 += D) {
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd) {
+                const int t = t0 + dd;
+                if (t >= T) break;
+                const int c = t % nchunks, buf = t & 1;
+                int *pq = P32(buf);
+                float *pd = DDp(buf), *pm = MWp(buf), *px = SXp(buf);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int flat = i * 64 + lane, u = flat >> 4, row = flat & 15;
+                    const int bl = wg * BPW + u, b = c * KC + bl;           // block inside the chunk / of the row
+                    const int bc = min(b, KB - 1);
+                    const uint4 x0 = *reinterpret_cast<const uint4 *>(lq + bc * 32), x1 = *reinterpret_cast<const uint4 *>(lq + bc * 32 + 16);
+                    const uint32_t xw[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};     // k-group g: (lo, hi) = xw[2g], xw[2g+1]
+                    const uint32_t wv[4] = {w[dd][i].x, w[dd][i].y, w[dd][i].z, w[dd][i].w};     // dword position p holds k-group p ^ sw
+                    const bool sw = row >= 8;
+                    int out[8];                                             // the 8 lane sums of (block, row), j = 2g + {0, 1}
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint32_t v = sw ? wv[g ^ 2] : wv[g];
+                        uint32_t wa, wb;
+                        unpack_lanes<TYPE>(v, wa, wb);
+                        out[2 * g] = __builtin_amdgcn_sdot4((int)wa, (int)perm_a(xw[2 * g + 1], xw[2 * g]), 0, false);
+                        out[2 * g + 1] = __builtin_amdgcn_sdot4((int)wb, (int)perm_b(xw[2 * g + 1], xw[2 * g]), 0, false);
+                    }
+                    if (b < KB) {
+                        uint4 *dst = reinterpret_cast<uint4 *>(pq + (bl * 16 + row) * 8);
+                        dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+                        dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+                    }
+                }
+                {   // scales of the wave's 8 blocks: lane L holds rows 2 (L & 7), +1 of block L >> 3
+                    const int bl = wg * BPW + (lane >> 3), b = c * KC + bl, bc = min(b, KB - 1);
+                    const float dx = ld_[bc];
+                    const float2 ddv = make_float2(__fmul_rn(dw[dd].x, dx), __fmul_rn(dw[dd].y, dx));
+                    if (b < KB) {
+                        *reinterpret_cast<float2 *>(pd + bl * 16 + 2 * (lane & 7)) = ddv;
+                        if (TYPE == FL_TYPE_Q4_1) {
+                            *reinterpret_cast<float2 *>(pm + bl * 16 + 2 * (lane & 7)) = mw[dd];
+                            if ((lane & 7) == 0) px[bl] = ls_[bc];
+                        }
+                    }
+                }
+                load_chunk(t + D, dd);
+                __syncthreads();            // chunk t is complete in LDS; the chain waves are done with chunk t - 1
+            }
+        }
+        return;
+    }
+
+    // chain waves: lane = 8 * (row & 7) + j, chain wave cw holds rows 8 cw .. 8 cw + 7
+    const int cw = wg - NWG, crow = cw * 8 + (lane >> 3), cj = lane & 7;
+    float acc = 0.f, summs = 0.f, y1 = 0.f;
+    // (all LDS reads of a batch of CB blocks are issued before the first fma: one round trip per batch instead of one per block)
+    constexpr int CB = TYPE == FL_TYPE_Q4_1 ? 16 : 32;
+    auto chain_chunk = [&](int t) {
+        const int gidx = t / nchunks, c = t - gidx * nchunks;
+        const int buf = t & 1, nb = min(KC, KB - c * KC);
+        const int *pq = P32(buf) + crow * 8 + cj;
+        const float *pd = DDp(buf) + crow, *pm = MWp(buf) + crow, *px = SXp(buf);
+#pragma unroll
+        for (int b0 = 0; b0 < KC; b0 += CB) {
+            if (b0 >= nb) break;
+            float dv[CB], mv[TYPE == FL_TYPE_Q4_1 ? CB : 1], sv[TYPE == FL_TYPE_Q4_1 ? CB : 1];
+            int qv[CB];
+#pragma unroll
+            for (int b = 0; b < CB; ++b) {
+                dv[b] = pd[(b0 + b) * 16];
+                qv[b] = pq[(b0 + b) * 128];
+                if (TYPE == FL_TYPE_Q4_1) {
+                    mv[b] = pm[(b0 + b) * 16];
+                    sv[b] = px[b0 + b];
+                }
+            }
+            if (b0 + CB <= nb) {
+#pragma unroll
+                for (int b = 0; b < CB; ++b) {
+                    acc = __fmaf_rn(dv[b], (float)qv[b], acc);
+                    if (TYPE == FL_TYPE_Q4_1) summs = __fmaf_rn(mv[b], sv[b], summs);
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < CB; ++b) {
+                    if (b0 + b < nb) {
+                        acc = __fmaf_rn(dv[b], (float)qv[b], acc);
+                        if (TYPE == FL_TYPE_Q4_1) summs = __fmaf_rn(mv[b], sv[b], summs);
+                    }
+                }
+            }
+        }
+        if (c != nchunks - 1) return;
+        // the row group is complete: ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)) over the 8 lanes of a row (all end with the same bits)
+        float v = acc;
+        v = __fadd_rn(v, __shfl_xor(v, 4));
+        v = __fadd_rn(v, __shfl_xor(v, 2));
+        v = __fadd_rn(v, __shfl_xor(v, 1));
+        if (TYPE == FL_TYPE_Q4_1) v = __fadd_rn(v, summs);
+        acc = 0.f;
+        summs = 0.f;
+        const int grp = group_of(gidx), row = grp * 16 + crow;
+        if constexpr (PAIR) {
+            if ((gidx & 1) == 0) {
+                y1 = v;                                                    // w1 . x of this feature; its w3 row comes next
+            } else if (cj == 0 && row < M) {
+                const uint16_t hx = __half_as_ushort(__float2half_rn(y1));                // GGML_FP32_TO_FP16
+                const float sl = __half2float(__ushort_as_half(aux2[hx]));               // table_silu_f16
+                y[(grp >> 1) * 16 + crow] = __fmul_rn(sl, v);                             // ggml_mul(silu, tmp)
+            }
+        } else if (cj == 0 && row < M) {
+            if (resid) v = __fadd_rn(v, resid[row]);
+            y[row] = v;
+        }
+    };
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        if (t > 0) chain_chunk(t - 1);
+        __syncthreads();
+    }
+    if (T > 0) chain_chunk(T - 1);
+}
+
+// false: the activation does not fit LDS next to the chunk buffers (K > ~100 000) -> the caller takes the per-op sequence
+template <int TYPE, int PRO, int PAIR>
+static bool launch_gemv1_exact(const fl_qtensor &W, const fl_qact *xq, float *y, hipStream_t st, const float *resid, const float *xf,
+                               const void *aux, float *ynorm, int woven, const uint16_t *aux2) {
+    constexpr int NWG = 8, G2 = PAIR ? 2 : 1, KC = 8 * NWG;
+    const int KB = W.KB, units = W.M16 / 16 / G2;
+    const size_t lds = (size_t)KB * 40 + (size_t)2 * KC * (512 + 64 + (TYPE == FL_TYPE_Q4_1 ? 64 + 4 : 0));
+    if (lds > 150 * 1024) return false;
+    static bool attr_set = false;          // (per instantiation) dynamic LDS beyond 64 KB must be asked for once
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemv1_q4_exact_kernel<TYPE, NWG, PRO, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const int grid = units < n_cu ? units : n_cu;                   // one resident workgroup per CU, each streaming its share of the rows
+    hipLaunchKernelGGL((gemv1_q4_exact_kernel<TYPE, NWG, PRO, PAIR>), dim3(grid), dim3(64 * (NWG + 2)), lds, st, W.qs, W.d, W.m,
+                       xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, W.M, units, KB, y, resid, xf, aux, ynorm, woven,
+                       aux2);
+    return true;
+}
+
+#define FL_TYPED(CALL0, CALL1) (W.type == FL_TYPE_Q4_0 ? (CALL0) : (CALL1))
+// the exact forms of gemv_q4 (N = 1) / gemv_q4_norm / gemv_q4_silu / gemv_q4_norm_silu / gemv_q4_quant (q4_kernels.h);
+// hipErrorInvalidValue: shape outside this kernel's reach -> the caller takes the per-op sequence
+hipError_t gemv1_q4_exact(const fl_qtensor &W, const fl_qact &xq, float *y, hipStream_t st, const float *resid) {
+    const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 0, 0>(W, &xq, y, st, resid, nullptr, nullptr, nullptr, 0, nullptr)),
+                             (launch_gemv1_exact<FL_TYPE_Q4_1, 0, 0>(W, &xq, y, st, resid, nullptr, nullptr, nullptr, 0, nullptr)));
+    return ok ? hipGetLastError() : hipErrorInvalidValue;
+}
+hipError_t gemv_q4_norm_exact(const fl_qtensor &W, const float *x, const float *norm_w, float *ynorm, float *y, hipStream_t st) {
+    if (W.K % 32 != 0 || W.K > 8192) return hipErrorInvalidValue;
+    const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 1, 0>(W, nullptr, y, st, nullptr, x, norm_w, ynorm, 0, nullptr)),
+                             (launch_gemv1_exact<FL_TYPE_Q4_1, 1, 0>(W, nullptr, y, st, nullptr, x, norm_w, ynorm, 0, nullptr)));
+    return ok ? hipGetLastError() : hipErrorInvalidValue;
+}
+hipError_t gemv_q4_silu_exact(const fl_qtensor &W, const float *h13, const uint16_t *silu_tab, float *y, const float *resid,
+                              hipStream_t st, bool woven) {
+    if (W.K % 32 != 0) return hipErrorInvalidValue;
+    const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 2, 0>(W, nullptr, y, st, resid, h13, silu_tab, nullptr, woven ? 1 : 0, nullptr)),
+                             (launch_gemv1_exact<FL_TYPE_Q4_1, 2, 0>(W, nullptr, y, st, resid, h13, silu_tab, nullptr, woven ? 1 : 0, nullptr)));
+    return ok ? hipGetLastError() : hipErrorInvalidValue;
+}
+hipError_t gemv_q4_norm_silu_exact(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act,
+                                   hipStream_t st) {
+    if (W.K % 32 != 0 || W.K > 8192 || W.M % 32 != 0) return hipErrorInvalidValue;
+    const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab)),
+                             (launch_gemv1_exact<FL_TYPE_Q4_1, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab)));
+    return ok ? hipGetLastError() : hipErrorInvalidValue;
+}
+hipError_t gemv_q4_quant_exact(const fl_qtensor &W, const float *x, float *y, const float *resid, hipStream_t st) {
+    if (W.K % 32 != 0) return hipErrorInvalidValue;
+    const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 3, 0>(W, nullptr, y, st, resid, x, nullptr, nullptr, 0, nullptr)),
+                             (launch_gemv1_exact<FL_TYPE_Q4_1, 3, 0>(W, nullptr, y, st, resid, x, nullptr, nullptr, 0, nullptr)));
+    return ok ? hipGetLastError() : hipErrorInvalidValue;
+}
+#undef FL_TYPED
 
 // ------------------------------------------------------------------------------------------------
 // N >= 9: a wave owns RG = 2 row groups (32 rows) x one QA16 column group (16 columns); a workgroup = 4 waves = 128 rows
@@ -301,9 +582,15 @@ __device__ __forceinline__ float dot_f32_ref_order(const float *__restrict__ x, 
     if (hl == 0 && np < n) {                         // leftovers, in order (gcc's vectorisation of the scalar loop)
         int i = np;
         for (; i + 8 <= n; i += 8)
-            for (int l = 0; l < 8; ++l) s = __fadd_rn(s, __fmul_rn(x[i + l], y[i + l]));
+            for (int l = 0; l < 8; ++l) {
+                const float pr = x[i + l] * y[i + l];     // (plain operators: this file is compiled with fp contract(off))
+                s = s + pr;
+            }
         if (n - i >= 4) {
-            for (int l = 0; l < 4; ++l) s = __fadd_rn(s, __fmul_rn(x[i + l], y[i + l]));
+            for (int l = 0; l < 4; ++l) {
+                const float pr = x[i + l] * y[i + l];
+                s = s + pr;
+            }
             i += 4;
         }
         for (; i < n; ++i) s = __fmaf_rn(x[i], y[i], s);

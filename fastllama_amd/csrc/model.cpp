@@ -425,7 +425,7 @@ static hipError_t mm(fl_model *m, const fl_qtensor *W, const fl_qact &a, int N, 
     hipEvent_t e1;
     hipError_t r = prof_begin(m, &e1);
     if (r != hipSuccess) return r;
-    if (m->exact) r = N <= 8 ? gemv_q4_exact(*W, a, N, y, ldy, m->stream, resid, ldr) : gemm_q4_exact(*W, a, N, y, ldy, m->stream, resid, ldr);
+    if (m->exact) r = N == 1 ? gemv_q4_exact(*W, a, N, y, ldy, m->stream, resid, ldr) : gemm_q4_exact(*W, a, N, y, ldy, m->stream, resid, ldr);
     else r = N <= 8 ? gemv_q4(*W, a, N, y, ldy, m->stream, resid, ldr) : gemm_q4_mfma(*W, a, N, y, ldy, m->stream, resid, ldr);
     prof_end(m, e1);
     return r;
@@ -436,7 +436,7 @@ static hipError_t mm_norm(fl_model *m, const fl_qtensor *W, const float *x, cons
     hipEvent_t e1;
     hipError_t r = prof_begin(m, &e1);
     if (r != hipSuccess) return r;
-    r = gemv_q4_norm(*W, x, norm_w, ynorm, y, m->stream);
+    r = (m->exact ? gemv_q4_norm_exact : gemv_q4_norm)(*W, x, norm_w, ynorm, y, m->stream);
     prof_end(m, e1);
     return r;
 }
@@ -466,7 +466,7 @@ static hipError_t mm_norm_silu(fl_model *m, const fl_qtensor *W, const float *x,
     hipEvent_t e1;
     hipError_t r = prof_begin(m, &e1);
     if (r != hipSuccess) return r;
-    r = gemv_q4_norm_silu(*W, x, norm_w, m->silu_tab, act, m->stream);
+    r = (m->exact ? gemv_q4_norm_silu_exact : gemv_q4_norm_silu)(*W, x, norm_w, m->silu_tab, act, m->stream);
     prof_end(m, e1);
     return r;
 }
@@ -476,7 +476,7 @@ static hipError_t mm_quant(fl_model *m, const fl_qtensor *W, const float *act, f
     hipEvent_t e1;
     hipError_t r = prof_begin(m, &e1);
     if (r != hipSuccess) return r;
-    r = gemv_q4_quant(*W, act, y, resid, m->stream);
+    r = (m->exact ? gemv_q4_quant_exact : gemv_q4_quant)(*W, act, y, resid, m->stream);
     prof_end(m, e1);
     return r;
 }
@@ -486,7 +486,7 @@ static hipError_t mm_silu(fl_model *m, const fl_qtensor *W, const float *h13, fl
     hipEvent_t e1;
     hipError_t r = prof_begin(m, &e1);
     if (r != hipSuccess) return r;
-    r = gemv_q4_silu(*W, h13, m->silu_tab, y, resid, m->stream, m->w13_il);
+    r = (m->exact ? gemv_q4_silu_exact : gemv_q4_silu)(*W, h13, m->silu_tab, y, resid, m->stream, m->w13_il);
     prof_end(m, e1);
     return r;
 }
@@ -507,12 +507,12 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
                             bool body_only = false, bool skip_head = false, const hipEvent_t *kv_wait = nullptr,
                             const hipEvent_t *kv_rec = nullptr) {
     const int E = m->E, El = m->El, Fl = m->Fl, D = m->D, Hl = m->Hl, V = m->V, n_ctx = m->n_ctx;
-    const int layout = N <= 8 ? 1 : 16;
+    const int layout = N <= (m->exact ? 1 : 8) ? 1 : 16;    // exact mode: only N = 1 takes the single-vector layout
     const int P = n_past + N;
     hipStream_t st = m->stream;
     const bool tp = m->G > 1;
     const bool exact = m->exact;        // reference-order matmuls: the per-op sequence, every matmul through exact_kernels.hip
-    const bool fused = N == 1 && D <= 128 && D % 32 == 0 && E <= 8192 && Fl <= 32768 && m->fuse_decode && !exact;   // single-token kernels
+    const bool fused = N == 1 && D <= 128 && D % 32 == 0 && E <= 8192 && Fl <= 32768 && m->fuse_decode;   // single-token kernels (both modes)
     const bool fuse_pa = m->fuse_prefill_attn && !exact;
     if (!body_only) M_HIP(get_rows_qw16(*m->tok_emb, m->tok_dev, N, m->x, E, st));      // inpL = get_rows  llama.cpp:304
     float *inp = m->x, *mid = m->x2;
@@ -527,10 +527,10 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
             if (kv_wait) M_HIP(hipStreamWaitEvent(st, kv_wait[l], 0));        // (a one-token chunk of a pipelined ingest)
             if (split_attn)
                 M_HIP(decode_attention_split(m->qkv, El, D, Hl, n_past, n_ctx, m->rope_tab, kc, vc, m->exp_tab, kq_scale,
-                                             m->att, &m->qEl, st, dyn));
+                                             m->att, &m->qEl, st, dyn, exact));
             else
                 M_HIP(decode_attention(m->qkv, El, D, Hl, n_past, n_ctx, m->rope_tab, kc, vc, m->exp_tab, kq_scale,
-                                       &m->qEl, st, dyn));
+                                       &m->qEl, st, dyn, exact));
             if (kv_rec) M_HIP(hipEventRecord(kv_rec[l], st));
         } else {
             // norm + attention_norm*cur -> Q8_0                                                        llama.cpp:311-319
@@ -1140,13 +1140,14 @@ int fl_debug_rmsnorm_quant(const float *x, int ldx, const float *w, int N, int E
     M_HIP(rmsnorm_quant(x, ldx, w, N, E, y_f32, ldy, out, layout, (hipStream_t)stream));
     return FL_OK;
 }
+int g_debug_exact = 0;      // fl_debug_set(2, 1): the single-token test hooks below run the reference-order kernels
 int fl_debug_gemv_norm(const fl_qtensor *W, const float *x, const float *norm_w, float *ynorm, float *y, void *stream) {
-    M_HIP(gemv_q4_norm(*W, x, norm_w, ynorm, y, (hipStream_t)stream));
+    M_HIP((g_debug_exact ? gemv_q4_norm_exact : gemv_q4_norm)(*W, x, norm_w, ynorm, y, (hipStream_t)stream));
     return FL_OK;
 }
 int fl_debug_gemv_silu(const fl_qtensor *W, const float *h13, const uint16_t *silu_tab, float *y, const float *resid,
                        void *stream) {
-    M_HIP(gemv_q4_silu(*W, h13, silu_tab, y, resid, (hipStream_t)stream, false));
+    M_HIP((g_debug_exact ? gemv_q4_silu_exact : gemv_q4_silu)(*W, h13, silu_tab, y, resid, (hipStream_t)stream, false));
     return FL_OK;
 }
 static float *g_pa_scratch = nullptr;
@@ -1173,23 +1174,23 @@ int fl_debug_prefill_attention_scratch(float *scratch, int ld, long head_stride)
 }
 int fl_debug_gemv_norm_silu(const fl_qtensor *W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act,
                             void *stream) {
-    M_HIP(gemv_q4_norm_silu(*W, x, norm_w, silu_tab, act, (hipStream_t)stream));
+    M_HIP((g_debug_exact ? gemv_q4_norm_silu_exact : gemv_q4_norm_silu)(*W, x, norm_w, silu_tab, act, (hipStream_t)stream));
     return FL_OK;
 }
 int fl_debug_gemv_quant(const fl_qtensor *W, const float *x, float *y, const float *resid, void *stream) {
-    M_HIP(gemv_q4_quant(*W, x, y, resid, (hipStream_t)stream));
+    M_HIP((g_debug_exact ? gemv_q4_quant_exact : gemv_q4_quant)(*W, x, y, resid, (hipStream_t)stream));
     return FL_OK;
 }
 int fl_debug_decode_attention(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab_dev,
                               float *kc, float *vc, const uint16_t *exp_tab_dev, float scale, fl_qact *out, void *stream) {
-    M_HIP(decode_attention(qkv, E, D, H, n_past, n_ctx, rope_tab_dev, kc, vc, exp_tab_dev, scale, out, (hipStream_t)stream));
+    M_HIP(decode_attention(qkv, E, D, H, n_past, n_ctx, rope_tab_dev, kc, vc, exp_tab_dev, scale, out, (hipStream_t)stream, nullptr, g_debug_exact != 0));
     return FL_OK;
 }
 int fl_debug_decode_attention_split(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab_dev,
                                     float *kc, float *vc, const uint16_t *exp_tab_dev, float scale, float *scores,
                                     fl_qact *out, const int *dyn_past, void *stream) {
     M_HIP(decode_attention_split(qkv, E, D, H, n_past, n_ctx, rope_tab_dev, kc, vc, exp_tab_dev, scale, scores, out,
-                                 (hipStream_t)stream, dyn_past));
+                                 (hipStream_t)stream, dyn_past, g_debug_exact != 0));
     return FL_OK;
 }
 int fl_debug_silu_mul_quant(const float *h13, int ld, int N, int F, const uint16_t *silu_tab_dev, fl_qact *out, int layout,

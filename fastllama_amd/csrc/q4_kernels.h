@@ -49,6 +49,12 @@ hipError_t gemm_q4_mfma_qkv(const fl_qtensor &W, const fl_qact &xq, int N, float
 // reference-order ("exact") forms: 8 lane accumulators per output in block order + the AVX2 hsum (exact_kernels.hip)
 hipError_t gemv_q4_exact(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                          const float *resid = nullptr, int ldr = 0);
+hipError_t gemv_q4_norm_exact(const fl_qtensor &W, const float *x, const float *norm_w, float *ynorm, float *y, hipStream_t st);
+hipError_t gemv_q4_silu_exact(const fl_qtensor &W, const float *h13, const uint16_t *silu_tab, float *y, const float *resid,
+                              hipStream_t st, bool woven = false);
+hipError_t gemv_q4_norm_silu_exact(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act,
+                                   hipStream_t st);
+hipError_t gemv_q4_quant_exact(const fl_qtensor &W, const float *x, float *y, const float *resid, hipStream_t st);
 hipError_t gemm_q4_exact(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                          const float *resid = nullptr, int ldr = 0);
 hipError_t gemm_q4_naive(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st);

@@ -289,7 +289,7 @@ int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a, float *y_dev, int 
                        void *stream);
 int fl_debug_qact_layout(const fl_qact *a); /* 16 = QA16, 1 = QA1 */
 int fl_debug_gemm_mixed_split(int row_groups, int col_groups, int *n_a, int *mg_split, int *n_b);  /* host logic of the two-tile-shape launch */
-int fl_debug_set(int what, int value);      /* what 0: force GEMM tile configuration id (-1 = automatic); 1: GEMV waves per row group (0 = automatic) */
+int fl_debug_set(int what, int value);      /* what 0: force GEMM tile configuration id (-1 = automatic); 1: GEMV waves per row group (0 = automatic); 2: the single-token hooks run the exact-mode kernels */
 int fl_quantize_q8_layout(fl_qact *a, const float *x_dev, int ldx, int N, int K, int layout, void *stream);
 
 #ifdef __cplusplus

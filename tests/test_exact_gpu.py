@@ -193,3 +193,160 @@ def test_model_exact_mode_chunked_ingest_and_decode_steps(tmp_path, torch, port,
         lg = m.eval([tok], n_past=n_past)
         n_past += 1
     m.free()
+
+
+@pytest.mark.parametrize("nm,qt", Q4)
+def test_exact_decode_forms_agree_with_each_other_and_the_reference(tmp_path, torch, port, reflib, nm, qt):
+    """Decode behind a 300-token context (key counts with every leftover form, past the 256-position switch to the two-launch
+    attention): the fused single-token kernels (producer/chain-wave matmuls with their prologues, one-launch attention), the
+    same with the split attention, and the generic per-op sequence return the same bits in exact mode -- the reference's."""
+    from fastllama_amd import hip
+    from harness.flmodel import FlModel
+    L = hip.load()
+    cfg = ggjt.SMALL
+    tensors = ggjt.synth_tensors(cfg, qt, port.quantize_q4, seed=31)
+    path = str(tmp_path / "m.bin")
+    ggjt.write_ggjt(path, cfg, qt, tensors)
+    rng = np.random.default_rng(1)
+    prompt = bytes(rng.integers(33, 127, size=297).astype(np.uint8)).decode()
+    toks = ggjt.text_tokens(" " + prompt)
+    ref = llama_capi.Session(reflib, path, n_ctx=512, n_batch=512)
+    assert ref.ingest(prompt)
+    want = []
+    for _ in range(5):
+        ok, _ = ref.generate(1, temp=0.0)
+        want.append(ref.logits().copy())
+    ref.close()
+    m = FlModel(cfg, qt, tensors, n_ctx=512, max_batch=512)
+    m.set_exact(True)
+    for mode, what in [(1, "fused, automatic attention form"), (1 | 8, "fused, one-launch attention"), (1 | 16, "fused, split attention"),
+                       (1 | 2, "generic per-op kernels"), (0, "no hipGraph")]:
+        hip.check(L.fl_model_set_graph(m.h, mode))
+        lg = m.eval(toks, n_past=0)
+        n_past = len(toks)
+        for i in range(5):
+            assert np.array_equal(bits(lg[-1]), bits(want[i])), (what, i, float(np.abs(lg[-1] - want[i]).max()))
+            lg = m.eval([int(np.argmax(want[i]))], n_past=n_past)
+            n_past += 1
+    m.free()
+
+
+# ------------------------------------------------------------------ the single-token (decode) kernels, op by op ------------
+from oracle import llama_eval as le  # noqa: E402
+
+
+@pytest.fixture()
+def exact_hooks():
+    """fl_debug_set(2, 1): the single-token test hooks run the exact-mode kernels"""
+    from fastllama_amd import hip
+    L = hip.load()
+    L.fl_debug_set(2, 1)
+    yield L
+    L.fl_debug_set(2, 0)
+
+
+@pytest.mark.parametrize("nm,qt", Q4)
+@pytest.mark.parametrize("M,K", [(48, 64), (300, 256), (4096, 4096), (12288, 4096), (1024, 8192), (32, 2560)])
+def test_exact_gemv_with_norm_prologue(torch, ops, port, exact_hooks, nm, qt, M, K):
+    """rms_norm * w -> Q8_0 -> mul_mat in one launch (producer / chain waves): the oracle's bits."""
+    from fastllama_amd import hip
+    L = exact_hooks
+    rng = np.random.default_rng(M + K + qt)
+    wq = port.quantize_q4(qt, (rng.standard_normal((M, K)) * 0.05).astype(np.float32))
+    W = ops.QTensor(qt, wq, M, K)
+    x = (rng.standard_normal((1, K)) * 1.7).astype(np.float32)
+    nw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    xd, nd = dev(torch, x), dev(torch, nw)
+    y = torch.full((M,), 3.0, device="cuda")
+    yn = torch.zeros((1, K), device="cuda")
+    hip.check(L.fl_debug_gemv_norm(W.handle, xd.data_ptr(), nd.data_ptr(), yn.data_ptr(), y.data_ptr(), None))
+    cur = le.rms_norm_mul(x, nw)
+    assert np.array_equal(bits(yn.cpu().numpy()), bits(cur))
+    want = port.mul_mat_q(qt, wq, cur, strict=False)[0]
+    assert np.array_equal(bits(y.cpu().numpy()), bits(want)), float(np.abs(y.cpu().numpy() - want).max())
+
+
+@pytest.mark.parametrize("nm,qt", Q4)
+@pytest.mark.parametrize("F,K,E", [(64, 64, 48), (704, 256, 256), (11008, 4096, 4096), (13824, 5120, 512)])
+def test_exact_feed_forward_pair_and_quant_prologue(torch, ops, port, exact_hooks, nm, qt, F, K, E):
+    """(a) woven w1|w3: norm prologue + the two dots + silu*mul epilogue in one launch; (b) w2 with the Q8_0 prologue
+    (+ residual); (c) w2 with the silu*mul prologue on an f32 [w1 x | w3 x] vector -- each the oracle's bits."""
+    from fastllama_amd import hip
+    L = exact_hooks
+    rng = np.random.default_rng(F + K + qt)
+    w1 = port.quantize_q4(qt, (rng.standard_normal((F, K)) * 0.05).astype(np.float32))
+    w3 = port.quantize_q4(qt, (rng.standard_normal((F, K)) * 0.05).astype(np.float32))
+    rb = w1.shape[1]
+    woven = np.empty((2 * F, rb), np.uint8)
+    wv = woven.reshape(F // 16, 2, 16, rb)
+    wv[:, 0] = w1.reshape(F // 16, 16, rb)
+    wv[:, 1] = w3.reshape(F // 16, 16, rb)
+    W = ops.QTensor(qt, woven, 2 * F, K)
+    x = (rng.standard_normal((1, K)) * 1.3).astype(np.float32)
+    nw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    s = np.empty(1 << 16, np.uint16)
+    L.fl_debug_tables(None, s.ctypes.data_as(C.c_void_p))
+    xd, nd, sd = dev(torch, x), dev(torch, nw), dev(torch, s.view(np.int16))
+    act = torch.full((F,), 9.0, device="cuda")
+    hip.check(L.fl_debug_gemv_norm_silu(W.handle, xd.data_ptr(), nd.data_ptr(), sd.data_ptr(), act.data_ptr(), None))
+    cur = le.rms_norm_mul(x, nw)
+    h1, h3 = port.mul_mat_q(qt, w1, cur, strict=False), port.mul_mat_q(qt, w3, cur, strict=False)
+    want_act = (le.silu(h1) * h3).astype(np.float32)
+    assert np.array_equal(bits(act.cpu().numpy()), bits(want_act[0]))
+    w2 = port.quantize_q4(qt, (rng.standard_normal((E, F)) * 0.05).astype(np.float32))
+    W2 = ops.QTensor(qt, w2, E, F)
+    res = rng.standard_normal(E).astype(np.float32)
+    rd = dev(torch, res)
+    y = torch.empty(E, device="cuda")
+    hip.check(L.fl_debug_gemv_quant(W2.handle, act.data_ptr(), y.data_ptr(), rd.data_ptr(), None))
+    want = (port.mul_mat_q(qt, w2, want_act, strict=False)[0] + res).astype(np.float32)
+    assert np.array_equal(bits(y.cpu().numpy()), bits(want))
+    h13 = np.concatenate([h1, h3], axis=1)
+    hip.check(L.fl_debug_gemv_silu(W2.handle, dev(torch, h13).data_ptr(), sd.data_ptr(), y.data_ptr(), None, None))
+    assert np.array_equal(bits(y.cpu().numpy()), bits(port.mul_mat_q(qt, w2, want_act, strict=False)[0]))
+
+
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("D,H,n_past", [(32, 4, 0), (32, 4, 9), (128, 32, 0), (128, 32, 1), (128, 32, 31), (128, 8, 130), (128, 4, 511),
+                                        (64, 5, 37), (128, 3, 290), (96, 2, 515)])
+def test_exact_decode_attention(torch, ops, port, exact_hooks, D, H, n_past, split):
+    """The single-token attention (one launch, and the two-launch form for long contexts): rope + KV store, K.q and V.p in
+    ggml_vec_dot_f32's order (leftover forms included: P = n_past + 1 keys), fp16-table soft_max, Q8_0 of the result --
+    the oracle's block bytes."""
+    from fastllama_amd import hip
+    L = exact_hooks
+    n_ctx, E, P = 1024, H * D, n_past + 1
+    rng = np.random.default_rng(D + H + n_past)
+    qkv = rng.standard_normal((1, 3 * E)).astype(np.float32)
+    kc = np.zeros((n_ctx, E), np.float32)
+    vc = np.zeros((E, n_ctx), np.float32)
+    kc[:n_past] = rng.standard_normal((n_past, E))
+    vc[:, :n_past] = rng.standard_normal((E, n_past))
+    vc[:, n_past:] = 7.0                                     # stale values beyond the position must not leak in
+    e = np.empty(1 << 16, np.uint16)
+    L.fl_debug_tables(e.ctypes.data_as(C.c_void_p), None)
+    rt = np.empty((n_ctx, D // 2, 2), np.float32)
+    L.fl_debug_rope_table(rt.ctypes.data_as(C.c_void_p), n_ctx, D)
+    ed, rd, qd, kd, vd = dev(torch, e.view(np.int16)), dev(torch, rt), dev(torch, qkv), dev(torch, kc), dev(torch, vc)
+    a = ops.QAct(1, E)
+    hip.check(L.fl_quantize_q8_layout(a.handle, qd.data_ptr(), 3 * E, 1, E, 1, None))
+    a.N, a.K = 1, E
+    scale = np.float32(1.0) / np.sqrt(np.float32(D))
+    if split:
+        sc = torch.full((H, n_ctx), float("nan"), device="cuda")
+        hip.check(L.fl_debug_decode_attention_split(qd.data_ptr(), E, D, H, n_past, n_ctx, rd.data_ptr(), kd.data_ptr(), vd.data_ptr(),
+                                                    ed.data_ptr(), float(scale), sc.data_ptr(), a.handle, None, None))
+    else:
+        hip.check(L.fl_debug_decode_attention(qd.data_ptr(), E, D, H, n_past, n_ctx, rd.data_ptr(), kd.data_ptr(), vd.data_ptr(),
+                                              ed.data_ptr(), float(scale), a.handle, None))
+    q_r = le.rope(qkv[:, :E], n_past, H)
+    k_r = le.rope(qkv[:, E:2 * E], n_past, H)
+    kc2, vc2 = kd.cpu().numpy(), vd.cpu().numpy()
+    assert np.array_equal(bits(kc2[n_past]), bits(k_r[0])) and np.array_equal(vc2[:, n_past], qkv[0, 2 * E:])
+    want = np.empty((1, E), np.float32)
+    for h in range(H):
+        sl = slice(h * D, (h + 1) * D)
+        s = (port.mul_mat_f32(np.ascontiguousarray(kc2[:P, sl]), np.ascontiguousarray(q_r[:, sl])) * scale).astype(np.float32)
+        p = le.soft_max_rows(s)
+        want[:, sl] = port.mul_mat_f32(np.ascontiguousarray(vc2[sl, :P]), p)
+    assert np.array_equal(a.export().cpu().numpy()[0], port.quantize_row_q8_0(want[0]))

@@ -368,3 +368,58 @@ def test_multi_part_checkpoint_merges_to_the_same_model(tmp_path_factory, n_part
     os.remove(many + ".1")
     with pytest.raises(RuntimeError):
         llama_capi.Session(lib, many, n_ctx=64, n_batch=64)
+
+
+def test_perplexity_then_generate_samples_from_current_logits(libs, model_file):
+    """llama_perplexity keeps its block's logits in HBM; a llama_generate that follows with nothing staged samples from the last
+    row of those logits, exactly as the reference does with its m_logits (lib/bridge.cpp:262-266) -- the host copy must be
+    refreshed first, also when perplexity was the very first call after load.  (Sampled with temp > 0 and top_k = 1, i.e. the
+    arg-max of the last row through the sampling branch: the reference's temp <= 0 branch returns the arg-max's offset from the
+    START of m_logits, lib/bridge.cpp:39-42, which is not a token id once m_logits holds more than one row.)"""
+    path, cfg = model_file
+    first = []
+    for lib in libs:
+        s = llama_capi.Session(lib, path, n_ctx=128, n_batch=32)
+        assert s.perplexity(TEXT[:30]) > 0
+        last_row = s.logits().reshape(-1, cfg["n_vocab"])[-1]
+        ok, text = s.generate(1, top_k=1, top_p=1.0, temp=0.8)
+        assert ok
+        first.append((text, int(np.argmax(last_row))))
+        s.close()
+    assert first[0] == first[1] and len(first[1][0]) > 0, first   # the same first token from both libraries: the last row's arg-max
+
+
+def test_exact_mode_through_the_primary_boundary(libs, model_file, tmp_path, monkeypatch):
+    """FL_EXACT=1 (the mode that meets north_star's tolerance, read when the model is created): through the 17-symbol boundary the
+    library returns the reference's BITS -- all-logits perplexity, a greedy stream with n_batch-8 ingest and context recycling,
+    and a session state file (n_past, RNG, token windows, logits, the whole f32 K/V cache) that is byte-identical to the file
+    the reference itself writes after the same calls."""
+    path, cfg = model_file
+    ref, ours = libs
+    monkeypatch.setenv("FL_EXACT", "1")
+    out = []
+    for lib in libs:
+        s = llama_capi.Session(lib, path, n_ctx=128, n_batch=32, all_logits=True, embeddings=True)
+        ppl = s.perplexity(TEXT)
+        out.append((ppl, s.logits(), s.embeddings()))
+        s.close()
+    assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    assert np.array_equal(out[0][2].view(np.uint32), out[1][2].view(np.uint32))
+    assert abs(out[0][0] - out[1][0]) / out[0][0] <= 1e-5     # (the row softmax is summed in f64 on the device: DESIGN.md)
+    res = []
+    for i, lib in enumerate(libs):
+        s = llama_capi.Session(lib, path, n_ctx=48, n_batch=8, n_keep=8, last_n_tokens=24)
+        assert s.ingest("Sys", system=True) and s.ingest(" abcdefghijklmnopqrstuvwxyz")
+        ok, text = s.generate(40, temp=0.0)                   # overflows the context: recycling included
+        st = str(tmp_path / f"s{i}.state")
+        assert ok and s.save_state(st)
+        res.append((text, s.logits(), open(st, "rb").read()))
+        s.close()
+    assert res[0][0] == res[1][0]
+    assert np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
+
+    def masked(blob):                                         # mem_per_token = ggml_used_mem(ctx0) / N of the reference's first eval:
+        n = int.from_bytes(blob[4:12], "little")              # an allocator statistic of the CPU graph, not a result (we store 1)
+        off = 4 + 8 + n
+        return blob[:off] + b"\0" * 8 + blob[off + 8:]
+    assert masked(res[0][2]) == masked(res[1][2])             # n_past, RNG, token windows, logits, K/V cache: byte-identical
