@@ -460,7 +460,10 @@ int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy
     const fl_qact_impl *a = static_cast<const fl_qact_impl *>(a_);
     int rc = check_mm(W, a, y, ldy);
     if (rc != FL_OK) return rc;
-    if (which == 3) {                      // reference-order kernels, whichever the layout says
+    if (which == 4) {                      // reference-order tile kernel in its VALU (v_dot4) form: cross-check of the MFMA form
+        if (a->layout != 16) return set_error(FL_EINVAL, "gemm needs the QA16 layout");
+        FL_HIP(gemm_q4_exact_valu(*W, *a, a->N, y, ldy, S(st)));
+    } else if (which == 3) {               // reference-order kernels, whichever the layout says
         if (a->layout == 1) FL_HIP(gemv_q4_exact(*W, *a, a->N, y, ldy, S(st)));
         else FL_HIP(gemm_q4_exact(*W, *a, a->N, y, ldy, S(st)));
     } else if (which == 2) {

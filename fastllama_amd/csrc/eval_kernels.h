@@ -25,6 +25,12 @@ hipError_t gemm_f32_abt(const float *A, int lda, int64_t sAz, const float *B, in
 hipError_t dot_f32_abt_exact(const float *A, int lda, int64_t sAz, const float *B, int ldb, int64_t sBz, float *C, int ldc,
                              int64_t sCz, int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past,
                              hipStream_t st, const int *dyn_past = nullptr, int nn_max = 0);
+// exact mode, prefill (n_past + N <= 512): the same two products on the f32-input MFMA, whose k = 0, 1 chain IS the reference's
+// fma chain (exact_kernels.hip); hipErrorInvalidValue: shape outside their reach -> dot_f32_abt_exact
+hipError_t attn_scores_exact(const float *qkv, int ldq, int D, int H, int N, int n_past, const float *kc, int ldk, float scale,
+                             float *att, int ld_att, int64_t head_stride, hipStream_t st);
+hipError_t attn_pv_exact(const float *att, int ld_att, int64_t head_stride, int D, int H, int N, int n_past, const float *vc, int n_ctx,
+                         float *ao, int ldo, hipStream_t st);
 hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab,
                         hipStream_t st, const int *dyn_past = nullptr);
 // prefill: KQ*scale + mask + soft_max + KQV per (head, 32 query rows), score rows in LDS; q = roped Q rows of qkv,

@@ -545,8 +545,9 @@ __global__ __launch_bounds__(256) void gemm_q4_exact_kernel(const uint32_t *__re
     }
 }
 
-hipError_t gemm_q4_exact(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st, const float *resid,
-                         int ldr) {
+// the VALU form (v_dot4 + v_cvt + v_fma): the on-device cross-check of gemm_q4_exact_mfma.hip, fl_debug_mul_mat_q which = 4
+hipError_t gemm_q4_exact_valu(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st, const float *resid,
+                              int ldr) {
     if (N < 1) return hipErrorInvalidValue;
     const int groups = W.M16 / 16;
     const dim3 grid((groups + 7) / 8, (N + 15) / 16);
@@ -626,6 +627,278 @@ hipError_t dot_f32_abt_exact(const float *A, int lda, int64_t sAz, const float *
     const dim3 grid(((dyn_past && causal_mode == 1 ? nn_max : Nn) + 7) / 8, M, batch);
     hipLaunchKernelGGL(dot_f32_abt_exact_kernel, grid, dim3(256), 0, st, A, lda, sAz, B, ldb, sBz, C, ldc, sCz, M, Nn, K, alpha,
                        causal_mode, n_past, dyn_past);
+    return hipGetLastError();
+}
+
+}  // namespace fl
+
+namespace fl {
+hipError_t gemm_q4_exact(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st, const float *resid,
+                         int ldr) {
+    return gemm_q4_exact_mfma(W, xq, N, y, ldy, st, resid, ldr);
+}
+}  // namespace fl
+
+namespace fl {
+// ------------------------------------------------------------------------------------------------
+// Prefill attention in exact mode: the two f32 matmuls (K.Q and V.P, lib/llama.cpp:364,389) on the f32-input MFMA.
+// v_mfma_f32_32x32x2_f32 is bitwise a chain of two fmaf per output, k = 0 then k = 1, on top of C (MI355X_MICROARCH.md) -- and
+// ggml_vec_dot_f32's 32 partial sums are exactly such chains: sum[jj][l] takes the elements 32 st + 8 jj + l, st = 0, 1, 2, ...
+// in order.  So for one (jj, l) a 32x32 tile of partial sums is a chain of MFMAs whose k = 0 / 1 operands (lanes 0-31 / 32-63)
+// are the elements of two consecutive 32-element steps; the fixed reduction tree over the 32 partial sums is 31 vector adds
+// on result tiles.  Same arithmetic, bit for bit, as dot_f32_abt_exact_kernel (one half-wave per dot), at the MFMA's f32 rate.
+//   scores  grid (query blocks of 32, heads): Q tile and the waves' K tiles (32 keys each, dealt round-robin, causal tiles
+//           only) in LDS; per tile 32 x 2 MFMAs + the tree -> scale -> att[head][q][key]
+//   pv      grid (query blocks of 32, heads): the block's probability rows (<= 512 keys) stay in LDS, the four 32-feature
+//           blocks of V pass through it one after the other; wave w owns the partial sums l = w and w + 4 (8 chains over all
+//           32-key steps), the waves' results meet in LDS for the last two tree levels; leftover keys (P % 32) in order.
+// Longer contexts (n_past + N > 512) take dot_f32_abt_exact: the 32 chains of an output run over ALL keys, so a key-tiled form
+// would have to carry 32 accumulator tiles.
+// ------------------------------------------------------------------------------------------------
+constexpr int XA_KT = 512;      // keys the pv kernel holds in LDS
+constexpr int XA_LD = XA_KT + 1;
+
+// lane (i, h) of an MFMA supplies, for the 32-element step st = 2 m + h, element 8 jj + l of row i.  The key row of a tile is kept in
+// registers (the 32 elements of each of the lane's MS = ceil(NST / 2) steps, zeros for a step past the row; straight from HBM/L2
+// as 128-byte pieces), the 32 query rows of the workgroup in LDS.
+template <int NST>
+__global__ __launch_bounds__(512) void attn_scores_exact_kernel(const float *__restrict__ qkv, int ldq, int N, int n_past,
+                                                                const float *__restrict__ kc, int ldk, float scale,
+                                                                float *__restrict__ att, int ld_att, int64_t head_stride) {
+    constexpr int D = 32 * NST, MS = (NST + 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qb = blockIdx.x, hd = blockIdx.y, q0 = qb * 32;
+    const int i = lane & 31, h = lane >> 5;
+    auto load_row = [&](const float *row, float (&dst)[MS][32]) {
+#pragma unroll
+        for (int m = 0; m < MS; ++m) {
+            const int st = 2 * m + h;
+            const bool ok = st < NST;
+            const float4 *p4 = reinterpret_cast<const float4 *>(row + 32 * (ok ? st : 0));
+#pragma unroll
+            for (int q4 = 0; q4 < 8; ++q4) {
+                const float4 v = p4[q4];
+                dst[m][4 * q4 + 0] = ok ? v.x : 0.f;
+                dst[m][4 * q4 + 1] = ok ? v.y : 0.f;
+                dst[m][4 * q4 + 2] = ok ? v.z : 0.f;
+                dst[m][4 * q4 + 3] = ok ? v.w : 0.f;
+            }
+        }
+    };
+    // the query rows sit in LDS (one read per MFMA, requested ahead by the compiler); the key rows in registers
+    __shared__ float Qs[32][D + 1];
+    for (int idx = threadIdx.x; idx < 32 * (D / 4); idx += 512) {
+        const int r = idx / (D / 4), c4 = idx % (D / 4);
+        const float4 v = *reinterpret_cast<const float4 *>(qkv + (int64_t)min(q0 + r, N - 1) * ldq + hd * D + c4 * 4);   // rows past N: the last one, never stored
+        Qs[r][c4 * 4 + 0] = v.x; Qs[r][c4 * 4 + 1] = v.y; Qs[r][c4 * 4 + 2] = v.z; Qs[r][c4 * 4 + 3] = v.w;
+    }
+    __syncthreads();
+    float kv[MS][32];
+    const int last_key = n_past + min(q0 + 31, N - 1);       // keys this query block can see: [0, last_key]
+    const int ntiles = last_key / 32 + 1;
+    for (int kt = wave; kt < ntiles; kt += 8) {
+        const int k0 = kt * 32;
+        load_row(kc + (int64_t)min(k0 + i, last_key) * ldk + hd * D, kv);
+        // t_l = v_l + v_{l+4} (lo128 + hi128), (t0 + t1) and (t2 + t3) (hadd), their sum (hadd); v_l = (s0l + s1l) + (s2l + s3l)
+        v16f total, u, t;
+        v16f z = {};                                         // the chains' zero start -- and the token that orders the groups (below)
+#pragma unroll
+        for (int lo = 0; lo < 8; ++lo) {                     // l in the order 0, 4, 1, 5, 2, 6, 3, 7
+            const int l = (lo >> 1) + 4 * (lo & 1);
+            v16f p01, vs;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                v16f c = z;
+#pragma unroll
+                for (int m = 0; m < MS; ++m) {
+                    const float qa = 2 * m + h < NST ? Qs[i][32 * min(2 * m + h, NST - 1) + 8 * jj + l] : 0.f;
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, kv[m][8 * jj + l], c, 0, 0, 0);
+                }
+                if (jj == 0) p01 = c;
+                else if (jj == 1) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) p01[e] = __fadd_rn(p01[e], c[e]);      // s0 + s1
+                } else if (jj == 2) vs = c;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) vs[e] = __fadd_rn(p01[e], __fadd_rn(vs[e], c[e]));   // (s0 + s1) + (s2 + s3)
+                }
+                if (NST > 2 && jj < 3) asm volatile("" : "+v"(z), "+v"(p01));   // (one chain at a time: 128 operand registers leave room for few tiles)
+            }
+            if ((lo & 1) == 0) t = vs;                       // v_l, waits for v_{l+4}
+            else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) t[e] = __fadd_rn(t[e], vs[e]);            // t_l
+                if (lo == 1 || lo == 5) u = t;               // t0 / t2
+                else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) u[e] = __fadd_rn(u[e], t[e]);         // t0 + t1 / t2 + t3
+                    if (lo == 3) total = u;
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) total[e] = __fadd_rn(total[e], u[e]);
+                    }
+                }
+            }
+            // every MFMA of the next group starts from z, which passes through this statement together with the group's result:
+            // left alone the compiler issues all 32 x MS (pure) MFMAs first and keeps their result tiles alive (1.6 KB of scratch)
+            asm volatile("" : "+v"(z), "+v"(t));
+        }
+        // C layout: col = lane & 31 (key), row = (e & 3) + 8 (e >> 2) + 4 h (query)
+        float *out = att + hd * head_stride;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int q = q0 + (e & 3) + 8 * (e >> 2) + 4 * h, key = k0 + i;
+            if (q < N && key <= n_past + q) out[(int64_t)q * ld_att + key] = __fmul_rn(total[e], scale);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restrict__ att, int ld_att, int64_t head_stride, int D, int N,
+                                                            int n_past, const float *__restrict__ vc, int n_ctx, float *__restrict__ ao,
+                                                            int ldo) {
+    extern __shared__ __attribute__((aligned(16))) float xs_[];
+    float *Ps = xs_;                                         // [32 queries][XA_LD]   probabilities, zero past each query's last key
+    float *Vs = xs_ + 32 * XA_LD;                            // [32 features][XA_LD]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qb = blockIdx.x, hd = blockIdx.y, q0 = qb * 32;
+    const int i = lane & 31, h = lane >> 5;
+    const int P = n_past + N;                                // the dot runs over all P keys (soft_max wrote zeros past the diagonal)
+    const int kend = min(P, n_past + min(q0 + 31, N - 1) + 1);     // ... but past this block's last visible key every term is +0
+    const int np = P & ~31, nbody = min(np, (kend + 31) & ~31);     // whole 32-key steps that can hold a non-zero probability
+    const int KT = (max(nbody, kend) + 63) & ~63;             // staged keys (zero padded to whole MFMA pairs)
+    const float *prow = att + hd * head_stride;
+    // staging: float4 pieces, sixteen loads in flight per thread (a one-load-at-a-time loop is a chain of L2 round trips)
+    auto stage = [&](float *dst, const float *src, int64_t row_stride, int rows_valid) {
+        const int q4n = KT / 4, total4 = 32 * q4n;
+        for (int base = threadIdx.x; base < total4; base += 16 * 256) {
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int idx = min(base + u * 256, total4 - 1), r = idx / q4n, k4 = idx % q4n;
+                v[u] = *reinterpret_cast<const float4 *>(src + (int64_t)min(r, rows_valid - 1) * row_stride + min(k4 * 4, n_ctx - 4));
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int idx = base + u * 256;
+                if (idx < total4) {
+                    const int r = idx / q4n, k = (idx % q4n) * 4;
+                    float *d = dst + r * XA_LD + k;
+                    const bool rv = r < rows_valid;
+                    d[0] = rv && k < kend ? v[u].x : 0.f;
+                    d[1] = rv && k + 1 < kend ? v[u].y : 0.f;
+                    d[2] = rv && k + 2 < kend ? v[u].z : 0.f;
+                    d[3] = rv && k + 3 < kend ? v[u].w : 0.f;
+                }
+            }
+        }
+    };
+    stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, min(32, N - q0));
+    float *Ts = xs_ + 64 * XA_LD;                            // the waves' t tiles meet here: [4][64][16]
+    const int nleft = P - np;                                // < 32 keys behind the body, taken in order
+    for (int d0 = 0; d0 < D; d0 += 32) {
+        __syncthreads();                                     // P staged / the previous feature block is done with Vs and Ts
+        stage(Vs, vc + (int64_t)(hd * D + d0) * n_ctx, n_ctx, 32);
+        __syncthreads();
+        // wave w: partial sums l = w and l = w + 4, all four jj: chains over the 32-key steps, two steps per MFMA
+        v16f tw;
+#pragma unroll
+        for (int li = 0; li < 2; ++li) {
+            const int l = wave + 4 * li;
+            v16f tl[4] = {{}, {}, {}, {}};
+            for (int cs = 0; cs < nbody; cs += 128) {         // two MFMAs (four 32-key steps) per chain and trip: 16 operand reads, then 8 MFMAs
+                float a[2][4], b[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c0 = cs + 64 * u + 32 * h;      // (a step past the body: zeros -- fma(0, 0, c) = c)
+                    const bool ok = c0 < nbody;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int e = (ok ? c0 : 0) + 8 * jj + l;
+                        const float av = Ps[i * XA_LD + e], bv = Vs[i * XA_LD + e];
+                        a[u][jj] = ok ? av : 0.f;
+                        b[u][jj] = ok ? bv : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) tl[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][jj], b[u][jj], tl[jj], 0, 0, 0);
+            }
+            v16f vs;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) vs[e] = __fadd_rn(__fadd_rn(tl[0][e], tl[1][e]), __fadd_rn(tl[2][e], tl[3][e]));   // (s0+s1)+(s2+s3)
+            if (li == 0) tw = vs;
+            else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) tw[e] = __fadd_rn(tw[e], vs[e]);          // t_w = v_w + v_{w+4} (lo128 + hi128)
+            }
+        }
+        {
+            float *dst = Ts + (wave * 64 + lane) * 16;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dst[e] = tw[e];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const float *t0 = Ts + (0 * 64 + lane) * 16, *t1 = Ts + (1 * 64 + lane) * 16, *t2 = Ts + (2 * 64 + lane) * 16,
+                        *t3 = Ts + (3 * 64 + lane) * 16;
+            // C layout: col = lane & 31 = feature, row = (e & 3) + 8 (e >> 2) + 4 h = query
+            const float *vr = Vs + i * XA_LD + np;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float s = __fadd_rn(__fadd_rn(t0[e], t1[e]), __fadd_rn(t2[e], t3[e]));       // (t0+t1) + (t2+t3) (hadd, hadd)
+                const int ql = (e & 3) + 8 * (e >> 2) + 4 * h, q = q0 + ql;
+                const float *pr = Ps + ql * XA_LD + np;
+                // the n % 32 leftovers as the reference's build compiled them (chunks of 8, one of 4: rounded products added in
+                // order; the last n % 4: FMAs); keys past this block's last visible one carry p = +0 and change nothing
+                int k = 0;
+                for (; k + 8 <= nleft; k += 8)
+                    for (int u = 0; u < 8; ++u)
+                        if (np + k + u < kend) {
+                            const float prd = pr[k + u] * vr[k + u];
+                            s = s + prd;
+                        }
+                if (nleft - k >= 4) {
+                    for (int u = 0; u < 4; ++u)
+                        if (np + k + u < kend) {
+                            const float prd = pr[k + u] * vr[k + u];
+                            s = s + prd;
+                        }
+                    k += 4;
+                }
+                for (; k < nleft; ++k)
+                    if (np + k < kend) s = __fmaf_rn(pr[k], vr[k], s);
+                if (q < N) ao[(int64_t)q * ldo + hd * D + d0 + i] = s;
+            }
+        }
+    }
+}
+
+// hipErrorInvalidValue: shape outside these kernels' reach (n_past + N > 512, head_dim not a multiple of 32 or > 128)
+hipError_t attn_scores_exact(const float *qkv, int ldq, int D, int H, int N, int n_past, const float *kc, int ldk, float scale,
+                             float *att, int ld_att, int64_t head_stride, hipStream_t st) {
+    if (D % 32 != 0 || D > 128 || N < 1 || (ldq & 3) || (ldk & 3)) return hipErrorInvalidValue;
+    const dim3 grid((N + 31) / 32, H);
+#define FL_XS(NST) hipLaunchKernelGGL(attn_scores_exact_kernel<NST>, grid, dim3(512), 0, st, qkv, ldq, N, n_past, kc, ldk, scale, att, ld_att, head_stride)
+    if (D == 32) FL_XS(1);
+    else if (D == 64) FL_XS(2);
+    else if (D == 96) FL_XS(3);
+    else FL_XS(4);
+#undef FL_XS
+    return hipGetLastError();
+}
+hipError_t attn_pv_exact(const float *att, int ld_att, int64_t head_stride, int D, int H, int N, int n_past, const float *vc, int n_ctx,
+                         float *ao, int ldo, hipStream_t st) {
+    if (D % 32 != 0 || D > 128 || N < 1 || n_past + N > XA_KT) return hipErrorInvalidValue;
+    const size_t lds = (size_t)2 * 32 * XA_LD * 4 + 4 * 64 * 16 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attn_pv_exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_pv_exact_kernel, dim3((N + 31) / 32, H), dim3(256), lds, st, att, ld_att, head_stride, D, N, n_past, vc, n_ctx,
+                       ao, ldo);
     return hipGetLastError();
 }
 

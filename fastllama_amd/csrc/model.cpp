@@ -552,12 +552,17 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
             if (pe != hipSuccess) {
                 (void)hipGetLastError();
                 // KQ, scale, mask, soft_max                                                            :364-379
-                M_HIP((exact ? dot_f32_abt_exact : gemm_f32_abt)(m->qkv, 3 * El, D, kc, El, D, m->att, n_ctx, (int64_t)N * n_ctx, N, P, D, Hl,
-                                                                 kq_scale, 1, n_past, st, dyn, n_ctx));
+                const bool xa = exact && !dyn && N >= 2 && P <= 512 && D % 32 == 0 && D <= 128;   // the MFMA forms of the exact products
+                if (xa) M_HIP(attn_scores_exact(m->qkv, 3 * El, D, Hl, N, n_past, kc, El, kq_scale, m->att, n_ctx, (int64_t)N * n_ctx, st));
+                else
+                    M_HIP((exact ? dot_f32_abt_exact : gemm_f32_abt)(m->qkv, 3 * El, D, kc, El, D, m->att, n_ctx, (int64_t)N * n_ctx, N, P, D, Hl,
+                                                                     kq_scale, 1, n_past, st, dyn, n_ctx));
                 M_HIP(softmax_rows(m->att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, Hl, m->exp_tab, st, dyn));
                 // KQV, merged back to [N, n_embd]                                                      :389-398
-                M_HIP((exact ? dot_f32_abt_exact : gemm_f32_abt)(m->att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, m->ao, El, D, N,
-                                                                 D, P, Hl, 1.0f, 2, n_past, st, dyn, n_ctx));
+                if (xa) M_HIP(attn_pv_exact(m->att, n_ctx, (int64_t)N * n_ctx, D, Hl, N, n_past, vc, n_ctx, m->ao, El, st));
+                else
+                    M_HIP((exact ? dot_f32_abt_exact : gemm_f32_abt)(m->att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, m->ao, El, D, N,
+                                                                     D, P, Hl, 1.0f, 2, n_past, st, dyn, n_ctx));
                 M_HIP((layout == 16 ? quantize_q8_qa16 : quantize_q8_qa1)(m->ao, El, N, El, m->qEl, st));
             }   // (the one-launch kernel wrote the Q8_0 operand of the wo matmul itself)
         }
@@ -1216,6 +1221,19 @@ int fl_debug_gemm_f32_abt(const float *A, int lda, long sAz, const float *B, int
 int fl_debug_gemm_f32_abt_exact(const float *A, int lda, long sAz, const float *B, int ldb, long sBz, float *Cc, int ldc, long sCz,
                                 int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past, void *stream) {
     M_HIP(dot_f32_abt_exact(A, lda, sAz, B, ldb, sBz, Cc, ldc, sCz, M, Nn, K, batch, alpha, causal_mode, n_past, (hipStream_t)stream));
+    return FL_OK;
+}
+/* test hook: exact-mode prefill attention on caller-provided buffers: scores (MFMA form when which = 1, one half-wave per dot when 0)
+ * -> soft_max -> P.V; att: [H][N][n_ctx] scratch, ao: [N][E] f32 result */
+int fl_debug_attn_exact(const float *qkv, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc, const float *vc,
+                        const uint16_t *exp_tab_dev, float scale, float *att, float *ao, int which, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int P = n_past + N;
+    if (which) M_HIP(attn_scores_exact(qkv, ldq, D, H, N, n_past, kc, E, scale, att, n_ctx, (int64_t)N * n_ctx, st));
+    else M_HIP(dot_f32_abt_exact(qkv, ldq, D, kc, E, D, att, n_ctx, (int64_t)N * n_ctx, N, P, D, H, scale, 1, n_past, st));
+    M_HIP(softmax_rows(att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, H, exp_tab_dev, st));
+    if (which) M_HIP(attn_pv_exact(att, n_ctx, (int64_t)N * n_ctx, D, H, N, n_past, vc, n_ctx, ao, E, st));
+    else M_HIP(dot_f32_abt_exact(att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, ao, E, D, N, D, P, H, 1.0f, 2, n_past, st));
     return FL_OK;
 }
 int fl_debug_softmax_rows(float *S, int ld, long sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab_dev,

@@ -57,6 +57,10 @@ hipError_t gemv_q4_norm_silu_exact(const fl_qtensor &W, const float *x, const fl
 hipError_t gemv_q4_quant_exact(const fl_qtensor &W, const float *x, float *y, const float *resid, hipStream_t st);
 hipError_t gemm_q4_exact(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                          const float *resid = nullptr, int ldr = 0);
+hipError_t gemm_q4_exact_mfma(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
+                              const float *resid = nullptr, int ldr = 0);   // K = 4 f16 MFMA form (gemm_q4_exact_mfma.hip)
+hipError_t gemm_q4_exact_valu(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
+                              const float *resid = nullptr, int ldr = 0);   // v_dot4 form (exact_kernels.hip), cross-check
 hipError_t gemm_q4_naive(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st);
 
 size_t qact_bytes_q(int N, int K);      // bytes of the q plane for N columns (padded to 16)

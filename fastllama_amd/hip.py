@@ -146,6 +146,8 @@ _PROTOS = {
     "fl_model_set_exact": (C.c_int, [C.c_void_p, C.c_int]),
     "fl_model_get_exact": (C.c_int, [C.c_void_p]),
     "fl_default_exact": (C.c_int, []),
+    "fl_debug_attn_exact": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "fl_debug_softmax_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                         C.c_void_p]),
     "fl_debug_mul_mat_q": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

@@ -276,6 +276,9 @@ int fl_debug_gemm_f32_abt(const float *A, int lda, long sAz, const float *B, int
 int fl_debug_gemm_f32_abt_exact(const float *A, int lda, long sAz, const float *B, int ldb, long sBz, float *C, int ldc, long sCz,
                                 int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past, void *stream);
                                 /* the same product in ggml_vec_dot_f32's order (exact mode's attention matmuls) */
+int fl_debug_attn_exact(const float *qkv_dev, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc_dev,
+                        const float *vc_dev, const uint16_t *exp_tab_dev, float scale, float *att_dev /* [H][N][n_ctx] scratch */,
+                        float *ao_dev /* [N][E] */, int which /* 1: MFMA forms (n_past + N <= 512), 0: one half-wave per dot */, void *stream);
 int fl_debug_softmax_rows(float *S_dev, int ld, long sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab_dev,
                           void *stream);
 
@@ -285,7 +288,7 @@ int fl_debug_mul_mat_q_resid(const fl_qtensor *W, const fl_qact *a, float *y_dev
 int fl_debug_gemm_qkv(const fl_qtensor *W, const fl_qact *a, float *y_dev, int ldy, const float *rope_tab_dev, float *kc_dev,
                       float *vc_dev, int El, int D, int n_past, int n_ctx, void *stream);
 int fl_debug_gemm_silu(const fl_qtensor *W, const fl_qact *a, const uint16_t *silu_tab_dev, fl_qact *out, void *stream);
-int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a, float *y_dev, int ldy, int which /*0 naive,1 mfma,2 gemv,3 reference-order (exact)*/,
+int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a, float *y_dev, int ldy, int which /*0 naive,1 mfma,2 gemv,3 reference-order (exact),4 exact tile kernel in its v_dot4 form*/,
                        void *stream);
 int fl_debug_qact_layout(const fl_qact *a); /* 16 = QA16, 1 = QA1 */
 int fl_debug_gemm_mixed_split(int row_groups, int col_groups, int *n_a, int *mg_split, int *n_b);  /* host logic of the two-tile-shape launch */

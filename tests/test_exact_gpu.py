@@ -74,6 +74,29 @@ def test_mul_mat_q_exact_is_bit_identical_to_the_reference_order(torch, ops, por
 
 
 @pytest.mark.parametrize("nm,qt", Q4)
+@pytest.mark.parametrize("M,K", [(4096, 4096), (11008, 4096), (4096, 11008), (32000, 4096), (5120, 5120), (13824, 5120), (5120, 13824),
+                                 (8192, 8192), (22016, 8192), (8192, 22016)])
+def test_exact_tile_kernel_at_llama_shapes(torch, ops, port, nm, qt, M, K):
+    """N = 512 at every LLaMA matrix shape (7B / 13B / 65B): the K = 4 MFMA form equals the v_dot4 form bit for bit over the whole
+    output, and sampled rows / columns equal the oracle."""
+    from harness import synth
+    N = 512
+    blocks = synth.synth_q4(M, K, qt, 11 + M % 13)
+    W = ops.QTensor(qt, blocks, M, K)
+    x = dev(torch, make_x(N, K, 17))
+    a = ops.QAct(N, K).quantize(x)
+    y_mfma = ops.mul_mat_q(W, a, which=3).clone()
+    y_valu = ops.mul_mat_q(W, a, which=4)
+    assert torch.equal(y_mfma, y_valu), int((y_mfma != y_valu).sum())
+    rng = np.random.default_rng(M + K)
+    rows = np.sort(rng.choice(M, size=16, replace=False))
+    cols = np.sort(rng.choice(N, size=12, replace=False))
+    want = port.mul_mat_q(qt, blocks[torch.from_numpy(rows).cuda()].cpu().numpy(), x.cpu().numpy()[cols])
+    assert np.array_equal(bits(y_mfma.cpu().numpy()[np.ix_(cols, rows)]), bits(want))
+    W.free()
+
+
+@pytest.mark.parametrize("nm,qt", Q4)
 def test_mul_mat_q_exact_large_scales_and_signs(torch, ops, port, nm, qt):
     """Weights and activations spanning many orders of magnitude: the 16x / (1/16) bookkeeping of the Q4_0 layout (q4_layout.h)
     must stay exact, and the residual add must be the plain f32 add that follows the matmul (lib/llama.cpp:407)."""
@@ -350,3 +373,39 @@ def test_exact_decode_attention(torch, ops, port, exact_hooks, D, H, n_past, spl
         p = le.soft_max_rows(s)
         want[:, sl] = port.mul_mat_f32(np.ascontiguousarray(vc2[sl, :P]), p)
     assert np.array_equal(a.export().cpu().numpy()[0], port.quantize_row_q8_0(want[0]))
+
+
+@pytest.mark.parametrize("D,H,N,n_past", [(128, 4, 64, 0), (128, 3, 100, 37), (128, 2, 512, 0), (64, 5, 70, 11), (96, 2, 33, 200), (32, 4, 40, 0),
+                                          (128, 2, 9, 500), (128, 2, 200, 312), (32, 3, 2, 5)])
+def test_exact_prefill_attention_mfma_forms(torch, ops, port, D, H, N, n_past):
+    """K.Q and V.P of a batch on the f32-input MFMA (its k = 0, 1 chain is the reference's fma chain): the same bits as the
+    one-half-wave-per-dot kernel and as the oracle -- every leftover form (P % 32), causal tiles, ragged last query block."""
+    from fastllama_amd import hip
+    L = hip.load()
+    n_ctx, E, P = 512, H * D, n_past + N
+    rng = np.random.default_rng(D + H + N + n_past)
+    qkv = rng.standard_normal((N, 3 * E)).astype(np.float32)
+    kc = np.zeros((n_ctx, E), np.float32)
+    vc = np.full((E, n_ctx), 7.0, np.float32)                 # stale values beyond the context must not leak in
+    kc[:P] = rng.standard_normal((P, E))
+    vc[:, :P] = rng.standard_normal((E, P))
+    e = np.empty(1 << 16, np.uint16)
+    L.fl_debug_tables(e.ctypes.data_as(C.c_void_p), None)
+    ed, qd, kd, vd = dev(torch, e.view(np.int16)), dev(torch, qkv), dev(torch, kc), dev(torch, vc)
+    scale = np.float32(1.0) / np.sqrt(np.float32(D))
+    outs = []
+    for which in (0, 1):
+        att = torch.full((H, N, n_ctx), float("nan"), device="cuda")
+        ao = torch.full((N, E), 3.0, device="cuda")
+        hip.check(L.fl_debug_attn_exact(qd.data_ptr(), 3 * E, D, H, N, n_past, n_ctx, E, kd.data_ptr(), vd.data_ptr(), ed.data_ptr(),
+                                        float(scale), att.data_ptr(), ao.data_ptr(), which, None))
+        torch.cuda.synchronize()
+        outs.append(ao.cpu().numpy())
+    assert np.array_equal(bits(outs[0]), bits(outs[1])), int((bits(outs[0]) != bits(outs[1])).sum())
+    want = np.empty((N, E), np.float32)
+    for h in range(H):
+        sl = slice(h * D, (h + 1) * D)
+        s = (port.mul_mat_f32(np.ascontiguousarray(kc[:P, sl]), np.ascontiguousarray(qkv[:, sl])) * scale).astype(np.float32)
+        s[np.arange(P)[None, :] > (n_past + np.arange(N))[:, None]] = -np.inf
+        want[:, sl] = port.mul_mat_f32(np.ascontiguousarray(vc[sl, :P]), le.soft_max_rows(s))
+    assert np.array_equal(bits(outs[1]), bits(want))
