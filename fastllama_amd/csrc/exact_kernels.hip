@@ -220,11 +220,18 @@ __global__ __launch_bounds__(64 * (NWG + 2)) void gemv1_q4_exact_kernel(
         for (int i = 0; i < 2; ++i) {
             const int flat = i * 64 + lane;
             const int64_t gb = min(gb0 + (flat >> 4), gbl);
-            w[slot][i] = reinterpret_cast<const uint4 *>(qs)[gb * 16 + (flat & 15)];
+            typedef unsigned int nt_v4u __attribute__((ext_vector_type(4)));     // (nontemporal: every weight byte is read once, by one CU)
+            const nt_v4u tq = __builtin_nontemporal_load(reinterpret_cast<const nt_v4u *>(qs) + gb * 16 + (flat & 15));
+            w[slot][i] = make_uint4(tq.x, tq.y, tq.z, tq.w);
         }
         const int64_t gs = min(gb0 + (lane >> 3), gbl);
-        dw[slot] = *reinterpret_cast<const float2 *>(dW + gs * 16 + 2 * (lane & 7));
-        if (TYPE == FL_TYPE_Q4_1) mw[slot] = *reinterpret_cast<const float2 *>(mW + gs * 16 + 2 * (lane & 7));
+        typedef float nt_v2f __attribute__((ext_vector_type(2)));
+        const nt_v2f td = __builtin_nontemporal_load(reinterpret_cast<const nt_v2f *>(dW + gs * 16 + 2 * (lane & 7)));
+        dw[slot] = make_float2(td.x, td.y);
+        if (TYPE == FL_TYPE_Q4_1) {
+            const nt_v2f tm = __builtin_nontemporal_load(reinterpret_cast<const nt_v2f *>(mW + gs * 16 + 2 * (lane & 7)));
+            mw[slot] = make_float2(tm.x, tm.y);
+        }
     };
     if (T == 0) return;                                             // (more workgroups than row groups: never launched that way)
     // Every load of the stream is issued unconditionally -- past the end of the stream and in the chain waves it reads a

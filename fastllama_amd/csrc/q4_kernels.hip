@@ -510,9 +510,19 @@ __global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__res
             const int b = (q0 + uq * NWAVES) * 4 + bq;
             ok[u] = (q0 + uq * NWAVES) < nquads && b < KB;
             const int64_t idx = (gbase + (int64_t)g2 * KB + (ok[u] ? b : 0)) * 16 + r;
+#ifndef FL_GEMV_NO_NT  // streamed once, by one CU: nontemporal loads (1.541 -> 1.446 ms per 7B token, profiles/r03_decode_nt.txt)
+            {
+                typedef unsigned int nt_v4u __attribute__((ext_vector_type(4)));
+                const nt_v4u t = __builtin_nontemporal_load(reinterpret_cast<const nt_v4u *>(&qs[idx]));
+                w[u] = make_uint4(t.x, t.y, t.z, t.w);
+            }
+            dw[u] = __builtin_nontemporal_load(&dW[idx]);
+            mw[u] = TYPE == FL_TYPE_Q4_1 ? __builtin_nontemporal_load(&mW[idx]) : 0.f;
+#else
             w[u] = qs[idx];
             dw[u] = dW[idx];
             mw[u] = TYPE == FL_TYPE_Q4_1 ? mW[idx] : 0.f;
+#endif
         }
     };
     // Vector-memory loads return in order: the small activation loads of the prologue are issued BEFORE the weight
