@@ -130,6 +130,7 @@ static int dev_alloc(fl_model *m, void **p, size_t bytes) {
 static int qact_alloc(fl_model *m, fl_qact *a, int maxN, int K) {
     memset(a, 0, sizeof *a);
     int rc = dev_alloc(m, (void **)&a->q, qact_bytes_q(maxN, K));
+    if (rc == FL_OK && gemm_fp6_enabled()) rc = dev_alloc(m, (void **)&a->q6, qact_bytes_q(maxN, K) / 2 * 3);
     if (rc == FL_OK) rc = dev_alloc(m, (void **)&a->d, qact_bytes_scale(maxN, K));
     if (rc == FL_OK) rc = dev_alloc(m, (void **)&a->s, qact_bytes_scale(maxN, K));
     a->KB = K / FL_QK;
@@ -224,6 +225,7 @@ static int stage_rows(const void *host, int bs, int KB_full, int row0, int rows,
 static int make_qtensor(fl_model *m, fl_qtensor **out, const void *aos_dev, int M, int K) {
     *out = fl_qtensor_from_device(m->qtype, aos_dev, M, K, nullptr);
     if (!*out) return FL_EHIP;
+    if (out == &m->tok_emb) fl_qtensor_drop_f6(*out);      // only ever a get_rows source
     m->dev_bytes += fl_qtensor_device_bytes(*out);
     return FL_OK;
 }
@@ -1034,6 +1036,7 @@ extern "C" int fl_model_lora_apply(fl_model *m, const char *base_name, const flo
     cleanup();
     if (e != hipSuccess) return hip_fail(e, "fl_model_lora_apply");
     if (bad) return set_error(FL_EINVAL, "lora: a merged Q4_0 block scale fell below 2^-122");
+    if (t->f6) return fl_qtensor_build_f6(t, m->stream);    // the prefill path's copy follows the merged nibbles
     return FL_OK;
 }
 
@@ -1046,6 +1049,10 @@ extern "C" int fl_model_lora_restore(fl_model *m) {
         M_HIP(hipMemcpy(bk.t->qs, bk.qs, nblk * 16, hipMemcpyDeviceToDevice));
         M_HIP(hipMemcpy(bk.t->d, bk.d, nblk * 4, hipMemcpyDeviceToDevice));
         if (bk.mm) M_HIP(hipMemcpy(bk.t->m, bk.mm, nblk * 4, hipMemcpyDeviceToDevice));
+        if (bk.t->f6) {
+            const int rc = fl_qtensor_build_f6(bk.t, m->stream);
+            if (rc != FL_OK) return rc;
+        }
         (void)hipFree(bk.qs); (void)hipFree(bk.d);
         if (bk.mm) (void)hipFree(bk.mm);
     }

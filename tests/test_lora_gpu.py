@@ -79,6 +79,45 @@ def test_lora_merge_bit_exact_vs_oracle(port, qtype, r):
     m.free()
 
 
+@pytest.mark.parametrize("qtype", [ggjt.Q4_0, ggjt.Q4_1])
+def test_fp6_operand_copies_follow_the_weights_through_merge_and_restore(port, qtype):
+    """A model created with FL_FP6 on (fl_debug_set(3, 1)) evaluates its prefill GEMMs on fp6 copies of the weights (q4_layout.h
+    "F6 copies"): same logit bits as the int8 form -- before a LoRA merge, after it (the copy is rebuilt from the merged
+    nibbles) and after the restore."""
+    import torch
+    from fastllama_amd import hip
+    from harness import synth
+    from harness.flmodel import FlModel
+    L = hip.load()
+    cfg = dict(n_vocab=512, n_embd=1024, n_head=8, n_layer=2, n_ff=2816)
+    N, r = 96, 8
+    toks = np.random.default_rng(2).integers(3, 259, N).astype(np.int32)
+    E = cfg["n_embd"]
+    rng = np.random.default_rng(qtype)
+    a = (rng.standard_normal((E, r)) * 0.05).astype(np.float32)
+    b = (rng.standard_normal((E, r)) * 0.05).astype(np.float32)
+    L.fl_debug_set(3, 1)
+    try:
+        m = FlModel(cfg, qtype, synth.synth_model_tensors(cfg, qtype, seed=4), n_ctx=128, max_batch=N)
+        seen = []
+        for step in ("base", "merged", "restored"):
+            if step == "merged":
+                hip.check(L.fl_model_lora_apply(m.h, b"layers.1.attention.wo.weight", None, ptr(a), ptr(b), r, 1.0, 1), "lora_apply")
+            if step == "restored":
+                hip.check(L.fl_model_lora_restore(m.h), "restore")
+            L.fl_debug_set(3, 1)
+            got6 = m.eval(toks, all_logits=True).copy()
+            L.fl_debug_set(3, 0)
+            got8 = m.eval(toks, all_logits=True).copy()
+            assert np.array_equal(got6.view(np.int32), got8.view(np.int32)), step
+            seen.append(got8)
+        assert not np.array_equal(seen[0], seen[1]) and np.array_equal(seen[0], seen[2])
+        m.free()
+    finally:
+        L.fl_debug_set(3, 0)
+    torch.cuda.empty_cache()
+
+
 def test_lora_merge_under_tensor_parallel_slices(port):
     """rank 1 of 2: the row shard (wq, w1) takes B's rows, the K shard (wo, w2) takes A's rows -- against the oracle
     applied to the full tensor and then sliced the way fl_model_set_tensor slices."""
