@@ -216,13 +216,17 @@ def main():
         return dt
 
     def pmc_traffic(kernel, tp):
-        """HBM bytes per launch from the committed PMC passes (profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE /
+        """HBM bytes per launch from the committed PMC passes (profiles/r03_pmc_traffic.json, else r02_: rocprofv3 --pmc FETCH_SIZE /
         WRITE_SIZE in separate passes, gfx950 correction applied) -- valid for the default 7B Q4_0 n_batch=512 workload."""
         try:
             if args.model != "7B" or qtype != 2 or N != 512 or tp:
                 return None
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-                return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+            for rnd in ("r03", "r02"):              # the latest committed pass
+                path = os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json")
+                if os.path.exists(path):
+                    with open(path) as f:
+                        return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+            return None
         except Exception:
             return None
 
@@ -327,7 +331,7 @@ def main():
                      "the 5 POP/s dense int8 MFMA rate, which v_mfma_i32_32x32x32_i8 (K = 32 = one quant block) runs at; the exact "
                      "per-block scaling adds 32 VALU ops + half an f32 outer-product MFMA per 32x32 tile and block, and on gfx950 the "
                      "VALU and the matrix pipe of a SIMD do not overlap: measured instruction-mix ceiling ~1.0 POP/s (DESIGN.md 3.1, "
-                     "profiles/r02_ubench_coexec3.txt)") % (wk["n_matmuls"], n_launch // evals),
+                     "profiles/r02_ubench_coexec3.txt, r03_ubench_coexec4.txt)") % (wk["n_matmuls"], n_launch // evals),
         }
         model.profile(1)
         for i in range(8):

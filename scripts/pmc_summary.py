@@ -1,4 +1,4 @@
-"""Summarise the rocprofv3 PMC passes into profiles/r02_pmc_traffic.{json,md}.
+"""Summarise the rocprofv3 PMC passes into profiles/<round>_pmc_traffic.{json,md} (ROUND=r03 by default).
 
 Inputs (written on the GPU box, merged back under gpurun_out/):
   rocprofv3 --kernel-trace --pmc FETCH_SIZE  -d gpurun_out/pmc_pre_FETCH_SIZE  -- python scripts/prefill_only.py 2
@@ -7,6 +7,7 @@ Inputs (written on the GPU box, merged back under gpurun_out/):
 (separate passes, no trace domains mixed in).  FETCH_SIZE is in KB and counts half of the bytes of 16 B/lane streaming
 reads on gfx950 (MI355X_MICROARCH.md, HBM section): read bytes = FETCH_SIZE * 1024 * 2; WRITE_SIZE * 1024 uncorrected."""
 import collections, csv, glob, json, os
+ROUND = os.environ.get("ROUND", "r03")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -36,8 +37,8 @@ for leg, mm, pat in (("pre", "gemm_q4_mfma32_kernel", "gemm_q4_mfma32_"), ("dec"
 json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes), scripts/prefill_only.py 2 and "
                      "scripts/decode_only.py 8 0, LLaMA-7B Q4_0 synthetic, MI355X",
            "correction": "read bytes = FETCH_SIZE*1024*2 (gfx950: 64 B tallied per 128-B request of 16 B/lane streaming reads); WRITE_SIZE*1024",
-           "kernels": out}, open(f"{ROOT}/profiles/r02_pmc_traffic.json", "w"), indent=1)
-head = ("# HBM-side traffic of the eval kernels from PMC counters (round 2, MI355X, LLaMA-7B Q4_0 synthetic)\n\n" + __doc__.split("\n\n", 1)[1] +
+           "kernels": out}, open(f"{ROOT}/profiles/{ROUND}_pmc_traffic.json", "w"), indent=1)
+head = ("# HBM-side traffic of the eval kernels from PMC counters (" + ROUND + ", MI355X, LLaMA-7B Q4_0 synthetic)\n\n" + __doc__.split("\n\n", 1)[1] +
         "\n\nCalibration on our own kernels: the decode GEMV of w1|w3 reads 22016 x 4096 / 32 x 20 B = 56.36 MB of weights; its corrected "
         "FETCH_SIZE is within 2 % of that (table below).\n\nSummary used by bench.py (`roofline.traffic`):\n\n" +
         "\n".join(f"* `{k}`: {v['hbm_bytes_per_launch'] / 1e6:.1f} MB per launch (read {v['fetch_bytes_per_launch'] / 1e6:.1f} MB + write "
@@ -45,5 +46,5 @@ head = ("# HBM-side traffic of the eval kernels from PMC counters (round 2, MI35
         "\n\nReading: decode GEMVs fetch ~1.0x their algorithmic bytes (weights once, activations from L2).  The prefill GEMMs fetch more than "
         "the algorithmic bytes (each W row panel is needed by 4 N-tiles of 128 columns; the XCD-aware tile order keeps part of those re-reads "
         "inside one XCD's L2) -- at well under 1 TB/s they are far from HBM-bound; the matrix/VALU issue of the SIMDs is the limit.\n")
-open(f"{ROOT}/profiles/r02_pmc_traffic.md", "w").write(head + "\n".join(md) + "\n")
+open(f"{ROOT}/profiles/{ROUND}_pmc_traffic.md", "w").write(head + "\n".join(md) + "\n")
 print(head)
