@@ -900,6 +900,7 @@ size_t fl_model_device_bytes(const fl_model *m) { return m ? m->dev_bytes : 0; }
 int fl_model_kv_read(const fl_model *m, float *k_host, float *v_host) {
     if (!m || !m->finalized || m->G != 1) return set_error(FL_EINVAL, "kv_read: need a finalized single-GPU model");
     const size_t n = (size_t)m->L * m->n_ctx * m->E * 4;
+    M_HIP(hipStreamSynchronize(m->stream));                      // (the eval stream is non-blocking: the null stream does not wait for it)
     M_HIP(hipMemcpy(k_host, m->kc, n, hipMemcpyDeviceToHost));
     M_HIP(hipMemcpy(v_host, m->vc, n, hipMemcpyDeviceToHost));
     return FL_OK;
@@ -907,8 +908,10 @@ int fl_model_kv_read(const fl_model *m, float *k_host, float *v_host) {
 int fl_model_kv_write(fl_model *m, const float *k_host, const float *v_host) {
     if (!m || !m->finalized || m->G != 1) return set_error(FL_EINVAL, "kv_write: need a finalized single-GPU model");
     const size_t n = (size_t)m->L * m->n_ctx * m->E * 4;
+    M_HIP(hipStreamSynchronize(m->stream));
     M_HIP(hipMemcpy(m->kc, k_host, n, hipMemcpyHostToDevice));
     M_HIP(hipMemcpy(m->vc, v_host, n, hipMemcpyHostToDevice));
+    M_HIP(hipDeviceSynchronize());                               // the copies have landed before the next eval's stream reads them
     return FL_OK;
 }
 
@@ -967,6 +970,7 @@ static int dev_copy_f32(const float *src, size_t n, float **out) {
     if (!src) return FL_OK;
     M_HIP(hipMalloc((void **)out, n * 4));
     M_HIP(hipMemcpy(*out, src, n * 4, hipMemcpyDefault));       // host or device source
+    M_HIP(hipDeviceSynchronize());                               // (a device source copies on the null stream; the merge runs on the eval stream)
     return FL_OK;
 }
 
@@ -1002,11 +1006,11 @@ extern "C" int fl_model_lora_apply(fl_model *m, const char *base_name, const flo
             fl_model::LoraBackup bk{t, nullptr, nullptr, nullptr};
             M_HIP(hipMalloc(&bk.qs, nblk * 16));
             M_HIP(hipMalloc(&bk.d, nblk * 4));
-            M_HIP(hipMemcpy(bk.qs, t->qs, nblk * 16, hipMemcpyDeviceToDevice));
-            M_HIP(hipMemcpy(bk.d, t->d, nblk * 4, hipMemcpyDeviceToDevice));
+            M_HIP(hipMemcpyAsync(bk.qs, t->qs, nblk * 16, hipMemcpyDeviceToDevice, m->stream));   // (on the stream the merge kernels run on)
+            M_HIP(hipMemcpyAsync(bk.d, t->d, nblk * 4, hipMemcpyDeviceToDevice, m->stream));
             if (t->m) {
                 M_HIP(hipMalloc(&bk.mm, nblk * 4));
-                M_HIP(hipMemcpy(bk.mm, t->m, nblk * 4, hipMemcpyDeviceToDevice));
+                M_HIP(hipMemcpyAsync(bk.mm, t->m, nblk * 4, hipMemcpyDeviceToDevice, m->stream));
             }
             m->lora_backups.push_back(bk);
         }
@@ -1044,15 +1048,19 @@ extern "C" int fl_model_lora_apply(fl_model *m, const char *base_name, const flo
 extern "C" int fl_model_lora_restore(fl_model *m) {
     if (!m) return set_error(FL_EINVAL, "null model");
     M_HIP(hipStreamSynchronize(m->stream));
+    // (device-to-device copies on the EVAL stream: a plain hipMemcpy runs on the null stream, which a non-blocking stream does not wait for)
     for (auto &bk : m->lora_backups) {
         const size_t nblk = (size_t)bk.t->M16 * bk.t->KB;
-        M_HIP(hipMemcpy(bk.t->qs, bk.qs, nblk * 16, hipMemcpyDeviceToDevice));
-        M_HIP(hipMemcpy(bk.t->d, bk.d, nblk * 4, hipMemcpyDeviceToDevice));
-        if (bk.mm) M_HIP(hipMemcpy(bk.t->m, bk.mm, nblk * 4, hipMemcpyDeviceToDevice));
+        M_HIP(hipMemcpyAsync(bk.t->qs, bk.qs, nblk * 16, hipMemcpyDeviceToDevice, m->stream));
+        M_HIP(hipMemcpyAsync(bk.t->d, bk.d, nblk * 4, hipMemcpyDeviceToDevice, m->stream));
+        if (bk.mm) M_HIP(hipMemcpyAsync(bk.t->m, bk.mm, nblk * 4, hipMemcpyDeviceToDevice, m->stream));
         if (bk.t->f6) {
             const int rc = fl_qtensor_build_f6(bk.t, m->stream);
             if (rc != FL_OK) return rc;
         }
+    }
+    M_HIP(hipStreamSynchronize(m->stream));
+    for (auto &bk : m->lora_backups) {
         (void)hipFree(bk.qs); (void)hipFree(bk.d);
         if (bk.mm) (void)hipFree(bk.mm);
     }
