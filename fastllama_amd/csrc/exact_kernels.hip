@@ -249,6 +249,14 @@ __global__ __launch_bounds__(64 * (NWG + 2)) void gemv1_q4_exact_kernel(
         }
         __syncthreads();
     }
+    // the activation's k-groups, once per workgroup, in the byte order the lane sums need: (lo, hi) = elements (0,2,4,6 | 1,3,5,7)
+    // -> (elements 0..3 | elements 4..7), i.e. what the producers would otherwise v_perm again for every row of every block
+    for (int i = threadIdx.x; i < KB * 4; i += NT) {
+        uint2 *px2 = reinterpret_cast<uint2 *>(lq) + i;
+        const uint2 lh = *px2;
+        *px2 = make_uint2(perm_a(lh.y, lh.x), perm_b(lh.y, lh.x));
+    }
+    __syncthreads();
 
     // The two roles run separate loops (their register sets must not be live together); every wave of the workgroup passes
     // the same number of barriers -- one per chunk -- and the branch is wave-uniform.
@@ -267,23 +275,24 @@ __global__ __launch_bounds__(64 * (NWG + 2)) void gemv1_q4_exact_kernel(
                     const int flat = i * 64 + lane, u = flat >> 4, row = flat & 15;
                     const int bl = wg * BPW + u, b = c * KC + bl;           // block inside the chunk / of the row
                     const int bc = min(b, KB - 1);
-                    const uint4 x0 = *reinterpret_cast<const uint4 *>(lq + bc * 32), x1 = *reinterpret_cast<const uint4 *>(lq + bc * 32 + 16);
-                    const uint32_t xw[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};     // k-group g: (lo, hi) = xw[2g], xw[2g+1]
-                    const uint32_t wv[4] = {w[dd][i].x, w[dd][i].y, w[dd][i].z, w[dd][i].w};     // dword position p holds k-group p ^ sw
-                    const bool sw = row >= 8;
-                    int out[8];                                             // the 8 lane sums of (block, row), j = 2g + {0, 1}
+                    // dword position p of the row holds k-group p ^ 2 sw (sw = rows 8..15, constant per lane): the two 16-byte halves
+                    // of the activation block are read swapped and the two halves of the result stored swapped -- no selects
+                    const int sw = (row >> 3) & 1;
+                    const uint4 x0 = *reinterpret_cast<const uint4 *>(lq + bc * 32 + sw * 16), x1 = *reinterpret_cast<const uint4 *>(lq + bc * 32 + (sw ^ 1) * 16);
+                    const uint32_t xw[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};     // position p: (elements 0..3, 4..7) = xw[2p], xw[2p+1]
+                    const uint32_t wv[4] = {w[dd][i].x, w[dd][i].y, w[dd][i].z, w[dd][i].w};
+                    int out[8];                                             // the lane sums j = 2 (p ^ 2 sw) + {0, 1} at out[2p], out[2p+1]
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const uint32_t v = sw ? wv[g ^ 2] : wv[g];
+                    for (int p4 = 0; p4 < 4; ++p4) {
                         uint32_t wa, wb;
-                        unpack_lanes<TYPE>(v, wa, wb);
-                        out[2 * g] = __builtin_amdgcn_sdot4((int)wa, (int)perm_a(xw[2 * g + 1], xw[2 * g]), 0, false);
-                        out[2 * g + 1] = __builtin_amdgcn_sdot4((int)wb, (int)perm_b(xw[2 * g + 1], xw[2 * g]), 0, false);
+                        unpack_lanes<TYPE>(wv[p4], wa, wb);
+                        out[2 * p4] = __builtin_amdgcn_sdot4((int)wa, (int)xw[2 * p4], 0, false);
+                        out[2 * p4 + 1] = __builtin_amdgcn_sdot4((int)wb, (int)xw[2 * p4 + 1], 0, false);
                     }
                     if (b < KB) {
                         uint4 *dst = reinterpret_cast<uint4 *>(pq + (bl * 16 + row) * 8);
-                        dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
-                        dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+                        dst[sw] = make_uint4(out[0], out[1], out[2], out[3]);
+                        dst[sw ^ 1] = make_uint4(out[4], out[5], out[6], out[7]);
                     }
                 }
                 {   // scales of the wave's 8 blocks: lane L holds rows 2 (L & 7), +1 of block L >> 3
