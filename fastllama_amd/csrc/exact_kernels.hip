@@ -665,11 +665,11 @@ namespace fl {
 // on result tiles.  Same arithmetic, bit for bit, as dot_f32_abt_exact_kernel (one half-wave per dot), at the MFMA's f32 rate.
 //   scores  grid (query blocks of 32, heads): Q tile and the waves' K tiles (32 keys each, dealt round-robin, causal tiles
 //           only) in LDS; per tile 32 x 2 MFMAs + the tree -> scale -> att[head][q][key]
-//   pv      grid (query blocks of 32, heads): the block's probability rows (<= 512 keys) stay in LDS, the four 32-feature
-//           blocks of V pass through it one after the other; wave w owns the partial sums l = w and w + 4 (8 chains over all
-//           32-key steps), the waves' results meet in LDS for the last two tree levels; leftover keys (P % 32) in order.
-// Longer contexts (n_past + N > 512) take dot_f32_abt_exact: the 32 chains of an output run over ALL keys, so a key-tiled form
-// would have to carry 32 accumulator tiles.
+//   pv      grid (query blocks of 32, heads): probability rows and V rows pass through LDS in 512-key pieces, feature block by
+//           feature block; wave w owns the partial sums l = w and w + 4 -- 8 chains that run over ALL 32-key steps, i.e. 8
+//           accumulator tiles (128 VGPRs) carried across the pieces; the waves' results meet in LDS for the last two tree
+//           levels; leftover keys (P % 32) in order.  Any context length (round 3; contexts beyond 512 keys used to fall back
+//           to dot_f32_abt_exact, one half-wave per dot).
 // ------------------------------------------------------------------------------------------------
 constexpr int XA_KT = 512;      // keys the pv kernel holds in LDS
 constexpr int XA_LD = XA_KT + 1;
@@ -782,17 +782,18 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
     const int P = n_past + N;                                // the dot runs over all P keys (soft_max wrote zeros past the diagonal)
     const int kend = min(P, n_past + min(q0 + 31, N - 1) + 1);     // ... but past this block's last visible key every term is +0
     const int np = P & ~31, nbody = min(np, (kend + 31) & ~31);     // whole 32-key steps that can hold a non-zero probability
-    const int KT = (max(nbody, kend) + 63) & ~63;             // staged keys (zero padded to whole MFMA pairs)
+    const int nchunk = (nbody + XA_KT - 1) / XA_KT;          // 512-key pieces of the body: the 32 chains of an output run through all of them
     const float *prow = att + hd * head_stride;
-    // staging: float4 pieces, sixteen loads in flight per thread (a one-load-at-a-time loop is a chain of L2 round trips)
-    auto stage = [&](float *dst, const float *src, int64_t row_stride, int rows_valid) {
-        const int q4n = KT / 4, total4 = 32 * q4n;
+    // staging of keys [k0, k0 + kt): float4 pieces, sixteen loads in flight per thread (a one-load-at-a-time loop is a chain of L2
+    // round trips); keys >= kend and rows >= rows_valid become +0
+    auto stage = [&](float *dst, const float *src, int64_t row_stride, int rows_valid, int k0, int kt) {
+        const int q4n = kt / 4, total4 = 32 * q4n;
         for (int base = threadIdx.x; base < total4; base += 16 * 256) {
             float4 v[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int idx = min(base + u * 256, total4 - 1), r = idx / q4n, k4 = idx % q4n;
-                v[u] = *reinterpret_cast<const float4 *>(src + (int64_t)min(r, rows_valid - 1) * row_stride + min(k4 * 4, n_ctx - 4));
+                v[u] = *reinterpret_cast<const float4 *>(src + (int64_t)min(r, rows_valid - 1) * row_stride + min(k0 + k4 * 4, n_ctx - 4));
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
@@ -801,54 +802,66 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
                     const int r = idx / q4n, k = (idx % q4n) * 4;
                     float *d = dst + r * XA_LD + k;
                     const bool rv = r < rows_valid;
-                    d[0] = rv && k < kend ? v[u].x : 0.f;
-                    d[1] = rv && k + 1 < kend ? v[u].y : 0.f;
-                    d[2] = rv && k + 2 < kend ? v[u].z : 0.f;
-                    d[3] = rv && k + 3 < kend ? v[u].w : 0.f;
+                    d[0] = rv && k0 + k < kend ? v[u].x : 0.f;
+                    d[1] = rv && k0 + k + 1 < kend ? v[u].y : 0.f;
+                    d[2] = rv && k0 + k + 2 < kend ? v[u].z : 0.f;
+                    d[3] = rv && k0 + k + 3 < kend ? v[u].w : 0.f;
                 }
             }
         }
     };
-    stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, min(32, N - q0));
+    auto chunk_len = [&](int c) { return min(XA_KT, ((nbody - c * XA_KT) + 63) & ~63); };   // zero padded to whole MFMA pairs
+    const int rows_q = min(32, N - q0);
+    if (nchunk == 1) stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, rows_q, 0, chunk_len(0));   // short contexts: P staged once
     float *Ts = xs_ + 64 * XA_LD;                            // the waves' t tiles meet here: [4][64][16]
     const int nleft = P - np;                                // < 32 keys behind the body, taken in order
+    const bool left_visible = nleft > 0 && kend > np;
     for (int d0 = 0; d0 < D; d0 += 32) {
-        __syncthreads();                                     // P staged / the previous feature block is done with Vs and Ts
-        stage(Vs, vc + (int64_t)(hd * D + d0) * n_ctx, n_ctx, 32);
-        __syncthreads();
-        // wave w: partial sums l = w and l = w + 4, all four jj: chains over the 32-key steps, two steps per MFMA
+        // wave w: partial sums l = w and l = w + 4, all four jj: chains over ALL 32-key steps of the body, two steps per MFMA
+        v16f tl[2][4] = {{{}, {}, {}, {}}, {{}, {}, {}, {}}};
+        for (int c = 0; c < nchunk; ++c) {
+            const int k0 = c * XA_KT, kt = chunk_len(c);
+            __syncthreads();                                 // P staged / the previous piece is done with Ps, Vs and Ts
+            if (nchunk > 1) stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, rows_q, k0, kt);
+            stage(Vs, vc + (int64_t)(hd * D + d0) * n_ctx, n_ctx, 32, k0, kt);
+            __syncthreads();
+            const int cend = min(nbody, k0 + XA_KT);
+#pragma unroll
+            for (int li = 0; li < 2; ++li) {
+                const int l = wave + 4 * li;
+                for (int cs = k0; cs < cend; cs += 128) {     // two MFMAs (four 32-key steps) per chain and trip: 16 operand reads, then 8 MFMAs
+                    float a[2][4], b[2][4];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int c0 = cs + 64 * u + 32 * h;  // (a step past the body: zeros -- fma(0, 0, c) = c)
+                        const bool ok = c0 < cend;
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int e = (ok ? c0 - k0 : 0) + 8 * jj + l;
+                            const float av = Ps[i * XA_LD + e], bv = Vs[i * XA_LD + e];
+                            a[u][jj] = ok ? av : 0.f;
+                            b[u][jj] = ok ? bv : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+                            tl[li][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][jj], b[u][jj], tl[li][jj], 0, 0, 0);
+                }
+            }
+        }
         v16f tw;
 #pragma unroll
-        for (int li = 0; li < 2; ++li) {
-            const int l = wave + 4 * li;
-            v16f tl[4] = {{}, {}, {}, {}};
-            for (int cs = 0; cs < nbody; cs += 128) {         // two MFMAs (four 32-key steps) per chain and trip: 16 operand reads, then 8 MFMAs
-                float a[2][4], b[2][4];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int c0 = cs + 64 * u + 32 * h;      // (a step past the body: zeros -- fma(0, 0, c) = c)
-                    const bool ok = c0 < nbody;
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const int e = (ok ? c0 : 0) + 8 * jj + l;
-                        const float av = Ps[i * XA_LD + e], bv = Vs[i * XA_LD + e];
-                        a[u][jj] = ok ? av : 0.f;
-                        b[u][jj] = ok ? bv : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) tl[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][jj], b[u][jj], tl[jj], 0, 0, 0);
-            }
-            v16f vs;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) vs[e] = __fadd_rn(__fadd_rn(tl[0][e], tl[1][e]), __fadd_rn(tl[2][e], tl[3][e]));   // (s0+s1)+(s2+s3)
-            if (li == 0) tw = vs;
-            else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) tw[e] = __fadd_rn(tw[e], vs[e]);          // t_w = v_w + v_{w+4} (lo128 + hi128)
-            }
+        for (int e = 0; e < 16; ++e) {
+            const float v0 = __fadd_rn(__fadd_rn(tl[0][0][e], tl[0][1][e]), __fadd_rn(tl[0][2][e], tl[0][3][e]));   // (s0+s1)+(s2+s3)
+            const float v1 = __fadd_rn(__fadd_rn(tl[1][0][e], tl[1][1][e]), __fadd_rn(tl[1][2][e], tl[1][3][e]));
+            tw[e] = __fadd_rn(v0, v1);                                                                              // t_w = v_w + v_{w+4} (lo128 + hi128)
+        }
+        __syncthreads();                                     // every wave is done with Ps / Vs
+        if (left_visible) {                                  // the leftover keys [np, P) to columns 0.. of both tiles
+            stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, rows_q, np, 32);
+            stage(Vs, vc + (int64_t)(hd * D + d0) * n_ctx, n_ctx, 32, np, 32);
         }
         {
             float *dst = Ts + (wave * 64 + lane) * 16;
@@ -860,12 +873,12 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
             const float *t0 = Ts + (0 * 64 + lane) * 16, *t1 = Ts + (1 * 64 + lane) * 16, *t2 = Ts + (2 * 64 + lane) * 16,
                         *t3 = Ts + (3 * 64 + lane) * 16;
             // C layout: col = lane & 31 = feature, row = (e & 3) + 8 (e >> 2) + 4 h = query
-            const float *vr = Vs + i * XA_LD + np;
+            const float *vr = Vs + i * XA_LD;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float s = __fadd_rn(__fadd_rn(t0[e], t1[e]), __fadd_rn(t2[e], t3[e]));       // (t0+t1) + (t2+t3) (hadd, hadd)
                 const int ql = (e & 3) + 8 * (e >> 2) + 4 * h, q = q0 + ql;
-                const float *pr = Ps + ql * XA_LD + np;
+                const float *pr = Ps + ql * XA_LD;
                 // the n % 32 leftovers as the reference's build compiled them (chunks of 8, one of 4: rounded products added in
                 // order; the last n % 4: FMAs); keys past this block's last visible one carry p = +0 and change nothing
                 int k = 0;
@@ -888,6 +901,10 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
                 if (q < N) ao[(int64_t)q * ldo + hd * D + d0 + i] = s;
             }
         }
+        if (nchunk == 1 && left_visible && d0 + 32 < D) {    // the single staged P piece was overwritten by the leftovers: stage it again
+            __syncthreads();
+            stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, rows_q, 0, chunk_len(0));
+        }
     }
 }
 
@@ -906,7 +923,7 @@ hipError_t attn_scores_exact(const float *qkv, int ldq, int D, int H, int N, int
 }
 hipError_t attn_pv_exact(const float *att, int ld_att, int64_t head_stride, int D, int H, int N, int n_past, const float *vc, int n_ctx,
                          float *ao, int ldo, hipStream_t st) {
-    if (D % 32 != 0 || D > 128 || N < 1 || n_past + N > XA_KT) return hipErrorInvalidValue;
+    if (D % 32 != 0 || D > 128 || N < 1 || (n_ctx & 3)) return hipErrorInvalidValue;
     const size_t lds = (size_t)2 * 32 * XA_LD * 4 + 4 * 64 * 16 * 4;
     static bool attr_set = false;
     if (!attr_set) {

@@ -554,7 +554,7 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
             if (pe != hipSuccess) {
                 (void)hipGetLastError();
                 // KQ, scale, mask, soft_max                                                            :364-379
-                const bool xa = exact && !dyn && N >= 2 && P <= 512 && D % 32 == 0 && D <= 128;   // the MFMA forms of the exact products
+                const bool xa = exact && !dyn && N >= 2 && D % 32 == 0 && D <= 128;   // the MFMA forms of the exact products
                 if (xa) M_HIP(attn_scores_exact(m->qkv, 3 * El, D, Hl, N, n_past, kc, El, kq_scale, m->att, n_ctx, (int64_t)N * n_ctx, st));
                 else
                     M_HIP((exact ? dot_f32_abt_exact : gemm_f32_abt)(m->qkv, 3 * El, D, kc, El, D, m->att, n_ctx, (int64_t)N * n_ctx, N, P, D, Hl,

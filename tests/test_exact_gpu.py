@@ -191,6 +191,33 @@ def test_model_exact_mode_equals_reference_bit_for_bit(tmp_path, torch, port, re
     m.free()
 
 
+def test_model_exact_mode_deep_context(tmp_path, torch, port, reflib):
+    """A prompt of three n_batch evals (512 + 512 + 40 tokens): the later chunks' attention runs over 1024+ keys -- several
+    512-key pieces of the V.P kernel, leftover forms included -- and the last logits still equal the LIVE reference's bits."""
+    from harness.flmodel import FlModel
+    cfg, qt = ggjt.SMALL, oracle.Q4_0
+    tensors = ggjt.synth_tensors(cfg, qt, port.quantize_q4, seed=7)
+    path = str(tmp_path / "m.bin")
+    ggjt.write_ggjt(path, cfg, qt, tensors)
+    rng = np.random.default_rng(11)
+    prompt = bytes(rng.integers(33, 127, size=1062).astype(np.uint8)).decode()
+    toks = ggjt.text_tokens(" " + prompt)
+    assert len(toks) == 1064
+    ref = llama_capi.Session(reflib, path, n_ctx=1100, n_batch=512, n_threads=8)
+    assert ref.ingest(prompt)
+    ok, _ = ref.generate(1, temp=0.0)
+    want = ref.logits().copy()
+    ref.close()
+    m = FlModel(cfg, qt, tensors, n_ctx=1100, max_batch=512)
+    m.set_exact(True)
+    n_past, lg = 0, None
+    for i in range(0, len(toks), 512):
+        lg = m.eval(toks[i:i + 512], n_past=n_past)
+        n_past += len(toks[i:i + 512])
+    assert np.array_equal(bits(lg[-1]), bits(want))
+    m.free()
+
+
 def test_model_exact_mode_chunked_ingest_and_decode_steps(tmp_path, torch, port, reflib):
     """The session pattern: n_batch-8 chunks (N <= 8 kernels on the prompt), then greedy decode steps (N = 1, hipGraph replay)."""
     from harness.flmodel import FlModel
@@ -376,13 +403,18 @@ def test_exact_decode_attention(torch, ops, port, exact_hooks, D, H, n_past, spl
 
 
 @pytest.mark.parametrize("D,H,N,n_past", [(128, 4, 64, 0), (128, 3, 100, 37), (128, 2, 512, 0), (64, 5, 70, 11), (96, 2, 33, 200), (32, 4, 40, 0),
-                                          (128, 2, 9, 500), (128, 2, 200, 312), (32, 3, 2, 5)])
+                                          (128, 2, 9, 500), (128, 2, 200, 312), (32, 3, 2, 5),
+                                          # contexts beyond one 512-key piece of the V.P kernel: the 8 chains of a wave are carried across pieces
+                                          (128, 2, 70, 600), (64, 3, 33, 1000), (128, 1, 512, 512), (128, 2, 100, 1947), (32, 2, 40, 1003),
+                                          (128, 1, 64, 448), (96, 2, 31, 993)])
 def test_exact_prefill_attention_mfma_forms(torch, ops, port, D, H, N, n_past):
     """K.Q and V.P of a batch on the f32-input MFMA (its k = 0, 1 chain is the reference's fma chain): the same bits as the
-    one-half-wave-per-dot kernel and as the oracle -- every leftover form (P % 32), causal tiles, ragged last query block."""
+    one-half-wave-per-dot kernel and as the oracle -- every leftover form (P % 32), causal tiles, ragged last query block, and
+    contexts of several 512-key pieces."""
     from fastllama_amd import hip
     L = hip.load()
-    n_ctx, E, P = 512, H * D, n_past + N
+    E, P = H * D, n_past + N
+    n_ctx = 512 if P <= 512 else (P + 63) // 64 * 64
     rng = np.random.default_rng(D + H + N + n_past)
     qkv = rng.standard_normal((N, 3 * E)).astype(np.float32)
     kc = np.zeros((n_ctx, E), np.float32)
