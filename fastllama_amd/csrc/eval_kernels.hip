@@ -92,8 +92,19 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_kernel(const float *__restr
     __shared__ double sh[4];
     const int n = blockIdx.x;
     const int gpr = E >> 3, KB = E >> 5;
-    float v[RN_MAXIT][8];
+    float v[RN_MAXIT][8], ww[RN_MAXIT][8];
     double sum = 0.0;
+    // (the norm weights are requested with the row, not after the reduction: one L2 round trip less on the critical path)
+#pragma unroll
+    for (int it = 0; it < RN_MAXIT; ++it) {
+        const int kg = threadIdx.x + it * 256;
+        if (kg < gpr) {
+            const float4 wa = *reinterpret_cast<const float4 *>(w + kg * 8);
+            const float4 wc = *reinterpret_cast<const float4 *>(w + kg * 8 + 4);
+            ww[it][0] = wa.x; ww[it][1] = wa.y; ww[it][2] = wa.z; ww[it][3] = wa.w;
+            ww[it][4] = wc.x; ww[it][5] = wc.y; ww[it][6] = wc.z; ww[it][7] = wc.w;
+        }
+    }
 #pragma unroll
     for (int it = 0; it < RN_MAXIT; ++it) {
         const int kg = threadIdx.x + it * 256;
@@ -117,11 +128,8 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_kernel(const float *__restr
         const int kg = threadIdx.x + it * 256;
         if (kg >= gpr) continue;   // whole quads leave together (gpr is a multiple of 4)
         float o[8];
-        const float4 wa = *reinterpret_cast<const float4 *>(w + kg * 8);
-        const float4 wc = *reinterpret_cast<const float4 *>(w + kg * 8 + 4);
-        const float ww[8] = {wa.x, wa.y, wa.z, wa.w, wc.x, wc.y, wc.z, wc.w};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = __fmul_rn(ww[i], __fmul_rn(v[it][i], scale));  // w * (x*scale)
+        for (int i = 0; i < 8; ++i) o[i] = __fmul_rn(ww[it][i], __fmul_rn(v[it][i], scale));  // w * (x*scale)
         if (y_f32 && n < N) {
             float4 *yp = reinterpret_cast<float4 *>(y_f32 + (int64_t)n * ldy + kg * 8);
             yp[0] = make_float4(o[0], o[1], o[2], o[3]);
