@@ -1260,12 +1260,14 @@ __device__ __forceinline__ float att_leftovers(float s, const float *__restrict_
 constexpr int DA_T = 512, DA_KPRE = 4, DA_VPRE = 8;
 
 template <int ORD>
-__global__ __launch_bounds__(DA_T) void decode_attention_kernel(const float *__restrict__ qkv, int E, int D, int n_past,
-                                                                int n_ctx, const float2 *__restrict__ rope_tab,
-                                                                float *__restrict__ kc, float *__restrict__ vc,
+// (argument order: the position pointer and what the first requests need lead -- those 14 dwords are preloaded into SGPRs,
+//  -mllvm -amdgpu-kernarg-preload-count in build.sh, so the kernel's first round trip is the position, not its own arguments)
+__global__ __launch_bounds__(DA_T) void decode_attention_kernel(const int *__restrict__ dyn_past, const float *__restrict__ qkv,
+                                                                const float2 *__restrict__ rope_tab, float *__restrict__ kc,
+                                                                float *__restrict__ vc, int E, int D, int n_past, int n_ctx,
                                                                 const uint16_t *__restrict__ exp_tab, float scale,
                                                                 int8_t *__restrict__ oq, float *__restrict__ od,
-                                                                float *__restrict__ os, const int *__restrict__ dyn_past) {
+                                                                float *__restrict__ os) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     DA_STAMP(0);
     if (dyn_past) n_past = *dyn_past;
@@ -1443,11 +1445,11 @@ hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, i
     if (D % 32 != 0 || D > 128 || n_ctx % 4 != 0 || E % 4 != 0) return hipErrorInvalidValue;
     const size_t lds = (size_t)(4 * D + n_ctx + 4) * 4 + 8 * 8 + 8 * 4;
     if (exact)
-        hipLaunchKernelGGL(decode_attention_kernel<1>, dim3(H), dim3(DA_T), lds, st, qkv, E, D, n_past, n_ctx,
-                           reinterpret_cast<const float2 *>(rope_tab), kc, vc, exp_tab, scale, out->q, out->d, out->s, dyn_past);
+        hipLaunchKernelGGL(decode_attention_kernel<1>, dim3(H), dim3(DA_T), lds, st, dyn_past, qkv, reinterpret_cast<const float2 *>(rope_tab),
+                           kc, vc, E, D, n_past, n_ctx, exp_tab, scale, out->q, out->d, out->s);
     else
-        hipLaunchKernelGGL(decode_attention_kernel<0>, dim3(H), dim3(DA_T), lds, st, qkv, E, D, n_past, n_ctx,
-                           reinterpret_cast<const float2 *>(rope_tab), kc, vc, exp_tab, scale, out->q, out->d, out->s, dyn_past);
+        hipLaunchKernelGGL(decode_attention_kernel<0>, dim3(H), dim3(DA_T), lds, st, dyn_past, qkv, reinterpret_cast<const float2 *>(rope_tab),
+                           kc, vc, E, D, n_past, n_ctx, exp_tab, scale, out->q, out->d, out->s);
     return hipGetLastError();
 }
 

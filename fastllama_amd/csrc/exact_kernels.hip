@@ -177,10 +177,10 @@ hipError_t gemv_q4_exact(const fl_qtensor &W, const fl_qact &xq, int N, float *y
 // ------------------------------------------------------------------------------------------------
 template <int TYPE, int NWG, int PRO, int PAIR>
 __global__ __launch_bounds__(64 * (NWG + 2)) void gemv1_q4_exact_kernel(
-    const uint32_t *__restrict__ qs, const float *__restrict__ dW, const float *__restrict__ mW, const int8_t *__restrict__ xq,
-    const float *__restrict__ xd, const float *__restrict__ xs, int M, int units, int KB, float *__restrict__ y,
-    const float *__restrict__ resid, const float *__restrict__ xf, const void *__restrict__ aux, float *__restrict__ ynorm,
-    int woven, const uint16_t *__restrict__ aux2) {
+    int M, int units, int KB, int woven,                      // (the leading 12-14 dwords are preloaded into SGPRs: build.sh)
+    const uint32_t *__restrict__ qs, const float *__restrict__ dW, const float *__restrict__ xf, const void *__restrict__ aux,
+    const float *__restrict__ mW, const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs,
+    float *__restrict__ y, const float *__restrict__ resid, float *__restrict__ ynorm, const uint16_t *__restrict__ aux2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     constexpr int G2 = PAIR ? 2 : 1, NT = 64 * (NWG + 2);
     constexpr int BPW = 8, KC = BPW * NWG, D = 6;                   // blocks per producer wave and chunk; chunk; chunks in flight
@@ -406,9 +406,8 @@ static bool launch_gemv1_exact(const fl_qtensor &W, const fl_qact *xq, float *y,
         if (n_cu <= 0) n_cu = 256;
     }
     const int grid = units < n_cu ? units : n_cu;                   // one resident workgroup per CU, each streaming its share of the rows
-    hipLaunchKernelGGL((gemv1_q4_exact_kernel<TYPE, NWG, PRO, PAIR>), dim3(grid), dim3(64 * (NWG + 2)), lds, st, W.qs, W.d, W.m,
-                       xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, W.M, units, KB, y, resid, xf, aux, ynorm, woven,
-                       aux2);
+    hipLaunchKernelGGL((gemv1_q4_exact_kernel<TYPE, NWG, PRO, PAIR>), dim3(grid), dim3(64 * (NWG + 2)), lds, st, W.M, units, KB, woven,
+                       W.qs, W.d, xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid, ynorm, aux2);
     return true;
 }
 

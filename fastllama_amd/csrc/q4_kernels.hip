@@ -475,14 +475,18 @@ __device__ __forceinline__ void quantize_group_lds(const float o[8], int kg, int
 // SiLU table): ggml_silu + ggml_mul of lib/llama.cpp:428-431 as the epilogue of the matmul.  Slot u of a wave's U loads
 // belongs to group u & 1.
 template <int TYPE, int NC, int NWAVES, int PRO, int U, int PAIR>
-__global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(const uint4 *__restrict__ qs, const float *__restrict__ dW,
+// (argument order: what the first weight / activation requests need comes first -- the leading 12 dwords of the kernarg segment
+//  are preloaded into SGPRs by the command processor (-mllvm -amdgpu-kernarg-preload-count, build.sh), so those requests go out
+//  without waiting for the s_load round trip of the rest)
+__global__ __launch_bounds__(64 * NWAVES) void gemv_q4_kernel(int N, int M, int KB, int woven,
+                                                      const uint4 *__restrict__ qs, const float *__restrict__ dW,
+                                                      const float *__restrict__ xf, const void *__restrict__ aux,
                                                       const float *__restrict__ mW,
                                                       const int8_t *__restrict__ xq, const float *__restrict__ xd,
-                                                      const float *__restrict__ xs, int N, int M, int KB,
+                                                      const float *__restrict__ xs,
                                                       float *__restrict__ y, int ldy,
                                                       const float *__restrict__ resid, int ldr,
-                                                      const float *__restrict__ xf, const void *__restrict__ aux,
-                                                      float *__restrict__ ynorm, int woven,
+                                                      float *__restrict__ ynorm,
                                                       const uint16_t *__restrict__ aux2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     static_assert(!PAIR || (NC == 1 && U % 2 == 0), "pair mode: single column, even number of load slots");
@@ -769,9 +773,9 @@ static hipError_t launch_gemv1(const fl_qtensor &W, const fl_qact *xq, float *y,
     const int u = per_wave <= 2 ? 2 : per_wave <= 4 ? 4 : per_wave <= 6 ? 6 : 8;
     const size_t lds = PRO ? (size_t)W.KB * 40 : 0;
 #define FL_GEMV(NW, UU)                                                                                              \
-    hipLaunchKernelGGL((gemv_q4_kernel<TYPE, 1, NW, PRO, UU, PAIR>), grid, dim3(64 * NW), lds, st, qs, W.d, W.m,     \
-                       xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, 1, W.M, W.KB, y, 0, resid, 0, \
-                       xf, aux, ynorm, woven, aux2)
+    hipLaunchKernelGGL((gemv_q4_kernel<TYPE, 1, NW, PRO, UU, PAIR>), grid, dim3(64 * NW), lds, st, 1, W.M, W.KB, woven, qs, W.d, \
+                       xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, 0, resid, 0,        \
+                       ynorm, aux2)
 #define FL_GEMV_U(NW)                   \
     do {                                \
         if (u == 2) FL_GEMV(NW, 2);     \
@@ -797,8 +801,9 @@ static hipError_t launch_gemv(const fl_qtensor &W, const fl_qact &xq, int N, flo
     // more waves per group (each takes every NWAVES-th block-quad) so that >= ~16 waves per CU are loading.
     const int nw = gemv_waves(W.M16 / 16);
 #define FL_GEMV(NC, NW, UU)                                                                                             \
-    hipLaunchKernelGGL((gemv_q4_kernel<TYPE, NC, NW, 0, UU, 0>), grid, dim3(64 * NW), 0, st, qs, W.d, W.m, xq.q, xq.d, xq.s, \
-                       N, W.M, W.KB, y, ldy, resid, ldr, nullptr, nullptr, nullptr, 0, nullptr)
+    hipLaunchKernelGGL((gemv_q4_kernel<TYPE, NC, NW, 0, UU, 0>), grid, dim3(64 * NW), 0, st, N, W.M, W.KB, 0, qs, W.d,      \
+                       static_cast<const float *>(nullptr), static_cast<const void *>(nullptr), W.m, xq.q, xq.d, xq.s, y, ldy,  \
+                       resid, ldr, static_cast<float *>(nullptr), static_cast<const uint16_t *>(nullptr))
 #define FL_GEMV_NW(NC, UU)                       \
     do {                                         \
         if (nw == 4) FL_GEMV(NC, 4, UU);         \

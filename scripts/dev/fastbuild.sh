@@ -15,7 +15,7 @@ for src in fastllama_amd/csrc/*.hip fastllama_amd/csrc/*.cpp; do
     extra=""
     [ "$(basename "$src")" = "${X_SRC:-}" ] && extra="${X_FLAGS:-}"
     if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ "$newest_hdr" -nt "$o" ]; then
-        hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -x hip $extra -c "$src" -o "$o" 2> "$o.log" &
+        hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC ${KPRE--mllvm -amdgpu-kernarg-preload-count=16} -Iinclude -x hip $extra -c "$src" -o "$o" 2> "$o.log" &
         pids+=($!)
     fi
 done
