@@ -393,18 +393,22 @@ static bool launch_gemv1_exact(const fl_qtensor &W, const fl_qact *xq, float *y,
     const int KB = W.KB, units = W.M16 / 16 / G2;
     const size_t lds = (size_t)KB * 40 + (size_t)2 * KC * (512 + 64 + (TYPE == FL_TYPE_Q4_1 ? 64 + 4 : 0));
     if (lds > 150 * 1024) return false;
-    static bool attr_set = false;          // (per instantiation) dynamic LDS beyond 64 KB must be asked for once
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemv1_q4_exact_kernel<TYPE, NWG, PRO, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
+    // dynamic LDS beyond 64 KB must be asked for once per instantiation AND device (several GPUs in one process)
+    static bool attr_set[64] = {false};
+    static int n_cu_dev[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemv1_q4_exact_kernel<TYPE, NWG, PRO, PAIR>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return false;
+        attr_set[dev] = true;
     }
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
+    if (!n_cu_dev[dev]) {
         hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
+        n_cu_dev[dev] = hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
     }
+    const int n_cu = n_cu_dev[dev];
     const int grid = units < n_cu ? units : n_cu;                   // one resident workgroup per CU, each streaming its share of the rows
     hipLaunchKernelGGL((gemv1_q4_exact_kernel<TYPE, NWG, PRO, PAIR>), dim3(grid), dim3(64 * (NWG + 2)), lds, st, W.M, units, KB, woven,
                        W.qs, W.d, xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid, ynorm, aux2);
@@ -924,10 +928,14 @@ hipError_t attn_pv_exact(const float *att, int ld_att, int64_t head_stride, int 
                          float *ao, int ldo, hipStream_t st) {
     if (D % 32 != 0 || D > 128 || N < 1 || (n_ctx & 3)) return hipErrorInvalidValue;
     const size_t lds = (size_t)2 * 32 * XA_LD * 4 + 4 * 64 * 16 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attn_pv_exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    static bool attr_set[64] = {false};      // (per device)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_pv_exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(attn_pv_exact_kernel, dim3((N + 31) / 32, H), dim3(256), lds, st, att, ld_att, head_stride, D, N, n_past, vc, n_ctx,
                        ao, ldo);
