@@ -217,6 +217,22 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert not r.stdout.strip().startswith("{")
 
 
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the form the driver uses) must start two ranks itself: here, without a
+    GPU, both ranks come up under torch.distributed.run (RANK / WORLD_SIZE set) and each refuses loudly -- no silent 1-rank run."""
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present (tests/test_bench_gpu.py covers the launch there)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    out = r.stderr + r.stdout
+    assert r.returncode != 0
+    assert out.count("no CPU path") >= 2, out[-2000:]            # one refusal per rank
+    assert not any(line.startswith("{") for line in r.stdout.splitlines())
+
+
 def test_mixed_tile_split_covers_every_row_group_once():
     """Host logic of the GEMM launch with two tile shapes (gemm_q4_mfma32.hip, cfg 116): row groups [0, mg_split) go to whole
     rounds of 256 workgroups of 128x64 tiles, the rest to 128x32 tiles.  Whatever the shape: the two regions partition the row
