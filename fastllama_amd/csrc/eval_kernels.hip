@@ -1468,10 +1468,10 @@ hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, i
 constexpr int DS_T = 512, DS_POS = 128, DP_T = 256, DP_BATCH = 16;
 
 template <int ORD>
-__global__ __launch_bounds__(DS_T) void decode_scores_kernel(const float *__restrict__ qkv, int E, int D, int n_past,
-                                                             int n_ctx, const float2 *__restrict__ rope_tab,
+__global__ __launch_bounds__(DS_T) void decode_scores_kernel(const int *__restrict__ dyn_past, const float *__restrict__ qkv, int E, int D,
+                                                             int n_past, int n_ctx, const float2 *__restrict__ rope_tab,
                                                              float *__restrict__ kc, float *__restrict__ vc, float scale,
-                                                             float *__restrict__ scores, const int *__restrict__ dyn_past) {
+                                                             float *__restrict__ scores) {      // (position pointer first: preloaded kernargs)
     __shared__ __attribute__((aligned(16))) float qs[128], ks[128];
     if (dyn_past) n_past = *dyn_past;
     const int h = blockIdx.x, tid = threadIdx.x, pos = n_past, P = n_past + 1;
@@ -1532,11 +1532,10 @@ __global__ __launch_bounds__(DS_T) void decode_scores_kernel(const float *__rest
 }
 
 template <int ORD>
-__global__ __launch_bounds__(DP_T) void decode_pv_kernel(const float *__restrict__ scores, int E, int D, int n_past,
-                                                         int n_ctx, const float *__restrict__ vc,
+__global__ __launch_bounds__(DP_T) void decode_pv_kernel(const int *__restrict__ dyn_past, const float *__restrict__ scores, int E, int D,
+                                                         int n_past, int n_ctx, const float *__restrict__ vc,
                                                          const uint16_t *__restrict__ exp_tab, int8_t *__restrict__ oq,
-                                                         float *__restrict__ od, float *__restrict__ os,
-                                                         const int *__restrict__ dyn_past) {
+                                                         float *__restrict__ od, float *__restrict__ os) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     if (dyn_past) n_past = *dyn_past;
     const int h = blockIdx.x, tid = threadIdx.x, pos = n_past, P = n_past + 1;
@@ -1648,20 +1647,20 @@ hipError_t decode_attention_split(const float *qkv, int E, int D, int H, int n_p
     if (D % 32 != 0 || D > 128 || n_ctx % 4 != 0 || E % 4 != 0) return hipErrorInvalidValue;
     const int slices = dyn_past ? (n_ctx + DS_POS - 1) / DS_POS : (n_past + DS_POS) / DS_POS;
     if (exact)
-        hipLaunchKernelGGL(decode_scores_kernel<1>, dim3(H, slices), dim3(DS_T), 0, st, qkv, E, D, n_past, n_ctx,
-                           reinterpret_cast<const float2 *>(rope_tab), kc, vc, scale, scores, dyn_past);
+        hipLaunchKernelGGL(decode_scores_kernel<1>, dim3(H, slices), dim3(DS_T), 0, st, dyn_past, qkv, E, D, n_past, n_ctx,
+                           reinterpret_cast<const float2 *>(rope_tab), kc, vc, scale, scores);
     else
-        hipLaunchKernelGGL(decode_scores_kernel<0>, dim3(H, slices), dim3(DS_T), 0, st, qkv, E, D, n_past, n_ctx,
-                           reinterpret_cast<const float2 *>(rope_tab), kc, vc, scale, scores, dyn_past);
+        hipLaunchKernelGGL(decode_scores_kernel<0>, dim3(H, slices), dim3(DS_T), 0, st, dyn_past, qkv, E, D, n_past, n_ctx,
+                           reinterpret_cast<const float2 *>(rope_tab), kc, vc, scale, scores);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t lds = 4 * 8 + 4 * 4 + 32 * 4 + (size_t)((n_ctx + 511) / 512 * 512 + 512) * 4;
     if (exact)
-        hipLaunchKernelGGL(decode_pv_kernel<1>, dim3(H, D / 32), dim3(DP_T), lds, st, scores, E, D, n_past, n_ctx, vc, exp_tab,
-                           out->q, out->d, out->s, dyn_past);
+        hipLaunchKernelGGL(decode_pv_kernel<1>, dim3(H, D / 32), dim3(DP_T), lds, st, dyn_past, scores, E, D, n_past, n_ctx, vc, exp_tab,
+                           out->q, out->d, out->s);
     else
-        hipLaunchKernelGGL(decode_pv_kernel<0>, dim3(H, D / 32), dim3(DP_T), lds, st, scores, E, D, n_past, n_ctx, vc, exp_tab,
-                           out->q, out->d, out->s, dyn_past);
+        hipLaunchKernelGGL(decode_pv_kernel<0>, dim3(H, D / 32), dim3(DP_T), lds, st, dyn_past, scores, E, D, n_past, n_ctx, vc, exp_tab,
+                           out->q, out->d, out->s);
     return hipGetLastError();
 }
 
