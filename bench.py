@@ -289,7 +289,7 @@ def main():
         r["decode_ms"] = timed(dec, dsteps) / dsteps * 1e3
         # ---- the same two timings in EXACT mode (reference-order kernels: logits bit-identical to the reference's x86 build,
         #      tests/test_parity_7b_gpu.py); the fast mode above computes exact block dots and adds them in its own f32 order
-        if not args.no_exact:
+        if not args.no_exact and not tp:       # (a single-GPU property: under tensor parallelism wo / w2 end in a sum of G partial results)
             model.set_exact(True)
             xsteps = max(2, steps // 4)
             prefill(0)
