@@ -219,6 +219,27 @@ int fl_qtensor_build_f6(fl_qtensor *W, void *stream) {
     return FL_OK;
 }
 
+/* (re)build the f16 fragment copy the reference-order prefill GEMM reads (q4_layout.h "H16 copies"; 4 x the nibble bytes) */
+int fl_qtensor_build_h16(fl_qtensor *W, void *stream) {
+    if (!W) return set_error(FL_EINVAL, "null tensor");
+    if (!W->h16) {
+        hipError_t ea = hipMalloc((void **)&W->h16, wh16_bytes(*W));
+        if (ea != hipSuccess) {
+            W->h16 = nullptr;
+            return hip_fail(ea, "hipMalloc(WH16)");
+        }
+    }
+    hipError_t e = qw16_to_h16(*W, W->h16, S(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(S(stream));
+    if (e != hipSuccess) return hip_fail(e, "fl_qtensor_build_h16");
+    return FL_OK;
+}
+
+void fl_qtensor_drop_h16(fl_qtensor *W) {
+    if (W && W->h16) (void)hipFree(W->h16);
+    if (W) W->h16 = nullptr;
+}
+
 void fl_qtensor_drop_f6(fl_qtensor *W) {
     if (W && W->f6) (void)hipFree(W->f6);
     if (W) W->f6 = nullptr;
@@ -265,7 +286,7 @@ int fl_qtensor_info(const fl_qtensor *W, int *type, int *M, int *K) {
 size_t fl_qtensor_device_bytes(const fl_qtensor *W) {
     if (!W) return 0;
     const size_t nblk = (size_t)W->M16 * W->KB;
-    return nblk * (16 + 4 + (W->type == FL_TYPE_Q4_1 ? 4 : 0) + (W->f6 ? 24 : 0));
+    return nblk * (16 + 4 + (W->type == FL_TYPE_Q4_1 ? 4 : 0) + (W->f6 ? 24 : 0)) + (W->h16 ? wh16_bytes(*W) : 0);
 }
 
 void fl_qtensor_free(fl_qtensor *W) {
@@ -276,6 +297,7 @@ void fl_qtensor_free(fl_qtensor *W) {
         if (W->m) (void)hipFree(W->m);
     }
     if (W->f6) (void)hipFree(W->f6);
+    if (W->h16) (void)hipFree(W->h16);
     delete W;
 }
 
@@ -393,6 +415,8 @@ fl_qact *fl_qact_create(int max_N, int K) {
     if (e == hipSuccess) e = hipMalloc((void **)&a->d, a->s_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&a->s, a->s_bytes);
     if (e == hipSuccess && gemm_fp6_enabled()) e = hipMalloc((void **)&a->q6, a->q_bytes / 2 * 3);
+    if (e == hipSuccess) e = hipMalloc((void **)&a->h16, xh16_bytes(a->cap_N16, K));
+    if (e == hipSuccess) e = hipMemset(a->h16, 0, xh16_bytes(a->cap_N16, K));
     if (e != hipSuccess) {
         hip_fail(e, "fl_qact_create");
         fl_qact_free(a);
@@ -407,6 +431,7 @@ void fl_qact_free(fl_qact *a) {
     if (a->d) (void)hipFree(a->d);
     if (a->s) (void)hipFree(a->s);
     if (a->q6) (void)hipFree(a->q6);
+    if (a->h16) (void)hipFree(a->h16);
     delete static_cast<fl_qact_impl *>(a);
 }
 
@@ -483,7 +508,16 @@ int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy
     const fl_qact_impl *a = static_cast<const fl_qact_impl *>(a_);
     int rc = check_mm(W, a, y, ldy);
     if (rc != FL_OK) return rc;
-    if (which == 4) {                      // reference-order tile kernel in its VALU (v_dot4) form: cross-check of the MFMA form
+    if (which == 5 || which == 6) {        // reference-order kernels of record for N >= 2: 5 = the H16 form (round 4), 6 = round 3's nibble form
+        if (a->layout != 16) return set_error(FL_EINVAL, "gemm needs the QA16 layout");
+        if (which == 6) {
+            FL_HIP(gemm_q4_exact_mfma(*W, *a, a->N, y, ldy, S(st)));
+            return FL_OK;
+        }
+        if (!W->h16 && (rc = fl_qtensor_build_h16(const_cast<fl_qtensor *>(W), st)) != FL_OK) return rc;
+        FL_HIP(qa16_to_h16(*a, a->N, S(st)));
+        FL_HIP(gemm_q4_exact_h16(*W, *a, a->N, y, ldy, S(st)));
+    } else if (which == 4) {               // reference-order tile kernel in its VALU (v_dot4) form: cross-check of the MFMA form
         if (a->layout != 16) return set_error(FL_EINVAL, "gemm needs the QA16 layout");
         FL_HIP(gemm_q4_exact_valu(*W, *a, a->N, y, ldy, S(st)));
     } else if (which == 3) {               // reference-order kernels, whichever the layout says

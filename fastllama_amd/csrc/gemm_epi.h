@@ -14,6 +14,7 @@ struct GemmSiluEpi {
     int8_t *oq;
     float *od, *os;
     int KBo;                    // n_ff / 32
+    uint16_t *oh;               // optional XH16 copy of the output (q4_layout.h), written next to oq
     // second optional epilogue, for the fused wq|wk|wv matrix: rope on Q (stored to y) and on K (stored to the K cache
     // row of the token's position), V stored transposed into the V cache -- ggml_rope + the two ggml_cpy into memory_k /
     // memory_v (lib/llama.cpp:328-347) without a pass over the [N][3 n_embd] result.  Arithmetic of rope_kv_kernel.

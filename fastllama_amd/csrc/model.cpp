@@ -97,6 +97,8 @@ struct fl_model : Act {
     bool ingest_one_stream = false;  // debugging: fl_model_ingest takes its chunks one after the other
     bool exact = false;              // reference-order kernels (exact_kernels.hip): logits bit-identical to the reference's x86 build
     bool w13_il = false;             // w1|w3 woven by 16-row groups (n_ff/tp a multiple of 32): silu epilogue in the matmul
+    int h16_state = 0;               // WH16 copies of the matmul weights (reference-order prefill): 0 not built, 1 ready, -1 no memory for them
+    bool xh = false;                 // the eval in flight takes the H16 form of the reference-order GEMM
     int exp_tab_n = 0;               // fp16 exp-table entries after 0x8000 that are non-zero (rounded up to 8): the LDS copy
     // LoRA: originals of the tensors an adapter touched (the reference's use_mmap path keeps them too, llama.cpp:868-874)
     struct LoraBackup { fl_qtensor *t; void *qs, *d, *mm; };
@@ -133,6 +135,10 @@ static int qact_alloc(fl_model *m, fl_qact *a, int maxN, int K) {
     if (rc == FL_OK && gemm_fp6_enabled()) rc = dev_alloc(m, (void **)&a->q6, qact_bytes_q(maxN, K) / 2 * 3);
     if (rc == FL_OK) rc = dev_alloc(m, (void **)&a->d, qact_bytes_scale(maxN, K));
     if (rc == FL_OK) rc = dev_alloc(m, (void **)&a->s, qact_bytes_scale(maxN, K));
+    if (rc == FL_OK && maxN >= 9) {      // XH16 operand of the reference-order prefill GEMM (q4_layout.h)
+        rc = dev_alloc(m, (void **)&a->h16, xh16_bytes(maxN, K));
+        if (rc == FL_OK) M_HIP(hipMemset(a->h16, 0, xh16_bytes(maxN, K)));
+    }
     a->KB = K / FL_QK;
     return rc;
 }
@@ -158,7 +164,7 @@ static int act_alloc(fl_model *m, Act &a) {      // the work buffers of one eval
 static void act_free(Act &a) {
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(a.tok_dev); fr(a.x); fr(a.x2); fr(a.xn); fr(a.part); fr(a.qkv); fr(a.att); fr(a.ao); fr(a.h13); fr(a.logits);
-    for (fl_qact *q : {&a.qE, &a.qEl, &a.qF}) { fr(q->q); fr(q->d); fr(q->s); }
+    for (fl_qact *q : {&a.qE, &a.qEl, &a.qF}) { fr(q->q); fr(q->d); fr(q->s); fr(q->q6); fr(q->h16); }
     a = Act{};
 }
 
@@ -427,7 +433,8 @@ static hipError_t mm(fl_model *m, const fl_qtensor *W, const fl_qact &a, int N, 
     hipEvent_t e1;
     hipError_t r = prof_begin(m, &e1);
     if (r != hipSuccess) return r;
-    if (m->exact) r = N == 1 ? gemv_q4_exact(*W, a, N, y, ldy, m->stream, resid, ldr) : gemm_q4_exact(*W, a, N, y, ldy, m->stream, resid, ldr);
+    if (m->exact && m->xh && gemm_q4_exact_h16_supports(*W, a, N)) r = gemm_q4_exact_h16(*W, a, N, y, ldy, m->stream, resid, ldr);
+    else if (m->exact) r = N == 1 ? gemv_q4_exact(*W, a, N, y, ldy, m->stream, resid, ldr) : gemm_q4_exact(*W, a, N, y, ldy, m->stream, resid, ldr);
     else r = N <= 8 ? gemv_q4(*W, a, N, y, ldy, m->stream, resid, ldr) : gemm_q4_mfma(*W, a, N, y, ldy, m->stream, resid, ldr);
     prof_end(m, e1);
     return r;
@@ -448,7 +455,7 @@ static hipError_t mm_qkv_rope(fl_model *m, const fl_qtensor *W, const fl_qact &a
     hipEvent_t e1;
     hipError_t r = prof_begin(m, &e1);
     if (r != hipSuccess) return r;
-    r = gemm_q4_mfma_qkv(*W, a, N, m->qkv, 3 * m->El, m->rope_tab, kc, vc, m->El, m->D, n_past, m->n_ctx, m->stream);
+    r = (m->exact ? gemm_q4_exact_h16_qkv : gemm_q4_mfma_qkv)(*W, a, N, m->qkv, 3 * m->El, m->rope_tab, kc, vc, m->El, m->D, n_past, m->n_ctx, m->stream);
     prof_end(m, e1);
     return r;
 }
@@ -458,7 +465,7 @@ static hipError_t mm_silu_gemm(fl_model *m, const fl_qtensor *W, const fl_qact &
     hipEvent_t e1;
     hipError_t r = prof_begin(m, &e1);
     if (r != hipSuccess) return r;
-    r = gemm_q4_mfma_silu(*W, a, N, m->silu_tab, m->qF, m->stream);
+    r = (m->exact ? gemm_q4_exact_h16_silu : gemm_q4_mfma_silu)(*W, a, N, m->silu_tab, m->qF, m->stream);
     prof_end(m, e1);
     return r;
 }
@@ -493,6 +500,25 @@ static hipError_t mm_silu(fl_model *m, const fl_qtensor *W, const float *h13, fl
     return r;
 }
 
+// The WH16 copies of every matmul weight (4 x the nibble bytes: 13 GB at 7B of the 288 GB), built on the first reference-order
+// eval with N >= 9.  No memory for them: the round-3 kernel, which reads the nibbles, keeps the mode working.
+static void ensure_h16(fl_model *m) {
+    if (m->h16_state != 0) return;
+    std::vector<fl_qtensor *> ts;
+    for (Layer &ly : m->layers) for (fl_qtensor *t : {ly.wqkv, ly.wo, ly.w13, ly.w2}) ts.push_back(t);
+    ts.push_back(m->output);
+    m->h16_state = 1;
+    for (fl_qtensor *t : ts) {
+        if (t->h16) continue;
+        if (fl_qtensor_build_h16(t, m->stream) != FL_OK) { m->h16_state = -1; break; }
+        m->dev_bytes += wh16_bytes(*t);
+    }
+    if (m->h16_state < 0) {
+        (void)hipGetLastError();
+        for (fl_qtensor *t : ts) if (t->h16) { m->dev_bytes -= wh16_bytes(*t); fl_qtensor_drop_h16(t); }
+    }
+}
+
 static int allreduce_if_tp(fl_model *m, float *buf, size_t count) {
     if (m->G == 1) return FL_OK;
     if (!m->comm) return set_error(FL_EINVAL, "tensor-parallel eval without a communicator");
@@ -516,6 +542,11 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
     const bool exact = m->exact;        // reference-order matmuls: the per-op sequence, every matmul through exact_kernels.hip
     const bool fused = N == 1 && D <= 128 && D % 32 == 0 && E <= 8192 && Fl <= 32768 && m->fuse_decode;   // single-token kernels (both modes)
     const bool fuse_pa = m->fuse_prefill_attn && !exact;
+    if (exact && N >= 9 && !dyn) ensure_h16(m);
+    // reference-order prefill: the H16 form of the GEMM (gemm_q4_exact_h16.hip) with rope / K-V stores and silu * mul -> Q8_0 as its
+    // epilogues; every Q8_0 operand gets its XH16 copy
+    const bool xh = exact && N >= 9 && !dyn && m->h16_state > 0 && m->qE.h16 && m->qEl.h16 && m->qF.h16 && !getenv("FL_EXACT_R3");
+    m->xh = xh;
     if (!body_only) M_HIP(get_rows_qw16(*m->tok_emb, m->tok_dev, N, m->x, E, st));      // inpL = get_rows  llama.cpp:304
     float *inp = m->x, *mid = m->x2;
     if (l1 < 0) l1 = m->L;
@@ -537,7 +568,8 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
         } else {
             // norm + attention_norm*cur -> Q8_0                                                        llama.cpp:311-319
             M_HIP(rmsnorm_quant(inp, E, ly.attn_norm, N, E, nullptr, 0, &m->qE, layout, st));
-            if (N >= 9 && !dyn && fuse_pa) {
+            if (xh) M_HIP(qa16_to_h16(m->qE, N, st));
+            if ((N >= 9 && !dyn && fuse_pa) || xh) {
                 M_HIP(mm_qkv_rope(m, ly.wqkv, m->qE, N, kc, vc, n_past));                              // wq, wk, wv + rope + KV store
             } else {
                 M_HIP(mm(m, ly.wqkv, m->qE, N, m->qkv, 3 * El, nullptr, 0));                           // wq, wk, wv  :328-334
@@ -566,6 +598,7 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
                     M_HIP((exact ? dot_f32_abt_exact : gemm_f32_abt)(m->att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, m->ao, El, D, N,
                                                                      D, P, Hl, 1.0f, 2, n_past, st, dyn, n_ctx));
                 M_HIP((layout == 16 ? quantize_q8_qa16 : quantize_q8_qa1)(m->ao, El, N, El, m->qEl, st));
+                if (xh) M_HIP(qa16_to_h16(m->qEl, N, st));
             }   // (the one-launch kernel wrote the Q8_0 operand of the wo matmul itself)
         }
         // wo projection + residual                                                                 :401-407
@@ -578,7 +611,7 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
             M_HIP(add_rows(m->part, E, inp, E, mid, E, N, E, st));
         }
         // feed-forward                                                                             :412-436
-        const bool silu_in_gemm = N >= 9 && m->w13_il && !exact;    // silu * mul -> Q8_0 is the epilogue of the w1|w3 matmul
+        const bool silu_in_gemm = N >= 9 && m->w13_il && (!exact || xh);   // silu * mul -> Q8_0 is the epilogue of the w1|w3 matmul
         const bool silu_in_gemv = fused && m->w13_il;         // decode: silu * mul is the epilogue of the w1|w3 GEMV
         if (silu_in_gemv) {
             M_HIP(mm_norm_silu(m, ly.w13, mid, ly.ffn_norm, m->h13));
@@ -586,10 +619,14 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
             M_HIP(mm_norm(m, ly.w13, mid, ly.ffn_norm, nullptr, m->h13));
         } else {
             M_HIP(rmsnorm_quant(mid, E, ly.ffn_norm, N, E, nullptr, 0, &m->qE, layout, st));
+            if (xh) M_HIP(qa16_to_h16(m->qE, N, st));
             if (silu_in_gemm) M_HIP(mm_silu_gemm(m, ly.w13, m->qE, N));
             else M_HIP(mm(m, ly.w13, m->qE, N, m->h13, 2 * Fl, nullptr, 0));
         }
-        if (!fused && !silu_in_gemm) M_HIP(silu_mul_quant(m->h13, 2 * Fl, N, Fl, m->silu_tab, &m->qF, layout, st, m->w13_il));
+        if (!fused && !silu_in_gemm) {
+            M_HIP(silu_mul_quant(m->h13, 2 * Fl, N, Fl, m->silu_tab, &m->qF, layout, st, m->w13_il));
+            if (xh) M_HIP(qa16_to_h16(m->qF, N, st));
+        }
         if (!tp) {
             if (silu_in_gemv) M_HIP(mm_quant(m, ly.w2, m->h13, inp, mid));
             else if (fused) M_HIP(mm_silu(m, ly.w2, m->h13, inp, mid));
@@ -611,6 +648,7 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
         M_HIP(mm_norm(m, m->output, inp, m->norm_w, m->xn, lg));
     } else {
         M_HIP(rmsnorm_quant(inp, E, m->norm_w, N, E, m->xn, E, &m->qE, layout, st));
+        if (xh) M_HIP(qa16_to_h16(m->qE, N, st));
         M_HIP(mm(m, m->output, m->qE, N, lg, ldlg, nullptr, 0));
     }
     if (m->Vl > 0) {                                          // rows V/G of the lm-head per rank -> gather the logits slices
@@ -1040,7 +1078,8 @@ extern "C" int fl_model_lora_apply(fl_model *m, const char *base_name, const flo
     cleanup();
     if (e != hipSuccess) return hip_fail(e, "fl_model_lora_apply");
     if (bad) return set_error(FL_EINVAL, "lora: a merged Q4_0 block scale fell below 2^-122");
-    if (t->f6) return fl_qtensor_build_f6(t, m->stream);    // the prefill path's copy follows the merged nibbles
+    if (t->f6 && (rc = fl_qtensor_build_f6(t, m->stream)) != FL_OK) return rc;    // the prefill paths' copies follow the merged nibbles
+    if (t->h16) return fl_qtensor_build_h16(t, m->stream);
     return FL_OK;
 }
 
@@ -1056,6 +1095,10 @@ extern "C" int fl_model_lora_restore(fl_model *m) {
         if (bk.mm) M_HIP(hipMemcpyAsync(bk.t->m, bk.mm, nblk * 4, hipMemcpyDeviceToDevice, m->stream));
         if (bk.t->f6) {
             const int rc = fl_qtensor_build_f6(bk.t, m->stream);
+            if (rc != FL_OK) return rc;
+        }
+        if (bk.t->h16) {
+            const int rc = fl_qtensor_build_h16(bk.t, m->stream);
             if (rc != FL_OK) return rc;
         }
     }

@@ -59,6 +59,18 @@ hipError_t gemm_q4_exact(const fl_qtensor &W, const fl_qact &xq, int N, float *y
                          const float *resid = nullptr, int ldr = 0);
 hipError_t gemm_q4_exact_mfma(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                               const float *resid = nullptr, int ldr = 0);   // K = 4 f16 MFMA form (gemm_q4_exact_mfma.hip)
+// round 4 form: ready-made f16 fragments (WH16 x XH16, q4_layout.h) by LDS-DMA, optional fused epilogues (gemm_q4_exact_h16.hip)
+size_t wh16_bytes(const fl_qtensor &W);
+size_t xh16_bytes(int N, int K);
+hipError_t qw16_to_h16(const fl_qtensor &W, uint16_t *wh, hipStream_t st);   // W.qs (QW16) -> WH16
+hipError_t qa16_to_h16(const fl_qact &xq, int N, hipStream_t st);            // xq.q (QA16) -> xq.h16
+bool gemm_q4_exact_h16_supports(const fl_qtensor &W, const fl_qact &xq, int N);
+hipError_t gemm_q4_exact_h16(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
+                             const float *resid = nullptr, int ldr = 0);
+hipError_t gemm_q4_exact_h16_qkv(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, const float *rope_tab, float *kc,
+                                 float *vc, int El, int D, int n_past, int n_ctx, hipStream_t st);
+hipError_t gemm_q4_exact_h16_silu(const fl_qtensor &W, const fl_qact &xq, int N, const uint16_t *silu_tab, const fl_qact &out,
+                                  hipStream_t st);
 hipError_t gemm_q4_exact_valu(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                               const float *resid = nullptr, int ldr = 0);   // v_dot4 form (exact_kernels.hip), cross-check
 hipError_t gemm_q4_naive(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st);

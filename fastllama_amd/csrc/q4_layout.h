@@ -64,6 +64,22 @@
 //   * code k occupies bits [6k, 6k+6) of the 24-byte string; element order inside a block is the one of QA16
 //     (position 8g + t = byte t of group g), on both sides.
 //   * fp6 E2M3 code of x/2, m = |x|: m < 4: 4m; m < 8: 8 + 2m; else 16 + m; sign in bit 5.
+//
+// ---------------------------------------------------------------------------------------------
+// H16 copies -- operands of the reference-order ("exact") prefill GEMM (gemm_q4_exact_h16.hip).  That kernel needs the EIGHT
+// 4-element sums of every (output, block) separately, as floats (the AVX2 lanes of ggml_vec_dot_q4_{0,1}_q8_0,
+// /root/reference/lib/ggml.c:2445-2487); v_mfma_f32_32x32x4_2b_f16 delivers two of them per instruction from f16 operands.
+// Nibbles and int8 quants are exact in f16, so the copies hold the integers themselves, already in the order the MFMA
+// fragments are read -- the inner loop has no unpack instruction left, and both operands reach LDS by DMA:
+//
+//   WH16 : f16 [ceil(M16/32) row tiles][KB][2 parts][64 lanes][8]     2 KiB per (32-row tile, block)
+//   XH16 : f16 [ceil(N/32) column tiles][KB][2 parts][64 lanes][8]    the same, columns instead of rows
+//
+//   * lane = i + 32 h is the MFMA lane that reads the 16 bytes: row (column) i of the tile, element half h
+//   * the 8 f16 of (part p, lane) are the MFMA steps s = 2p and 2p + 1, four elements each: elements 8s + 4h + {0,1,2,3}
+//     of the block -- step s, half h is the reference's AVX2 lane j = 2s + h (elements 4j .. 4j + 3)
+//   * WH16 values: Q4_0 16 (nib - 8) (the stored scale is d_w / 16, as for QW16), Q4_1 nib;  XH16 values: the int8 quants
+//   * rows / columns past the tensor are zero; derived data: QW16 / QA16 stay the forms of record
 #pragma once
 #include <stdint.h>
 
@@ -80,6 +96,7 @@ struct fl_qtensor {
     float *m;            // device (Q4_1) or nullptr
     int owns;            // 1: qs/d/m were hipMalloc'ed by the library
     uint8_t *f6;         // device, QW16F6 copy (always library-owned) or nullptr: the prefill path then takes the i8 form
+    uint16_t *h16;       // device, WH16 copy (always library-owned) or nullptr: operand of the reference-order prefill GEMM
 };
 
 // Quantized-activation workspace (either QA16 or QA1 depending on the consumer).
@@ -89,6 +106,7 @@ struct fl_qact {
     float *s;
     int N, N16, KB;
     uint8_t *q6;         // QA16F6 workspace (1.5 x the bytes of q) or nullptr
+    uint16_t *h16;       // XH16 workspace (2 x the bytes of q, columns padded to 32) or nullptr
 };
 
 static inline int fl_roundup(int x, int a) { return (x + a - 1) / a * a; }

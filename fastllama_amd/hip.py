@@ -69,6 +69,8 @@ _PROTOS = {
     "fl_qtensor_device_bytes": (C.c_size_t, [C.c_void_p]),
     "fl_qtensor_build_f6": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fl_qtensor_drop_f6": (None, [C.c_void_p]),
+    "fl_qtensor_build_h16": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fl_qtensor_drop_h16": (None, [C.c_void_p]),
     "fl_qtensor_free": (None, [C.c_void_p]),
     "fl_quantize_row_q8_0": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "fl_dequantize_row_q4_0": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

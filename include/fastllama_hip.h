@@ -80,6 +80,12 @@ void fl_qtensor_free(fl_qtensor *W);
  * only ever see the nibbles.  No reference counterpart (ggml keeps one host copy: lib/llama.cpp:223-258). */
 int fl_qtensor_build_f6(fl_qtensor *W, void *stream);
 void fl_qtensor_drop_f6(fl_qtensor *W);
+/* The reference-order prefill GEMM's f16 fragment copy of the weights (q4_layout.h "H16 copies", 64 bytes per row and block):
+ * the integers of the nibbles, laid out as the v_mfma_f32_32x32x4_2b_f16 A fragments whose results ARE the AVX2 lane sums of
+ * ggml_vec_dot_q4_{0,1}_q8_0 (lib/ggml.c:2445-2487).  A model builds the copies of its tensors on the first reference-order eval
+ * with N >= 9 (fl_model_eval); a caller that rewrites a tensor's blocks in place rebuilds it.  Derived data, like the fp6 copy. */
+int fl_qtensor_build_h16(fl_qtensor *W, void *stream);
+void fl_qtensor_drop_h16(fl_qtensor *W);
 
 /* ---------------------------------------------------------------- quantize_fns_t mirror -------- */
 /* Same five entry points, same argument meaning as `quantize_fns_t` (include/ggml.h:850-862,
