@@ -59,7 +59,24 @@ struct fl_qact_impl : fl_qact {
     int cap_N16, K;
     int layout;  // 16 or 1
     size_t q_bytes, s_bytes;
+    int h16_valid;   // the XH16 copy (q4_layout.h) matches q: written by fl_quantize_q8* in reference-order mode, a fused epilogue, or on demand
 };
+
+// Which arithmetic the operator-level entry points (fl_mul_mat_q, fl_mul_mat_q_f32) run: the reference's summation order (default, as
+// for models: fl_default_exact()) or the fast kernels.  fl_debug_set(4, 1 | 0) pins it for a process, -1 returns to the default.
+static int g_op_mode = -1;
+static bool op_exact() { return g_op_mode < 0 ? fl_default_exact() != 0 : g_op_mode != 0; }
+static int ensure_h16(const fl_qtensor *W, fl_qact_impl *a, void *st) {
+    if (!W->h16) {
+        const int rc = fl_qtensor_build_h16(const_cast<fl_qtensor *>(W), st);      // (a derived copy: logically const)
+        if (rc != FL_OK) return rc;
+    }
+    if (!a->h16_valid) {
+        FL_HIP(qa16_to_h16(*a, a->N, S(st)));
+        a->h16_valid = 1;
+    }
+    return FL_OK;
+}
 
 namespace fl { void gemm32_mixed_split(int MGT, int NGT, int *n_a, int *mg_split, int *n_b); }   // gemm_q4_mfma32.hip
 
@@ -447,6 +464,7 @@ int fl_quantize_q8_layout(fl_qact *a_, const float *x, int ldx, int N, int K, in
     a->N16 = fl_roundup(N, 16);
     a->KB = K / FL_QK;
     a->layout = layout;
+    a->h16_valid = 0;
     if (layout == 1) FL_HIP(quantize_q8_qa1(x, ldx, N, K, *a, S(st)));
     else FL_HIP(quantize_q8_qa16(x, ldx, N, K, *a, S(st)));
     return FL_OK;
@@ -469,6 +487,7 @@ int fl_debug_set(int what, int value) {
     if (what == 1) fl::g_gemv_force_waves = value;   // 0 = automatic, else 4 / 8 / 16 waves per 16-row group
     if (what == 3) fl::g_gemm_fp6 = value != 0;      // prefill GEMM: fp6 block-scaled form (1) or the i8 form (0, default) of the same tiles
     if (what == 2) g_debug_exact = value;            // the single-token test hooks (fl_debug_gemv_*, fl_debug_decode_attention*) in exact mode
+    if (what == 4) g_op_mode = value;                // operator-level entry points: 1 reference order, 0 fast kernels, -1 the default
     return FL_OK;
 }
 
@@ -495,6 +514,7 @@ int fl_mul_mat_q(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy, void
     const fl_qact_impl *a = static_cast<const fl_qact_impl *>(a_);
     int rc = check_mm(W, a, y, ldy);
     if (rc != FL_OK) return rc;
+    if (op_exact()) return fl_debug_mul_mat_q(W, a_, y, ldy, 3, st);
     if (a->layout == 1) {
         FL_HIP(gemv_q4(*W, *a, a->N, y, ldy, S(st)));
     } else {
@@ -505,17 +525,17 @@ int fl_mul_mat_q(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy, void
 }
 
 int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy, int which, void *st) {
-    const fl_qact_impl *a = static_cast<const fl_qact_impl *>(a_);
+    fl_qact_impl *a = const_cast<fl_qact_impl *>(static_cast<const fl_qact_impl *>(a_));
     int rc = check_mm(W, a, y, ldy);
     if (rc != FL_OK) return rc;
-    if (which == 5 || which == 6) {        // reference-order kernels of record for N >= 2: 5 = the H16 form (round 4), 6 = round 3's nibble form
+    if (which == 3 && a->layout == 16 && a->N >= 9) which = 5;     // the reference-order kernel of record for prefill sizes
+    if (which == 5 || which == 6) {        // reference-order tile kernels: 5 = the H16 form (round 4), 6 = round 3's nibble form
         if (a->layout != 16) return set_error(FL_EINVAL, "gemm needs the QA16 layout");
         if (which == 6) {
             FL_HIP(gemm_q4_exact_mfma(*W, *a, a->N, y, ldy, S(st)));
             return FL_OK;
         }
-        if (!W->h16 && (rc = fl_qtensor_build_h16(const_cast<fl_qtensor *>(W), st)) != FL_OK) return rc;
-        FL_HIP(qa16_to_h16(*a, a->N, S(st)));
+        if ((rc = ensure_h16(W, a, st)) != FL_OK) return rc;
         FL_HIP(gemm_q4_exact_h16(*W, *a, a->N, y, ldy, S(st)));
     } else if (which == 4) {               // reference-order tile kernel in its VALU (v_dot4) form: cross-check of the MFMA form
         if (a->layout != 16) return set_error(FL_EINVAL, "gemm needs the QA16 layout");
@@ -540,6 +560,12 @@ int fl_debug_mul_mat_q_resid(const fl_qtensor *W, const fl_qact *a_, float *y, i
     int rc = check_mm(W, a, y, ldy);
     if (rc != FL_OK) return rc;
     if (a->layout != 16) return set_error(FL_EINVAL, "gemm needs the QA16 layout");
+    if (op_exact()) {
+        fl_qact_impl *am = const_cast<fl_qact_impl *>(a);
+        if ((rc = ensure_h16(W, am, st)) != FL_OK) return rc;
+        FL_HIP(gemm_q4_exact_h16(*W, *a, a->N, y, ldy, S(st), resid, ldr));
+        return FL_OK;
+    }
     FL_HIP(gemm_q4_mfma(*W, *a, a->N, y, ldy, S(st), resid, ldr));
     return FL_OK;
 }
@@ -549,6 +575,12 @@ int fl_debug_gemm_qkv(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy,
     int rc = check_mm(W, a, y, ldy);
     if (rc != FL_OK) return rc;
     if (a->layout != 16) return set_error(FL_EINVAL, "gemm needs the QA16 layout");
+    if (op_exact()) {
+        fl_qact_impl *am = const_cast<fl_qact_impl *>(a);
+        if ((rc = ensure_h16(W, am, st)) != FL_OK) return rc;
+        FL_HIP(gemm_q4_exact_h16_qkv(*W, *a, a->N, y, ldy, rope_tab_dev, kc, vc, El, D, n_past, n_ctx, S(st)));
+        return FL_OK;
+    }
     FL_HIP(gemm_q4_mfma_qkv(*W, *a, a->N, y, ldy, rope_tab_dev, kc, vc, El, D, n_past, n_ctx, S(st)));
     return FL_OK;
 }
@@ -559,6 +591,14 @@ int fl_debug_gemm_silu(const fl_qtensor *W, const fl_qact *a_, const uint16_t *s
     if (a->layout != 16 || a->KB != W->KB) return set_error(FL_EINVAL, "gemm_silu: bad activation workspace");
     if ((size_t)a->N16 * (size_t)(W->M / 2) > out->q_bytes) return set_error(FL_EINVAL, "gemm_silu: output workspace too small");
     out->N = a->N; out->N16 = a->N16; out->KB = W->M / 64; out->layout = 16;
+    out->h16_valid = 0;
+    if (op_exact()) {
+        const int rc = ensure_h16(W, const_cast<fl_qact_impl *>(a), st);
+        if (rc != FL_OK) return rc;
+        FL_HIP(gemm_q4_exact_h16_silu(*W, *a, a->N, silu_tab_dev, *out, S(st)));
+        out->h16_valid = 1;
+        return FL_OK;
+    }
     FL_HIP(gemm_q4_mfma_silu(*W, *a, a->N, silu_tab_dev, *out, S(st)));
     return FL_OK;
 }

@@ -61,5 +61,10 @@ hipError_t quantize_row_q4_aos(int type, bool reference, const float *x, void *y
 hipError_t logits_nll(const float *logits, int ld, int V, const int *next_tok_dev, int j0, int rows, double *out_dev, hipStream_t st);
 hipError_t gather_cols(const float *tmp, int G, int N, int Vl, int ldp, float *out, int ldo, hipStream_t st);
 hipError_t add_rows(const float *a, int lda, const float *b, int ldb, float *o, int ldo, int N, int E, hipStream_t st);
+// row-split tensor parallelism (reference-order mode): the byte work around its all-gathers (eval_kernels.hip)
+hipError_t pack3(void *dst, const void *s0, size_t b0, const void *s1, size_t b1, const void *s2, size_t b2, hipStream_t st);
+hipError_t unpack3(const void *stage, size_t msg_bytes, int G, int rows, void *o0, size_t chunk0, void *o1, size_t chunk1, void *o2,
+                   size_t chunk2, hipStream_t st);
+hipError_t gather_rows_add(const float *tmp, int G, int N, int Ml, const float *resid, int ldr, float *out, int ldo, hipStream_t st);
 
 }  // namespace fl

@@ -1801,4 +1801,78 @@ hipError_t gather_cols(const float *tmp, int G, int N, int Vl, int ldp, float *o
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Row-split tensor parallelism (reference-order mode): every matmul is split by OUTPUT rows -- the reference's own split across
+// threads (/root/reference/lib/ggml.c:8127-8135) -- so each output is one rank's full-K dot in the reference's order and nothing is
+// ever summed across ranks.  What travels instead: the Q8_0 operand of wo / w2 (each rank quantized the 32-element blocks of its
+// own features) and the f32 output rows, both by all-gather.  The three kernels below are the byte work around those collectives.
+// ------------------------------------------------------------------------------------------------
+// dst <- seg0 | seg1 | seg2 (4-byte units): the used part of a Q8_0 workspace's q, d, s planes as ONE message
+__global__ void pack3_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ s0, int64_t n0, const uint32_t *__restrict__ s1, int64_t n1,
+                             const uint32_t *__restrict__ s2, int64_t n2) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < n0) dst[gid] = s0[gid];
+    else if (gid < n0 + n1) dst[gid] = s1[gid - n0];
+    else if (gid < n0 + n1 + n2) dst[gid] = s2[gid - n0 - n1];
+}
+hipError_t pack3(void *dst, const void *s0, size_t b0, const void *s1, size_t b1, const void *s2, size_t b2, hipStream_t st) {
+    if ((b0 | b1 | b2) & 3) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)((b0 + b1 + b2) >> 2);
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, reinterpret_cast<uint32_t *>(dst),
+                       reinterpret_cast<const uint32_t *>(s0), (int64_t)(b0 >> 2), reinterpret_cast<const uint32_t *>(s1), (int64_t)(b1 >> 2),
+                       reinterpret_cast<const uint32_t *>(s2), (int64_t)(b2 >> 2));
+    return hipGetLastError();
+}
+
+// The all-gathered messages (`stage`: G messages of `msg` bytes, rank order) back into full-K planes.  In every layout here a rank's
+// K slice is a run of `chunk` bytes per row of the plane (QA16: row = column group, chunk = KB_local * 512 for q, KB_local * 64 for
+// d / s; QA1: one row): out[row][r][chunk] = message r [seg offset + row * chunk ...].  4-byte units.
+__global__ void unpack3_kernel(const uint32_t *__restrict__ stage, int64_t msg_w, int G, int rows, uint32_t *__restrict__ o0, int c0,
+                               uint32_t *__restrict__ o1, int c1, uint32_t *__restrict__ o2, int c2) {
+    const int64_t n0 = (int64_t)rows * c0, n1 = (int64_t)rows * c1, n2 = (int64_t)rows * c2, per = n0 + n1 + n2;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= per * G) return;
+    const int r = (int)(gid / per);
+    int64_t u = gid % per;
+    uint32_t *o;
+    int c;
+    if (u < n0) { o = o0; c = c0; }
+    else if (u < n0 + n1) { u -= n0; o = o1; c = c1; }
+    else { u -= n0 + n1; o = o2; c = c2; }
+    const int64_t row = u / c, i = u % c;
+    o[(row * G + r) * c + i] = stage[(int64_t)r * msg_w + (gid % per)];
+}
+hipError_t unpack3(const void *stage, size_t msg_bytes, int G, int rows, void *o0, size_t chunk0, void *o1, size_t chunk1, void *o2,
+                   size_t chunk2, hipStream_t st) {
+    if ((msg_bytes | chunk0 | chunk1 | chunk2) & 3) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)rows * (int64_t)((chunk0 + chunk1 + chunk2) >> 2) * G;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const uint32_t *>(stage),
+                       (int64_t)(msg_bytes >> 2), G, rows, reinterpret_cast<uint32_t *>(o0), (int)(chunk0 >> 2), reinterpret_cast<uint32_t *>(o1),
+                       (int)(chunk1 >> 2), reinterpret_cast<uint32_t *>(o2), (int)(chunk2 >> 2));
+    return hipGetLastError();
+}
+
+// out[n][r * Ml + j] = tmp[r][n][j] + resid[n][r * Ml + j]: the all-gathered output rows of a row-split matmul and the ggml_add
+// that follows wo / w2 (lib/llama.cpp:407, :441) -- one plain f32 add per element, as in the single-GPU epilogue
+__global__ void gather_rows_add_kernel(const float *__restrict__ tmp, int G, int N, int Ml, const float *__restrict__ resid, int ldr,
+                                       float *__restrict__ out, int ldo) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int m4 = Ml >> 2;
+    if (gid >= (int64_t)G * N * m4) return;
+    const int j = (int)(gid % m4) * 4, n = (int)((gid / m4) % N), r = (int)(gid / ((int64_t)m4 * N));
+    const float4 v = *reinterpret_cast<const float4 *>(tmp + ((int64_t)r * N + n) * Ml + j);
+    const float4 q = *reinterpret_cast<const float4 *>(resid + (int64_t)n * ldr + (int64_t)r * Ml + j);
+    *reinterpret_cast<float4 *>(out + (int64_t)n * ldo + (int64_t)r * Ml + j) =
+        make_float4(__fadd_rn(v.x, q.x), __fadd_rn(v.y, q.y), __fadd_rn(v.z, q.z), __fadd_rn(v.w, q.w));
+}
+hipError_t gather_rows_add(const float *tmp, int G, int N, int Ml, const float *resid, int ldr, float *out, int ldo, hipStream_t st) {
+    if ((Ml | ldr | ldo) & 3) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)G * N * (Ml >> 2);
+    hipLaunchKernelGGL(gather_rows_add_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, tmp, G, N, Ml, resid, ldr, out, ldo);
+    return hipGetLastError();
+}
+
 }  // namespace fl

@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include "q4_device.h"
 #include "q4_kernels.h"
+#include <type_traits>
 #include "gemm_epi.h"
 
 #pragma clang fp contract(off)
@@ -38,23 +39,28 @@ typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
 template <int TYPE>
 struct XH {
     static constexpr bool Q41 = TYPE == FL_TYPE_Q4_1;
-    static constexpr int NSTAGE = 3;
-    static constexpr int OFF_B = 8192;                         // A: [2 row tiles][2 blocks][2 parts][1 KiB], then B the same
-    static constexpr int OFF_SC = 16384;                       // d_w [2 blocks][64 rows], d_x [2][64 cols] (, m_w, s_x)
-    static constexpr int STAGE = OFF_SC + (Q41 ? 2048 : 1024);
-    static constexpr int LPW = Q41 ? 6 : 5;                    // DMA instructions per wave and stage
+    static constexpr int KS = 4;                               // blocks per K-step (one barrier per step)
+    static constexpr int OFF_B = 16384;                        // A: [2 row tiles][4 blocks][2 parts][1 KiB], then B the same
+    static constexpr int OFF_SC = 32768;                       // d_w [4 groups][4 blocks][16 rows], d_x the same (, m_w, s_x): 1 KiB each
+    static constexpr int STAGE = OFF_SC + (Q41 ? 4096 : 2048);
+    static constexpr int LPW = 9;                              // DMA instructions per wave and stage: 8 fragment pieces + 1 scale piece
     static constexpr int ACT_BYTES = 32 * 64 * 4;              // f32 tile of the silu epilogue (reuses the ring)
-    static constexpr int LDS_BYTES = NSTAGE * STAGE;
+    static constexpr int LDS_BYTES = 2 * STAGE;                // two stages: 68 / 72 KiB, two workgroups per CU
 };
 
 enum { EPI_PLAIN = 0, EPI_ROPE = 1, EPI_SILU = 2 };
 
-#if defined(__HIP_DEVICE_COMPILE__)
-#ifdef XH_NOPK
-#define XH_ATTR __attribute__((target("no-packed-fp32-ops")))
+#ifdef XH_TIMING   // development build only: per-workgroup clocks of the launch phases (scripts/dev/xh_timeline.py)
+__device__ long long xh_dbg[8192 * 8];
+#define XH_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) xh_dbg[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 #else
-#define XH_ATTR
+#define XH_STAMP(k) do {} while (0)
 #endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// (no packed f32: beside MFMAs v_pk_fma_f32 costs twice what two v_fma_f32 do, profiles/r04_ubench_coexec5.txt)
+#define XH_ATTR __attribute__((target("no-packed-fp32-ops")))
+#define XIC(x) std::integral_constant<int, (x)>{}
 template <int TYPE, int EPI>
 __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
     const uint16_t *wh, const float *dW, const float *mW, const uint16_t *xh, const float *xd, const float *xs, int N, int M,
@@ -62,6 +68,8 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
     const float *__restrict__ resid, int ldr, GemmSiluEpi epi) {
     using C = XH<TYPE>;
     constexpr bool Q41 = C::Q41;
+    constexpr int KS = C::KS;
+    XH_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -78,59 +86,55 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
     }
     const int tn = bid % tiles_n, tm = bid / tiles_n;
 
-    // ---- DMA plan.  Slots 0..3 of a wave: 1-KiB fragment pieces p = wave + 4 s (p < 8: A, else B); slot 4: one 256-byte scale
-    //      piece (wave 0/1: d_w of block 0/1, wave 2/3: d_x); slot 5 (Q4_1): m_w / s_x likewise.  Everything but the lane offset is
-    //      wave-uniform.  Out-of-range tiles / groups (and, on the activation side, blocks past K) read zeros through the bounds
-    //      check of the buffer descriptor.
-    v4i rsrc[C::LPW];
-    uint32_t voff[C::LPW];
-    int unit[C::LPW], loff[C::LPW], tailblk[C::LPW];
-#pragma unroll
-    for (int s = 0; s < C::LPW; ++s) {
-        const void *base;
-        uint32_t bytes;
-        tailblk[s] = -1;
-        if (s < 4) {
-            const int p = wave + 4 * s, side = p >> 3, t = (p >> 2) & 1, blk = (p >> 1) & 1, pp = p & 1;
-            const int tile = (side ? tn : tm) * 2 + t, ntile = side ? NT32 : MT32;
-            base = side ? (const void *)xh : (const void *)wh;
-            bytes = (uint32_t)ntile * (uint32_t)KB * 2048u;
-            voff[s] = tile < ntile ? ((uint32_t)tile * (uint32_t)KB + (uint32_t)blk) * 2048u + (uint32_t)pp * 1024u + (uint32_t)lane * 16u
-                                   : 0x80000000u;
-            unit[s] = 2048;
-            loff[s] = side * C::OFF_B + ((t * 2 + blk) * 2 + pp) * 1024;
-        } else {
-            const int side = wave >> 1, blk = wave & 1, pl = s - 4;            // pl 0: d planes, 1: m_w / s_x
-            const int g = (side ? tn : tm) * 4 + (lane >> 4), ng = side ? NGT : MGT;
-            base = side ? (const void *)(pl ? xs : xd) : (const void *)(pl ? mW : dW);
-            bytes = (uint32_t)ng * (uint32_t)KB * 64u;
-            voff[s] = g < ng ? (((uint32_t)g * (uint32_t)KB + (uint32_t)blk) * 16u + (uint32_t)(lane & 15)) * 4u : 0x80000000u;
-            unit[s] = 64;
-            loff[s] = C::OFF_SC + pl * 1024 + side * 512 + blk * 256;
-            if (side) tailblk[s] = blk;                                        // a block past K must contribute nothing: d_x = s_x = 0
-        }
-        const uint64_t bp = (uint64_t)(uintptr_t)base;
-        rsrc[s] = v4i{__builtin_amdgcn_readfirstlane((int)(uint32_t)bp), __builtin_amdgcn_readfirstlane((int)((bp >> 32) & 0xFFFF)),
-                      __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
-        unit[s] = __builtin_amdgcn_readfirstlane(unit[s]);
-        loff[s] = __builtin_amdgcn_readfirstlane(loff[s]);
-        tailblk[s] = __builtin_amdgcn_readfirstlane(tailblk[s]);
-    }
-    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-    auto fill = [&](int st, int kb0, int s_lo = 0, int s_hi = C::LPW) __attribute__((always_inline)) {
-#pragma unroll
-        for (int s = 0; s < C::LPW; ++s) {
-            if (s < s_lo || s >= s_hi) continue;
-            uint32_t vo = voff[s];
-            if (s >= 4 && tailblk[s] >= 0 && kb0 + tailblk[s] >= KB) vo = 0x80000000u;
-            const uint32_t dst = lds0 + (uint32_t)(st * C::STAGE + loff[s]);
-            if (s < 4)
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                             :: "s"(dst), "v"(vo), "s"(rsrc[s]), "s"(kb0 * unit[s]) : "memory", "m0");
-            else
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                             :: "s"(dst), "v"(vo), "s"(rsrc[s]), "s"(kb0 * unit[s]) : "memory", "m0");
-        }
+    // ---- DMA plan.  Per K-step (4 blocks) a wave moves 8 fragment pieces of 1 KiB (piece p = wave + 4 j of 32: side p >> 4, tile
+    //      (p >> 3) & 1, block (p >> 1) & 3, part p & 1) and one scale piece of 1 KiB (Q4_0: waves 0 / 1 d_w / d_x, waves 2 / 3 the same
+    //      again -- every wave issues the same number of loads, so one counted wait is valid for all; Q4_1: d_w, d_x, m_w, s_x).
+    //      Everything wave-uniform travels in SGPRs (descriptor, scalar offset); the lane part is ONE VGPR per kind: lane * 16 for
+    //      the fragments, the (group, block, 4 rows) gather offset for the scales.  Tiles / groups past the tensor re-read the last
+    //      one (their outputs are never stored); blocks past K re-read block K - 1 for the fragments and read ZERO scales on the
+    //      activation side (bounds check of the descriptor): d_x = s_x = 0, the block contributes nothing.
+    uint32_t lane16 = (uint32_t)lane * 16u;
+    int tileA0 = min(tm * 2, MT32 - 1), tileA1 = min(tm * 2 + 1, MT32 - 1), tileB0 = min(tn * 2, NT32 - 1), tileB1 = min(tn * 2 + 1, NT32 - 1);
+    const uint64_t wbp = (uint64_t)(uintptr_t)wh, xbp = (uint64_t)(uintptr_t)xh;
+    v4i rA = v4i{(int)(uint32_t)wbp, (int)((wbp >> 32) & 0xFFFF), (int)((uint32_t)MT32 * (uint32_t)KB * 2048u), 0x00020000};
+    v4i rB = v4i{(int)(uint32_t)xbp, (int)((xbp >> 32) & 0xFFFF), (int)((uint32_t)NT32 * (uint32_t)KB * 2048u), 0x00020000};
+    const int sc_kind = Q41 ? wave : (wave & 1);                               // 0 d_w, 1 d_x, 2 m_w, 3 s_x
+    bool sc_act = (sc_kind & 1) != 0;
+    const float *scp = sc_kind == 0 ? dW : sc_kind == 1 ? xd : sc_kind == 2 ? mW : xs;
+    const uint64_t sbp = (uint64_t)(uintptr_t)scp;
+    const int sc_ng = sc_act ? NGT : MGT;
+    v4i rS = v4i{__builtin_amdgcn_readfirstlane((int)(uint32_t)sbp), __builtin_amdgcn_readfirstlane((int)((sbp >> 32) & 0xFFFF)),
+                       __builtin_amdgcn_readfirstlane((int)((uint32_t)sc_ng * (uint32_t)KB * 64u)), 0x00020000};
+    // lane -> (group lane >> 4, 16-byte chunk lane & 15 of the group's 4 blocks x 16 rows): byte offset relative to block kb0 of group 0
+    int sc_g = min((sc_act ? tn : tm) * 4 + (lane >> 4), sc_ng - 1), sc_blk = (lane & 15) >> 2;
+    uint32_t sc_voff = ((uint32_t)sc_g * (uint32_t)KB + (uint32_t)sc_blk) * 64u + (uint32_t)(lane & 3) * 16u;
+    int sc_loff = C::OFF_SC + (Q41 ? ((sc_kind & 1) * 1024 + (sc_kind >> 1) * 2048) : sc_kind * 1024);
+    uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    // fragment piece j (0..7) of this wave for the K-step starting at block kb0, into stage st.  With p = wave + 4 j: side = j >> 2,
+    // tile = (j >> 1) & 1 are compile-time, block = (wave >> 1) + 2 (j & 1), part = wave & 1 -- scalars.
+    const int wb = __builtin_amdgcn_readfirstlane(wave >> 1), wp = __builtin_amdgcn_readfirstlane(wave & 1);
+    uint32_t tbase[4];                                                         // byte offset of block 0, part wp of tiles A0, A1, B0, B1
+    tbase[0] = (uint32_t)__builtin_amdgcn_readfirstlane(tileA0 * KB * 2048 + wp * 1024);
+    tbase[1] = (uint32_t)__builtin_amdgcn_readfirstlane(tileA1 * KB * 2048 + wp * 1024);
+    tbase[2] = (uint32_t)__builtin_amdgcn_readfirstlane(tileB0 * KB * 2048 + wp * 1024);
+    tbase[3] = (uint32_t)__builtin_amdgcn_readfirstlane(tileB1 * KB * 2048 + wp * 1024);
+    uint32_t dstw = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds0 + (wb * 2 + wp) * 1024);
+    auto fill_frag = [&](auto JJ, int st, int kb0) XH_ATTR __attribute__((always_inline)) {
+        constexpr int j = decltype(JJ)::value, side = j >> 2, t = (j >> 1) & 1;
+        const int kb = min(kb0 + wb + 2 * (j & 1), KB - 1);
+        const uint32_t soff = tbase[side * 2 + t] + (uint32_t)kb * 2048u;
+        const uint32_t dst = dstw + (uint32_t)(st * C::STAGE + side * C::OFF_B + (t * 4 + 2 * (j & 1)) * 2048);
+        const uint32_t vo = lane16;                                            // (named copies: a generic lambda does not capture a
+        const v4i rs = side ? rB : rA;                                         //  variable that only an asm operand mentions)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory", "m0");
+    };
+    auto fill_scale = [&](int st, int kb0) XH_ATTR __attribute__((always_inline)) {
+        uint32_t vo = sc_voff;
+        if (sc_act && kb0 + sc_blk >= KB) vo = 0x80000000u;                     // activation scales of a block past K: zero
+        else if (kb0 + sc_blk >= KB) vo = sc_voff - (uint32_t)(kb0 + sc_blk - (KB - 1)) * 64u;   // weight scales: block K - 1 again (finite)
+        const uint32_t dst = lds0 + (uint32_t)(st * C::STAGE + sc_loff);
+        const v4i rs = rS;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(dst), "v"(vo), "s"(rs), "s"(kb0 * 64) : "memory", "m0");
     };
 
     v16f acc[8], summs;
@@ -141,69 +145,109 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
 #pragma unroll
     for (int e = 0; e < 16; ++e) summs[e] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(acc[j]));    // (opaque zeros: no peeled first trip with four D tiles alive)
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(acc[j]));    // (opaque zeros: no peeled first trip)
     const v32f zero32 = {};
 
-    // per-lane LDS offsets inside a stage: fragments of block u at + u * 2048 (+ 1024 for the second part), scales of block h
-    const int a_off = wr * 4096 + lane * 16, b_off = C::OFF_B + wc * 4096 + lane * 16;
-    const int sw_off = C::OFF_SC + h * 256 + (32 * wr + i) * 4, sx_off = C::OFF_SC + 512 + h * 256 + (32 * wc + i) * 4;
+    // per-lane LDS offsets inside a stage: fragments of block u at + u * 2048 (+ 1024 for the second part); scales of block u
+    const int a_off = wr * 8192 + lane * 16, b_off = C::OFF_B + wc * 8192 + lane * 16;
+    const int sw_off = C::OFF_SC + ((2 * wr + (i >> 4)) * 4 + h) * 64 + (i & 15) * 4;          // + 128 for the second pair, + 2048: m_w
+    const int sx_off = C::OFF_SC + 1024 + ((2 * wc + (i >> 4)) * 4 + h) * 64 + (i & 15) * 4;   // + 2048: s_x
 
-    const int nsteps = (KB + 1) >> 1;
-    fill(0, 0);
-    fill(1, 2);
+    const int nsteps = (KB + KS - 1) / KS;
+    fill_frag(XIC(0), 0, 0); fill_frag(XIC(1), 0, 0); fill_frag(XIC(2), 0, 0); fill_frag(XIC(3), 0, 0);
+    fill_frag(XIC(4), 0, 0); fill_frag(XIC(5), 0, 0); fill_frag(XIC(6), 0, 0); fill_frag(XIC(7), 0, 0);
+    fill_scale(0, 0);
     int cur = 0;
 #pragma unroll 1
     for (int t = 0; t < nsteps; ++t) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::LPW) : "memory");          // this wave's pieces of stage t have landed
-        __builtin_amdgcn_s_barrier();                                          // ... everyone's have, and everyone is done with stage t - 1
-        const int nst = cur == 0 ? 2 : cur - 1;                                // block pair t + 2 goes into the stage pair t - 1 occupied
-#if !defined(XH_SPREAD) && !defined(XH_NODMA)
-        fill(nst, 2 * (t + 2));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's pieces of K-step t have landed
+#ifndef XH_NOBAR
+        __builtin_amdgcn_s_barrier();                                          // ... everyone's have, and everyone is done with step t - 1
 #endif
+        if (t == 0) XH_STAMP(1);
+        if (t == 1) XH_STAMP(2);
+        if (t == 2) XH_STAMP(3);
         const unsigned char *base = smem + cur * C::STAGE;
-        const float dw = *reinterpret_cast<const float *>(base + sw_off), dx = *reinterpret_cast<const float *>(base + sx_off);
-        const v32f P = __builtin_amdgcn_mfma_f32_32x32x1f32(dw, dx, zero32, 0, 0, 0);       // rn(d_w d_x) of blocks 2t (regs 0..15), 2t+1
-        if (Q41) {                                                             // summs: one chain, block 2t then 2t + 1 (k = 0, 1)
-            const float mw = *reinterpret_cast<const float *>(base + sw_off + 1024), sx = *reinterpret_cast<const float *>(base + sx_off + 1024);
-            summs = __builtin_amdgcn_mfma_f32_32x32x2f32(mw, sx, summs, 0, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint4 a01 = *reinterpret_cast<const uint4 *>(base + a_off + u * 2048);
-            const uint4 a23 = *reinterpret_cast<const uint4 *>(base + a_off + u * 2048 + 1024);
-            const uint4 b01 = *reinterpret_cast<const uint4 *>(base + b_off + u * 2048);
-            const uint4 b23 = *reinterpret_cast<const uint4 *>(base + b_off + u * 2048 + 1024);
-            v2u32 af[4] = {{a01.x, a01.y}, {a01.z, a01.w}, {a23.x, a23.y}, {a23.z, a23.w}};
-            const v2u32 bf[4] = {{b01.x, b01.y}, {b01.z, b01.w}, {b23.x, b23.y}, {b23.z, b23.w}};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#ifdef XH_NOCOMP
-                v32f D = zero32;
-                asm volatile("" : "+v"(D) : "v"(af[s]), "v"(bf[s]));
-#else
-                const v32f D = __builtin_amdgcn_mfma_f32_32x32x4f16(__builtin_bit_cast(v4h, af[s]), __builtin_bit_cast(v4h, bf[s]), zero32, 0, 0, 0);
+        const int nst = cur ^ 1, nkb = (t + 1) * KS;                           // K-step t + 1 goes into the stage step t - 1 occupied
+        // Software pipeline inside the wave: the lane-sum MFMA of group g + 1 is issued BEFORE the 32 fma of group g (two D tiles),
+        // so a wave alone on its SIMD (its neighbour waiting at a barrier) still keeps both pipes fed: coexec5, 277 vs 529 ns.
+        // fragments: 8 bytes per lane and MFMA (steps 2p, 2p + 1 of a block sit side by side in a 16-byte slot), read one group ahead
+        auto frag_a = [&](auto G) XH_ATTR __attribute__((always_inline)) -> v2u32 {
+            constexpr int g = decltype(G)::value, u = g >> 2, s = g & 3;
+            return *reinterpret_cast<const v2u32 *>(base + a_off + u * 2048 + (s >> 1) * 1024 + (s & 1) * 8);
+        };
+        auto frag_b = [&](auto G) XH_ATTR __attribute__((always_inline)) -> v2u32 {
+            constexpr int g = decltype(G)::value, u = g >> 2, s = g & 3;
+            return *reinterpret_cast<const v2u32 *>(base + b_off + u * 2048 + (s >> 1) * 1024 + (s & 1) * 8);
+        };
+        v2u32 fa = frag_a(XIC(0)), fb = frag_b(XIC(0)), fan = frag_a(XIC(1)), fbn = frag_b(XIC(1));
+        float dw = *reinterpret_cast<const float *>(base + sw_off), dx = *reinterpret_cast<const float *>(base + sx_off);
+        v32f P = __builtin_amdgcn_mfma_f32_32x32x1f32(dw, dx, zero32, 0, 0, 0);             // rn(d_w d_x) of blocks 0 (regs 0..15), 1
+#ifndef XH_PIPE
+#define XH_PIPE 0
 #endif
-#if defined(XH_SPREAD) && !defined(XH_NODMA)
-                if (u * 4 + s < C::LPW) fill(nst, 2 * (t + 2), u * 4 + s, u * 4 + s + 1);   // one DMA piece in the shadow of each of the first MFMAs
-#endif
-#ifndef XH_NOCOMP
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    acc[2 * s][e] = __builtin_fmaf(P[16 * u + e], D[e], acc[2 * s][e]);
-                    acc[2 * s + 1][e] = __builtin_fmaf(P[16 * u + e], D[16 + e], acc[2 * s + 1][e]);
+        v32f D0, D1;
+        if (XH_PIPE) D0 = __builtin_amdgcn_mfma_f32_32x32x4f16(__builtin_bit_cast(v4h, fa), __builtin_bit_cast(v4h, fb), zero32, 0, 0, 0);
+        auto group = [&](auto G) XH_ATTR __attribute__((always_inline)) {
+            constexpr int g = decltype(G)::value, u = g >> 2, s = g & 3;
+            v32f &Dg = (XH_PIPE && (g & 1)) ? D1 : D0;
+            v32f &Dn = (g & 1) ? D0 : D1;
+            if (XH_PIPE) {
+                if (g + 1 < 4 * KS) {
+                    Dn = __builtin_amdgcn_mfma_f32_32x32x4f16(__builtin_bit_cast(v4h, fan), __builtin_bit_cast(v4h, fbn), zero32, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g + 2 < 4 * KS) {            // operands of the group after next, in the shadow of that MFMA
+                        fan = frag_a(XIC(g + 2 < 4 * KS ? g + 2 : 0));
+                        fbn = frag_b(XIC(g + 2 < 4 * KS ? g + 2 : 0));
+                    }
                 }
+            } else {
+                D0 = __builtin_amdgcn_mfma_f32_32x32x4f16(__builtin_bit_cast(v4h, fa), __builtin_bit_cast(v4h, fb), zero32, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                fa = fan; fb = fbn;
+#ifdef XH_NOLDS
+                asm volatile("" : "+v"(fan), "+v"(fbn));
+                if (false) {
 #else
-                acc[2 * s][0] += D[0];
+                if (g + 2 < 4 * KS) {
 #endif
-                // Pin the order: these 32 fma are issued before the NEXT lane-sum MFMA (whose A operand passes through this
-                // statement) -- left alone, the compiler sinks them to the next block's and keeps four D tiles (128 VGPRs) alive.
-                if (s < 3) asm volatile("" : "+v"(acc[2 * s]), "+v"(acc[2 * s + 1]), "+v"(af[s + 1]));
-                else asm volatile("" : "+v"(acc[2 * s]), "+v"(acc[2 * s + 1]));
+                    fan = frag_a(XIC(g + 2 < 4 * KS ? g + 2 : 0));
+                    fbn = frag_b(XIC(g + 2 < 4 * KS ? g + 2 : 0));
+                }
+            }
+            if (g == 4) {                        // scales of the second block pair
+                dw = *reinterpret_cast<const float *>(base + sw_off + 128);
+                dx = *reinterpret_cast<const float *>(base + sx_off + 128);
+            }
+#ifndef XH_NODMA
+            if (g < 8) fill_frag(XIC(g < 8 ? g : 0), nst, nkb);          // ... and the DMA of K-step t + 1
+            if (g == 8) fill_scale(nst, nkb);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[2 * s][e] = __builtin_fmaf(P[16 * (u & 1) + e], Dg[e], acc[2 * s][e]);
+                acc[2 * s + 1][e] = __builtin_fmaf(P[16 * (u & 1) + e], Dg[16 + e], acc[2 * s + 1][e]);
+            }
+            // Pin the order: these 32 fma complete before anything of the next group (left alone, the compiler sinks them).
+            asm volatile("" : "+v"(acc[2 * s]), "+v"(acc[2 * s + 1]));
+            if (g == 7 && KS > 2) {              // blocks 2, 3: their d_w x d_x (after the last use of the first pair's)
+                asm volatile("" : "+v"(dw), "+v"(dx), "+v"(acc[2 * s]));
+                P = __builtin_amdgcn_mfma_f32_32x32x1f32(dw, dx, zero32, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+        };
+        if (Q41) {                                                             // summs: one chain in block order (k = 0, 1 per MFMA)
+            const float mw0 = *reinterpret_cast<const float *>(base + sw_off + 2048), sx0 = *reinterpret_cast<const float *>(base + sx_off + 2048);
+            const float mw1 = *reinterpret_cast<const float *>(base + sw_off + 2048 + 128), sx1 = *reinterpret_cast<const float *>(base + sx_off + 2048 + 128);
+            summs = __builtin_amdgcn_mfma_f32_32x32x2f32(mw0, sx0, summs, 0, 0, 0);
+            summs = __builtin_amdgcn_mfma_f32_32x32x2f32(mw1, sx1, summs, 0, 0, 0);
         }
-        cur = cur == 2 ? 0 : cur + 1;
+        group(XIC(0)); group(XIC(1)); group(XIC(2)); group(XIC(3)); group(XIC(4)); group(XIC(5)); group(XIC(6)); group(XIC(7));
+        group(XIC(8)); group(XIC(9)); group(XIC(10)); group(XIC(11)); group(XIC(12)); group(XIC(13)); group(XIC(14)); group(XIC(15));
+        cur ^= 1;
     }
+    XH_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // the fills past the last pair (zeros / unused)
 
     // ---- ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)) [+ summs]: C layout col = i, row = (e & 3) + 8 (e >> 2) + 4 h ----
@@ -323,6 +367,7 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
             for (int k = 0; k < 4 && row + k < M; ++k) yp[k] = rp ? __fadd_rn(ov[k], rp[k]) : ov[k];
         }
     }
+    XH_STAMP(5);
 }
 #else
 template <int TYPE, int EPI>
@@ -436,7 +481,14 @@ template <int TYPE, int EPI>
 static hipError_t launch_xh(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st, const float *resid, int ldr,
                             const GemmSiluEpi &epi) {
     using C = XH<TYPE>;
-    static_assert(C::LDS_BYTES <= 65536 && C::ACT_BYTES <= C::LDS_BYTES, "no dynamic-LDS attribute needed");
+    static_assert(C::ACT_BYTES <= C::LDS_BYTES && 2 * C::LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+    static bool attr_set = false;                                              // (more than 64 KiB of dynamic LDS must be asked for)
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_q4_exact_h16_kernel<TYPE, EPI>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
     const int MT32 = (W.M16 + 31) / 32, NT32 = (N + 31) / 32;
     const int tiles = ((MT32 + 1) / 2) * ((NT32 + 1) / 2);
     hipLaunchKernelGGL((gemm_q4_exact_h16_kernel<TYPE, EPI>), dim3(tiles), dim3(256), C::LDS_BYTES, st, W.h16, W.d, W.m, xq.h16, xq.d, xq.s, N,
@@ -476,3 +528,6 @@ hipError_t gemm_q4_exact_h16_silu(const fl_qtensor &W, const fl_qact &xq, int N,
 }
 
 }  // namespace fl
+#ifdef XH_TIMING
+extern "C" int fl_debug_xh_timing(long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fl::xh_dbg), sizeof(long long) * (size_t)n * 8); }
+#endif

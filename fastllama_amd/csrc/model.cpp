@@ -33,8 +33,11 @@
 
 using namespace fl;
 
+// The arithmetic new models (and the operator-level entry points) run by default: 1 = the reference's summation order -- logits
+// bit-identical to the reference's x86 build, the mode that honours the llama_eval() contract; the faster kernels with their own
+// f32 order (~1e-2 on 7B logits) are the opt-in: FL_FAST=1 in the environment or fl_model_set_exact(m, 0).
 #ifndef FL_DEFAULT_EXACT
-#define FL_DEFAULT_EXACT 0
+#define FL_DEFAULT_EXACT 1
 #endif
 
 namespace {
@@ -74,6 +77,13 @@ struct fl_model : Act {
     bool tp_graph_failed = false;   // capturing the RCCL collectives into the decode hipGraph failed once: plain launches from then on
     int ldl = 0;                // row stride of `logits` (n_vocab rounded up to 4: 16-byte rows for the GEMM's vector stores)
     int G = 1, rank = 0;        // tensor parallel
+    // tp_rows: EVERY matmul split by output rows (wo / w2 too: rows E/G over the full K), the reference's own split across threads
+    // (lib/ggml.c:8127-8135): each output is one rank's reference-order dot, nothing is summed across ranks -- the tensor-parallel
+    // form of the reference-order mode.  What travels: the Q8_0 operands of wo / w2 and the f32 output rows, by all-gather.
+    // !tp_rows: wo / w2 split by K blocks, two all-reduces of partial sums per layer (the fast mode's split).
+    bool tp_rows = false;
+    fl_qact qFf{};              // tp_rows: the gathered Q8_0 operand of w2 (K = n_ff); the one of wo is gathered into qE
+    unsigned char *ag_send = nullptr, *ag_tmp = nullptr;   // tp_rows: one rank's message / the G gathered messages
     int El = 0, Hl = 0, Fl = 0; // local (per rank) widths
     fl_qtensor *tok_emb = nullptr, *output = nullptr;
     float *norm_w = nullptr;
@@ -203,6 +213,7 @@ fl_model *fl_model_create(const fl_model_params *p) {
     m->El = m->E / G; m->Hl = m->H / G; m->Fl = m->F / G;
     m->w13_il = m->Fl % 32 == 0;
     m->exact = fl_default_exact() != 0;
+    m->tp_rows = G > 1 && (getenv("FL_TP_ROWS") ? atoi(getenv("FL_TP_ROWS")) != 0 : m->exact);
     if (G > 1 && m->V % G == 0) { m->Vl = m->V / G; m->ldp = fl_roundup(m->Vl, 4); }
     m->layers.resize(m->L);
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -331,6 +342,13 @@ int fl_model_set_tensor(fl_model *m, const char *name, int type, const void *hos
         if ((rc = want_q(K, E)) != FL_OK) return rc;
         if (is_wo ? ly.wo : ly.w2) return set_error(FL_EINVAL, "%s was set twice", name);
         void *tmp = nullptr;
+        if (m->tp_rows) {                                   // rows [r E/G, (r+1) E/G) over the full K
+            M_HIP(hipMalloc(&tmp, (size_t)m->El * (K / FL_QK) * bs));
+            rc = stage_rows(host, bs, K / FL_QK, r * m->El, m->El, 0, K / FL_QK, tmp);
+            if (rc == FL_OK) rc = make_qtensor(m, is_wo ? &ly.wo : &ly.w2, tmp, m->El, K);
+            (void)hipFree(tmp);
+            return rc;
+        }
         M_HIP(hipMalloc(&tmp, (size_t)E * (Kl / FL_QK) * bs));
         rc = stage_rows(host, bs, K / FL_QK, 0, E, r * (Kl / FL_QK), (r + 1) * (Kl / FL_QK), tmp);   // K blocks of rank r
         if (rc == FL_OK) rc = make_qtensor(m, is_wo ? &ly.wo : &ly.w2, tmp, E, Kl);
@@ -395,6 +413,14 @@ int fl_model_finalize(fl_model *m) {
     M_HIP(hipHostMalloc((void **)&m->pinned, 16, hipHostMallocDefault));
     m->ldl = fl_roundup(V, 4);   // e.g. the 32001-token vocabularies of Alpaca / Vicuna style checkpoints
     if ((rc = act_alloc(m, *m)) != FL_OK) return rc;
+    if (m->tp_rows) {
+        if ((rc = qact_alloc(m, &m->qFf, m->B, m->F)) != FL_OK) return rc;
+        const size_t B16 = (size_t)fl_roundup(B, 16);
+        const size_t msg = B16 * (size_t)Fl + 2 * B16 * (size_t)(Fl / FL_QK) * 4;           // the largest Q8_0 message (operand of w2)
+        const size_t all = std::max((size_t)m->G * msg, std::max((size_t)B * E * 4, (size_t)m->F * 4));
+        if ((rc = dev_alloc(m, (void **)&m->ag_send, msg)) != FL_OK) return rc;
+        if ((rc = dev_alloc(m, (void **)&m->ag_tmp, all)) != FL_OK) return rc;
+    }
     if (m->Vl > 0) {
         if ((rc = dev_alloc(m, (void **)&m->logits_part, (size_t)B * m->ldp * 4)) != FL_OK) return rc;
         if ((rc = dev_alloc(m, (void **)&m->gather_tmp, (size_t)m->G * B * m->ldp * 4)) != FL_OK) return rc;
@@ -525,6 +551,34 @@ static int allreduce_if_tp(fl_model *m, float *buf, size_t count) {
     return fl_comm_allreduce_sum_f32(m->comm, buf, count, m->stream);
 }
 
+// tp_rows: the Q8_0 operand `loc` (K = Kl: the blocks of this rank's features) of every rank -> `full` (K = G Kl), the operand of
+// the row-split wo / w2 matmul; xh: also its XH16 copy (the H16 form of the reference-order GEMM)
+static int tp_gather_qact(fl_model *m, const fl_qact &loc, const fl_qact &full, int N, int Kl, int layout, bool xh) {
+    if (!m->comm) return set_error(FL_EINVAL, "tensor-parallel eval without a communicator");
+    const int KBl = Kl / FL_QK, G = m->G;
+    const size_t N16 = (size_t)fl_roundup(N, 16);
+    const size_t nv = layout == 16 ? N16 : (size_t)N;                          // vectors in the planes (QA1: q [n][KB][32], d / s [n][KB])
+    const size_t nq = nv * (size_t)Kl, nd = nv * (size_t)KBl * 4;
+    const size_t msg = nq + 2 * nd;
+    const int rows = layout == 16 ? (int)(N16 / 16) : N;
+    const size_t cq = layout == 16 ? (size_t)KBl * 512 : (size_t)Kl, cd = layout == 16 ? (size_t)KBl * 64 : (size_t)KBl * 4;
+    M_HIP(pack3(m->ag_send, loc.q, nq, loc.d, nd, loc.s, nd, m->stream));
+    const int rc = fl_comm_allgather_f32(m->comm, reinterpret_cast<const float *>(m->ag_send), msg / 4, reinterpret_cast<float *>(m->ag_tmp), m->stream);
+    if (rc != FL_OK) return rc;
+    M_HIP(unpack3(m->ag_tmp, msg, G, rows, full.q, cq, full.d, cd, full.s, cd, m->stream));
+    if (xh) M_HIP(qa16_to_h16(full, N, m->stream));
+    return FL_OK;
+}
+
+// tp_rows: out[N][E] = all ranks' output rows part[N][El] (+ resid): all-gather, then the ggml_add that follows wo / w2
+static int tp_gather_rows_add(fl_model *m, const float *part, int N, const float *resid, float *out) {
+    if (!m->comm) return set_error(FL_EINVAL, "tensor-parallel eval without a communicator");
+    const int rc = fl_comm_allgather_f32(m->comm, part, (size_t)N * m->El, reinterpret_cast<float *>(m->ag_tmp), m->stream);
+    if (rc != FL_OK) return rc;
+    M_HIP(gather_rows_add(reinterpret_cast<const float *>(m->ag_tmp), m->G, N, m->El, resid, m->E, out, m->E, m->stream));
+    return FL_OK;
+}
+
 // The fixed kernel sequence of one eval (what ggml_graph_compute walks node by node in the reference).  `dyn` != null:
 // positions are read from device memory (m->npast_dev) instead of the n_past argument -- the decode hipGraph.
 // [l0, l1): the layers to run; body_only: neither the token-embedding lookup before nor the final norm + lm-head after
@@ -598,12 +652,17 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
                     M_HIP((exact ? dot_f32_abt_exact : gemm_f32_abt)(m->att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, m->ao, El, D, N,
                                                                      D, P, Hl, 1.0f, 2, n_past, st, dyn, n_ctx));
                 M_HIP((layout == 16 ? quantize_q8_qa16 : quantize_q8_qa1)(m->ao, El, N, El, m->qEl, st));
-                if (xh) M_HIP(qa16_to_h16(m->qEl, N, st));
+                if (xh && !m->tp_rows) M_HIP(qa16_to_h16(m->qEl, N, st));
             }   // (the one-launch kernel wrote the Q8_0 operand of the wo matmul itself)
         }
         // wo projection + residual                                                                 :401-407
         if (!tp) {
             M_HIP(mm(m, ly.wo, m->qEl, N, mid, E, inp, E));
+        } else if (m->tp_rows) {
+            int rc = tp_gather_qact(m, m->qEl, m->qE, N, El, layout, xh);                           // the operand, K = n_embd
+            if (rc != FL_OK) return rc;
+            M_HIP(mm(m, ly.wo, m->qE, N, m->part, El, nullptr, 0));                                 // this rank's rows
+            if ((rc = tp_gather_rows_add(m, m->part, N, inp, mid)) != FL_OK) return rc;
         } else {
             M_HIP(mm(m, ly.wo, m->qEl, N, m->part, E, nullptr, 0));
             int rc = allreduce_if_tp(m, m->part, (size_t)N * E);
@@ -631,6 +690,19 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
             if (silu_in_gemv) M_HIP(mm_quant(m, ly.w2, m->h13, inp, mid));
             else if (fused) M_HIP(mm_silu(m, ly.w2, m->h13, inp, mid));
             else M_HIP(mm(m, ly.w2, m->qF, N, inp, E, mid, E));                                   // + inpFF :441
+        } else if (m->tp_rows) {
+            int rc;
+            if (silu_in_gemv) {                   // decode: the f32 silu * mul features of every rank, quantized by the GEMV's prologue
+                if (!m->comm) return set_error(FL_EINVAL, "tensor-parallel eval without a communicator");
+                rc = fl_comm_allgather_f32(m->comm, m->h13, (size_t)Fl, reinterpret_cast<float *>(m->ag_tmp), st);
+                if (rc != FL_OK) return rc;
+                M_HIP(mm_quant(m, ly.w2, reinterpret_cast<const float *>(m->ag_tmp), m->part, nullptr));
+            } else {
+                if (fused) return set_error(FL_EINVAL, "row-split tensor parallelism needs n_ff / tp_size to be a multiple of 32");
+                if ((rc = tp_gather_qact(m, m->qF, m->qFf, N, Fl, layout, xh)) != FL_OK) return rc;     // the operand, K = n_ff
+                M_HIP(mm(m, ly.w2, m->qFf, N, m->part, El, nullptr, 0));
+            }
+            if ((rc = tp_gather_rows_add(m, m->part, N, mid, inp)) != FL_OK) return rc;
         } else {
             if (silu_in_gemv) M_HIP(mm_quant(m, ly.w2, m->h13, m->part, nullptr));
             else if (fused) M_HIP(mm_silu(m, ly.w2, m->h13, m->part, nullptr));
@@ -858,10 +930,13 @@ int fl_model_set_exact(fl_model *m, int on) {
     return FL_OK;
 }
 int fl_model_get_exact(const fl_model *m) { return m && m->exact ? 1 : 0; }
-/* the mode new models start in: FL_EXACT=1 / FL_EXACT=0 in the environment, else the built-in default */
+/* the mode new models start in: FL_FAST=1 (or FL_EXACT=0) in the environment selects the fast kernels, FL_EXACT=1 the reference
+ * order; else the built-in default (reference order) */
 int fl_default_exact(void) {
     const char *e = getenv("FL_EXACT");
     if (e && *e) return atoi(e) != 0;
+    const char *f = getenv("FL_FAST");
+    if (f && *f) return atoi(f) == 0;
     return FL_DEFAULT_EXACT;
 }
 
@@ -994,10 +1069,12 @@ static int locate_tensor(fl_model *m, const char *name, TensorRef *o) {
     }
     if (sub == "attention.wo.weight") {
         o->t = ly.wo; o->rows = E; o->gcol0 = r * (E / G); o->Kfull = E; o->Mfull = E;
+        if (m->tp_rows) { o->rows = m->El; o->grow0 = r * m->El; o->gcol0 = 0; }
         return FL_OK;
     }
     if (sub == "feed_forward.w2.weight") {
         o->t = ly.w2; o->rows = E; o->gcol0 = r * (F / G); o->Kfull = F; o->Mfull = E;
+        if (m->tp_rows) { o->rows = m->El; o->grow0 = r * m->El; o->gcol0 = 0; }
         return FL_OK;
     }
     return set_error(FL_EINVAL, "tensor '%s' is not a quantized matrix of the model", name);

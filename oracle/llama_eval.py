@@ -7,7 +7,8 @@ Pinned against the compiled reference itself in tests/test_llama_eval_oracle.py 
 reference's own C-ABI on a synthetic GGJT model).
 
 Besides checking the GPU engine, this is the CPU stand-in used by the world_size-2 gloo tests to prove the
-tensor-parallel split (row/column shards + all-reduce of the partial sums) reproduces the unsharded eval.
+tensor-parallel splits reproduce the unsharded eval: row / column shards + all-reduce of the partial sums (to round-off), and the
+all-rows split + all-gathers of the reference-order mode (bit for bit).
 """
 from __future__ import annotations
 
@@ -141,7 +142,7 @@ class KV:
 
 
 def layer_forward(w: Weights, kv: KV, il: int, x: np.ndarray, n_past: int, port: Port, tp_rank: int = 0, tp_size: int = 1,
-                  allreduce=None):
+                  allreduce=None, allgather=None):
     """One transformer layer of Model::eval (lib/llama.cpp:308-443) on the layer input x [N, E].  Returns the layer output and
     the f32 tensors whose Q8_0 quantization feeds the wo / w1|w3 / w2 matmuls ("att", "ffn_in", "act") -- the discrete
     intermediates in which a rounding flip of an implementation that sums in another order becomes visible."""
@@ -176,9 +177,15 @@ def layer_forward(w: Weights, kv: KV, il: int, x: np.ndarray, n_past: int, port:
             vt = np.ascontiguousarray(Vv[:, h, :].T)                         # the reference's V view: D rows of P keys
             att[:, h * D:(h + 1) * D] = port.mul_mat_f32(vt, pr)             # ggml_mul_mat(V_trans, KQ_soft_max): [N, D]
         kb = (El // QK)
-        part = port.mul_mat_q(qt, slice_kblocks(w.q(p + "attention.wo.weight"), qt, r * kb, (r + 1) * kb), att, strict=G == 1)
-        if G > 1:
-            part = allreduce(part)
+        if G > 1 and allgather is not None:
+            # ROW split of wo (the reference's own split across threads, lib/ggml.c:8127-8135): the operand of every rank -- each rank
+            # holds whole 32-element blocks of its features, so quantizing the gathered f32 rows equals gathering the Q8_0 blocks the
+            # device exchanges -- then this rank's rows over the full K, then the rows of every rank.  Nothing is summed across ranks.
+            part = allgather(port.mul_mat_q(qt, slice_rows(w.q(p + "attention.wo.weight"), r * El, (r + 1) * El), allgather(att)))
+        else:
+            part = port.mul_mat_q(qt, slice_kblocks(w.q(p + "attention.wo.weight"), qt, r * kb, (r + 1) * kb), att, strict=G == 1)
+            if G > 1:
+                part = allreduce(part)
         x2 = (part + x).astype(f32)                                          # inpFF = cur + inpSA
         cur = rms_norm_mul(x2, w.f(p + "ffn_norm.weight"))
         F = w.q(p + "feed_forward.w1.weight").shape[0]
@@ -187,18 +194,23 @@ def layer_forward(w: Weights, kv: KV, il: int, x: np.ndarray, n_past: int, port:
         h1 = port.mul_mat_q(qt, slice_rows(w.q(p + "feed_forward.w1.weight"), r * Fl, (r + 1) * Fl), cur)
         hh = (silu(h1) * h3).astype(f32)
         kbf = Fl // QK
-        part = port.mul_mat_q(qt, slice_kblocks(w.q(p + "feed_forward.w2.weight"), qt, r * kbf, (r + 1) * kbf), hh, strict=G == 1)
-        if G > 1:
-            part = allreduce(part)
+        if G > 1 and allgather is not None:
+            part = allgather(port.mul_mat_q(qt, slice_rows(w.q(p + "feed_forward.w2.weight"), r * El, (r + 1) * El), allgather(hh)))
+        else:
+            part = port.mul_mat_q(qt, slice_kblocks(w.q(p + "feed_forward.w2.weight"), qt, r * kbf, (r + 1) * kbf), hh, strict=G == 1)
+            if G > 1:
+                part = allreduce(part)
         x = (part + x2).astype(f32)
     return x, dict(att=att, ffn_in=cur, act=hh)
 
 
 def eval_tokens(w: Weights, kv: KV, tokens, n_past: int, port: Port | None = None, tp_rank: int = 0, tp_size: int = 1,
-                allreduce=None) -> tuple[np.ndarray, np.ndarray]:
+                allreduce=None, allgather=None) -> tuple[np.ndarray, np.ndarray]:
     """Model::eval for N tokens at n_past.  Returns (logits [N, V], embeddings [N, E] = final normed activations).
     With tp_size > 1 this computes rank `tp_rank`'s shard (heads / ffn rows split, wo / w2 column blocks) and calls
-    allreduce(partial [N, E]) -> summed array after wo and w2 -- the exchange SURVEY.md 8(e) specifies."""
+    allreduce(partial [N, E]) -> summed array after wo and w2 -- the exchange SURVEY.md 8(e) specifies.  With `allgather`
+    (allgather(a [N, w]) -> [N, G w], rank order) wo / w2 are split by ROWS instead and nothing is summed: the reference-order
+    mode's tensor parallelism, bit-identical to the unsharded eval."""
     port = port or Port()
     E, H, L = w.E, w.H, w.L
     D = E // H
@@ -208,7 +220,7 @@ def eval_tokens(w: Weights, kv: KV, tokens, n_past: int, port: Port | None = Non
     N = len(tokens)
     x = np.stack([port.dequantize_row(qt, w.q("tok_embeddings.weight")[t], E) for t in tokens])   # get_rows_q
     for il in range(L):
-        x, _ = layer_forward(w, kv, il, x, n_past, port, tp_rank, tp_size, allreduce)
+        x, _ = layer_forward(w, kv, il, x, n_past, port, tp_rank, tp_size, allreduce, allgather)
     xn = rms_norm_mul(x, w.f("norm.weight"))
     logits = port.mul_mat_q(qt, w.q("output.weight"), xn)
     return logits, xn

@@ -9,7 +9,7 @@ import pytest
 import oracle
 from oracle import llama_eval as le
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fast_mode")]   # (conftest.py: the fast kernels, explicitly)
 
 
 @pytest.fixture(scope="module")

@@ -13,7 +13,7 @@ import pytest
 import oracle
 from util import bits, golden, make_weights, make_x, rel_err_rows, rel_max_err
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fast_mode")]   # (conftest.py: the fast kernels, explicitly)
 
 TOL = 1e-5
 Q4 = [("q40", oracle.Q4_0), ("q41", oracle.Q4_1)]

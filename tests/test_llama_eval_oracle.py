@@ -115,6 +115,44 @@ def test_tensor_parallel_split_in_process(port, cfgname, G):
     assert err[0] <= 1e-5 and err.max() <= 5e-2, err              # only the order of the partial sums differs
 
 
+@pytest.mark.parametrize("cfgname,G,qtype", [("SMALL", 2, ggjt.Q4_0), ("TINY", 4, ggjt.Q4_1)])
+def test_row_split_tensor_parallel_is_bit_identical_in_process(port, cfgname, G, qtype):
+    """The reference-order mode's split: every matmul by output rows, all-gathers of the wo / w2 operands and output rows, nothing
+    summed across ranks -- every rank ends with the UNSHARDED logits, bit for bit (prefill, then a decode step on the same caches)."""
+    import threading
+    cfg = getattr(ggjt, cfgname)
+    tensors = ggjt.synth_tensors(cfg, qtype, port.quantize_q4, seed=6)
+    toks = ggjt.text_tokens(TEXT[:24])
+    w = le.Weights(cfg, qtype, tensors)
+    kvf = le.KV(cfg["n_layer"], 64, cfg["n_embd"])
+    full, _ = le.eval_tokens(w, kvf, toks, 0, port)
+    full1, _ = le.eval_tokens(w, kvf, toks[3:4], len(toks), port)
+    parts, results, results1 = {}, [None] * G, [None] * G
+    barrier = threading.Barrier(G)
+
+    def allgather_for(rank):
+        def ag(a):
+            parts[rank] = a
+            barrier.wait()
+            out = np.concatenate([parts[r] for r in range(G)], axis=1)
+            barrier.wait()
+            return out
+        return ag
+
+    def run(rank):
+        kv = le.KV(cfg["n_layer"], 64, cfg["n_embd"] // G)
+        P = oracle.Port()
+        results[rank], _ = le.eval_tokens(w, kv, toks, 0, P, tp_rank=rank, tp_size=G, allgather=allgather_for(rank))
+        results1[rank], _ = le.eval_tokens(w, kv, toks[3:4], len(toks), P, tp_rank=rank, tp_size=G, allgather=allgather_for(rank))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for r in range(G):
+        assert np.array_equal(results[r].view(np.uint32), full.view(np.uint32)), r
+        assert np.array_equal(results1[r].view(np.uint32), full1.view(np.uint32)), r
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -146,6 +184,43 @@ def _gloo_worker(rank, world, port_no, out_path):
         np.savez(out_path, tp=lg, full=full)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _gloo_rows_worker(rank, world, port_no, out_path):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port_no}", rank=rank, world_size=world)
+    P = oracle.Port()
+    cfg, qtype = ggjt.TINY, ggjt.Q4_0
+    tensors = ggjt.synth_tensors(cfg, qtype, P.quantize_q4, seed=12)
+    toks = ggjt.text_tokens("row split over gloo")
+
+    def allgather(a):
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        return np.concatenate([o.numpy() for o in outs], axis=1)
+
+    w = le.Weights(cfg, qtype, tensors)
+    lg, _ = le.eval_tokens(w, le.KV(cfg["n_layer"], 64, cfg["n_embd"] // world), toks, 0, P, tp_rank=rank, tp_size=world,
+                           allgather=allgather)
+    if rank == 0:
+        full, _ = le.eval_tokens(w, le.KV(cfg["n_layer"], 64, cfg["n_embd"]), toks, 0, P)
+        np.savez(out_path, tp=lg, full=full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_split_tensor_parallel_two_processes_gloo(tmp_path):
+    """world_size 2 over torch.distributed/gloo, the collective pattern of the reference-order mode (4 all-gathers per layer:
+    the wo / w2 operands and their output rows): the sharded logits ARE the unsharded ones."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "tpr.npz")
+    port_no = _free_port()
+    mp.spawn(_gloo_rows_worker, args=(2, port_no, out), nprocs=2, join=True)
+    d = np.load(out)
+    assert np.array_equal(d["tp"].view(np.uint32), d["full"].view(np.uint32))
 
 
 def test_tensor_parallel_two_processes_gloo(tmp_path):

@@ -12,7 +12,7 @@ import pytest
 import oracle
 from harness import ggjt, llama_capi
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fast_mode")]   # (conftest.py: the fast kernels, explicitly)
 OURS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fastllama_amd", "libfastllama_hip.so")
 TEXT = "The quick brown fox jumps over the lazy dog; 0123456789 times!?"
 

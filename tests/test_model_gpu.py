@@ -13,7 +13,7 @@ import pytest
 import oracle
 from harness import ggjt, llama_capi
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fast_mode")]   # (conftest.py: the fast kernels, explicitly)
 
 
 def check_logits(got, want, what=""):

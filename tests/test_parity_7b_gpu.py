@@ -143,10 +143,13 @@ def test_llama7b_full_model_nbatch512_vs_reference(tmp_path_factory, reflib, qty
     # (At this width the reference is bit-identical to itself across batch splits -- no remainder loops in its f32 dots --
     #  so its self-deviation, printed above, is no yardstick here; test_deviation_floor_of_a_reordered_cpu_implementation is.)
     assert abs(ppl - ppl_ref) / ppl_ref < (2e-3 if wname.startswith("nonexpansive") else 1e-2), (ppl, ppl_ref)
+    # (round 4: the bounds sit at the measured order -- max 1.8e-2 / 2.0e-2, rel-L2 1.1e-2 / 1.2e-2, greedy 99.2 % / 98.4 % non-expansive;
+    #  max 9.8e-2 / 1.0e-1, rel-L2 7.0e-2 / 7.2e-2, greedy 83 % / 86 % with the recipe weights, profiles/r03_parity_7b.json --
+    #  they characterise the opt-in fast mode; the contract is the exact-mode assertion above)
     if wname.startswith("nonexpansive"):
-        assert per_pos.max() <= 4e-2 and rel_l2 <= 2.5e-2 and greedy >= 0.95, (per_pos.max(), rel_l2, greedy)
+        assert per_pos.max() <= 2.5e-2 and rel_l2 <= 1.5e-2 and greedy >= 0.97, (per_pos.max(), rel_l2, greedy)
     else:
-        assert per_pos.max() <= 0.2 and rel_l2 <= 0.12 and greedy >= 0.75, (per_pos.max(), rel_l2, greedy)
+        assert per_pos.max() <= 0.12 and rel_l2 <= 0.09 and greedy >= 0.78, (per_pos.max(), rel_l2, greedy)
 
 
 def test_oracle_reference_and_exact_gpu_agree_at_7b_width(tmp_path_factory, reflib):
