@@ -9,12 +9,16 @@ A "step" is ONE Model::eval of an n_batch=512 batch at n_past=0 on synthetic LLa
 wq|wk|wv Q4xQ8 GEMM, rope + KV store, KQ / soft_max / KQV, wo, rms_norm+Q8_0, fused w1|w3 GEMM, silu*mul+Q8_0,
 w2), final norm and the lm-head -- i.e. the hot path (225 mul_mat_q_f32 = 129 GEMM launches after fusion) plus
 everything around it; nothing is skipped or cached.  Token ids and weights are resident in HBM, logits stay in HBM.
-`value` = prefill tokens/s summed over ranks.  Decode (N=1, greedy position stepping, the wave-dot GEMV path) is
-reported beside it.
+`value` = prefill tokens/s summed over ranks IN THE LIBRARY'S DEFAULT MODE: the reference-order kernels, whose logits are
+bit-identical to the reference's x86 build (tests/test_parity_7b_gpu.py).  Decode (N=1, greedy position stepping) is reported
+beside it; the opt-in fast mode (FL_FAST=1: exact integer block dots, own f32 summation order, ~1e-2 on 7B logits) is timed in
+the same run and reported under "fast_mode".
 
---gpus N > 1 (default --parallel auto): the headline is the TENSOR-PARALLEL eval of ONE batch (wq/wk/wv/w1/w3
-  by rows, wo/w2 by K blocks, lm-head by rows; two RCCL all-reduces of the [N, n_embd] partial sums per layer and one
-  all-gather of the logits over xGMI; decode replays one hipGraph with the collectives inside) -- strong scaling.  A
+--gpus N > 1 (default --parallel auto): the headline is the TENSOR-PARALLEL eval of ONE batch, every matmul split by output rows
+  (the reference's own split across threads, lib/ggml.c:8127-8135): four RCCL all-gathers per layer -- the Q8_0 operands of wo / w2
+  and their output rows -- and one of the logits over xGMI, nothing summed across ranks, so the sharded logits are still the
+  reference's bit for bit; decode replays one hipGraph with the collectives inside -- strong scaling.  (The fast mode keeps
+  SURVEY.md 8e's K-block split of wo / w2 with two all-reduces per layer: "fast_mode" of the same line.)  A
   replica leg (every rank a full model and its own batch, no collective; weak scaling) is measured in the same run and
   reported beside it under "replicas".  --parallel dp measures replicas only.
   BASELINE.json configs 4 / 5: `bench.py --model 13B --gpus 2|4` and `bench.py --model 65B --gpus 8 --n-ctx 2048`.
@@ -112,6 +116,37 @@ def cpu_config1(cfg, qtype, budget_s=12.0):
             "sample": "BASELINE.json configs[0]: one layer's 7 mul_mat_q_f32 + lm-head at N=128, 8 threads, median of 2, extrapolated to one eval"}
 
 
+def cpu_end_to_end(cfg, N, qtype):
+    """SURVEY.md 8(d)'s CPU baseline: the SAME synthetic 7B model as a GGJT file through the reference's own library (oracle/_ref:
+    llama_load_model, then one n_batch eval of N tokens via llama_ingest + the first step of llama_generate, exactly what
+    tests/test_parity_7b_gpu.py compares bit for bit) on this box's host cores.  One eval: ~10-20 s of CPU work."""
+    import tempfile
+    import oracle
+    from harness import ggjt, llama_capi, synth
+    if not oracle.have_ref():
+        return None
+    lib = llama_capi.LlamaLib(os.path.join(oracle.REF_DIR, "pyfastllama.so"))
+    gcfg = dict(n_vocab=cfg["n_vocab"], n_embd=cfg["n_embd"], n_mult=256, n_head=cfg["n_head"], n_layer=cfg["n_layer"])
+    nthr = min(32, os.cpu_count() or 8)
+    rng = np.random.default_rng(7)
+    text = bytes(rng.integers(33, 127, size=N - 2).astype(np.uint8)).decode()       # BOS + the inserted space + N - 2 bytes = N tokens
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "m.bin")
+        ggjt.write_ggjt_stream(path, gcfg, qtype, synth.synth_model_tensors(cfg, qtype, seed=1234))
+        t0 = time.perf_counter()
+        ref = llama_capi.Session(lib, path, n_ctx=max(1024, 2 * N), n_batch=N, n_threads=nthr, all_logits=False)
+        t_load = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ok = ref.ingest(text) and ref.generate(1, temp=0.0)[0]
+        t_eval = time.perf_counter() - t0
+        ref.close()
+    if not ok:
+        return None
+    return {"value": N / t_eval, "unit": "tokens/s", "cores": nthr, "kind": "reference", "seconds_eval": t_eval, "seconds_load": t_load,
+            "sample": (f"the reference's own llama_ingest + first llama_generate step = ONE Model::eval of {N} tokens on the same synthetic "
+                       f"7B file, {nthr} threads of {os.cpu_count()} logical CPUs (includes tokenizing {N} bytes and one argmax)")}
+
+
 def self_launch(n):
     """Re-run this command line under torch.distributed.run with n ranks on 127.0.0.1; returns its exit code."""
     import socket
@@ -144,10 +179,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--peer-exchange", action="store_true", help="tensor-parallel leg: decode-size messages through peer-mapped buffers (FL_P2P=1) instead of RCCL; never run over xGMI so far")
     ap.add_argument("--tp-timeout", type=int, default=300, help="seconds the tensor-parallel leg may take before the replica leg is reported alone")
-    ap.add_argument("--no-exact", action="store_true", help="skip the exact-mode (reference-order kernels) timings")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the short 7B Q4_1 leg (BASELINE.json config 3)")
-    ap.add_argument("--all-configs", action="store_true", help="also run BASELINE.json configs 4/5 (13B, 65B n_ctx 2048) as short legs "
-                    "on this rank's GPU and report them under other_configs (config 3, 7B Q4_1, always runs at --gpus 1)")
+    ap.add_argument("--no-fast", action="store_true", help="skip the fast-mode timings reported beside the headline")
+    ap.add_argument("--no-cpu-e2e", action="store_true", help="skip cpu_baseline.end_to_end (the reference's own eval of the same 7B file)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs of BASELINE.json configs 3 / 4 / 5 on this GPU "
+                    "(7B Q4_1; 13B; 65B at n_ctx 2048), reported under other_configs")
+    ap.add_argument("--all-configs", action="store_true", help="(kept for old command lines: configs 3 / 4 / 5 run by default at --gpus 1)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -216,171 +252,198 @@ def main():
         return dt
 
     def pmc_traffic(kernel, tp):
-        """HBM bytes per launch from the committed PMC passes (profiles/r03_pmc_traffic.json, else r02_: rocprofv3 --pmc FETCH_SIZE /
-        WRITE_SIZE in separate passes, gfx950 correction applied) -- valid for the default 7B Q4_0 n_batch=512 workload."""
+        """(HBM bytes per launch, source file) from the committed PMC passes (profiles/r04_pmc_traffic.json, else older rounds':
+        rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied) -- valid for the default 7B Q4_0
+        n_batch=512 workload.  Not measured in this run: PMC counters need rocprofv3 around the process."""
         try:
             if args.model != "7B" or qtype != 2 or N != 512 or tp:
-                return None
-            for rnd in ("r03", "r02"):              # the latest committed pass
+                return None, None
+            for rnd in ("r04", "r03", "r02"):              # the latest committed pass that has the kernel
                 path = os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json")
                 if os.path.exists(path):
                     with open(path) as f:
-                        return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
-            return None
+                        k = json.load(f)["kernels"]
+                    if kernel in k:
+                        return k[kernel]["hbm_bytes_per_launch"], "profiles/" + rnd + "_pmc_traffic.json"
+            return None, None
         except Exception:
-            return None
+            return None, None
+
+    KERNELS = {   # (prefill GEMM, decode GEMV) of a mode: names as rocprofv3 prints them
+        "exact": ("gemm_q4_exact_h16_kernel", "gemv1_q4_exact_kernel"),
+        "fast": ("gemm_q4_mfma32_kernel", "gemv_q4_kernel"),
+    }
 
     def run_leg(tp, cfg=cfg, qtype=qtype, N=N, n_ctx=n_ctx, short=False):
-        """One model (a replica per rank, or this rank's tensor-parallel shard) through the prefill / decode / roofline legs.
+        """One model (a replica per rank, or this rank's tensor-parallel shard) through the prefill / decode / roofline legs, in the
+        default (reference-order, "exact") mode and -- unless --no-fast -- in the fast mode.  Under tensor parallelism the split of
+        wo / w2 belongs to the mode (rows / K blocks), so each mode gets its own model.
         short: prefill + decode timings only, fewer steps (the other BASELINE configs reported beside the headline)."""
         wk, wk1 = synth.algorithmic_work(cfg, N, qtype), synth.algorithmic_work(cfg, 1, qtype)
         steps = max(2, args.steps // 4) if short else args.steps
         dsteps = max(8, args.decode_steps // 4) if short else args.decode_steps
-        model = FlModel(cfg, qtype, synth.synth_model_tensors(cfg, qtype), n_ctx=n_ctx, max_batch=N,
-                        tp_rank=rank if tp else 0, tp_size=world if tp else 1, device=local)
-        model.set_exact(False)
-        comm = None
-        if tp and p2p_only:
-            comm = L.fl_comm_create_p2p(rank, world)
-            if not comm:
-                raise SystemExit("fl_comm_create_p2p failed: " + L.fl_last_error().decode())
-            mine = (ctypes.c_ubyte * 128)()
-            hip.check(L.fl_comm_p2p_export(ctypes.c_void_p(comm), mine), "p2p_export")
-            gathered = [None] * world
-            dist.all_gather_object(gathered, bytes(mine))
-            allh = b"".join(gathered)
-            hip.check(L.fl_comm_p2p_import(ctypes.c_void_p(comm), (ctypes.c_ubyte * len(allh))(*allh)), "p2p_import")
-            model.set_comm(ctypes.c_void_p(comm))
-            peer_exchange = True
-        elif tp:
-            idbuf = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
-                raw = (ctypes.c_ubyte * 128)()
-                hip.check(L.fl_comm_unique_id(raw))
-                idbuf = torch.tensor(list(raw), dtype=torch.uint8)
-            idbuf = idbuf.cuda()
-            dist.broadcast(idbuf, src=0)
-            raw = (ctypes.c_ubyte * 128)(*idbuf.cpu().tolist())
-            comm = L.fl_comm_create(raw, rank, world)
-            if not comm:
-                raise SystemExit("fl_comm_create failed: " + L.fl_last_error().decode())
-            model.set_comm(ctypes.c_void_p(comm))
-            peer_exchange = bool(L.fl_comm_has_p2p(ctypes.c_void_p(comm)))
-        rng = np.random.default_rng(7 + (0 if tp else rank))
-        toks = rng.integers(3, 259, size=N).astype(np.int32)      # SURVEY.md 8d: uniform ids in [3, 258]
-        tok1 = toks[:1].copy()
         seqs = 1 if tp else world
         shard = world if tp else 1
         r = {"seqs": seqs, "wk": wk, "wk1": wk1, "shard": shard}
-        if tp:
-            r["peer_exchange"] = peer_exchange      # decode-size messages go through peer-mapped buffers instead of a ring collective
-            r["n_ranks_rccl"] = int(L.fl_comm_rccl_ranks(ctypes.c_void_p(comm)))
-        # ---- prefill (the headline): K timed evals after W warm-ups
-        prefill = lambda i: model.eval_nocopy(toks, 0)
-        for i in range(args.warmup):
-            prefill(i)
-        dt = timed(prefill, steps)
-        r["ms_per_step"] = dt / steps * 1e3
-        r["prefill_tokens_per_s"] = N * seqs / (dt / steps)
-        # ---- decode: N = 1 at n_past = 128.. (KV holds the prefill)
-        dec = lambda i: model.eval_nocopy(tok1, min(128, N) + i)
-        for i in range(3):
-            dec(i)
-        r["decode_ms"] = timed(dec, dsteps) / dsteps * 1e3
-        # ---- the same two timings in EXACT mode (reference-order kernels: logits bit-identical to the reference's x86 build,
-        #      tests/test_parity_7b_gpu.py); the fast mode above computes exact block dots and adds them in its own f32 order
-        if not args.no_exact and not tp:       # (a single-GPU property: under tensor parallelism wo / w2 end in a sum of G partial results)
-            model.set_exact(True)
-            xsteps = max(2, steps // 4)
-            prefill(0)
-            xdt = timed(prefill, xsteps) / xsteps
-            for i in range(3):
-                dec(i)
-            xdec = timed(dec, dsteps) / dsteps
-            model.set_exact(False)
-            r["exact"] = {"ms_per_step": xdt * 1e3, "prefill_tokens_per_s": N * seqs / xdt, "decode_ms": xdec * 1e3,
-                          "decode_tokens_per_s": seqs / xdec}
-        if short:
+        rng = np.random.default_rng(7 + (0 if tp else rank))
+        toks = rng.integers(3, 259, size=N).astype(np.int32)      # SURVEY.md 8d: uniform ids in [3, 258]
+        tok1 = toks[:1].copy()
+
+        def make_model(mode):
+            if tp:                      # the split is fixed when the model is created (fl_model_create reads the mode)
+                os.environ["FL_EXACT"] = "1" if mode == "exact" else "0"
+            model = FlModel(cfg, qtype, synth.synth_model_tensors(cfg, qtype), n_ctx=n_ctx, max_batch=N,
+                            tp_rank=rank if tp else 0, tp_size=world if tp else 1, device=local)
+            os.environ.pop("FL_EXACT", None)
+            comm = None
+            if tp and p2p_only:
+                comm = L.fl_comm_create_p2p(rank, world)
+                if not comm:
+                    raise SystemExit("fl_comm_create_p2p failed: " + L.fl_last_error().decode())
+                mine = (ctypes.c_ubyte * 128)()
+                hip.check(L.fl_comm_p2p_export(ctypes.c_void_p(comm), mine), "p2p_export")
+                gathered = [None] * world
+                dist.all_gather_object(gathered, bytes(mine))
+                allh = b"".join(gathered)
+                hip.check(L.fl_comm_p2p_import(ctypes.c_void_p(comm), (ctypes.c_ubyte * len(allh))(*allh)), "p2p_import")
+                model.set_comm(ctypes.c_void_p(comm))
+                r["peer_exchange"] = True
+            elif tp:
+                idbuf = torch.zeros(128, dtype=torch.uint8)
+                if rank == 0:
+                    raw = (ctypes.c_ubyte * 128)()
+                    hip.check(L.fl_comm_unique_id(raw))
+                    idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+                idbuf = idbuf.cuda()
+                dist.broadcast(idbuf, src=0)
+                raw = (ctypes.c_ubyte * 128)(*idbuf.cpu().tolist())
+                comm = L.fl_comm_create(raw, rank, world)
+                if not comm:
+                    raise SystemExit("fl_comm_create failed: " + L.fl_last_error().decode())
+                model.set_comm(ctypes.c_void_p(comm))
+                r["peer_exchange"] = bool(L.fl_comm_has_p2p(ctypes.c_void_p(comm)))   # decode-size messages through peer-mapped buffers
+            if tp:
+                r["n_ranks_rccl"] = int(L.fl_comm_rccl_ranks(ctypes.c_void_p(comm)))
+            return model, comm
+
+        def drop(model, comm):
             barrier()
             model.free()
             if comm:
                 L.fl_comm_destroy(ctypes.c_void_p(comm))
             torch.cuda.empty_cache()
-            return r
-        # ---- the same at the end of the context (K/V stream of n_past positions per layer; two-launch attention)
-        long_steps = min(32, args.decode_steps)
-        r["long_past"] = n_ctx - long_steps - 4
-        decl = lambda i: model.eval_nocopy(tok1, r["long_past"] + i)
-        for i in range(3):
-            decl(i)
-        r["decode_long_ms"] = timed(decl, long_steps) / long_steps * 1e3
-        # ---- roofline of the dominant kernels: HIP events around every matmul launch on the eval stream
-        model.profile(1)
-        evals = max(2, args.steps // 3)
-        for i in range(evals):
-            prefill(i)
-        mm_ms, n_launch = model.profile(0)
-        tops = wk["flops"] / shard * evals / (mm_ms * 1e-3) / 1e12
-        r["roofline"] = {
-            "kernel": "gemm_q4_mfma32_kernel<Q4_%d,...>" % (qtype - 2), "bound": "mfma",
-            "achieved": tops, "peak": PEAK_I8_TOPS, "unit": "TOP/s", "frac": tops / PEAK_I8_TOPS,
-            "traffic": pmc_traffic("gemm_q4_mfma32_kernel", tp),
-            "launches_per_step": n_launch // evals, "avg_launch_us": mm_ms * 1e3 / max(1, n_launch),
-            "algorithmic_flops_per_launch": wk["flops"] / shard / (n_launch / evals),
-            "note": ("ALGORITHMIC 2*M*K*N of the %d mul_mat_q_f32 (fused into %d launches) / event-timed launch durations.  peak = "
-                     "the 5 POP/s dense int8 MFMA rate, which v_mfma_i32_32x32x32_i8 (K = 32 = one quant block) runs at; the exact "
-                     "per-block scaling adds 32 VALU ops + half an f32 outer-product MFMA per 32x32 tile and block, and on gfx950 the "
-                     "VALU and the matrix pipe of a SIMD do not overlap: measured instruction-mix ceiling ~1.0 POP/s (DESIGN.md 3.1, "
-                     "profiles/r02_ubench_coexec3.txt, r03_ubench_coexec4.txt)") % (wk["n_matmuls"], n_launch // evals),
-        }
-        model.profile(1)
-        for i in range(8):
-            dec(i)
-        mm1_ms, n1 = model.profile(0)
-        gbs = wk1["bytes"] / shard * 8 / (mm1_ms * 1e-3) / 1e9
-        r["roofline_decode"] = {
-            "kernel": "gemv_q4_kernel<Q4_%d,1>" % (qtype - 2), "bound": "hbm",
-            "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-            "traffic": pmc_traffic("gemv_q4_kernel", tp),
-            "launches_per_step": n1 // 8, "avg_launch_us": mm1_ms * 1e3 / max(1, n1),
-            "algorithmic_bytes_per_launch": wk1["bytes"] / shard / (n1 / 8),
-        }
-        r["model_device_bytes"] = hip.load().fl_model_device_bytes(model.h)
-        # ---- a prompt longer than n_batch: the session's ingest loop evaluates it n_batch tokens at a time; fl_model_ingest keeps two
-        #      of those evals in flight (same results).  Reported beside the headline, which stays the single n_batch eval.
-        if not tp and n_ctx >= 2 * N:
-            n_long = min(n_ctx // N, 4) * N
-            tl = rng.integers(3, 259, size=n_long).astype(np.int32)
-            one_by_one = lambda i: [model.eval_nocopy(tl[j:j + N], j) for j in range(0, n_long, N)]
-            pipelined = lambda i: model.ingest(tl, N, want_logits=False)
-            lsteps = max(2, args.steps // 4)
-            one_by_one(0); pipelined(0)
-            t_seq, t_pipe = timed(one_by_one, lsteps) / lsteps, timed(pipelined, lsteps) / lsteps
-            r["long_prompt"] = {"tokens": n_long, "n_batch": N, "tokens_per_s": n_long * seqs / t_pipe, "ms": t_pipe * 1e3,
-                                "chunk_by_chunk_tokens_per_s": n_long * seqs / t_seq,
-                                "note": "fl_model_ingest: the consecutive n_batch evals of one prompt, two in flight on two streams (one stream from 65B width on); bit-identical to chunk by chunk"}
-        barrier()
-        model.free()
-        if comm:
-            L.fl_comm_destroy(ctypes.c_void_p(comm))
-        torch.cuda.empty_cache()
+
+        def time_mode(model, mode, full):
+            """prefill + decode (+ roofline legs when `full`) of `model` in `mode`"""
+            model.set_exact(mode == "exact")
+            m = {}
+            prefill = lambda i: model.eval_nocopy(toks, 0)
+            dec = lambda i: model.eval_nocopy(tok1, min(128, N) + i)
+            nst = steps if mode == "exact" or short else max(2, steps // 2)
+            # ---- prefill: K timed evals after W warm-ups (the first exact eval also builds the f16 fragment copies of the weights)
+            for i in range(max(1, args.warmup)):
+                prefill(i)
+            dt = timed(prefill, nst)
+            m["ms_per_step"] = dt / nst * 1e3
+            m["prefill_tokens_per_s"] = N * seqs / (dt / nst)
+            # ---- decode: N = 1 at n_past = 128.. (KV holds the prefill)
+            for i in range(3):
+                dec(i)
+            m["decode_ms"] = timed(dec, dsteps) / dsteps * 1e3
+            m["decode_tokens_per_s"] = seqs / (m["decode_ms"] * 1e-3)
+            if not full:
+                return m
+            # ---- roofline of the dominant kernels: HIP events around every matmul launch on the eval stream
+            gemm, gemv = KERNELS[mode]
+            model.profile(1)
+            evals = max(2, args.steps // 3)
+            for i in range(evals):
+                prefill(i)
+            mm_ms, n_launch = model.profile(0)
+            tops = wk["flops"] / shard * evals / (mm_ms * 1e-3) / 1e12
+            traffic, tsrc = pmc_traffic(gemm, tp)
+            note = ("ALGORITHMIC 2*M*K*N of the %d mul_mat_q_f32 (fused into %d launches) / event-timed launch durations; peak = the 5 POP/s "
+                    "dense int8 MFMA rate.  " % (wk["n_matmuls"], n_launch // evals))
+            if mode == "exact":
+                note += ("The reference's summation order needs, per output and 32-element block, 8 separate 4-element sums (2 per "
+                         "v_mfma_f32_32x32x4_2b_f16: 256 matrix cycles per 32x32 tile and block, the pipe's output rate whatever the shape) and "
+                         "8 f32 fma (256+ VALU cycles); the two pipes of a gfx950 SIMD do not overlap: measured floor of the mix 232 ns per "
+                         "tile and block = 0.29 POP/s chip-wide (DESIGN.md 3.7, profiles/r04_ubench_coexec5.txt)")
+            else:
+                note += ("v_mfma_i32_32x32x32_i8 (K = 32 = one quant block) runs at that rate; the exact per-block scaling adds 32 VALU ops + "
+                         "half an f32 outer-product MFMA per 32x32 tile and block: measured instruction-mix ceiling ~1.0 POP/s (DESIGN.md 3.1)")
+            m["roofline"] = {
+                "kernel": "%s<Q4_%d,...>" % (gemm, qtype - 2), "bound": "mfma",
+                "achieved": tops, "peak": PEAK_I8_TOPS, "unit": "TOP/s", "frac": tops / PEAK_I8_TOPS,
+                "traffic": traffic, "traffic_source": tsrc,
+                "launches_per_step": n_launch // evals, "avg_launch_us": mm_ms * 1e3 / max(1, n_launch),
+                "algorithmic_flops_per_launch": wk["flops"] / shard / (n_launch / evals), "note": note,
+            }
+            model.profile(1)
+            for i in range(8):
+                dec(i)
+            mm1_ms, n1 = model.profile(0)
+            gbs = wk1["bytes"] / shard * 8 / (mm1_ms * 1e-3) / 1e9
+            traffic1, tsrc1 = pmc_traffic(gemv, tp)
+            m["roofline_decode"] = {
+                "kernel": "%s<Q4_%d,...>" % (gemv, qtype - 2), "bound": "hbm",
+                "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                "traffic": traffic1, "traffic_source": tsrc1,
+                "launches_per_step": n1 // 8, "avg_launch_us": mm1_ms * 1e3 / max(1, n1),
+                "algorithmic_bytes_per_launch": wk1["bytes"] / shard / (n1 / 8),
+            }
+            return m
+
+        model, comm = make_model("exact")
+        r["exact"] = time_mode(model, "exact", not short)
+        if not short:
+            # ---- decode at the end of the context (K/V stream of n_past positions per layer; two-launch attention)
+            long_steps = min(32, args.decode_steps)
+            r["long_past"] = n_ctx - long_steps - 4
+            decl = lambda i: model.eval_nocopy(tok1, r["long_past"] + i)
+            for i in range(3):
+                decl(i)
+            r["decode_long_ms"] = timed(decl, long_steps) / long_steps * 1e3
+            r["model_device_bytes"] = hip.load().fl_model_device_bytes(model.h)
+            # ---- a prompt longer than n_batch: the session's ingest loop evaluates it n_batch tokens at a time; fl_model_ingest keeps
+            #      two of those evals in flight (same results).  Reported beside the headline, which stays the single n_batch eval.
+            if not tp and n_ctx >= 2 * N:
+                n_long = min(n_ctx // N, 4) * N
+                tl = rng.integers(3, 259, size=n_long).astype(np.int32)
+                one_by_one = lambda i: [model.eval_nocopy(tl[j:j + N], j) for j in range(0, n_long, N)]
+                pipelined = lambda i: model.ingest(tl, N, want_logits=False)
+                lsteps = max(2, args.steps // 4)
+                one_by_one(0); pipelined(0)
+                t_seq, t_pipe = timed(one_by_one, lsteps) / lsteps, timed(pipelined, lsteps) / lsteps
+                r["long_prompt"] = {"tokens": n_long, "n_batch": N, "tokens_per_s": n_long * seqs / t_pipe, "ms": t_pipe * 1e3,
+                                    "chunk_by_chunk_tokens_per_s": n_long * seqs / t_seq,
+                                    "note": "fl_model_ingest: the consecutive n_batch evals of one prompt, two in flight on two streams (one stream from 65B width on); bit-identical to chunk by chunk"}
+        if not args.no_fast:
+            if tp:                      # the fast mode's own split (K blocks of wo / w2, all-reduces)
+                drop(model, comm)
+                model, comm = make_model("fast")
+            r["fast"] = time_mode(model, "fast", not short)
+        drop(model, comm)
         return r
 
     def summary(leg, name):
         """the short form of a leg: other_configs entries"""
         t_hbm = leg["wk"]["bytes"] / leg["shard"] / (PEAK_HBM_GBS * 1e9) * 1e3
         t_hbm1 = leg["wk1"]["bytes"] / leg["shard"] / (PEAK_HBM_GBS * 1e9) * 1e3
-        o = {"config": name, "prefill_tokens_per_s": leg["prefill_tokens_per_s"], "ms_per_step": leg["ms_per_step"],
-             "decode_tokens_per_s": leg["seqs"] / (leg["decode_ms"] * 1e-3),
-             "hbm_roofline_frac": {"prefill": t_hbm / leg["ms_per_step"], "decode": t_hbm1 / leg["decode_ms"]}}
-        if "exact" in leg:
-            o["exact_mode"] = {"prefill_tokens_per_s": leg["exact"]["prefill_tokens_per_s"],
-                               "decode_tokens_per_s": leg["exact"]["decode_tokens_per_s"]}
+        x = leg["exact"]
+        o = {"config": name, "prefill_tokens_per_s": x["prefill_tokens_per_s"], "ms_per_step": x["ms_per_step"],
+             "decode_tokens_per_s": x["decode_tokens_per_s"],
+             "hbm_roofline_frac": {"prefill": t_hbm / x["ms_per_step"], "decode": t_hbm1 / x["decode_ms"]}}
+        if "fast" in leg:
+            f = leg["fast"]
+            o["fast_mode"] = {"prefill_tokens_per_s": f["prefill_tokens_per_s"], "decode_tokens_per_s": f["decode_tokens_per_s"],
+                              "hbm_roofline_frac": {"prefill": t_hbm / f["ms_per_step"], "decode": t_hbm1 / f["decode_ms"]}}
         return o
 
     def emit(legs, tp_error, others=()):
-        head = legs["tp"] if "tp" in legs else legs["dp"]
+        leg = legs["tp"] if "tp" in legs else legs["dp"]
         tp = "tp" in legs
+        head = leg["exact"]
         # fraction of the HBM roofline BASELINE.json's target is written in: time to move the ALGORITHMIC bytes of one step
         # (SURVEY.md 8d: Q4 weights once + f32 activations in and out of the 225 matmuls) at 8 TB/s / measured time per step
         shard = world if tp else 1
@@ -393,60 +456,65 @@ def main():
             "dtype": "i8", "data": "synthetic",
             "config": {
                 "workload": (f"LLaMA-{args.model} {args.qtype.upper()} n_batch={N} prefill; step = one full device-resident "
-                             f"Model::eval (n_past=0, {wk['n_matmuls']} mul_mat_q_f32 + attention/norm/rope ops), synthetic weights"),
-                "n_batch": N, "n_ctx": n_ctx, "global_batch_tokens": N * head["seqs"],
-                "parallelism": (f"tp{world} (ONE batch: wq/wk/wv/w1/w3 by rows, wo/w2 by K blocks, lm-head by rows; 2 RCCL all-reduces per layer "
-                                f"+ 1 all-gather of the logits over xGMI)" if tp else
+                             f"Model::eval (n_past=0, {wk['n_matmuls']} mul_mat_q_f32 + attention/norm/rope ops), synthetic weights, "
+                             f"reference-order arithmetic (logits bit-identical to the reference's)"),
+                "n_batch": N, "n_ctx": n_ctx, "global_batch_tokens": N * leg["seqs"],
+                "parallelism": (f"tp{world} (ONE batch: every matmul by output rows; 4 RCCL all-gathers per layer (Q8_0 operands of wo / w2, their "
+                                f"output rows) + 1 of the logits over xGMI; nothing summed across ranks)" if tp else
                                 f"dp{world} (one model replica and one batch per GPU, no data-path collective)"),
             },
+            "mode": "exact",
+            "mode_note": ("value / ms_per_step / roofline = the library's DEFAULT mode: the reference's summation order in every matmul and "
+                          "attention dot -- logits bit-identical to the reference's x86 build on this configuration (tests/test_parity_7b_gpu.py), "
+                          "also under tensor parallelism (tests/test_wide_models_gpu.py).  fast_mode = FL_FAST=1 / fl_model_set_exact(m, 0): exact "
+                          "integer block dots, per-block f32 terms added in the kernels' own order (1e-7 per matmul; ~1e-2 on 7B logits after 32 layers)"),
             "prefill_tokens_per_s": head["prefill_tokens_per_s"],
-            "decode_tokens_per_s": head["seqs"] / (head["decode_ms"] * 1e-3), "decode_ms_per_token": head["decode_ms"],
-            "decode_long_context": {"n_past": head["long_past"], "tokens_per_s": head["seqs"] / (head["decode_long_ms"] * 1e-3),
-                                    "ms_per_token": head["decode_long_ms"]},
+            "decode_tokens_per_s": head["decode_tokens_per_s"], "decode_ms_per_token": head["decode_ms"],
+            "decode_long_context": {"n_past": leg["long_past"], "tokens_per_s": leg["seqs"] / (leg["decode_long_ms"] * 1e-3),
+                                    "ms_per_token": leg["decode_long_ms"]},
             "hbm_roofline": {"peak_GBs": PEAK_HBM_GBS,
                              "prefill": {"algorithmic_bytes_per_step": wk["bytes"] / shard, "t_hbm_ms": t_hbm_prefill_ms,
                                          "frac": t_hbm_prefill_ms / head["ms_per_step"]},
                              "decode": {"algorithmic_bytes_per_token": wk1["bytes"] / shard, "t_hbm_ms": t_hbm_decode_ms,
                                         "frac": t_hbm_decode_ms / head["decode_ms"]},
                              "note": "whole-step fractions (every kernel of the eval, not only the matmuls); BASELINE.json's target is 0.40 for prefill"},
-            "prefill_long_prompt": head.get("long_prompt"),
+            "prefill_long_prompt": leg.get("long_prompt"),
             "roofline": head["roofline"], "roofline_decode": head["roofline_decode"],
-            "model_device_bytes": head["model_device_bytes"],
+            "model_device_bytes": leg["model_device_bytes"],
             # is the headline the tensor-parallel eval over RCCL, and how many ranks does the RCCL communicator itself count?
-            "tp_ok": bool(tp) if world > 1 else None, "n_ranks_rccl": head.get("n_ranks_rccl", 0) if world > 1 else None,
-            "mode": "fast",
-            "mode_note": ("value = fast mode: exact integer block dots on the MFMA units, per-block f32 terms added in the kernels' own order "
-                          "(1e-7 per matmul; ~1e-2 on 7B logits after 32 layers).  exact_mode = the reference-order kernels (FL_EXACT=1 / "
-                          "fl_model_set_exact): logits bit-identical to the reference's x86 build, tests/test_parity_7b_gpu.py"),
+            "tp_ok": bool(tp) if world > 1 else None, "n_ranks_rccl": leg.get("n_ranks_rccl", 0) if world > 1 else None,
         }
-        if "exact" in head:
-            x = head["exact"]
-            out["exact_mode"] = {"prefill_tokens_per_s": x["prefill_tokens_per_s"], "ms_per_step": x["ms_per_step"],
-                                 "decode_tokens_per_s": x["decode_tokens_per_s"], "decode_ms_per_token": x["decode_ms"],
-                                 "hbm_roofline_frac": {"prefill": t_hbm_prefill_ms / x["ms_per_step"], "decode": t_hbm_decode_ms / x["decode_ms"]},
-                                 "parity": "bit-identical logits vs oracle/_ref on this configuration (tests/test_parity_7b_gpu.py)"}
+        if "fast" in leg:
+            f = leg["fast"]
+            out["fast_mode"] = {"prefill_tokens_per_s": f["prefill_tokens_per_s"], "ms_per_step": f["ms_per_step"],
+                                "decode_tokens_per_s": f["decode_tokens_per_s"], "decode_ms_per_token": f["decode_ms"],
+                                "hbm_roofline_frac": {"prefill": t_hbm_prefill_ms / f["ms_per_step"], "decode": t_hbm_decode_ms / f["decode_ms"]},
+                                "roofline": f["roofline"], "roofline_decode": f["roofline_decode"],
+                                "parity": "logits ~1e-2 from the reference on this configuration (profiles/r03_parity_7b.json): opt-in, not the contract"}
+            if tp:
+                out["fast_mode"]["parallelism"] = f"tp{world}: wo / w2 by K blocks, 2 RCCL all-reduces of the [N, n_embd] partial sums per layer"
         if others:
             out["other_configs"] = list(others)
         if tp and "dp" in legs:
-            d = legs["dp"]
+            d = legs["dp"]["exact"]
             out["replicas"] = {"scaling": "weak", "parallelism": f"dp{world}: a full replica and its own batch per GPU, no collective",
                                "prefill_tokens_per_s": d["prefill_tokens_per_s"], "ms_per_step": d["ms_per_step"],
-                               "decode_tokens_per_s": d["seqs"] / (d["decode_ms"] * 1e-3)}
+                               "decode_tokens_per_s": d["decode_tokens_per_s"]}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, N, qtype)
                 out["cpu_baseline"]["config1"] = cpu_config1(cfg, qtype)
+                if not args.no_cpu_e2e and args.model == "7B":
+                    out["cpu_baseline"]["end_to_end"] = cpu_end_to_end(cfg, N, qtype)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "unavailable",
                                        "sample": f"failed: {e!r}"}
         if tp:
-            out["tp_small_message_path"] = "peer-mapped buffers (hipIpc), one kernel per rank" if head.get("peer_exchange") else "RCCL"
+            out["tp_small_message_path"] = "peer-mapped buffers (hipIpc), one kernel per rank" if leg.get("peer_exchange") else "RCCL"
         if tp_error:
             out["tp_error"] = tp_error + " -- the headline above is the replica leg"
         if rank == 0:
             print(json.dumps(out), flush=True)
-
-
 
     legs = {}
     others = []
@@ -457,10 +525,9 @@ def main():
         # BASELINE.json config 3 under the same clock as the headline; configs 4 / 5 (single-GPU form) on request
         try:
             others.append(summary(run_leg(False, qtype=synth.Q4_1, short=True), f"LLaMA-7B Q4_1 n_batch={N} (BASELINE config 3), 1 GPU"))
-            if args.all_configs:
-                others.append(summary(run_leg(False, cfg=dict(synth.MODELS["13B"]), short=True), f"LLaMA-13B Q4_0 n_batch={N} (BASELINE config 4 on 1 GPU)"))
-                others.append(summary(run_leg(False, cfg=dict(synth.MODELS["65B"]), n_ctx=2048, short=True),
-                                      f"LLaMA-65B Q4_0 n_batch={N} n_ctx=2048 (BASELINE config 5 on 1 GPU)"))
+            others.append(summary(run_leg(False, cfg=dict(synth.MODELS["13B"]), short=True), f"LLaMA-13B Q4_0 n_batch={N} (BASELINE config 4 on 1 GPU)"))
+            others.append(summary(run_leg(False, cfg=dict(synth.MODELS["65B"]), n_ctx=2048, short=True),
+                                  f"LLaMA-65B Q4_0 n_batch={N} n_ctx=2048 (BASELINE config 5 on 1 GPU)"))
         except Exception as e:  # noqa: BLE001 -- never lose the headline to a side leg
             others.append({"config": "other configs", "error": repr(e)})
     if want_tp:

@@ -82,11 +82,13 @@ def test_bench_self_launched_tensor_parallel_leg():
 
 
 def test_bench_reports_both_modes_and_config3():
-    """N = 1: the line carries the exact-mode timings beside the fast-mode headline; tp_ok / n_ranks_rccl are null."""
+    """N = 1: the headline is the default (reference-order) mode, the fast mode's timings sit beside it; tp_ok / n_ranks_rccl are null."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "tiny", "--n-batch", "64", "--steps", "2",
                         "--warmup", "1", "--decode-steps", "4", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
                        env=_clean_env())
     assert r.returncode == 0, r.stderr[-2000:]
     d = _line(r.stdout)
-    assert d["mode"] == "fast" and d["exact_mode"]["prefill_tokens_per_s"] > 0 and d["exact_mode"]["decode_tokens_per_s"] > 0
+    assert d["mode"] == "exact" and d["fast_mode"]["prefill_tokens_per_s"] > 0 and d["fast_mode"]["decode_tokens_per_s"] > 0
+    assert "exact_h16" in d["roofline"]["kernel"] and "exact" in d["roofline_decode"]["kernel"] and "traffic_source" in d["roofline"]
+    assert d["fast_mode"]["roofline"]["frac"] > 0
     assert d["tp_ok"] is None and d["n_ranks_rccl"] is None
