@@ -7,12 +7,14 @@
 namespace fl {
 
 // rms_norm(x) * w -> optional f32 copy y_f32 (may be null) -> optional Q8_0 workspace `out` (may be null)
+// with_h16 (layout 16): also the XH16 copy of the quants (q4_layout.h), the operand form of the reference-order prefill GEMM
 hipError_t rmsnorm_quant(const float *x, int ldx, const float *w, int N, int E, float *y_f32, int ldy,
-                         const fl_qact *out, int layout, hipStream_t st);
+                         const fl_qact *out, int layout, hipStream_t st, bool with_h16 = false);
 // silu_table(h13[:, :F]) * h13[:, F:2F] -> Q8_0
 hipError_t silu_mul_quant(const float *h13, int ld, int N, int F, const uint16_t *silu_tab, const fl_qact *out,
                           int layout, hipStream_t st,
-                          bool woven = false);   // woven: h13 = [w1 x 16 | w3 x 16 | ...] instead of [w1 x (F) | w3 x (F)]
+                          bool woven = false,    // woven: h13 = [w1 x 16 | w3 x 16 | ...] instead of [w1 x (F) | w3 x (F)]
+                          bool with_h16 = false);
 // rope on q (in place) and k (-> kc rows n_past..), v -> vc columns n_past..
 hipError_t rope_kv(float *qkv, int ld, int N, int E, int D, int n_past, int n_ctx, const float *rope_tab, float *kc,
                    float *vc, hipStream_t st, const int *dyn_past = nullptr);

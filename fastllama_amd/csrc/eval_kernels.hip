@@ -29,7 +29,7 @@ namespace fl {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void quantize_store_group(const float v[8], int n, int kg, int KB, int layout,
                                                      int8_t *__restrict__ q, float *__restrict__ d,
-                                                     float *__restrict__ s) {
+                                                     float *__restrict__ s, uint16_t *__restrict__ h16 = nullptr) {
     float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
@@ -56,6 +56,12 @@ __device__ __forceinline__ void quantize_store_group(const float v[8], int n, in
         if (g == 0) {
             d[cb] = dd;
             s[cb] = __fmul_rn(dd, (float)sum);
+        }
+        if (h16) {   // the XH16 copy (q4_layout.h): k-group g = MFMA step g, elements 0..3 in lane (n & 31), elements 4..7 in lane + 32
+            auto hb = [](int x) -> uint32_t { return (uint32_t)__half_as_ushort(__int2half_rn(x)); };
+            unsigned char *dst = reinterpret_cast<unsigned char *>(h16) + ((((int64_t)(n >> 5) * KB + b) * 2 + (g >> 1)) * 64 + (n & 31)) * 16 + (g & 1) * 8;
+            *reinterpret_cast<uint2 *>(dst) = make_uint2(hb(qi[0]) | (hb(qi[1]) << 16), hb(qi[2]) | (hb(qi[3]) << 16));
+            *reinterpret_cast<uint2 *>(dst + 512) = make_uint2(hb(qi[4]) | (hb(qi[5]) << 16), hb(qi[6]) | (hb(qi[7]) << 16));
         }
     } else {
         const int64_t vb = (int64_t)n * KB + b;
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_kernel(const float *__restr
                                                             const float *__restrict__ w, int N, int E,
                                                             float *__restrict__ y_f32, int ldy, int layout,
                                                             int8_t *__restrict__ q, float *__restrict__ d,
-                                                            float *__restrict__ s) {
+                                                            float *__restrict__ s, uint16_t *__restrict__ h16) {
     __shared__ double sh[4];
     const int n = blockIdx.x;
     const int gpr = E >> 3, KB = E >> 5;
@@ -135,16 +141,17 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_kernel(const float *__restr
             yp[0] = make_float4(o[0], o[1], o[2], o[3]);
             yp[1] = make_float4(o[4], o[5], o[6], o[7]);
         }
-        if (q) quantize_store_group(o, n, kg, KB, layout, q, d, s);
+        if (q) quantize_store_group(o, n, kg, KB, layout, q, d, s, h16);
     }
 }
 
 hipError_t rmsnorm_quant(const float *x, int ldx, const float *w, int N, int E, float *y_f32, int ldy,
-                         const fl_qact *out, int layout, hipStream_t st) {
+                         const fl_qact *out, int layout, hipStream_t st, bool with_h16) {
     if (E % 32 != 0 || E > 256 * 8 * RN_MAXIT) return hipErrorInvalidValue;
     const int rows = (out && layout == 16) ? fl_roundup(N, 16) : N;
     hipLaunchKernelGGL(rmsnorm_quant_kernel, dim3(rows), dim3(256), 0, st, x, ldx, w, N, E, y_f32, ldy, layout,
-                       out ? out->q : nullptr, out ? out->d : nullptr, out ? out->s : nullptr);
+                       out ? out->q : nullptr, out ? out->d : nullptr, out ? out->s : nullptr,
+                       out && with_h16 && layout == 16 ? out->h16 : nullptr);
     return hipGetLastError();
 }
 
@@ -154,7 +161,8 @@ hipError_t rmsnorm_quant(const float *x, int ldx, const float *w, int N, int E, 
 __global__ __launch_bounds__(256) void silu_mul_quant_kernel(const float *__restrict__ h13, int ld, int N, int NP,
                                                              int F, const uint16_t *__restrict__ silu_tab,
                                                              int layout, int8_t *__restrict__ q,
-                                                             float *__restrict__ d, float *__restrict__ s, int woven) {
+                                                             float *__restrict__ d, float *__restrict__ s, int woven,
+                                                             uint16_t *__restrict__ h16) {
     const int gpr = F >> 3, KB = F >> 5;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)NP * gpr;
@@ -180,15 +188,15 @@ __global__ __launch_bounds__(256) void silu_mul_quant_kernel(const float *__rest
         for (int i = 0; i < 8; ++i) o[i] = 0.f;
     }
     // all 4 lanes of a quad are live or dead together (gpr % 4 == 0); shuffles inside need full quads
-    if (live) quantize_store_group(o, n, kg, KB, layout, q, d, s);
+    if (live) quantize_store_group(o, n, kg, KB, layout, q, d, s, h16);
 }
 
 hipError_t silu_mul_quant(const float *h13, int ld, int N, int F, const uint16_t *silu_tab, const fl_qact *out,
-                          int layout, hipStream_t st, bool woven) {
+                          int layout, hipStream_t st, bool woven, bool with_h16) {
     const int NP = layout == 16 ? fl_roundup(N, 16) : N;
     const int64_t total = (int64_t)NP * (F >> 3);
     hipLaunchKernelGGL(silu_mul_quant_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st, h13, ld, N, NP, F,
-                       silu_tab, layout, out->q, out->d, out->s, woven ? 1 : 0);
+                       silu_tab, layout, out->q, out->d, out->s, woven ? 1 : 0, with_h16 && layout == 16 ? out->h16 : nullptr);
     return hipGetLastError();
 }
 

@@ -686,7 +686,10 @@ __global__ __launch_bounds__(512) void attn_scores_exact_kernel(const float *__r
                                                                 float *__restrict__ att, int ld_att, int64_t head_stride) {
     constexpr int D = 32 * NST, MS = (NST + 1) / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int qb = blockIdx.x, hd = blockIdx.y, q0 = qb * 32;
+    // heaviest query blocks first (block i sees (i + 1) 32-key steps): with one or two workgroups resident per CU the launch runs in
+    // rounds, and the CU that finishes a light block of the first round takes the heaviest one left -- every CU ends up with about
+    // the same number of key steps instead of two heavy blocks on some and two light ones on others (99 -> 80 us, 35 -> 24 us)
+    const int qb = (int)gridDim.y - 1 - (int)blockIdx.y, hd = blockIdx.x, q0 = qb * 32;
     const int i = lane & 31, h = lane >> 5;
     auto load_row = [&](const float *row, float (&dst)[MS][32]) {
 #pragma unroll
@@ -780,7 +783,10 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
     float *Ps = xs_;                                         // [32 queries][XA_LD]   probabilities, zero past each query's last key
     float *Vs = xs_ + 32 * XA_LD;                            // [32 features][XA_LD]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int qb = blockIdx.x, hd = blockIdx.y, q0 = qb * 32;
+    // heaviest query blocks first (block i sees (i + 1) 32-key steps): with one or two workgroups resident per CU the launch runs in
+    // rounds, and the CU that finishes a light block of the first round takes the heaviest one left -- every CU ends up with about
+    // the same number of key steps instead of two heavy blocks on some and two light ones on others (99 -> 80 us, 35 -> 24 us)
+    const int qb = (int)gridDim.y - 1 - (int)blockIdx.y, hd = blockIdx.x, q0 = qb * 32;
     const int i = lane & 31, h = lane >> 5;
     const int P = n_past + N;                                // the dot runs over all P keys (soft_max wrote zeros past the diagonal)
     const int kend = min(P, n_past + min(q0 + 31, N - 1) + 1);     // ... but past this block's last visible key every term is +0
@@ -915,7 +921,7 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
 hipError_t attn_scores_exact(const float *qkv, int ldq, int D, int H, int N, int n_past, const float *kc, int ldk, float scale,
                              float *att, int ld_att, int64_t head_stride, hipStream_t st) {
     if (D % 32 != 0 || D > 128 || N < 1 || (ldq & 3) || (ldk & 3)) return hipErrorInvalidValue;
-    const dim3 grid((N + 31) / 32, H);
+    const dim3 grid(H, (N + 31) / 32);
 #define FL_XS(NST) hipLaunchKernelGGL(attn_scores_exact_kernel<NST>, grid, dim3(512), 0, st, qkv, ldq, N, n_past, kc, ldk, scale, att, ld_att, head_stride)
     if (D == 32) FL_XS(1);
     else if (D == 64) FL_XS(2);
@@ -937,7 +943,7 @@ hipError_t attn_pv_exact(const float *att, int ld_att, int64_t head_stride, int 
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(attn_pv_exact_kernel, dim3((N + 31) / 32, H), dim3(256), lds, st, att, ld_att, head_stride, D, N, n_past, vc, n_ctx,
+    hipLaunchKernelGGL(attn_pv_exact_kernel, dim3(H, (N + 31) / 32), dim3(256), lds, st, att, ld_att, head_stride, D, N, n_past, vc, n_ctx,
                        ao, ldo);
     return hipGetLastError();
 }

@@ -621,8 +621,7 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
             if (kv_rec) M_HIP(hipEventRecord(kv_rec[l], st));
         } else {
             // norm + attention_norm*cur -> Q8_0                                                        llama.cpp:311-319
-            M_HIP(rmsnorm_quant(inp, E, ly.attn_norm, N, E, nullptr, 0, &m->qE, layout, st));
-            if (xh) M_HIP(qa16_to_h16(m->qE, N, st));
+            M_HIP(rmsnorm_quant(inp, E, ly.attn_norm, N, E, nullptr, 0, &m->qE, layout, st, xh));     // (xh: + the XH16 copy)
             if ((N >= 9 && !dyn && fuse_pa) || xh) {
                 M_HIP(mm_qkv_rope(m, ly.wqkv, m->qE, N, kc, vc, n_past));                              // wq, wk, wv + rope + KV store
             } else {
@@ -651,8 +650,8 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
                 else
                     M_HIP((exact ? dot_f32_abt_exact : gemm_f32_abt)(m->att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, m->ao, El, D, N,
                                                                      D, P, Hl, 1.0f, 2, n_past, st, dyn, n_ctx));
-                M_HIP((layout == 16 ? quantize_q8_qa16 : quantize_q8_qa1)(m->ao, El, N, El, m->qEl, st));
-                if (xh && !m->tp_rows) M_HIP(qa16_to_h16(m->qEl, N, st));
+                if (layout == 16) M_HIP(quantize_q8_qa16(m->ao, El, N, El, m->qEl, st, xh && !m->tp_rows));
+                else M_HIP(quantize_q8_qa1(m->ao, El, N, El, m->qEl, st));
             }   // (the one-launch kernel wrote the Q8_0 operand of the wo matmul itself)
         }
         // wo projection + residual                                                                 :401-407
@@ -677,14 +676,12 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
         } else if (fused) {
             M_HIP(mm_norm(m, ly.w13, mid, ly.ffn_norm, nullptr, m->h13));
         } else {
-            M_HIP(rmsnorm_quant(mid, E, ly.ffn_norm, N, E, nullptr, 0, &m->qE, layout, st));
-            if (xh) M_HIP(qa16_to_h16(m->qE, N, st));
+            M_HIP(rmsnorm_quant(mid, E, ly.ffn_norm, N, E, nullptr, 0, &m->qE, layout, st, xh));
             if (silu_in_gemm) M_HIP(mm_silu_gemm(m, ly.w13, m->qE, N));
             else M_HIP(mm(m, ly.w13, m->qE, N, m->h13, 2 * Fl, nullptr, 0));
         }
         if (!fused && !silu_in_gemm) {
-            M_HIP(silu_mul_quant(m->h13, 2 * Fl, N, Fl, m->silu_tab, &m->qF, layout, st, m->w13_il));
-            if (xh) M_HIP(qa16_to_h16(m->qF, N, st));
+            M_HIP(silu_mul_quant(m->h13, 2 * Fl, N, Fl, m->silu_tab, &m->qF, layout, st, m->w13_il, xh && !m->tp_rows));
         }
         if (!tp) {
             if (silu_in_gemv) M_HIP(mm_quant(m, ly.w2, m->h13, inp, mid));
@@ -719,8 +716,7 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
     if (fused) {
         M_HIP(mm_norm(m, m->output, inp, m->norm_w, m->xn, lg));
     } else {
-        M_HIP(rmsnorm_quant(inp, E, m->norm_w, N, E, m->xn, E, &m->qE, layout, st));
-        if (xh) M_HIP(qa16_to_h16(m->qE, N, st));
+        M_HIP(rmsnorm_quant(inp, E, m->norm_w, N, E, m->xn, E, &m->qE, layout, st, xh));
         M_HIP(mm(m, m->output, m->qE, N, lg, ldlg, nullptr, 0));
     }
     if (m->Vl > 0) {                                          // rows V/G of the lm-head per rank -> gather the logits slices

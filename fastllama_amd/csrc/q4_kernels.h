@@ -15,7 +15,8 @@ hipError_t unpack_from_qw16(int type, const uint32_t *qs, const float *d, const 
 // ---- a4: quantize_row_q8_0 (lib/ggml.c:1299-1441), three output layouts ----
 // x: N rows of K floats, row stride ldx (elements).
 hipError_t quantize_q8_aos(const float *x, int ldx, int N, int K, void *aos_dev, hipStream_t st);
-hipError_t quantize_q8_qa16(const float *x, int ldx, int N, int K, const fl_qact &out, hipStream_t st);
+hipError_t quantize_q8_qa16(const float *x, int ldx, int N, int K, const fl_qact &out, hipStream_t st,
+                            bool with_h16 = false);   // with_h16: also out.h16, the XH16 copy (q4_layout.h)
 hipError_t quantize_q8_qa1(const float *x, int ldx, int N, int K, const fl_qact &out, hipStream_t st);
 // QA16 / QA1 workspace -> reference AoS block_q8_0 (parity tests of the internal quantizers)
 hipError_t export_qa16_to_aos(const fl_qact &in, int N, int K, void *aos_dev, hipStream_t st);

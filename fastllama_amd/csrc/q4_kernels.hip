@@ -156,7 +156,7 @@ __device__ __forceinline__ Q8Quad quantize_group8(const float v[8]) {
 template <int LAYOUT>
 __global__ void quantize_q8_kernel(const float *__restrict__ x, int ldx, int N, int NP, int K,
                                    int8_t *__restrict__ q, float *__restrict__ d, float *__restrict__ s,
-                                   uint32_t *__restrict__ aos) {
+                                   uint32_t *__restrict__ aos, uint16_t *__restrict__ h16) {
     const int gpr = K >> 3;  // 8-element groups per row
     const int KB = K >> 5;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -195,6 +195,12 @@ __global__ void quantize_q8_kernel(const float *__restrict__ x, int ldx, int N, 
             d[cb] = o.d;
             s[cb] = o.s;
         }
+        if (h16) {   // the XH16 copy (q4_layout.h): w_nat holds the group's int8 in element order (0..3 | 4..7)
+            auto hb = [](uint32_t wv, int i) -> uint32_t { return (uint32_t)__half_as_ushort(__int2half_rn((int)(int8_t)((wv >> (8 * i)) & 0xFF))); };
+            unsigned char *dst = reinterpret_cast<unsigned char *>(h16) + ((((int64_t)(n >> 5) * KB + b) * 2 + (g >> 1)) * 64 + (n & 31)) * 16 + (g & 1) * 8;
+            *reinterpret_cast<uint2 *>(dst) = make_uint2(hb(o.w_nat[0], 0) | (hb(o.w_nat[0], 1) << 16), hb(o.w_nat[0], 2) | (hb(o.w_nat[0], 3) << 16));
+            *reinterpret_cast<uint2 *>(dst + 512) = make_uint2(hb(o.w_nat[1], 0) | (hb(o.w_nat[1], 1) << 16), hb(o.w_nat[1], 2) | (hb(o.w_nat[1], 3) << 16));
+        }
     } else {
         const int64_t vb = (int64_t)n * KB + b;
         uint2 w = make_uint2(o.w_perm[0], o.w_perm[1]);
@@ -211,20 +217,20 @@ size_t qact_bytes_scale(int N, int K) { return (size_t)fl_roundup(N, 16) * (size
 
 template <int LAYOUT>
 static hipError_t launch_quantize(const float *x, int ldx, int N, int NP, int K, int8_t *q, float *d, float *s,
-                                  void *aos, hipStream_t st) {
+                                  void *aos, hipStream_t st, uint16_t *h16 = nullptr) {
     const int64_t total = (int64_t)NP * (K >> 3);
     const int grid = (int)((total + 255) / 256);
     if (grid == 0) return hipSuccess;
     hipLaunchKernelGGL(quantize_q8_kernel<LAYOUT>, dim3(grid), dim3(256), 0, st, x, ldx, N, NP, K, q, d, s,
-                       (uint32_t *)aos);
+                       (uint32_t *)aos, h16);
     return hipGetLastError();
 }
 
 hipError_t quantize_q8_aos(const float *x, int ldx, int N, int K, void *aos, hipStream_t st) {
     return launch_quantize<Q8_AOS>(x, ldx, N, N, K, nullptr, nullptr, nullptr, aos, st);
 }
-hipError_t quantize_q8_qa16(const float *x, int ldx, int N, int K, const fl_qact &o, hipStream_t st) {
-    return launch_quantize<Q8_QA16>(x, ldx, N, fl_roundup(N, 16), K, o.q, o.d, o.s, nullptr, st);
+hipError_t quantize_q8_qa16(const float *x, int ldx, int N, int K, const fl_qact &o, hipStream_t st, bool with_h16) {
+    return launch_quantize<Q8_QA16>(x, ldx, N, fl_roundup(N, 16), K, o.q, o.d, o.s, nullptr, st, with_h16 ? o.h16 : nullptr);
 }
 hipError_t quantize_q8_qa1(const float *x, int ldx, int N, int K, const fl_qact &o, hipStream_t st) {
     return launch_quantize<Q8_QA1>(x, ldx, N, N, K, o.q, o.d, o.s, nullptr, st);
