@@ -105,6 +105,7 @@ struct fl_model : Act {
     bool fuse_prefill_attn = true;   // N >= 9: KQ + soft_max + KQV in one launch
     int force_deep_attn = 0;         // debugging: always the key-tiled form of that launch
     bool ingest_one_stream = false;  // debugging: fl_model_ingest takes its chunks one after the other
+    bool split_eval = false;         // opt-in (measured slower, profiles/r04_split_eval.txt): a prefill eval of >= 256 tokens as two halves on the two streams
     bool exact = false;              // reference-order kernels (exact_kernels.hip): logits bit-identical to the reference's x86 build
     bool w13_il = false;             // w1|w3 woven by 16-row groups (n_ff/tp a multiple of 32): silu epilogue in the matmul
     int h16_state = 0;               // WH16 copies of the matmul weights (reference-order prefill): 0 not built, 1 ready, -1 no memory for them
@@ -587,7 +588,7 @@ static int tp_gather_rows_add(fl_model *m, const float *part, int N, const float
 // (the previous chunk, running on the other stream, has stored its rows), and records kv_rec[l] once this chunk's rows are stored.
 static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool split_attn = false, int l0 = 0, int l1 = -1,
                             bool body_only = false, bool skip_head = false, const hipEvent_t *kv_wait = nullptr,
-                            const hipEvent_t *kv_rec = nullptr) {
+                            const hipEvent_t *kv_rec = nullptr, float *logits_dst = nullptr, float *xn_dst = nullptr) {
     const int E = m->E, El = m->El, Fl = m->Fl, D = m->D, Hl = m->Hl, V = m->V, n_ctx = m->n_ctx;
     const int layout = N <= (m->exact ? 1 : 8) ? 1 : 16;    // exact mode: only N = 1 takes the single-vector layout
     const int P = n_past + N;
@@ -711,12 +712,13 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
     }
     if (body_only || skip_head) return FL_OK;
     // final norm (kept in f32 for the embeddings) + lm head                                        :452-465
-    float *lg = m->Vl > 0 ? m->logits_part : m->logits;
+    float *lg = m->Vl > 0 ? m->logits_part : logits_dst ? logits_dst : m->logits;       // (the overrides: a half of a split eval writes
+    float *xn = xn_dst ? xn_dst : m->xn;                                                //  its rows of the primary set's buffers)
     const int ldlg = m->Vl > 0 ? m->ldp : m->ldl;
     if (fused) {
-        M_HIP(mm_norm(m, m->output, inp, m->norm_w, m->xn, lg));
+        M_HIP(mm_norm(m, m->output, inp, m->norm_w, xn, lg));
     } else {
-        M_HIP(rmsnorm_quant(inp, E, m->norm_w, N, E, m->xn, E, &m->qE, layout, st, xh));
+        M_HIP(rmsnorm_quant(inp, E, m->norm_w, N, E, xn, E, &m->qE, layout, st, xh));
         M_HIP(mm(m, m->output, m->qE, N, lg, ldlg, nullptr, 0));
     }
     if (m->Vl > 0) {                                          // rows V/G of the lm-head per rank -> gather the logits slices
@@ -724,6 +726,67 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
         const int rc = fl_comm_allgather_f32(m->comm, m->logits_part, (size_t)N * m->ldp, m->gather_tmp, st);
         if (rc != FL_OK) return rc;
         M_HIP(gather_cols(m->gather_tmp, m->G, N, m->Vl, m->ldp, m->logits, m->ldl, st));
+    }
+    return FL_OK;
+}
+
+// the second set of work buffers, its stream, the per-layer events of two evals in flight (fl_model_ingest, split evals)
+static int ensure_alt(fl_model *m) {
+    if (m->alt_ready) return FL_OK;
+    if (!m->alt.stream) M_HIP(hipStreamCreateWithFlags(&m->alt.stream, hipStreamNonBlocking));
+    hipStream_t st1 = m->alt.stream;
+    if (!m->alt.x) {                                  // (a previous call may have got this far and failed on an event below)
+        const int rc = act_alloc(m, m->alt);
+        if (rc != FL_OK) act_free(m->alt);            // (no half-allocated set left behind)
+        m->alt.stream = st1;
+        if (rc != FL_OK) return rc;
+    }
+    for (auto &v : m->kv_ev)
+        while ((int)v.size() < m->L) {
+            hipEvent_t e;
+            M_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            v.push_back(e);
+        }
+    if (!m->ev_fork) M_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    if (!m->ev_join) M_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    m->alt_ready = true;
+    return FL_OK;
+}
+
+/* One prefill eval as TWO halves in flight on the two streams (round 4).  OFF by default: built, bit-identical,
+ * and measured SLOWER in both modes -- fast 11.83 -> 12.63 ms, reference-order 35.38 -> 36.03 ms per 512-token eval
+ * (profiles/r04_split_eval.txt): half-size launches re-read every weight panel and double the launch count, which costs more than
+ * the covered ramps and tails give back (two INDEPENDENT evals, fl_model_ingest, still gain).  The idea: every launch of an n_batch eval is a few rounds of
+ * workgroups whose ramp, tail and -- for the latency-bound attention / norm kernels -- idle CUs are covered by nothing; the second
+ * half needs the first only where its attention reads the K/V cache, layer by layer (the events of fl_model_ingest).  Tokens are
+ * independent columns of every matmul, and a query's attention dots do not change when keys it cannot see leave its batch -- as
+ * long as the first half ends on a 32-key boundary, where ggml_vec_dot_f32's 32-element steps end too (no leftover loop changes
+ * hands): the split is chosen that way, so the logits are those of the single eval bit for bit in the reference-order mode
+ * (tests/test_exact_gpu.py).  n1: tokens of the first half. */
+static int eval_split(fl_model *m, const int32_t *tokens, int N, int n1, int n_past, bool all_logits) {
+    int rc = ensure_alt(m);
+    if (rc != FL_OK) return rc;
+    Act &prim = *m;
+    float *lg = m->logits, *xn = m->xn;                  // both halves write their rows of the PRIMARY set's logits / final-norm buffers
+    M_HIP(hipEventRecord(m->ev_fork, prim.stream));
+    M_HIP(hipStreamWaitEvent(m->alt.stream, m->ev_fork, 0));
+    std::swap(prim, m->alt);                             // first half: the second set of buffers, the second stream
+    hipError_t e = hipMemcpyAsync(m->tok_dev, tokens, (size_t)n1 * 4, hipMemcpyHostToDevice, m->stream);
+    rc = e != hipSuccess ? hip_fail(e, "hipMemcpyAsync(tokens)")
+                         : run_eval_kernels(m, n1, n_past, nullptr, false, 0, -1, false, !all_logits, nullptr, m->kv_ev[1].data(), lg, xn);
+    std::swap(prim, m->alt);
+    if (rc == FL_OK) {
+        e = hipMemcpyAsync(m->tok_dev, tokens + n1, (size_t)(N - n1) * 4, hipMemcpyHostToDevice, m->stream);
+        rc = e != hipSuccess ? hip_fail(e, "hipMemcpyAsync(tokens)")
+                             : run_eval_kernels(m, N - n1, n_past + n1, nullptr, false, 0, -1, false, false, m->kv_ev[1].data(), m->kv_ev[0].data(),
+                                                lg + (size_t)n1 * m->ldl, xn + (size_t)n1 * m->E);
+    }
+    e = hipEventRecord(m->ev_join, m->alt.stream);       // join: everything the second stream did happens-before what follows on the primary one
+    if (e == hipSuccess) e = hipStreamWaitEvent(prim.stream, m->ev_join, 0);
+    if (rc != FL_OK || e != hipSuccess) {
+        (void)hipStreamSynchronize(prim.stream);
+        (void)hipStreamSynchronize(m->alt.stream);
+        return rc != FL_OK ? rc : hip_fail(e, "eval_split: join");
     }
     return FL_OK;
 }
@@ -775,9 +838,20 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
             if (rc != FL_OK) return rc;
         }
     } else {
-        M_HIP(hipMemcpyAsync(m->tok_dev, tokens, (size_t)N * 4, hipMemcpyHostToDevice, st));
-        const int rc = run_eval_kernels(m, N, n_past, nullptr, split_attn);
-        if (rc != FL_OK) return rc;
+        // a prefill eval of >= 256 tokens: two halves in flight on the two streams, the first ending on a 32-key boundary (eval_split)
+        int n1 = 0;
+        if (N >= 256 && m->split_eval && m->G == 1 && m->E < 8192 && !m->profile) {
+            n1 = ((n_past + N / 2 + 31) & ~31) - n_past;
+            if (n1 < 64 || N - n1 < 64) n1 = 0;
+        }
+        if (n1 > 0) {
+            const int rc = eval_split(m, tokens, N, n1, n_past, all_logits != 0);
+            if (rc != FL_OK) return rc;
+        } else {
+            M_HIP(hipMemcpyAsync(m->tok_dev, tokens, (size_t)N * 4, hipMemcpyHostToDevice, st));
+            const int rc = run_eval_kernels(m, N, n_past, nullptr, split_attn);
+            if (rc != FL_OK) return rc;
+        }
     }
     if (logits_host) {
         if (all_logits) M_HIP(hipMemcpy2DAsync(logits_host, (size_t)V * 4, m->logits, (size_t)m->ldl * 4, (size_t)V * 4, N, hipMemcpyDeviceToHost, st));
@@ -842,25 +916,7 @@ int fl_model_ingest(fl_model *m, const int32_t *tokens, const int *chunk_len, in
         M_HIP(hipStreamSynchronize(m->stream));
         return FL_OK;
     }
-    if (!m->alt_ready) {                                  // the second set of work buffers, its stream, the per-layer events
-        if (!m->alt.stream) M_HIP(hipStreamCreateWithFlags(&m->alt.stream, hipStreamNonBlocking));
-        hipStream_t st1 = m->alt.stream;
-        if (!m->alt.x) {                                  // (a previous call may have got this far and failed on an event below)
-            const int rc = act_alloc(m, m->alt);
-            if (rc != FL_OK) act_free(m->alt);            // (no half-allocated set left behind)
-            m->alt.stream = st1;
-            if (rc != FL_OK) return rc;
-        }
-        for (auto &v : m->kv_ev)
-            while ((int)v.size() < m->L) {
-                hipEvent_t e;
-                M_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                v.push_back(e);
-            }
-        if (!m->ev_fork) M_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-        if (!m->ev_join) M_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
-        m->alt_ready = true;
-    }
+    { const int rca = ensure_alt(m); if (rca != FL_OK) return rca; }
     Act &prim = *m;
     // the second stream starts behind whatever the primary stream still has queued (an earlier eval's K/V stores)
     M_HIP(hipEventRecord(m->ev_fork, prim.stream));
@@ -894,8 +950,9 @@ int fl_model_ingest(fl_model *m, const int32_t *tokens, const int *chunk_len, in
 /* bit 0 (default 1): decode evals replay a captured hipGraph, else plain launches; bit 1 (default 0): decode uses the
  * generic per-op kernels instead of the fused single-token ones; bit 2: prefill attention as three kernels; bit 3: decode
  * attention always in one launch per layer; bit 4: always the two-launch split form (default: split from position 256 on);
- * bit 5: prefill attention always in its key-tiled (deep-context) form; bit 7: fl_model_ingest on one stream.
- * Debugging / A-B timing; results do not depend on bits 0, 2, 3, 4, 5, 7. */
+ * bit 5: prefill attention always in its key-tiled (deep-context) form; bit 7: fl_model_ingest on one stream; bit 8: a prefill
+ * eval of >= 256 tokens runs as two halves on the two streams (same bits; measured slower: profiles/r04_split_eval.txt).
+ * Debugging / A-B timing; results do not depend on bits 0, 2, 3, 4, 5, 7, 8. */
 int fl_model_set_graph(fl_model *m, int mode) {
     if (!m) return set_error(FL_EINVAL, "null model");
     m->graph_enabled = (mode & 1) != 0;
@@ -903,6 +960,7 @@ int fl_model_set_graph(fl_model *m, int mode) {
     m->fuse_prefill_attn = (mode & 4) == 0;
     m->force_deep_attn = (mode & 32) ? 1 : 0;
     m->ingest_one_stream = (mode & 128) != 0;
+    m->split_eval = (mode & 256) != 0;
     m->split_past = (mode & 8) ? INT_MAX : (mode & 16) ? 0 : 256;
     if (fuse != m->fuse_decode) {
         if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);

@@ -218,6 +218,36 @@ def test_model_exact_mode_deep_context(tmp_path, torch, port, reflib):
     m.free()
 
 
+@pytest.mark.parametrize("exact", [True, False])
+def test_split_prefill_eval_equals_the_single_eval(torch, port, exact):
+    """fl_model_set_graph bit 8: a prefill of >= 256 tokens runs as two halves on two streams, the first ending on a 32-key boundary
+    (eval_split, model.cpp; off by default -- measured slower, profiles/r04_split_eval.txt): every logit, the embedding of the last token and the K/V cache (through a decode step on top) equal the unsplit
+    eval's -- in the reference-order mode because nothing of a token's arithmetic depends on its batch once ggml_vec_dot_f32's
+    32-element steps end where the half ends, in the fast mode because its kernels are batch-split invariant too.  Positions off
+    the 32-key grid, ragged sizes and all-logits included."""
+    from fastllama_amd import hip
+    from harness.flmodel import FlModel
+    L = hip.load()
+    cfg, qt = ggjt.SMALL, oracle.Q4_1
+    tensors = ggjt.synth_tensors(cfg, qt, port.quantize_q4, seed=17)
+    rng = np.random.default_rng(4)
+    toks = rng.integers(3, 259, 1200).astype(np.int32)
+    outs = []
+    for mode in (0, 256):                                    # bit 8 of fl_model_set_graph: default (one eval) | split
+        m = FlModel(cfg, qt, tensors, n_ctx=1300, max_batch=512)
+        m.set_exact(exact)
+        hip.check(L.fl_model_set_graph(m.h, 1 | mode))
+        a, ea = m.eval(toks[:512], n_past=0, all_logits=True, embeddings=True)
+        b = m.eval(toks[512:512 + 300], n_past=512)                         # last logits only
+        c = m.eval(toks[812:812 + 37], n_past=812)                          # below the split threshold
+        d, ed = m.eval(toks[849:849 + 351], n_past=849, all_logits=True, embeddings=True)   # n_past off the 32-key grid
+        e = m.eval(toks[5:6], n_past=1200)                                  # a decode step over the whole cache
+        outs.append((a, ea, b, c, d, ed, e))
+        m.free()
+    for x, y in zip(*outs):
+        assert np.array_equal(bits(x), bits(y))
+
+
 def test_model_exact_mode_chunked_ingest_and_decode_steps(tmp_path, torch, port, reflib):
     """The session pattern: n_batch-8 chunks (N <= 8 kernels on the prompt), then greedy decode steps (N = 1, hipGraph replay)."""
     from harness.flmodel import FlModel
