@@ -44,6 +44,7 @@ struct P2PState {
     void *mapped[2 * FL_COMM_MAX_LOCAL] = {nullptr};
     int n_mapped = 0;
     bool ready = false;
+    unsigned timeouts_seen = 0;       // of peers.epoch[1] (the exchange kernel's give-up counter): fl_comm_p2p_check
 };
 
 struct fl_comm {
@@ -112,34 +113,44 @@ fl_comm *fl_comm_create(const void *id_bytes, int rank, int world) {
     }
     fl_comm *c = new (std::nothrow) fl_comm();
     if (!c) return nullptr;
+    // peer-mapped exchange buffers for the small messages: handles travel through the communicator itself
+    // (opt-in, FL_P2P=1: the exchange has run between processes on one GPU only -- no multi-GPU node was available to this
+    //  project -- and a communicator that every multi-GPU run depends on should not default to an untried path)
+    const char *want_p2p_env = getenv("FL_P2P");
+    const bool want_p2p = world >= 2 && world <= FL_COMM_MAX_LOCAL && want_p2p_env && want_p2p_env[0] == '1';
+    // The handshake's staging buffer is allocated BEFORE the communicator exists: once ncclCommInitRank has returned, every rank
+    // must execute both collectives below whatever happens locally (a local ncclCommAbort does not reliably unblock peers already
+    // inside ncclAllGather), so nothing that can fail may sit between the init and them.  Device memory first, pinned host memory
+    // (which RCCL reads and writes in place) if the device has none left; with neither, the rank gives up before joining anything.
+    constexpr size_t STAGE_BYTES = FL_COMM_P2P_HANDLE_BYTES * (FL_COMM_MAX_LOCAL + 1);
+    void *stage = nullptr;
+    bool stage_host = false;
+    if (want_p2p && hipMalloc(&stage, STAGE_BYTES) != hipSuccess) {
+        (void)hipGetLastError();
+        stage = nullptr;
+        if (hipHostMalloc(&stage, STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error(FL_ENOMEM, "fl_comm_create: no memory for the peer-exchange handshake (nothing joined yet)");
+            delete c;
+            return nullptr;
+        }
+        stage_host = true;
+    }
     ncclUniqueId id;
     memcpy(&id, id_bytes, sizeof id);
     ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
     if (r != ncclSuccess) {
         set_error(FL_EHIP, "ncclCommInitRank: %s", ncclGetErrorString(r));
+        if (stage) (void)(stage_host ? hipHostFree(stage) : hipFree(stage));
         delete c;
         return nullptr;
     }
     c->rank = rank;
     c->world = world;
-    // peer-mapped exchange buffers for the small messages: handles travel through the communicator itself
-    // (opt-in, FL_P2P=1: the exchange has run between processes on one GPU only -- no multi-GPU node was available to this
-    //  project -- and a communicator that every multi-GPU run depends on should not default to an untried path)
-    const char *want_p2p = getenv("FL_P2P");
-    if (world >= 2 && world <= FL_COMM_MAX_LOCAL && want_p2p && want_p2p[0] == '1') {
+    if (want_p2p) {
         unsigned char mine[FL_COMM_P2P_HANDLE_BYTES], all[FL_COMM_P2P_HANDLE_BYTES * FL_COMM_MAX_LOCAL];
-        void *stage = nullptr;
-        // The staging buffer comes first: a rank that cannot even allocate it cannot take part in the collectives below, and
-        // must not leave its peers waiting inside them -- it aborts the communicator (the peers' calls then fail instead of
-        // hanging) and reports the failure.  Everything after this point is collective-safe: a rank whose local setup failed
-        // still joins the all-gather with a zero handle and the agreement with a 0.
-        if (hipMalloc(&stage, sizeof all + sizeof mine) != hipSuccess) {
-            (void)hipGetLastError();
-            set_error(FL_ENOMEM, "fl_comm_create: no device memory for the peer-exchange handshake; communicator aborted");
-            (void)ncclCommAbort(c->comm);
-            delete c;
-            return nullptr;
-        }
+        // Everything from here on is collective-safe: a rank whose local setup failed still joins the all-gather with a zero handle
+        // and the agreement with a 0.
         bool ok = fl_comm_p2p_export(c, mine) == FL_OK;
         if (ok) ok = hipMemcpy(static_cast<unsigned char *>(stage) + sizeof all, mine, sizeof mine, hipMemcpyHostToDevice) == hipSuccess;
         // (every rank takes part in the collective whatever happened locally: a rank that failed contributes a zero handle)
@@ -169,7 +180,7 @@ fl_comm *fl_comm_create(const void *id_bytes, int rank, int world) {
         } else {
             p2p_free(c);
         }
-        (void)hipFree(stage);
+        (void)(stage_host ? hipHostFree(stage) : hipFree(stage));
         (void)hipGetLastError();
     }
     return c;
@@ -232,6 +243,21 @@ int fl_comm_p2p_timeouts(const fl_comm *c) {
     unsigned n = 0;
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&n, c->p2p.peers.epoch + 1, sizeof n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int)n;
+}
+
+/* After a synchronised tensor-parallel eval: did the exchange kernel of this rank give up waiting for a peer since the last check?
+ * (Its bounded spin then went on with whatever the slots held -- the results of that eval are invalid, and the epochs of the ranks
+ * may be out of step.)  The caller has synchronised the stream the exchanges ran on.  FL_OK, or FL_EHIP with the count. */
+int fl_comm_p2p_check(fl_comm *c) {
+    if (!c || !c->p2p.ready) return FL_OK;
+    unsigned n = 0;
+    if (hipMemcpy(&n, c->p2p.peers.epoch + 1, sizeof n, hipMemcpyDeviceToHost) != hipSuccess)
+        return set_error(FL_EHIP, "peer exchange: cannot read the timeout counter");
+    if (n == c->p2p.timeouts_seen) return FL_OK;
+    const unsigned fresh = n - c->p2p.timeouts_seen;
+    c->p2p.timeouts_seen = n;
+    return set_error(FL_EHIP, "peer exchange: %u exchange(s) of rank %d gave up waiting for a peer -- the tensor-parallel results of this eval "
+                              "are invalid and the communicator should be recreated", fresh, c->rank);
 }
 
 int fl_comm_create_local(int world, fl_comm **out) {

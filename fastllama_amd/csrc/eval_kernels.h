@@ -27,7 +27,7 @@ hipError_t gemm_f32_abt(const float *A, int lda, int64_t sAz, const float *B, in
 hipError_t dot_f32_abt_exact(const float *A, int lda, int64_t sAz, const float *B, int ldb, int64_t sBz, float *C, int ldc,
                              int64_t sCz, int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past,
                              hipStream_t st, const int *dyn_past = nullptr, int nn_max = 0);
-// exact mode, prefill (n_past + N <= 512): the same two products on the f32-input MFMA, whose k = 0, 1 chain IS the reference's
+// exact mode, prefill (any context length): the same two products on the f32-input MFMA, whose k = 0, 1 chain IS the reference's
 // fma chain (exact_kernels.hip); hipErrorInvalidValue: shape outside their reach -> dot_f32_abt_exact
 hipError_t attn_scores_exact(const float *qkv, int ldq, int D, int H, int N, int n_past, const float *kc, int ldk, float scale,
                              float *att, int ld_att, int64_t head_stride, hipStream_t st);

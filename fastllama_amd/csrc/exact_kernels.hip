@@ -917,7 +917,8 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
     }
 }
 
-// hipErrorInvalidValue: shape outside these kernels' reach (n_past + N > 512, head_dim not a multiple of 32 or > 128)
+// hipErrorInvalidValue: shape outside these kernels' reach (head_dim not a multiple of 32 or > 128, unaligned rows): the caller
+// (run_eval_kernels, model.cpp) then takes dot_f32_abt_exact
 hipError_t attn_scores_exact(const float *qkv, int ldq, int D, int H, int N, int n_past, const float *kc, int ldk, float scale,
                              float *att, int ld_att, int64_t head_stride, hipStream_t st) {
     if (D % 32 != 0 || D > 128 || N < 1 || (ldq & 3) || (ldk & 3)) return hipErrorInvalidValue;

@@ -14,7 +14,10 @@
 //
 // Workgroup = 4 waves = 128 rows x 32 columns; a wave owns 32 rows (two QW16 row groups) and streams its weights from L2/HBM
 // into registers one block pair ahead; the 32-column x 2-block activation tile of the next pair is converted int8 -> f16 once
-// per workgroup while it is staged into LDS, in the order the B fragments are read (conflict-free ds_read_b128).
+// per workgroup while it is staged into LDS, in the order the B fragments are read (one ds_read_b128 each; the 8-byte staging stores are
+// not conflict-free: SQ_LDS_BANK_CONFLICT ~ 1 cycle per LDS instruction, profiles/r03_gemm_exact_pmc.md).
+// Round 4: superseded for N >= 9 by gemm_q4_exact_h16.hip (ready-made f16 fragments by LDS-DMA, 1.45x faster); this kernel remains the
+// form for 2 <= N <= 8, the fallback when there is no memory for the H16 copies, and the independent cross-check (fl_debug_mul_mat_q 6).
 // Q4_0: the unpacked weights are 16 (nib - 8) and the stored scale is d / 16: fma(rn((d/16) d_x), 16 q, a) rounds the same real
 // number as the reference's fma(rn(d d_x), q, a).
 #include <hip/hip_runtime.h>

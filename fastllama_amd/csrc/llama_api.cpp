@@ -615,14 +615,19 @@ struct Session {
                 logits_on_device = 0;
                 logits.resize((size_t)hp.n_vocab);
                 if (fl_model_ingest(model, all.data(), lens.data(), (int)lens.size(), pending[i].past, logits.data()) != FL_OK) {
+                    // which block failed?  The reference stops AT the failing block (lib/bridge.cpp:214-219), with every block before
+                    // it in the K/V cache: take the group again one eval at a time (the K/V rows are simply rewritten)
                     log.err("Model::eval", std::string(fl_last_error()) + "\n");
-                    ok = false;
+                    for (size_t k = i; k < j && ok; ++k) {
+                        ok = eval(pending[k].past, pending[k].toks);
+                        if (!ok) failed = k;
+                    }
                 }
                 if (mem_per_token == 0) mem_per_token = 1;
             } else {
                 ok = eval(pending[i].past, pending[i].toks);
+                if (!ok) failed = i;
             }
-            if (!ok) failed = i;
             i = j;
         }
         return failed;
@@ -754,10 +759,13 @@ struct Session {
                     ok = true;
                     for (size_t j = j0; j < j1; ++j) {
                         const float *l = logits.data() + j * V;
+                        // the reference's own arithmetic (softmax(), lib/bridge.cpp:314-330, then :405): a float sum of float
+                        // exponentials taken in order, a float division, a float log -- with the host's libm, as there
                         const float mx = *std::max_element(l, l + V);
-                        double sum = 0.0;                   // as logits_nll_kernel: f64 sum of the f32 exponentials
-                        for (size_t k = 0; k < V; ++k) sum += (double)std::exp(l[k] - mx);
-                        row_nll[j - j0] = -std::log((double)std::exp(l[(size_t)next[j - j0]] - mx) / sum);
+                        float sum = 0.f;
+                        for (size_t k = 0; k < V; ++k) sum += std::exp(l[k] - mx);
+                        const float pr = std::exp(l[(size_t)next[j - j0]] - mx) / sum;
+                        row_nll[j - j0] = (double)(-std::log(pr));
                     }
                 }
                 if (!ok) { log.err("perplexity", std::string(fl_last_error()) + "\n"); all_logits = old; return -1.f; }

@@ -641,16 +641,23 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
                 (void)hipGetLastError();
                 // KQ, scale, mask, soft_max                                                            :364-379
                 const bool xa = exact && !dyn && N >= 2 && D % 32 == 0 && D <= 128;   // the MFMA forms of the exact products
-                if (xa) M_HIP(attn_scores_exact(m->qkv, 3 * El, D, Hl, N, n_past, kc, El, kq_scale, m->att, n_ctx, (int64_t)N * n_ctx, st));
-                else
-                    M_HIP((exact ? dot_f32_abt_exact : gemm_f32_abt)(m->qkv, 3 * El, D, kc, El, D, m->att, n_ctx, (int64_t)N * n_ctx, N, P, D, Hl,
-                                                                     kq_scale, 1, n_past, st, dyn, n_ctx));
+                hipError_t xe = xa ? attn_scores_exact(m->qkv, 3 * El, D, Hl, N, n_past, kc, El, kq_scale, m->att, n_ctx, (int64_t)N * n_ctx, st)
+                                   : hipErrorInvalidValue;
+                if (xe == hipErrorInvalidValue) {                   // (a shape or alignment outside the MFMA form's reach: the half-wave-per-dot kernel)
+                    (void)hipGetLastError();
+                    xe = (exact ? dot_f32_abt_exact : gemm_f32_abt)(m->qkv, 3 * El, D, kc, El, D, m->att, n_ctx, (int64_t)N * n_ctx, N, P, D, Hl,
+                                                                    kq_scale, 1, n_past, st, dyn, n_ctx);
+                }
+                M_HIP(xe);
                 M_HIP(softmax_rows(m->att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, Hl, m->exp_tab, st, dyn));
                 // KQV, merged back to [N, n_embd]                                                      :389-398
-                if (xa) M_HIP(attn_pv_exact(m->att, n_ctx, (int64_t)N * n_ctx, D, Hl, N, n_past, vc, n_ctx, m->ao, El, st));
-                else
-                    M_HIP((exact ? dot_f32_abt_exact : gemm_f32_abt)(m->att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, m->ao, El, D, N,
-                                                                     D, P, Hl, 1.0f, 2, n_past, st, dyn, n_ctx));
+                xe = xa ? attn_pv_exact(m->att, n_ctx, (int64_t)N * n_ctx, D, Hl, N, n_past, vc, n_ctx, m->ao, El, st) : hipErrorInvalidValue;
+                if (xe == hipErrorInvalidValue) {
+                    (void)hipGetLastError();
+                    xe = (exact ? dot_f32_abt_exact : gemm_f32_abt)(m->att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, m->ao, El, D, N,
+                                                                    D, P, Hl, 1.0f, 2, n_past, st, dyn, n_ctx);
+                }
+                M_HIP(xe);
                 if (layout == 16) M_HIP(quantize_q8_qa16(m->ao, El, N, El, m->qEl, st, xh && !m->tp_rows));
                 else M_HIP(quantize_q8_qa1(m->ao, El, N, El, m->qEl, st));
             }   // (the one-launch kernel wrote the Q8_0 operand of the wo matmul itself)
@@ -860,6 +867,10 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
     if (embeddings_host)
         M_HIP(hipMemcpyAsync(embeddings_host, m->xn + (size_t)(N - 1) * E, (size_t)E * 4, hipMemcpyDeviceToHost, st));
     M_HIP(hipStreamSynchronize(st));
+    if (m->G > 1 && m->comm) {                  // a peer exchange that gave up waiting for a peer summed / gathered stale slots: fail the eval
+        const int rc = fl_comm_p2p_check(m->comm);
+        if (rc != FL_OK) return rc;
+    }
     if (m->profile) {
         for (size_t i = 0; i + 1 < m->ev_used; i += 2) {
             float ms = 0.f;
@@ -914,6 +925,7 @@ int fl_model_ingest(fl_model *m, const int32_t *tokens, const int *chunk_len, in
         if (logits_host)
             M_HIP(hipMemcpyAsync(logits_host, m->logits + (size_t)(chunk_len[n_chunks - 1] - 1) * m->ldl, (size_t)m->V * 4, hipMemcpyDeviceToHost, m->stream));
         M_HIP(hipStreamSynchronize(m->stream));
+        if (m->G > 1 && m->comm) return fl_comm_p2p_check(m->comm);
         return FL_OK;
     }
     { const int rca = ensure_alt(m); if (rca != FL_OK) return rca; }

@@ -79,7 +79,7 @@ hipError_t gemm_q4_naive(const fl_qtensor &W, const fl_qact &xq, int N, float *y
 // fp6 operand copies of the prefill path (fp6_convert.hip; layouts: q4_layout.h "F6 copies")
 hipError_t qw16_to_f6(const fl_qtensor &W, uint8_t *f6, hipStream_t st);
 hipError_t qa16_to_f6(const fl_qact &xq, int N, hipStream_t st);      // xq.q (QA16) -> xq.q6
-bool gemm_fp6_enabled();                                              // FL_FP6 (default on) / fl_debug_set(3, v)
+bool gemm_fp6_enabled();                                              // FL_FP6=1 (default off) / fl_debug_set(3, v)
 
 size_t qact_bytes_q(int N, int K);      // bytes of the q plane for N columns (padded to 16)
 size_t qact_bytes_scale(int N, int K);  // bytes of one scale plane

@@ -95,6 +95,7 @@ _PROTOS = {
     "fl_comm_p2p_import": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fl_comm_has_p2p": (C.c_int, [C.c_void_p]),
     "fl_comm_p2p_timeouts": (C.c_int, [C.c_void_p]),
+    "fl_comm_p2p_check": (C.c_int, [C.c_void_p]),
     "fl_comm_debug_graph_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "fl_comm_rank": (C.c_int, [C.c_void_p]),
     "fl_comm_size": (C.c_int, [C.c_void_p]),

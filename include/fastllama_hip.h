@@ -174,6 +174,8 @@ int fl_comm_p2p_export(fl_comm *c, void *handles_out /* FL_COMM_P2P_HANDLE_BYTES
 int fl_comm_p2p_import(fl_comm *c, const void *handles_all /* world * FL_COMM_P2P_HANDLE_BYTES, rank order */);
 int fl_comm_has_p2p(const fl_comm *c);
 int fl_comm_p2p_timeouts(const fl_comm *c); /* exchanges that gave up waiting for a peer (~20 s each); 0 on a healthy group */
+int fl_comm_p2p_check(fl_comm *c);          /* FL_EHIP if that count advanced since the last check (fl_model_eval calls it after every
+                                              * synchronised tensor-parallel eval: such an eval's results are invalid); caller has synchronised */
 int fl_comm_debug_graph_allreduce(fl_comm *c, float *buf_dev, size_t count, int replays, void *stream);
 int fl_comm_rank(const fl_comm *c);
 int fl_comm_size(const fl_comm *c);
