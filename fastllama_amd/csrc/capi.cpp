@@ -252,6 +252,26 @@ int fl_qtensor_build_h16(fl_qtensor *W, void *stream) {
     return FL_OK;
 }
 
+/* (re)build the nibble copy the reference-order decode kernel reads (q4_layout.h "QWD"; the size of the nibbles again) */
+int fl_qtensor_build_qwd(fl_qtensor *W, void *stream) {
+    if (!W) return set_error(FL_EINVAL, "null tensor");
+    if (!W->qwd) {
+        hipError_t ea = hipMalloc((void **)&W->qwd, qwd_bytes(*W));
+        if (ea != hipSuccess) {
+            W->qwd = nullptr;
+            return hip_fail(ea, "hipMalloc(QWD)");
+        }
+    }
+    hipError_t e = qw16_to_qwd(*W, W->qwd, S(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(S(stream));
+    if (e != hipSuccess) return hip_fail(e, "fl_qtensor_build_qwd");
+    return FL_OK;
+}
+void fl_qtensor_drop_qwd(fl_qtensor *W) {
+    if (W && W->qwd) (void)hipFree(W->qwd);
+    if (W) W->qwd = nullptr;
+}
+
 void fl_qtensor_drop_h16(fl_qtensor *W) {
     if (W && W->h16) (void)hipFree(W->h16);
     if (W) W->h16 = nullptr;
@@ -303,7 +323,7 @@ int fl_qtensor_info(const fl_qtensor *W, int *type, int *M, int *K) {
 size_t fl_qtensor_device_bytes(const fl_qtensor *W) {
     if (!W) return 0;
     const size_t nblk = (size_t)W->M16 * W->KB;
-    return nblk * (16 + 4 + (W->type == FL_TYPE_Q4_1 ? 4 : 0) + (W->f6 ? 24 : 0)) + (W->h16 ? wh16_bytes(*W) : 0);
+    return nblk * (16 + 4 + (W->type == FL_TYPE_Q4_1 ? 4 : 0) + (W->f6 ? 24 : 0)) + (W->h16 ? wh16_bytes(*W) : 0) + (W->qwd ? qwd_bytes(*W) : 0);
 }
 
 void fl_qtensor_free(fl_qtensor *W) {
@@ -315,6 +335,7 @@ void fl_qtensor_free(fl_qtensor *W) {
     }
     if (W->f6) (void)hipFree(W->f6);
     if (W->h16) (void)hipFree(W->h16);
+    if (W->qwd) (void)hipFree(W->qwd);
     delete W;
 }
 
@@ -541,6 +562,7 @@ int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy
         if (a->layout != 16) return set_error(FL_EINVAL, "gemm needs the QA16 layout");
         FL_HIP(gemm_q4_exact_valu(*W, *a, a->N, y, ldy, S(st)));
     } else if (which == 3) {               // reference-order kernels, whichever the layout says
+        if (a->layout == 1 && a->N == 1 && !W->qwd && (rc = fl_qtensor_build_qwd(const_cast<fl_qtensor *>(W), st)) != FL_OK) return rc;
         if (a->layout == 1) FL_HIP(gemv_q4_exact(*W, *a, a->N, y, ldy, S(st)));
         else FL_HIP(gemm_q4_exact(*W, *a, a->N, y, ldy, S(st)));
     } else if (which == 2) {

@@ -23,6 +23,7 @@
 // inputs, so with these kernels the logits are the reference's, bit for bit (tests/test_parity_7b_gpu.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "eval_kernels.h"
 #include "q4_device.h"
 #include "gemv_prologue.h"
@@ -418,13 +419,17 @@ static bool launch_gemv1_exact(const fl_qtensor &W, const fl_qact *xq, float *y,
 #define FL_TYPED(CALL0, CALL1) (W.type == FL_TYPE_Q4_0 ? (CALL0) : (CALL1))
 // the exact forms of gemv_q4 (N = 1) / gemv_q4_norm / gemv_q4_silu / gemv_q4_norm_silu / gemv_q4_quant (q4_kernels.h);
 // hipErrorInvalidValue: shape outside this kernel's reach -> the caller takes the per-op sequence
+// (each entry point tries the round-4 lane-local-chain kernel first: it needs the tensor's QWD copy, gemv1_q4_exact_llc.hip)
+static bool llc_off() { static const bool off = getenv("FL_EXACT_R3") != nullptr; return off; }
 hipError_t gemv1_q4_exact(const fl_qtensor &W, const fl_qact &xq, float *y, hipStream_t st, const float *resid) {
+    if (!llc_off() && gemv1_llc(W, xq, y, st, resid)) return hipGetLastError();
     const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 0, 0>(W, &xq, y, st, resid, nullptr, nullptr, nullptr, 0, nullptr)),
                              (launch_gemv1_exact<FL_TYPE_Q4_1, 0, 0>(W, &xq, y, st, resid, nullptr, nullptr, nullptr, 0, nullptr)));
     return ok ? hipGetLastError() : hipErrorInvalidValue;
 }
 hipError_t gemv_q4_norm_exact(const fl_qtensor &W, const float *x, const float *norm_w, float *ynorm, float *y, hipStream_t st) {
     if (W.K % 32 != 0 || W.K > 8192) return hipErrorInvalidValue;
+    if (!llc_off() && gemv1_llc_norm(W, x, norm_w, ynorm, y, st)) return hipGetLastError();
     const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 1, 0>(W, nullptr, y, st, nullptr, x, norm_w, ynorm, 0, nullptr)),
                              (launch_gemv1_exact<FL_TYPE_Q4_1, 1, 0>(W, nullptr, y, st, nullptr, x, norm_w, ynorm, 0, nullptr)));
     return ok ? hipGetLastError() : hipErrorInvalidValue;
@@ -432,6 +437,7 @@ hipError_t gemv_q4_norm_exact(const fl_qtensor &W, const float *x, const float *
 hipError_t gemv_q4_silu_exact(const fl_qtensor &W, const float *h13, const uint16_t *silu_tab, float *y, const float *resid,
                               hipStream_t st, bool woven) {
     if (W.K % 32 != 0) return hipErrorInvalidValue;
+    if (!llc_off() && gemv1_llc_silu(W, h13, silu_tab, y, resid, st, woven)) return hipGetLastError();
     const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 2, 0>(W, nullptr, y, st, resid, h13, silu_tab, nullptr, woven ? 1 : 0, nullptr)),
                              (launch_gemv1_exact<FL_TYPE_Q4_1, 2, 0>(W, nullptr, y, st, resid, h13, silu_tab, nullptr, woven ? 1 : 0, nullptr)));
     return ok ? hipGetLastError() : hipErrorInvalidValue;
@@ -439,12 +445,14 @@ hipError_t gemv_q4_silu_exact(const fl_qtensor &W, const float *h13, const uint1
 hipError_t gemv_q4_norm_silu_exact(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act,
                                    hipStream_t st) {
     if (W.K % 32 != 0 || W.K > 8192 || W.M % 32 != 0) return hipErrorInvalidValue;
+    if (!llc_off() && gemv1_llc_norm_silu(W, x, norm_w, silu_tab, act, st)) return hipGetLastError();
     const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab)),
                              (launch_gemv1_exact<FL_TYPE_Q4_1, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab)));
     return ok ? hipGetLastError() : hipErrorInvalidValue;
 }
 hipError_t gemv_q4_quant_exact(const fl_qtensor &W, const float *x, float *y, const float *resid, hipStream_t st) {
     if (W.K % 32 != 0) return hipErrorInvalidValue;
+    if (!llc_off() && gemv1_llc_quant(W, x, y, resid, st)) return hipGetLastError();
     const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 3, 0>(W, nullptr, y, st, resid, x, nullptr, nullptr, 0, nullptr)),
                              (launch_gemv1_exact<FL_TYPE_Q4_1, 3, 0>(W, nullptr, y, st, resid, x, nullptr, nullptr, 0, nullptr)));
     return ok ? hipGetLastError() : hipErrorInvalidValue;

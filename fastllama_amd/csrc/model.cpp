@@ -109,6 +109,7 @@ struct fl_model : Act {
     bool exact = false;              // reference-order kernels (exact_kernels.hip): logits bit-identical to the reference's x86 build
     bool w13_il = false;             // w1|w3 woven by 16-row groups (n_ff/tp a multiple of 32): silu epilogue in the matmul
     int h16_state = 0;               // WH16 copies of the matmul weights (reference-order prefill): 0 not built, 1 ready, -1 no memory for them
+    int qwd_state = 0;               // QWD copies (reference-order decode), likewise
     bool xh = false;                 // the eval in flight takes the H16 form of the reference-order GEMM
     int exp_tab_n = 0;               // fp16 exp-table entries after 0x8000 that are non-zero (rounded up to 8): the LDS copy
     // LoRA: originals of the tensors an adapter touched (the reference's use_mmap path keeps them too, llama.cpp:868-874)
@@ -546,6 +547,25 @@ static void ensure_h16(fl_model *m) {
     }
 }
 
+// The QWD copies (reference-order decode kernel; the nibbles' size again), built before the first reference-order single-token eval
+// -- outside any graph capture.  No memory for them: round 3's producer / chain-wave kernel, which reads QW16, keeps the mode working.
+static void ensure_qwd(fl_model *m) {
+    if (m->qwd_state != 0) return;
+    std::vector<fl_qtensor *> ts;
+    for (Layer &ly : m->layers) for (fl_qtensor *t : {ly.wqkv, ly.wo, ly.w13, ly.w2}) ts.push_back(t);
+    ts.push_back(m->output);
+    m->qwd_state = 1;
+    for (fl_qtensor *t : ts) {
+        if (t->qwd) continue;
+        if (fl_qtensor_build_qwd(t, m->stream) != FL_OK) { m->qwd_state = -1; break; }
+        m->dev_bytes += qwd_bytes(*t);
+    }
+    if (m->qwd_state < 0) {
+        (void)hipGetLastError();
+        for (fl_qtensor *t : ts) if (t->qwd) { m->dev_bytes -= qwd_bytes(*t); fl_qtensor_drop_qwd(t); }
+    }
+}
+
 static int allreduce_if_tp(fl_model *m, float *buf, size_t count) {
     if (m->G == 1) return FL_OK;
     if (!m->comm) return set_error(FL_EINVAL, "tensor-parallel eval without a communicator");
@@ -678,7 +698,8 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
         }
         // feed-forward                                                                             :412-436
         const bool silu_in_gemm = N >= 9 && m->w13_il && (!exact || xh);   // silu * mul -> Q8_0 is the epilogue of the w1|w3 matmul
-        const bool silu_in_gemv = fused && m->w13_il;         // decode: silu * mul is the epilogue of the w1|w3 GEMV
+        static const bool nopair = getenv("FL_EXACT_NOPAIR") != nullptr;   // A/B: profiles/r04_decode_exact.md
+        const bool silu_in_gemv = fused && m->w13_il && !(exact && nopair && !tp);   // decode: silu * mul is the epilogue of the w1|w3 GEMV
         if (silu_in_gemv) {
             M_HIP(mm_norm_silu(m, ly.w13, mid, ly.ffn_norm, m->h13));
         } else if (fused) {
@@ -815,6 +836,7 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
     // Under tensor parallelism the RCCL all-reduces / all-gather are captured with the kernels (every rank replays the same
     // sequence); the single-process group of fl_comm_create_local rendezvouses on the host and cannot be captured.
     const bool tp_capturable = m->G == 1 || (m->comm && !fl_comm_is_local(m->comm) && !m->tp_graph_failed && !getenv("FL_TP_NO_GRAPH"));
+    if (N == 1 && m->exact) ensure_qwd(m);          // (before any capture: it allocates)
     const bool use_graph = N == 1 && tp_capturable && m->graph_enabled && !m->profile;
     const bool split_attn = N == 1 && n_past >= m->split_past;
     if (use_graph) {
@@ -1222,7 +1244,8 @@ extern "C" int fl_model_lora_apply(fl_model *m, const char *base_name, const flo
     if (e != hipSuccess) return hip_fail(e, "fl_model_lora_apply");
     if (bad) return set_error(FL_EINVAL, "lora: a merged Q4_0 block scale fell below 2^-122");
     if (t->f6 && (rc = fl_qtensor_build_f6(t, m->stream)) != FL_OK) return rc;    // the prefill paths' copies follow the merged nibbles
-    if (t->h16) return fl_qtensor_build_h16(t, m->stream);
+    if (t->h16 && (rc = fl_qtensor_build_h16(t, m->stream)) != FL_OK) return rc;
+    if (t->qwd) return fl_qtensor_build_qwd(t, m->stream);
     return FL_OK;
 }
 
@@ -1242,6 +1265,10 @@ extern "C" int fl_model_lora_restore(fl_model *m) {
         }
         if (bk.t->h16) {
             const int rc = fl_qtensor_build_h16(bk.t, m->stream);
+            if (rc != FL_OK) return rc;
+        }
+        if (bk.t->qwd) {
+            const int rc = fl_qtensor_build_qwd(bk.t, m->stream);
             if (rc != FL_OK) return rc;
         }
     }
@@ -1347,12 +1374,19 @@ int fl_debug_rmsnorm_quant(const float *x, int ldx, const float *w, int N, int E
     return FL_OK;
 }
 int g_debug_exact = 0;      // fl_debug_set(2, 1): the single-token test hooks below run the reference-order kernels
+// (the reference-order single-token hooks run the kernel of record: it reads the tensor's QWD copy)
+static int dbg_qwd(const fl_qtensor *W, void *stream) {
+    if (!g_debug_exact || !W || W->qwd || getenv("FL_EXACT_R3")) return FL_OK;
+    return fl_qtensor_build_qwd(const_cast<fl_qtensor *>(W), stream);
+}
 int fl_debug_gemv_norm(const fl_qtensor *W, const float *x, const float *norm_w, float *ynorm, float *y, void *stream) {
+    if (int rc = dbg_qwd(W, stream)) return rc;
     M_HIP((g_debug_exact ? gemv_q4_norm_exact : gemv_q4_norm)(*W, x, norm_w, ynorm, y, (hipStream_t)stream));
     return FL_OK;
 }
 int fl_debug_gemv_silu(const fl_qtensor *W, const float *h13, const uint16_t *silu_tab, float *y, const float *resid,
                        void *stream) {
+    if (int rc = dbg_qwd(W, stream)) return rc;
     M_HIP((g_debug_exact ? gemv_q4_silu_exact : gemv_q4_silu)(*W, h13, silu_tab, y, resid, (hipStream_t)stream, false));
     return FL_OK;
 }
@@ -1380,10 +1414,12 @@ int fl_debug_prefill_attention_scratch(float *scratch, int ld, long head_stride)
 }
 int fl_debug_gemv_norm_silu(const fl_qtensor *W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act,
                             void *stream) {
+    if (int rc = dbg_qwd(W, stream)) return rc;
     M_HIP((g_debug_exact ? gemv_q4_norm_silu_exact : gemv_q4_norm_silu)(*W, x, norm_w, silu_tab, act, (hipStream_t)stream));
     return FL_OK;
 }
 int fl_debug_gemv_quant(const fl_qtensor *W, const float *x, float *y, const float *resid, void *stream) {
+    if (int rc = dbg_qwd(W, stream)) return rc;
     M_HIP((g_debug_exact ? gemv_q4_quant_exact : gemv_q4_quant)(*W, x, y, resid, (hipStream_t)stream));
     return FL_OK;
 }

@@ -72,6 +72,15 @@ hipError_t gemm_q4_exact_h16_qkv(const fl_qtensor &W, const fl_qact &xq, int N, 
                                  float *vc, int El, int D, int n_past, int n_ctx, hipStream_t st);
 hipError_t gemm_q4_exact_h16_silu(const fl_qtensor &W, const fl_qact &xq, int N, const uint16_t *silu_tab, const fl_qact &out,
                                   hipStream_t st);
+// round 4 form of the N = 1 reference-order kernel: lane-local chains on the QWD nibble copy (gemv1_q4_exact_llc.hip); the bool
+// launchers return false when the tensor has no QWD copy or the shape is outside the kernel's reach (-> round 3's kernel)
+size_t qwd_bytes(const fl_qtensor &W);
+hipError_t qw16_to_qwd(const fl_qtensor &W, uint32_t *qwd, hipStream_t st);
+bool gemv1_llc(const fl_qtensor &W, const fl_qact &xq, float *y, hipStream_t st, const float *resid);
+bool gemv1_llc_norm(const fl_qtensor &W, const float *x, const float *norm_w, float *ynorm, float *y, hipStream_t st);
+bool gemv1_llc_silu(const fl_qtensor &W, const float *h13, const uint16_t *silu_tab, float *y, const float *resid, hipStream_t st, bool woven);
+bool gemv1_llc_norm_silu(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act, hipStream_t st);
+bool gemv1_llc_quant(const fl_qtensor &W, const float *x, float *y, const float *resid, hipStream_t st);
 hipError_t gemm_q4_exact_valu(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                               const float *resid = nullptr, int ldr = 0);   // v_dot4 form (exact_kernels.hip), cross-check
 hipError_t gemm_q4_naive(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st);

@@ -80,6 +80,15 @@
 //     of the block -- step s, half h is the reference's AVX2 lane j = 2s + h (elements 4j .. 4j + 3)
 //   * WH16 values: Q4_0 16 (nib - 8) (the stored scale is d_w / 16, as for QW16), Q4_1 nib;  XH16 values: the int8 quants
 //   * rows / columns past the tensor are zero; derived data: QW16 / QA16 stay the forms of record
+//
+// QWD -- the nibbles once more, for the reference-order decode kernel (gemv1_q4_exact_llc.hip), whose lane (row, k-group g) owns the
+// two AVX2-lane chains 2g, 2g + 1 of its row over the whole of K:
+//
+//   qwd : uint32 [M16/16][NQ = ceil(KB/4)][16 rows][4 k-groups][4 blocks]      1 KiB per (row group, block quad), lane-linear
+//
+//   * the dword of (row, g, block) holds the 8 nibbles of k-group g with byte t = element t | element t+4 << 4 (QW16: 2t | 2t+1 << 4),
+//     Q4_0 nibbles XOR 8 as in QW16: (v << 4) & 0xF0F0F0F0 and v & 0xF0F0F0F0 ARE the int8x4 operands of the two lane sums
+//   * blocks past K in the last quad are zero; scales are read from the QW16 planes (d, m)
 #pragma once
 #include <stdint.h>
 
@@ -97,6 +106,7 @@ struct fl_qtensor {
     int owns;            // 1: qs/d/m were hipMalloc'ed by the library
     uint8_t *f6;         // device, QW16F6 copy (always library-owned) or nullptr: the prefill path then takes the i8 form
     uint16_t *h16;       // device, WH16 copy (always library-owned) or nullptr: operand of the reference-order prefill GEMM
+    uint32_t *qwd;       // device, QWD copy (always library-owned) or nullptr: nibbles as the reference-order decode kernel reads them
 };
 
 // Quantized-activation workspace (either QA16 or QA1 depending on the consumer).

@@ -71,6 +71,8 @@ _PROTOS = {
     "fl_qtensor_drop_f6": (None, [C.c_void_p]),
     "fl_qtensor_build_h16": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fl_qtensor_drop_h16": (None, [C.c_void_p]),
+    "fl_qtensor_build_qwd": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fl_qtensor_drop_qwd": (None, [C.c_void_p]),
     "fl_qtensor_free": (None, [C.c_void_p]),
     "fl_quantize_row_q8_0": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "fl_dequantize_row_q4_0": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

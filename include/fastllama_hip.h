@@ -86,6 +86,11 @@ void fl_qtensor_drop_f6(fl_qtensor *W);
  * with N >= 9 (fl_model_eval); a caller that rewrites a tensor's blocks in place rebuilds it.  Derived data, like the fp6 copy. */
 int fl_qtensor_build_h16(fl_qtensor *W, void *stream);
 void fl_qtensor_drop_h16(fl_qtensor *W);
+/* The reference-order DECODE kernel's copy of the nibbles (q4_layout.h "QWD", 16 bytes per row and block once more): a lane owns two of
+ * a row's eight AVX2-lane chains and reads its dword of four blocks in one load.  Built by a model before its first reference-order
+ * single-token eval; same rules as the H16 copy. */
+int fl_qtensor_build_qwd(fl_qtensor *W, void *stream);
+void fl_qtensor_drop_qwd(fl_qtensor *W);
 
 /* ---------------------------------------------------------------- quantize_fns_t mirror -------- */
 /* Same five entry points, same argument meaning as `quantize_fns_t` (include/ggml.h:850-862,
