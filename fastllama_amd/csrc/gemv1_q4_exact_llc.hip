@@ -257,7 +257,10 @@ static bool launch_llc(const fl_qtensor &W, const fl_qact *xq, float *y, hipStre
     const size_t lds = (size_t)KB * 32 + (size_t)NQ * 32 + (size_t)NQ * 16 * 8;
     if (lds > 60 * 1024 || units < 1 || NQ > 88) return false;
     // (waves along K, quads a wave holds): 4 x 8 covers K <= 4096 with the fewest registers (three waves per SIMD), 4 x 11 K <= 5632,
-    // 8 x 11 K <= 11264 (LLaMA-7B / 13B w2; longer rows -- 65B's w2 -- stay on round 3's kernel)
+    // 8 x 11 K <= 11264 -- but an 8-wave workgroup at 186 registers is ONE per CU: good for a matrix of <= 256 row groups (LLaMA-7B's w2:
+    // 12.5 us against round 3's 15.1), bad for many groups of long rows (65B width, K = 8192: 57 / 93 us against 35 / 63 for
+    // wq|wk|wv / w1|w3, scripts/dev/dec_ab.sh) -- those, and rows beyond 11264 (13B / 65B w2), stay on round 3's kernel
+    if (NQ > 44 && units > 256) return false;
 #define FL_LLC(NK, QPW)                                                                                                                   \
     hipLaunchKernelGGL((gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW>), dim3(units), dim3(64 * NK), lds, st, W.M, units, KB, woven, \
                        W.qwd, W.d, xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid, ynorm, aux2)
