@@ -270,7 +270,7 @@ def main():
             return None, None
 
     KERNELS = {   # (prefill GEMM, decode GEMV) of a mode: names as rocprofv3 prints them
-        "exact": ("gemm_q4_exact_h16_kernel", "gemv1_q4_exact_kernel"),
+        "exact": ("gemm_q4_exact_h16_kernel", "gemv1_q4_exact_llc_kernel"),
         "fast": ("gemm_q4_mfma32_kernel", "gemv_q4_kernel"),
     }
 
