@@ -502,12 +502,13 @@ int fl_debug_gemm_mixed_split(int row_groups, int col_groups, int *n_a, int *mg_
     fl::gemm32_mixed_split(row_groups, col_groups, n_a, mg_split, n_b);
     return FL_OK;
 }
-extern int g_debug_exact;   // model.cpp
+extern int g_debug_exact, g_debug_pair1;   // model.cpp
 int fl_debug_set(int what, int value) {
     if (what == 0) fl::g_gemm_force_cfg = value;
     if (what == 1) fl::g_gemv_force_waves = value;   // 0 = automatic, else 4 / 8 / 16 waves per 16-row group
     if (what == 3) fl::g_gemm_fp6 = value != 0;      // prefill GEMM: fp6 block-scaled form (1) or the i8 form (0, default) of the same tiles
     if (what == 2) g_debug_exact = value;            // the single-token test hooks (fl_debug_gemv_*, fl_debug_decode_attention*) in exact mode
+    if (what == 5) g_debug_pair1 = value;            // fl_debug_gemv_norm_silu in exact mode: the one-workgroup-per-feature-pair form
     if (what == 4) g_op_mode = value;                // operator-level entry points: 1 reference order, 0 fast kernels, -1 the default
     return FL_OK;
 }
@@ -622,6 +623,17 @@ int fl_debug_gemm_silu(const fl_qtensor *W, const fl_qact *a_, const uint16_t *s
         return FL_OK;
     }
     FL_HIP(gemm_q4_mfma_silu(*W, *a, a->N, silu_tab_dev, *out, S(st)));
+    return FL_OK;
+}
+/* test hook: the P.V product of the reference-order prefill attention with its Q8_0 epilogue: att = soft_max'ed probabilities [H][N][n_ctx]
+ * (as fl_debug_attn_exact leaves them) -> out = Q8_0 of the merged [N, E] rows (QA16 + the XH16 copy) */
+int fl_debug_attn_pv_exact_q8(const float *att, int n_ctx, int D, int H, int N, int n_past, const float *vc, int E, fl_qact *out_, void *st) {
+    fl_qact_impl *out = static_cast<fl_qact_impl *>(out_);
+    if (!att || !vc || !out) return set_error(FL_EINVAL, "null argument");
+    if (E != out->K || N > out->cap_N16 || E != H * D) return set_error(FL_EINVAL, "attn_pv_exact_q8: bad output workspace");
+    out->N = N; out->N16 = fl_roundup(N, 16); out->KB = E / 32; out->layout = 16;
+    FL_HIP(attn_pv_exact(att, n_ctx, (int64_t)N * n_ctx, D, H, N, n_past, vc, n_ctx, nullptr, E, S(st), out, true));
+    out->h16_valid = 1;
     return FL_OK;
 }
 

@@ -24,55 +24,6 @@
 
 namespace fl {
 
-// ------------------------------------------------------------------------------------------------
-// shared: quantize one 8-element group (4 adjacent lanes = one Q8_0 block) and store it
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void quantize_store_group(const float v[8], int n, int kg, int KB, int layout,
-                                                     int8_t *__restrict__ q, float *__restrict__ d,
-                                                     float *__restrict__ s, uint16_t *__restrict__ h16 = nullptr) {
-    float amax = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
-    amax = quad_max_f32(amax);
-    const float dd = __fdiv_rn(amax, 127.0f);
-    const float id = amax != 0.0f ? __fdiv_rn(127.0f, amax) : 0.0f;
-    int qi[8], sum = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        qi[i] = (int)rintf(__fmul_rn(v[i], id));
-        sum += qi[i];
-    }
-    sum = quad_sum_i32(sum);
-    auto pk = [](int a, int b, int c, int e) -> uint32_t {
-        return (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(c & 0xFF) << 16) |
-               ((uint32_t)(e & 0xFF) << 24);
-    };
-    const uint2 w = make_uint2(pk(qi[0], qi[2], qi[4], qi[6]), pk(qi[1], qi[3], qi[5], qi[7]));
-    const int b = kg >> 2, g = kg & 3;
-    if (layout == 16) {
-        const int grp = n >> 4, c = n & 15;
-        const int64_t cb = ((int64_t)grp * KB + b) * 16 + c;
-        *reinterpret_cast<uint2 *>(q + cb * 32 + qw16_pos(c, g) * 8) = w;
-        if (g == 0) {
-            d[cb] = dd;
-            s[cb] = __fmul_rn(dd, (float)sum);
-        }
-        if (h16) {   // the XH16 copy (q4_layout.h): k-group g = MFMA step g, elements 0..3 in lane (n & 31), elements 4..7 in lane + 32
-            auto hb = [](int x) -> uint32_t { return (uint32_t)__half_as_ushort(__int2half_rn(x)); };
-            unsigned char *dst = reinterpret_cast<unsigned char *>(h16) + ((((int64_t)(n >> 5) * KB + b) * 2 + (g >> 1)) * 64 + (n & 31)) * 16 + (g & 1) * 8;
-            *reinterpret_cast<uint2 *>(dst) = make_uint2(hb(qi[0]) | (hb(qi[1]) << 16), hb(qi[2]) | (hb(qi[3]) << 16));
-            *reinterpret_cast<uint2 *>(dst + 512) = make_uint2(hb(qi[4]) | (hb(qi[5]) << 16), hb(qi[6]) | (hb(qi[7]) << 16));
-        }
-    } else {
-        const int64_t vb = (int64_t)n * KB + b;
-        *reinterpret_cast<uint2 *>(q + vb * 32 + g * 8) = w;
-        if (g == 0) {
-            d[vb] = dd;
-            s[vb] = __fmul_rn(dd, (float)sum);
-        }
-    }
-}
-
 __device__ __forceinline__ double block_sum_f64(double v, double *sh) {
     v = wave_sum_f64(v);
     const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -1244,24 +1195,32 @@ __device__ __forceinline__ float att_reduce8(float4 a) {
     return __fadd_rn(__fadd_rn(a.x, a.y), __fadd_rn(a.z, a.w));
 }
 // the n % 32 leftovers of that dot as the reference's build compiled them: chunks of 8, then one of 4 elements as rounded
-// products added in order, the last n % 4 as FMAs.  p[i], v(i) for i in [0, n): the elements behind the 32-wide body.
-template <typename VF>
-__device__ __forceinline__ float att_leftovers(float s, const float *__restrict__ p, int n, VF v) {
+// products added in order, the last n % 4 as FMAs.  The 8 lanes of a row each hold four of them (p4, v4: elements 4 l8 .. 4 l8 + 3
+// behind the 32-wide body; what lies past n is ignored); s: the body's sum, the same bits in all 8 lanes.  The running value walks up
+// the lanes (DPP row_shr:1), lane j adding its four rounded products -- or, the lane holding the last n % 4, its FMAs -- in order;
+// the result is lane 7's.  (Round 3 had lane 0 walk the elements itself, each one a dependent global load: 3.7 us of the reference-
+// order decode attention's 11.4 at n = 1 .. 31, profiles/r04_decode_exact.md.)
+constexpr int DPP_ROW_SHR1 = 0x111;
+__device__ __forceinline__ float att_leftovers_lanes(float s, const float4 p4, const float4 v4, int n, int l8) {
 #pragma clang fp contract(off)     // plain operators under this pragma: hipcc contracts a * b + c even across __fmul_rn / __fadd_rn
-    int i = 0;
-    for (; i + 8 <= n; i += 8)
-        for (int l = 0; l < 8; ++l) {
-            const float pr = p[i + l] * v(i + l);
-            s = s + pr;
+    const int nfull = n >> 2, nt = n & 3;
+    const float px = p4.x * v4.x, py = p4.y * v4.y, pz = p4.z * v4.z, pw = p4.w * v4.w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float t = s;
+        if (l8 < nfull) {
+            t = t + px;
+            t = t + py;
+            t = t + pz;
+            t = t + pw;
+        } else if (l8 == nfull) {
+            if (nt > 0) t = __fmaf_rn(p4.x, v4.x, t);
+            if (nt > 1) t = __fmaf_rn(p4.y, v4.y, t);
+            if (nt > 2) t = __fmaf_rn(p4.z, v4.z, t);
         }
-    if (n - i >= 4) {
-        for (int l = 0; l < 4; ++l) {
-            const float pr = p[i + l] * v(i + l);
-            s = s + pr;
-        }
-        i += 4;
+        const float up = dpp_f32<DPP_ROW_SHR1>(t);         // lane j + 1 takes over from lane j
+        s = l8 == j + 1 ? up : l8 == j ? t : s;
     }
-    for (; i < n; ++i) s = __fmaf_rn(p[i], v(i), s);
     return s;
 }
 
@@ -1396,17 +1355,20 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const int *__res
 
     DA_STAMP(4);
     // ---- KQV ----
-    auto pv = [&](float4 &a, int d, int c, float4 v4) {
-        const int p0 = c * 32 + l8 * 4;
-        if (p0 + 3 >= pos) {                               // piece holding the fresh position (and what lies beyond)
+    auto with_fresh = [&](int d, int p0, float4 v4) {      // piece holding the fresh position (and what lies beyond)
+        if (p0 + 3 >= pos) {
             const float fresh = vs[d];
             v4.x = p0 == pos ? fresh : p0 > pos ? 0.f : v4.x;
             v4.y = p0 + 1 == pos ? fresh : p0 + 1 > pos ? 0.f : v4.y;
             v4.z = p0 + 2 == pos ? fresh : p0 + 2 > pos ? 0.f : v4.z;
             v4.w = p0 + 3 == pos ? fresh : p0 + 3 > pos ? 0.f : v4.w;
         }
+        return v4;
+    };
+    auto pv = [&](float4 &a, int d, int c, float4 v4) {
+        const int p0 = c * 32 + l8 * 4;
         const float4 p4 = *reinterpret_cast<const float4 *>(sc + p0);
-        att_fma4<ORD>(a, p4, v4);
+        att_fma4<ORD>(a, p4, with_fresh(d, p0, v4));
     };
     // ORD = 1: only whole 32-position steps go through the lanes; the P % 32 positions behind them are the reference's leftover loop
     const int nlane = ORD ? (P >> 5) : nchunk;
@@ -1424,13 +1386,24 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const int *__res
                     pv(a4, d, c, *reinterpret_cast<const float4 *>(vc + (int64_t)(h * D + d) * n_ctx + c * 32 + l8 * 4));
         }
         float a = att_reduce8<ORD>(a4);
-        if (ORD && d < D && l8 == 0 && (P & 31)) {
-            const int np = P & ~31;
-            const float *vr = vc + (int64_t)(h * D + d) * n_ctx + np;
-            const float fresh = vs[d];
-            a = att_leftovers(a, sc + np, P - np, [&](int i) { return np + i == pos ? fresh : vr[i]; });
+        if (ORD && (P & 31)) {                             // the piece behind the body: already in the lanes' registers (or one load away)
+            const int np = P & ~31, p0 = np + l8 * 4;
+            float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nlane < DA_VPRE) {
+#pragma unroll
+                for (int c = 0; c < DA_VPRE; ++c)
+                    if (c == nlane) v4 = vreg[rp][c];
+            } else if (d < D && p0 < P) {
+                v4 = *reinterpret_cast<const float4 *>(vc + (int64_t)(h * D + d) * n_ctx + p0);
+            }
+            if (d < D) {
+                const float4 p4 = *reinterpret_cast<const float4 *>(sc + (p0 < P ? p0 : np));     // (a lane past P: ignored)
+                a = att_leftovers_lanes(a, p4, with_fresh(d, p0, v4), P - np, l8);
+                if (l8 == 7) out[d] = a;
+            }
+        } else if (d < D && l8 == 0) {
+            out[d] = a;
         }
-        if (d < D && l8 == 0) out[d] = a;
     }
     __syncthreads();
     DA_STAMP(5);
@@ -1566,6 +1539,8 @@ __global__ __launch_bounds__(DP_T) void decode_pv_kernel(const int *__restrict__
         }
     };
     load(va, 0);                                           // V does not depend on the scores: in flight under the soft_max
+    float4 vleft = make_float4(0.f, 0.f, 0.f, 0.f);        // ORD = 1: this lane's four of the P % 32 positions behind the body
+    if (ORD) vleft = *reinterpret_cast<const float4 *>(vrow + ((P & ~31) + l8 * 4 < P ? (P & ~31) + l8 * 4 : l8 * 4));
 
     // ---- soft_max of the head's row: fp16 exp table, f64 sum (ggml_compute_forward_soft_max_f32) ----
     // (8 entries per thread and pass, their loads / table gathers issued together: with one entry per loop iteration
@@ -1638,8 +1613,13 @@ __global__ __launch_bounds__(DP_T) void decode_pv_kernel(const int *__restrict__
         consume(vb, b + 1);
     }
     float a = att_reduce8<ORD>(a4);
-    if (ORD && l8 == 0 && (P & 31)) a = att_leftovers(a, sc + np, P - np, [&](int i) { return vrow[np + i]; });
-    if (l8 == 0) out[tid >> 3] = a;
+    if (ORD && (P & 31)) {
+        const float4 p4 = *reinterpret_cast<const float4 *>(sc + np + l8 * 4);
+        a = att_leftovers_lanes(a, p4, vleft, P - np, l8);
+        if (l8 == 7) out[tid >> 3] = a;
+    } else if (l8 == 0) {
+        out[tid >> 3] = a;
+    }
     __syncthreads();
     if (tid < 4) {                                         // one Q8_0 block: 4 adjacent lanes x 8 features
         float o8[8];

@@ -443,9 +443,9 @@ hipError_t gemv_q4_silu_exact(const fl_qtensor &W, const float *h13, const uint1
     return ok ? hipGetLastError() : hipErrorInvalidValue;
 }
 hipError_t gemv_q4_norm_silu_exact(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act,
-                                   hipStream_t st) {
+                                   hipStream_t st, float *pair_ws) {
     if (W.K % 32 != 0 || W.K > 8192 || W.M % 32 != 0) return hipErrorInvalidValue;
-    if (!llc_off() && gemv1_llc_norm_silu(W, x, norm_w, silu_tab, act, st)) return hipGetLastError();
+    if (!llc_off() && gemv1_llc_norm_silu(W, x, norm_w, silu_tab, act, st, pair_ws)) return hipGetLastError();
     const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab)),
                              (launch_gemv1_exact<FL_TYPE_Q4_1, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab)));
     return ok ? hipGetLastError() : hipErrorInvalidValue;
@@ -786,7 +786,8 @@ __global__ __launch_bounds__(512) void attn_scores_exact_kernel(const float *__r
 
 __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restrict__ att, int ld_att, int64_t head_stride, int D, int N,
                                                             int n_past, const float *__restrict__ vc, int n_ctx, float *__restrict__ ao,
-                                                            int ldo) {
+                                                            int ldo, int8_t *__restrict__ oq, float *__restrict__ od,
+                                                            float *__restrict__ os, uint16_t *__restrict__ oh) {
     extern __shared__ __attribute__((aligned(16))) float xs_[];
     float *Ps = xs_;                                         // [32 queries][XA_LD]   probabilities, zero past each query's last key
     float *Vs = xs_ + 32 * XA_LD;                            // [32 features][XA_LD]
@@ -827,10 +828,46 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
             }
         }
     };
+    // The whole context in one piece (<= 512 keys): load and store are separate steps, so that the next feature block's V rows are
+    // requested BEFORE the current block's MFMAs and written to LDS after them -- their round trip used to stand between every two
+    // blocks (profiles/r04_attn_exact.md).  Thread -> keys 4 (tid & 127) .. + 3 of rows 2 u + (tid >> 7), u = 0 .. 15: one 32-bit
+    // offset per thread next to a wave-uniform row base.
+    const int sk = (threadIdx.x & 127) * 4, srow = threadIdx.x >> 7;
+    auto wide_load = [&](float4 (&v)[16], const float *src, int row_stride, int rows_valid, int kt) {
+        const unsigned col = (unsigned)max(0, min(min(sk, kt - 4), n_ctx - 4));        // (a thread past the piece: a cache-hot address, never stored)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const unsigned off = (unsigned)min(2 * u + srow, rows_valid - 1) * (unsigned)row_stride + col;
+            v[u] = *reinterpret_cast<const float4 *>(src + off);
+        }
+    };
+    auto wide_store = [&](float *dst, const float4 (&v)[16], int rows_valid, int kt) {
+        if (sk < kt) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = 2 * u + srow;
+                float *d = dst + r * XA_LD + sk;
+                const bool rv = r < rows_valid;
+                d[0] = rv && sk < kend ? v[u].x : 0.f;
+                d[1] = rv && sk + 1 < kend ? v[u].y : 0.f;
+                d[2] = rv && sk + 2 < kend ? v[u].z : 0.f;
+                d[3] = rv && sk + 3 < kend ? v[u].w : 0.f;
+            }
+        }
+    };
     auto chunk_len = [&](int c) { return min(XA_KT, ((nbody - c * XA_KT) + 63) & ~63); };   // zero padded to whole MFMA pairs
     const int rows_q = min(32, N - q0);
-    if (nchunk == 1) stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, rows_q, 0, chunk_len(0));   // short contexts: P staged once
+    const bool one_piece = nchunk == 1;                      // short contexts: P staged once, V blocks requested one ahead
+    float4 vnext[16];
+    if (one_piece) {
+        float4 pfirst[16];
+        wide_load(pfirst, prow + (int64_t)q0 * ld_att, ld_att, rows_q, chunk_len(0));
+        wide_load(vnext, vc + (int64_t)(hd * D) * n_ctx, n_ctx, 32, chunk_len(0));
+        wide_store(Ps, pfirst, rows_q, chunk_len(0));
+        wide_store(Vs, vnext, 32, chunk_len(0));
+    }
     float *Ts = xs_ + 64 * XA_LD;                            // the waves' t tiles meet here: [4][64][16]
+    float *Os = Ts + 4 * 64 * 16;                            // oq: the finished [32 queries][33] tile of a feature block, on its way to Q8_0
     const int nleft = P - np;                                // < 32 keys behind the body, taken in order
     const bool left_visible = nleft > 0 && kend > np;
     for (int d0 = 0; d0 < D; d0 += 32) {
@@ -838,10 +875,14 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
         v16f tl[2][4] = {{{}, {}, {}, {}}, {{}, {}, {}, {}}};
         for (int c = 0; c < nchunk; ++c) {
             const int k0 = c * XA_KT, kt = chunk_len(c);
-            __syncthreads();                                 // P staged / the previous piece is done with Ps, Vs and Ts
-            if (nchunk > 1) stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, rows_q, k0, kt);
-            stage(Vs, vc + (int64_t)(hd * D + d0) * n_ctx, n_ctx, 32, k0, kt);
-            __syncthreads();
+            __syncthreads();                                 // P, V staged / the previous piece is done with Ps, Vs and Ts
+            if (one_piece) {
+                if (d0 + 32 < D) wide_load(vnext, vc + (int64_t)(hd * D + d0 + 32) * n_ctx, n_ctx, 32, kt);
+            } else {
+                stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, rows_q, k0, kt);
+                stage(Vs, vc + (int64_t)(hd * D + d0) * n_ctx, n_ctx, 32, k0, kt);
+                __syncthreads();
+            }
             const int cend = min(nbody, k0 + XA_KT);
 #pragma unroll
             for (int li = 0; li < 2; ++li) {
@@ -915,12 +956,34 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
                 }
                 for (; k < nleft; ++k)
                     if (np + k < kend) s = __fmaf_rn(pr[k], vr[k], s);
-                if (q < N) ao[(int64_t)q * ldo + hd * D + d0 + i] = s;
+                if (oq) Os[ql * 33 + i] = s;
+                else if (q < N) ao[(int64_t)q * ldo + hd * D + d0 + i] = s;
             }
         }
-        if (nchunk == 1 && left_visible && d0 + 32 < D) {    // the single staged P piece was overwritten by the leftovers: stage it again
+        if (oq) {
+            // the Q8_0 operand of the wo matmul, written here (quantize_row_q8_0 of the merged [N, n_embd] rows, lib/ggml.c:8063-8075: a
+            // block = 32 consecutive features of one query = one row of this tile): QA16 (+ its XH16 copy), 4 adjacent lanes per block,
+            // the arithmetic of quantize_q8_kernel; queries past N are the layout's padding: zero blocks
             __syncthreads();
-            stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, rows_q, 0, chunk_len(0));
+            if (threadIdx.x < 128) {
+                const int ql = threadIdx.x >> 2, part = threadIdx.x & 3, q = q0 + ql, KBo = ldo >> 5, kg = ((hd * D + d0) >> 3) + part;
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = q < N ? Os[ql * 33 + part * 8 + u] : 0.f;
+                if (q < ((N + 15) & ~15)) {
+                    quantize_store_group(v, q, kg, KBo, 16, oq, od, os, oh);
+                } else if (oh) {                                 // (columns [N16, N32) exist in the XH16 copy only)
+                    unsigned char *dst = reinterpret_cast<unsigned char *>(oh) + ((((int64_t)(q >> 5) * KBo + (kg >> 2)) * 2 + (part >> 1)) * 64 + (q & 31)) * 16 + (part & 1) * 8;
+                    *reinterpret_cast<uint2 *>(dst) = make_uint2(0, 0);
+                    *reinterpret_cast<uint2 *>(dst + 512) = make_uint2(0, 0);
+                }
+            }
+        }
+        if (one_piece && d0 + 32 < D) {
+            __syncthreads();                                 // wave 0 / the quantizing threads are done with Ps, Vs and Os
+            if (left_visible)                                // the single staged P piece was overwritten by the leftovers: stage it again
+                stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, rows_q, 0, chunk_len(0));
+            wide_store(Vs, vnext, 32, chunk_len(0));
         }
     }
 }
@@ -940,9 +1003,9 @@ hipError_t attn_scores_exact(const float *qkv, int ldq, int D, int H, int N, int
     return hipGetLastError();
 }
 hipError_t attn_pv_exact(const float *att, int ld_att, int64_t head_stride, int D, int H, int N, int n_past, const float *vc, int n_ctx,
-                         float *ao, int ldo, hipStream_t st) {
-    if (D % 32 != 0 || D > 128 || N < 1 || (n_ctx & 3)) return hipErrorInvalidValue;
-    const size_t lds = (size_t)2 * 32 * XA_LD * 4 + 4 * 64 * 16 * 4;
+                         float *ao, int ldo, hipStream_t st, const fl_qact *out, bool with_h16) {
+    if (D % 32 != 0 || D > 128 || N < 1 || (n_ctx & 3) || (out && (ldo & 31))) return hipErrorInvalidValue;
+    const size_t lds = (size_t)2 * 32 * XA_LD * 4 + 4 * 64 * 16 * 4 + 32 * 33 * 4;
     static bool attr_set[64] = {false};      // (per device)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -953,7 +1016,7 @@ hipError_t attn_pv_exact(const float *att, int ld_att, int64_t head_stride, int 
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(attn_pv_exact_kernel, dim3(H, (N + 31) / 32), dim3(256), lds, st, att, ld_att, head_stride, D, N, n_past, vc, n_ctx,
-                       ao, ldo);
+                       ao, ldo, out ? out->q : nullptr, out ? out->d : nullptr, out ? out->s : nullptr, out && with_h16 ? out->h16 : nullptr);
     return hipGetLastError();
 }
 

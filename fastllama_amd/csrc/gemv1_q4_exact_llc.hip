@@ -21,8 +21,11 @@
 //     prologue and re-requested as they are consumed; nontemporal loads (every byte is read once per token).
 // The activation's Q8_0 form is built in LDS once per workgroup by the prologues of round 3 (gemv_prologue.h: rms_norm / silu * mul /
 // plain Q8_0, bit-identical to the separate kernels), then re-laid so that a lane reads its 8 bytes of four blocks in two 16-byte
-// LDS reads.  PAIR (woven w1|w3): a wave takes the w1 group and then the w3 group of the same 16 features and stores
-// silu(w1 x) * (w3 x) -- ggml_silu + ggml_mul of lib/llama.cpp:428-431.
+// LDS reads.  Woven w1|w3 (ggml_silu + ggml_mul of lib/llama.cpp:428-431 as the epilogue): PAIR = 1: a workgroup takes the w1 group and
+// then the w3 group of the same 16 features and stores silu(w1 x) * (w3 x).  PAIR = 2: the two groups are two ordinary workgroups;
+// each leaves its 16 dot products in a workspace and counts itself in on the pair's flag (agent-scope release / acquire), and the one
+// that arrives second forms silu * mul for both -- the launch keeps the plain matrix's shape (every byte requested at once, no second
+// chain phase behind the first: 19.5 -> 16.9 us for LLaMA-7B's 22016 x 4096) and the flag is back at zero when the launch ends.
 // Q4_0 bookkeeping as everywhere: unpacked values are 16 (nib - 8), the stored scale is d / 16: fma(rn((d/16) d_x), 16 q, a) rounds
 // the same real number as the reference's fma(rn(d d_x), q, a).
 #include <hip/hip_runtime.h>
@@ -84,16 +87,17 @@ __device__ __forceinline__ float quad_bcast(float v) {
     return dpp_f32<SRC | (SRC << 2) | (SRC << 4) | (SRC << 6)>(v);
 }
 
-// NK waves share a 16-row group along K (wave k: quads [k NQ / NK, (k+1) NQ / NK)); PAIR: the workgroup takes the w1 group and then
+// NK waves share a 16-row group along K (wave k: quads [k NQ / NK, (k+1) NQ / NK)); PAIR = 1: the workgroup takes the w1 group and then
 // the w3 group of the same 16 features (one after the other: three workgroups per CU cover each other's round trips).  QPW: most quads a wave can hold (its lane sums stay in registers until its turn in the chain).
 template <int TYPE, int NK, int PRO, int PAIR, int QPW>
-__global__ __launch_bounds__(64 * NK, (PAIR && QPW <= 8 && NK == 4) ? 3 : 1) void gemv1_q4_exact_llc_kernel(
+__global__ __launch_bounds__(64 * NK, (PAIR == 1 && QPW <= 8 && NK == 4) ? 3 : 1) void gemv1_q4_exact_llc_kernel(
     int M, int units, int KB, int woven,
     const uint32_t *__restrict__ qwd, const float *__restrict__ dW, const float *__restrict__ xf, const void *__restrict__ aux,
     const float *__restrict__ mW, const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs,
-    float *__restrict__ y, const float *__restrict__ resid, float *__restrict__ ynorm, const uint16_t *__restrict__ aux2) {
+    float *__restrict__ y, const float *__restrict__ resid, float *__restrict__ ynorm, const uint16_t *__restrict__ aux2,
+    float *pair_ws /* PAIR = 2: [16 units] dot products, then [units / 2] int flags (zero between launches) */) {
     constexpr bool Q41 = TYPE == FL_TYPE_Q4_1;
-    constexpr int G2 = PAIR ? 2 : 1, NT = 64 * NK;
+    constexpr int G2 = PAIR == 1 ? 2 : 1, NT = 64 * NK;
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     __shared__ double sh[4];
     __shared__ float accs[64][3];                                               // the chains' state between the K slices: a_2g, a_2g+1, summs
@@ -220,7 +224,28 @@ __global__ __launch_bounds__(64 * NK, (PAIR && QPW <= 8 && NK == 4) ? 3 : 1) voi
             float v = __fadd_rn(e, o);
             if (Q41) v = __fadd_rn(v, summs);
             const int row = (unit * G2 + gi) * 16 + r;
-            if constexpr (PAIR) {
+            if constexpr (PAIR == 2) {
+                // groups 2u (w1) and 2u + 1 (w3) of the woven matrix are this pair; nothing here is ordered by which side comes first.
+                // Agent-scope atomics only (sc1: they pass the XCD's L2), ordered by the wave's own counters: a release / acquire FENCE
+                // writes back / invalidates the whole L2 of the XCD (buffer_wbl2 / buffer_inv sc1) -- 58 us for this launch instead of 17.
+                int *flag = reinterpret_cast<int *>(pair_ws + (size_t)units * 16) + (unit >> 1);
+                if (g == 0) __hip_atomic_store(pair_ws + unit * 16 + r, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the 16 values have left before the flag moves
+                int old = 0;
+                if (lane == 0) old = __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                old = __builtin_amdgcn_readfirstlane(old);
+                asm volatile("" ::: "memory");
+                if (old == 1) {                                                 // second to arrive: the partner's 16 values are there
+                    if (lane == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float other = __hip_atomic_load(pair_ws + (unit ^ 1) * 16 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float h1 = (unit & 1) ? other : v, h3 = (unit & 1) ? v : other;
+                    if (g == 0 && row < M) {
+                        const uint16_t hx = __half_as_ushort(__float2half_rn(h1));                // GGML_FP32_TO_FP16
+                        const float sl = __half2float(__ushort_as_half(aux2[hx]));               // table_silu_f16
+                        y[(unit >> 1) * 16 + r] = __fmul_rn(sl, h3);                              // ggml_mul(silu, tmp)
+                    }
+                }
+            } else if constexpr (PAIR == 1) {
                 if (gi == 0) {
                     y1 = v;                                                    // w1 . x of this feature; its w3 row comes next
                 } else if (g == 0 && row < M) {
@@ -233,7 +258,7 @@ __global__ __launch_bounds__(64 * NK, (PAIR && QPW <= 8 && NK == 4) ? 3 : 1) voi
                 y[row] = v;
             }
         }
-        if (PAIR && gi == 0) {
+        if (PAIR == 1 && gi == 0) {
             // the w3 group's slice is requested only now.  Requested before the w1 chains it keeps both groups' registers alive: 214
             // VGPRs = two workgroups per CU = 1.3 rounds of the 688 workgroups, 24 us; squeezed under the 170-register cap of three
             // workgroups per CU it spills (22 us, also with the lane sums packed as int16 pairs); this order: 19.5 us
@@ -243,16 +268,16 @@ __global__ __launch_bounds__(64 * NK, (PAIR && QPW <= 8 && NK == 4) ? 3 : 1) voi
         }
     };
     do_group(std::integral_constant<int, 0>{});
-    if constexpr (PAIR) do_group(std::integral_constant<int, 1>{});
+    if constexpr (PAIR == 1) do_group(std::integral_constant<int, 1>{});
 }
 
 // false: no QWD copy, or a shape outside the kernel's reach (rows too long for the slices' registers, activation beyond LDS)
 // -> the caller takes round 3's kernel
 template <int TYPE, int PRO, int PAIR>
 static bool launch_llc(const fl_qtensor &W, const fl_qact *xq, float *y, hipStream_t st, const float *resid, const float *xf, const void *aux,
-                       float *ynorm, int woven, const uint16_t *aux2) {
+                       float *ynorm, int woven, const uint16_t *aux2, float *pair_ws = nullptr) {
     if (!W.qwd) return false;
-    constexpr int G2 = PAIR ? 2 : 1;
+    constexpr int G2 = PAIR == 1 ? 2 : 1;
     const int KB = W.KB, NQ = (KB + 3) / 4, units = W.M16 / 16 / G2;
     const size_t lds = (size_t)KB * 32 + (size_t)NQ * 32 + (size_t)NQ * 16 * 8;
     if (lds > 60 * 1024 || units < 1 || NQ > 88) return false;
@@ -263,7 +288,7 @@ static bool launch_llc(const fl_qtensor &W, const fl_qact *xq, float *y, hipStre
     if (NQ > 44 && units > 256) return false;
 #define FL_LLC(NK, QPW)                                                                                                                   \
     hipLaunchKernelGGL((gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW>), dim3(units), dim3(64 * NK), lds, st, W.M, units, KB, woven, \
-                       W.qwd, W.d, xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid, ynorm, aux2)
+                       W.qwd, W.d, xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid, ynorm, aux2, pair_ws)
     if (NQ <= 32) FL_LLC(4, 8);
     else if (NQ <= 44) FL_LLC(4, 11);
     else FL_LLC(8, 11);
@@ -284,7 +309,12 @@ bool gemv1_llc_silu(const fl_qtensor &W, const float *h13, const uint16_t *silu_
     return FL_TYPED((launch_llc<FL_TYPE_Q4_0, 2, 0>(W, nullptr, y, st, resid, h13, silu_tab, nullptr, woven ? 1 : 0, nullptr)),
                     (launch_llc<FL_TYPE_Q4_1, 2, 0>(W, nullptr, y, st, resid, h13, silu_tab, nullptr, woven ? 1 : 0, nullptr)));
 }
-bool gemv1_llc_norm_silu(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act, hipStream_t st) {
+size_t gemv1_llc_pair_ws_bytes(int M) { return ((size_t)(M + 15) / 16 * 16 + (size_t)(M + 31) / 32) * 4; }
+bool gemv1_llc_norm_silu(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act, hipStream_t st,
+                         float *pair_ws) {
+    if (pair_ws && (W.M16 / 16) % 2 == 0)         // (pair_ws: gemv1_llc_pair_ws_bytes(W.M) bytes, zero before its first use)
+        return FL_TYPED((launch_llc<FL_TYPE_Q4_0, 1, 2>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab, pair_ws)),
+                        (launch_llc<FL_TYPE_Q4_1, 1, 2>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab, pair_ws)));
     return FL_TYPED((launch_llc<FL_TYPE_Q4_0, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab)),
                     (launch_llc<FL_TYPE_Q4_1, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab)));
 }

@@ -65,6 +65,7 @@ struct Act {
     float *x = nullptr, *x2 = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *ao = nullptr, *h13 = nullptr,
           *part = nullptr, *logits = nullptr;
     fl_qact qE{}, qEl{}, qF{};                      // K = E, K = E/G (input of wo), K = F/G (input of w2)
+    float *pair_ws = nullptr;                       // reference-order decode: where the w1 / w3 workgroups of a feature meet (q4_kernels.h)
     hipStream_t stream = nullptr;
 };
 
@@ -171,11 +172,14 @@ static int act_alloc(fl_model *m, Act &a) {      // the work buffers of one eval
     if ((rc = qact_alloc(m, &a.qE, m->B, m->E)) != FL_OK) return rc;
     if ((rc = qact_alloc(m, &a.qEl, m->B, m->El)) != FL_OK) return rc;
     if ((rc = qact_alloc(m, &a.qF, m->B, m->Fl)) != FL_OK) return rc;
+    const size_t wsb = gemv1_llc_pair_ws_bytes(2 * m->Fl);
+    if ((rc = dev_alloc(m, (void **)&a.pair_ws, wsb)) != FL_OK) return rc;
+    M_HIP(hipMemset(a.pair_ws, 0, wsb));             // (its flags return to zero by themselves after every launch)
     return FL_OK;
 }
 static void act_free(Act &a) {
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
-    fr(a.tok_dev); fr(a.x); fr(a.x2); fr(a.xn); fr(a.part); fr(a.qkv); fr(a.att); fr(a.ao); fr(a.h13); fr(a.logits);
+    fr(a.tok_dev); fr(a.x); fr(a.x2); fr(a.xn); fr(a.part); fr(a.qkv); fr(a.att); fr(a.ao); fr(a.h13); fr(a.logits); fr(a.pair_ws);
     for (fl_qact *q : {&a.qE, &a.qEl, &a.qF}) { fr(q->q); fr(q->d); fr(q->s); fr(q->q6); fr(q->h16); }
     a = Act{};
 }
@@ -503,7 +507,9 @@ static hipError_t mm_norm_silu(fl_model *m, const fl_qtensor *W, const float *x,
     hipEvent_t e1;
     hipError_t r = prof_begin(m, &e1);
     if (r != hipSuccess) return r;
-    r = (m->exact ? gemv_q4_norm_silu_exact : gemv_q4_norm_silu)(*W, x, norm_w, m->silu_tab, act, m->stream);
+    static const bool one_wg = getenv("FL_EXACT_PAIR1") != nullptr;     // A/B: profiles/r04_decode_exact.md
+    if (m->exact) r = gemv_q4_norm_silu_exact(*W, x, norm_w, m->silu_tab, act, m->stream, one_wg ? nullptr : m->pair_ws);
+    else r = gemv_q4_norm_silu(*W, x, norm_w, m->silu_tab, act, m->stream);
     prof_end(m, e1);
     return r;
 }
@@ -671,14 +677,19 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
                 M_HIP(xe);
                 M_HIP(softmax_rows(m->att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, Hl, m->exp_tab, st, dyn));
                 // KQV, merged back to [N, n_embd]                                                      :389-398
-                xe = xa ? attn_pv_exact(m->att, n_ctx, (int64_t)N * n_ctx, D, Hl, N, n_past, vc, n_ctx, m->ao, El, st) : hipErrorInvalidValue;
+                bool quantized = xa && layout == 16 && El % 32 == 0;        // the MFMA form writes the Q8_0 operand of wo itself
+                xe = xa ? attn_pv_exact(m->att, n_ctx, (int64_t)N * n_ctx, D, Hl, N, n_past, vc, n_ctx, m->ao, El, st, quantized ? &m->qEl : nullptr,
+                                        xh && !m->tp_rows)
+                        : hipErrorInvalidValue;
                 if (xe == hipErrorInvalidValue) {
                     (void)hipGetLastError();
+                    quantized = false;
                     xe = (exact ? dot_f32_abt_exact : gemm_f32_abt)(m->att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, m->ao, El, D, N,
                                                                     D, P, Hl, 1.0f, 2, n_past, st, dyn, n_ctx);
                 }
                 M_HIP(xe);
-                if (layout == 16) M_HIP(quantize_q8_qa16(m->ao, El, N, El, m->qEl, st, xh && !m->tp_rows));
+                if (quantized) {}
+                else if (layout == 16) M_HIP(quantize_q8_qa16(m->ao, El, N, El, m->qEl, st, xh && !m->tp_rows));
                 else M_HIP(quantize_q8_qa1(m->ao, El, N, El, m->qEl, st));
             }   // (the one-launch kernel wrote the Q8_0 operand of the wo matmul itself)
         }
@@ -1373,6 +1384,7 @@ int fl_debug_rmsnorm_quant(const float *x, int ldx, const float *w, int N, int E
     M_HIP(rmsnorm_quant(x, ldx, w, N, E, y_f32, ldy, out, layout, (hipStream_t)stream));
     return FL_OK;
 }
+int g_debug_pair1 = 0;      // fl_debug_set(5, 1): fl_debug_gemv_norm_silu runs the one-workgroup-per-pair form of the reference-order kernel
 int g_debug_exact = 0;      // fl_debug_set(2, 1): the single-token test hooks below run the reference-order kernels
 // (the reference-order single-token hooks run the kernel of record: it reads the tensor's QWD copy)
 static int dbg_qwd(const fl_qtensor *W, void *stream) {
@@ -1415,7 +1427,21 @@ int fl_debug_prefill_attention_scratch(float *scratch, int ld, long head_stride)
 int fl_debug_gemv_norm_silu(const fl_qtensor *W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act,
                             void *stream) {
     if (int rc = dbg_qwd(W, stream)) return rc;
-    M_HIP((g_debug_exact ? gemv_q4_norm_silu_exact : gemv_q4_norm_silu)(*W, x, norm_w, silu_tab, act, (hipStream_t)stream));
+    if (!g_debug_exact) {
+        M_HIP(gemv_q4_norm_silu(*W, x, norm_w, silu_tab, act, (hipStream_t)stream));
+        return FL_OK;
+    }
+    static float *ws = nullptr;                      // (test hook: one workspace, grown as needed, calls one at a time)
+    static size_t ws_bytes = 0;
+    const size_t need = gemv1_llc_pair_ws_bytes(W->M);
+    if (need > ws_bytes) {
+        if (ws) (void)hipFree(ws);
+        ws = nullptr; ws_bytes = 0;
+        M_HIP(hipMalloc((void **)&ws, need));
+        M_HIP(hipMemset(ws, 0, need));
+        ws_bytes = need;
+    }
+    M_HIP(gemv_q4_norm_silu_exact(*W, x, norm_w, silu_tab, act, (hipStream_t)stream, g_debug_pair1 ? nullptr : ws));
     return FL_OK;
 }
 int fl_debug_gemv_quant(const fl_qtensor *W, const float *x, float *y, const float *resid, void *stream) {

@@ -1,6 +1,7 @@
 // q4_device.h -- device-side helpers shared by the HIP translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 #include "q4_layout.h"
 
@@ -76,6 +77,55 @@ __device__ __forceinline__ double wave_sum_f64(double s) {
     s += dpp_f64<DPP_MIRROR>(s);
     s += __shfl_xor(s, 16);
     return s + __shfl_xor(s, 32);
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared: quantize one 8-element group (4 adjacent lanes = one Q8_0 block) and store it
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void quantize_store_group(const float v[8], int n, int kg, int KB, int layout,
+                                                     int8_t *__restrict__ q, float *__restrict__ d,
+                                                     float *__restrict__ s, uint16_t *__restrict__ h16 = nullptr) {
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
+    amax = quad_max_f32(amax);
+    const float dd = __fdiv_rn(amax, 127.0f);
+    const float id = amax != 0.0f ? __fdiv_rn(127.0f, amax) : 0.0f;
+    int qi[8], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        qi[i] = (int)rintf(__fmul_rn(v[i], id));
+        sum += qi[i];
+    }
+    sum = quad_sum_i32(sum);
+    auto pk = [](int a, int b, int c, int e) -> uint32_t {
+        return (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(c & 0xFF) << 16) |
+               ((uint32_t)(e & 0xFF) << 24);
+    };
+    const uint2 w = make_uint2(pk(qi[0], qi[2], qi[4], qi[6]), pk(qi[1], qi[3], qi[5], qi[7]));
+    const int b = kg >> 2, g = kg & 3;
+    if (layout == 16) {
+        const int grp = n >> 4, c = n & 15;
+        const int64_t cb = ((int64_t)grp * KB + b) * 16 + c;
+        *reinterpret_cast<uint2 *>(q + cb * 32 + qw16_pos(c, g) * 8) = w;
+        if (g == 0) {
+            d[cb] = dd;
+            s[cb] = __fmul_rn(dd, (float)sum);
+        }
+        if (h16) {   // the XH16 copy (q4_layout.h): k-group g = MFMA step g, elements 0..3 in lane (n & 31), elements 4..7 in lane + 32
+            auto hb = [](int x) -> uint32_t { return (uint32_t)__half_as_ushort(__int2half_rn(x)); };
+            unsigned char *dst = reinterpret_cast<unsigned char *>(h16) + ((((int64_t)(n >> 5) * KB + b) * 2 + (g >> 1)) * 64 + (n & 31)) * 16 + (g & 1) * 8;
+            *reinterpret_cast<uint2 *>(dst) = make_uint2(hb(qi[0]) | (hb(qi[1]) << 16), hb(qi[2]) | (hb(qi[3]) << 16));
+            *reinterpret_cast<uint2 *>(dst + 512) = make_uint2(hb(qi[4]) | (hb(qi[5]) << 16), hb(qi[6]) | (hb(qi[7]) << 16));
+        }
+    } else {
+        const int64_t vb = (int64_t)n * KB + b;
+        *reinterpret_cast<uint2 *>(q + vb * 32 + g * 8) = w;
+        if (g == 0) {
+            d[vb] = dd;
+            s[vb] = __fmul_rn(dd, (float)sum);
+        }
+    }
 }
 
 }  // namespace fl

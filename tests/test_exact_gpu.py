@@ -367,12 +367,18 @@ def test_exact_feed_forward_pair_and_quant_prologue(torch, ops, port, exact_hook
     s = np.empty(1 << 16, np.uint16)
     L.fl_debug_tables(None, s.ctypes.data_as(C.c_void_p))
     xd, nd, sd = dev(torch, x), dev(torch, nw), dev(torch, s.view(np.int16))
-    act = torch.full((F,), 9.0, device="cuda")
-    hip.check(L.fl_debug_gemv_norm_silu(W.handle, xd.data_ptr(), nd.data_ptr(), sd.data_ptr(), act.data_ptr(), None))
     cur = le.rms_norm_mul(x, nw)
     h1, h3 = port.mul_mat_q(qt, w1, cur, strict=False), port.mul_mat_q(qt, w3, cur, strict=False)
     want_act = (le.silu(h1) * h3).astype(np.float32)
-    assert np.array_equal(bits(act.cpu().numpy()), bits(want_act[0]))
+    # two forms of (a): the w1 / w3 groups of a feature as two workgroups meeting in a workspace (the default; launched three times:
+    # its flags must be back at zero after every launch) and as one workgroup (fl_debug_set(5, 1))
+    for form, reps in [(0, 3), (1, 1)]:
+        L.fl_debug_set(5, form)
+        for _ in range(reps):
+            act = torch.full((F,), 9.0, device="cuda")
+            hip.check(L.fl_debug_gemv_norm_silu(W.handle, xd.data_ptr(), nd.data_ptr(), sd.data_ptr(), act.data_ptr(), None))
+            assert np.array_equal(bits(act.cpu().numpy()), bits(want_act[0])), form
+    L.fl_debug_set(5, 0)
     w2 = port.quantize_q4(qt, (rng.standard_normal((E, F)) * 0.05).astype(np.float32))
     W2 = ops.QTensor(qt, w2, E, F)
     res = rng.standard_normal(E).astype(np.float32)
@@ -388,7 +394,8 @@ def test_exact_feed_forward_pair_and_quant_prologue(torch, ops, port, exact_hook
 
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("D,H,n_past", [(32, 4, 0), (32, 4, 9), (128, 32, 0), (128, 32, 1), (128, 32, 31), (128, 8, 130), (128, 4, 511),
-                                        (64, 5, 37), (128, 3, 290), (96, 2, 515)])
+                                        (64, 5, 37), (128, 3, 290), (96, 2, 515), (128, 4, 62), (128, 4, 60), (128, 4, 35), (128, 4, 38), (128, 3, 283),
+                                        (128, 2, 255), (64, 3, 285)])
 def test_exact_decode_attention(torch, ops, port, exact_hooks, D, H, n_past, split):
     """The single-token attention (one launch, and the two-launch form for long contexts): rope + KV store, K.q and V.p in
     ggml_vec_dot_f32's order (leftover forms included: P = n_past + 1 keys), fp16-table soft_max, Q8_0 of the result --
@@ -471,3 +478,21 @@ def test_exact_prefill_attention_mfma_forms(torch, ops, port, D, H, N, n_past):
         s[np.arange(P)[None, :] > (n_past + np.arange(N))[:, None]] = -np.inf
         want[:, sl] = port.mul_mat_f32(np.ascontiguousarray(vc[sl, :P]), le.soft_max_rows(s))
     assert np.array_equal(bits(outs[1]), bits(want))
+    # the form the model runs for N >= 9: P.V writes the Q8_0 operand of the wo matmul itself (att still holds the probabilities) ...
+    a = ops.QAct(N, E)
+    hip.check(L.fl_debug_attn_pv_exact_q8(att.data_ptr(), n_ctx, D, H, N, n_past, vd.data_ptr(), E, a.handle, None))
+    a.N, a.K = N, E
+    got_q = a.export().cpu().numpy()
+    for n in range(N):
+        assert np.array_equal(got_q[n], port.quantize_row_q8_0(want[n])), n
+    # ... and its f16 fragment copy, which the reference-order GEMM reads (q4_layout.h XH16): a matmul on it equals the oracle's
+    if N >= 9:
+        wq = port.quantize_q4(oracle.Q4_0, (rng.standard_normal((80, E)) * 0.05).astype(np.float32))
+        W = ops.QTensor(oracle.Q4_0, wq, 80, E)
+        y = torch.empty((N, 80), device="cuda")
+        L.fl_debug_set(4, 1)
+        try:
+            hip.check(L.fl_mul_mat_q(W.handle, a.handle, y.data_ptr(), 80, None))
+        finally:
+            L.fl_debug_set(4, -1)
+        assert np.array_equal(bits(y.cpu().numpy()), bits(port.mul_mat_q(oracle.Q4_0, wq, want, strict=False)))
