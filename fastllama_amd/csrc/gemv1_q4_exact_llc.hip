@@ -22,10 +22,10 @@
 // The activation's Q8_0 form is built in LDS once per workgroup by the prologues of round 3 (gemv_prologue.h: rms_norm / silu * mul /
 // plain Q8_0, bit-identical to the separate kernels), then re-laid so that a lane reads its 8 bytes of four blocks in two 16-byte
 // LDS reads.  Woven w1|w3 (ggml_silu + ggml_mul of lib/llama.cpp:428-431 as the epilogue): PAIR = 1: a workgroup takes the w1 group and
-// then the w3 group of the same 16 features and stores silu(w1 x) * (w3 x).  PAIR = 2: the two groups are two ordinary workgroups;
-// each leaves its 16 dot products in a workspace and counts itself in on the pair's flag (agent-scope release / acquire), and the one
-// that arrives second forms silu * mul for both -- the launch keeps the plain matrix's shape (every byte requested at once, no second
-// chain phase behind the first: 19.5 -> 16.9 us for LLaMA-7B's 22016 x 4096) and the flag is back at zero when the launch ends.
+// then the w3 group of the same 16 features and stores silu(w1 x) * (w3 x).  PAIR = 2: the two groups are two ordinary workgroups that
+// meet, feature by feature, in a 64-bit slot of a workspace (an atomic exchange: whoever finds the other's value there finishes the
+// feature) -- the launch keeps the plain matrix's shape (every byte requested at once, no second chain phase behind the first) and
+// the slots are back at zero when the launch ends.
 // Q4_0 bookkeeping as everywhere: unpacked values are 16 (nib - 8), the stored scale is d / 16: fma(rn((d/16) d_x), 16 q, a) rounds
 // the same real number as the reference's fma(rn(d d_x), q, a).
 #include <hip/hip_runtime.h>
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64 * NK, (PAIR == 1 && QPW <= 8 && NK == 4) ? 3 : 1
     const uint32_t *__restrict__ qwd, const float *__restrict__ dW, const float *__restrict__ xf, const void *__restrict__ aux,
     const float *__restrict__ mW, const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs,
     float *__restrict__ y, const float *__restrict__ resid, float *__restrict__ ynorm, const uint16_t *__restrict__ aux2,
-    float *pair_ws /* PAIR = 2: [16 units] dot products, then [units / 2] int flags (zero between launches) */) {
+    float *pair_ws /* PAIR = 2: [units / 2][16] 64-bit slots (zero between launches) */) {
     constexpr bool Q41 = TYPE == FL_TYPE_Q4_1;
     constexpr int G2 = PAIR == 1 ? 2 : 1, NT = 64 * NK;
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
@@ -225,24 +225,21 @@ __global__ __launch_bounds__(64 * NK, (PAIR == 1 && QPW <= 8 && NK == 4) ? 3 : 1
             if (Q41) v = __fadd_rn(v, summs);
             const int row = (unit * G2 + gi) * 16 + r;
             if constexpr (PAIR == 2) {
-                // groups 2u (w1) and 2u + 1 (w3) of the woven matrix are this pair; nothing here is ordered by which side comes first.
-                // Agent-scope atomics only (sc1: they pass the XCD's L2), ordered by the wave's own counters: a release / acquire FENCE
-                // writes back / invalidates the whole L2 of the XCD (buffer_wbl2 / buffer_inv sc1) -- 58 us for this launch instead of 17.
-                int *flag = reinterpret_cast<int *>(pair_ws + (size_t)units * 16) + (unit >> 1);
-                if (g == 0) __hip_atomic_store(pair_ws + unit * 16 + r, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the 16 values have left before the flag moves
-                int old = 0;
-                if (lane == 0) old = __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                old = __builtin_amdgcn_readfirstlane(old);
-                asm volatile("" ::: "memory");
-                if (old == 1) {                                                 // second to arrive: the partner's 16 values are there
-                    if (lane == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const float other = __hip_atomic_load(pair_ws + (unit ^ 1) * 16 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const float h1 = (unit & 1) ? other : v, h3 = (unit & 1) ? v : other;
-                    if (g == 0 && row < M) {
-                        const uint16_t hx = __half_as_ushort(__float2half_rn(h1));                // GGML_FP32_TO_FP16
-                        const float sl = __half2float(__ushort_as_half(aux2[hx]));               // table_silu_f16
-                        y[(unit >> 1) * 16 + r] = __fmul_rn(sl, h3);                              // ggml_mul(silu, tmp)
+                // groups 2u (w1) and 2u + 1 (w3) of the woven matrix are this pair.  One 64-bit slot per feature: each side EXCHANGES
+                // (1 << 32 | its dot product) into it; the side that gets the other's word back arrived second and finishes the
+                // feature, then clears the slot -- one agent-scope atomic round trip per workgroup, no fence (a release / acquire
+                // fence writes back / invalidates the whole L2 of the XCD: 58 us for this launch), no order between the sides.
+                if (g == 0 && row < M) {
+                    unsigned long long *slot = reinterpret_cast<unsigned long long *>(pair_ws) + (size_t)(unit >> 1) * 16 + r;
+                    const unsigned long long mine = (1ull << 32) | (unsigned long long)__float_as_uint(v);
+                    const unsigned long long old = __hip_atomic_exchange(slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (old >> 32) {
+                        __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const float other = __uint_as_float((unsigned)old);
+                        const float h1 = (unit & 1) ? other : v, h3 = (unit & 1) ? v : other;
+                        const uint16_t hx = __half_as_ushort(__float2half_rn(h1));                    // GGML_FP32_TO_FP16
+                        const float sl = __half2float(__ushort_as_half(aux2[hx]));                   // table_silu_f16
+                        y[(unit >> 1) * 16 + r] = __fmul_rn(sl, h3);                                  // ggml_mul(silu, tmp)
                     }
                 }
             } else if constexpr (PAIR == 1) {
@@ -309,7 +306,7 @@ bool gemv1_llc_silu(const fl_qtensor &W, const float *h13, const uint16_t *silu_
     return FL_TYPED((launch_llc<FL_TYPE_Q4_0, 2, 0>(W, nullptr, y, st, resid, h13, silu_tab, nullptr, woven ? 1 : 0, nullptr)),
                     (launch_llc<FL_TYPE_Q4_1, 2, 0>(W, nullptr, y, st, resid, h13, silu_tab, nullptr, woven ? 1 : 0, nullptr)));
 }
-size_t gemv1_llc_pair_ws_bytes(int M) { return ((size_t)(M + 15) / 16 * 16 + (size_t)(M + 31) / 32) * 4; }
+size_t gemv1_llc_pair_ws_bytes(int M) { return (size_t)(M + 31) / 32 * 16 * 8; }
 bool gemv1_llc_norm_silu(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act, hipStream_t st,
                          float *pair_ws) {
     if (pair_ws && (W.M16 / 16) % 2 == 0)         // (pair_ws: gemv1_llc_pair_ws_bytes(W.M) bytes, zero before its first use)
