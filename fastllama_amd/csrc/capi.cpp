@@ -44,7 +44,7 @@ int ensure_device() {
 
 }  // namespace fl
 
-namespace fl { extern int g_gemm_force_cfg; extern int g_gemv_force_waves; extern int g_gemm_fp6; }
+namespace fl { extern int g_gemm_force_cfg; extern int g_gemv_force_waves; }
 using namespace fl;
 
 #define FL_HIP(call)                                   \
@@ -219,21 +219,7 @@ fl_qtensor *fl_qtensor_from_device(int type, const void *blocks_dev, int M, int 
         fl_qtensor_free(W);
         return nullptr;
     }
-    if (gemm_fp6_enabled() && fl_qtensor_build_f6(W, stream) != FL_OK) {
-        fl_qtensor_free(W);
-        return nullptr;
-    }
     return W;
-}
-
-/* (re)build the fp6 operand copy of the prefill path from the nibbles of record (q4_layout.h "F6 copies") */
-int fl_qtensor_build_f6(fl_qtensor *W, void *stream) {
-    if (!W) return set_error(FL_EINVAL, "null tensor");
-    if (!W->f6) FL_HIP(hipMalloc((void **)&W->f6, (size_t)W->M16 * W->KB * 24));
-    hipError_t e = qw16_to_f6(*W, W->f6, S(stream));
-    if (e == hipSuccess) e = hipStreamSynchronize(S(stream));
-    if (e != hipSuccess) return hip_fail(e, "fl_qtensor_build_f6");
-    return FL_OK;
 }
 
 /* (re)build the f16 fragment copy the reference-order prefill GEMM reads (q4_layout.h "H16 copies"; 4 x the nibble bytes) */
@@ -277,11 +263,6 @@ void fl_qtensor_drop_h16(fl_qtensor *W) {
     if (W) W->h16 = nullptr;
 }
 
-void fl_qtensor_drop_f6(fl_qtensor *W) {
-    if (W && W->f6) (void)hipFree(W->f6);
-    if (W) W->f6 = nullptr;
-}
-
 fl_qtensor *fl_qtensor_upload(int type, const void *blocks_host, int M, int K, void *stream) {
     if (ensure_device() != FL_OK || check_wshape(type, M, K) != FL_OK) return nullptr;
     const size_t bytes = (size_t)M * (K / FL_QK) * (type == FL_TYPE_Q4_0 ? 20 : 24);
@@ -323,7 +304,7 @@ int fl_qtensor_info(const fl_qtensor *W, int *type, int *M, int *K) {
 size_t fl_qtensor_device_bytes(const fl_qtensor *W) {
     if (!W) return 0;
     const size_t nblk = (size_t)W->M16 * W->KB;
-    return nblk * (16 + 4 + (W->type == FL_TYPE_Q4_1 ? 4 : 0) + (W->f6 ? 24 : 0)) + (W->h16 ? wh16_bytes(*W) : 0) + (W->qwd ? qwd_bytes(*W) : 0);
+    return nblk * (16 + 4 + (W->type == FL_TYPE_Q4_1 ? 4 : 0)) + (W->h16 ? wh16_bytes(*W) : 0) + (W->qwd ? qwd_bytes(*W) : 0);
 }
 
 void fl_qtensor_free(fl_qtensor *W) {
@@ -333,7 +314,6 @@ void fl_qtensor_free(fl_qtensor *W) {
         if (W->d) (void)hipFree(W->d);
         if (W->m) (void)hipFree(W->m);
     }
-    if (W->f6) (void)hipFree(W->f6);
     if (W->h16) (void)hipFree(W->h16);
     if (W->qwd) (void)hipFree(W->qwd);
     delete W;
@@ -452,7 +432,6 @@ fl_qact *fl_qact_create(int max_N, int K) {
     hipError_t e = hipMalloc((void **)&a->q, a->q_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&a->d, a->s_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&a->s, a->s_bytes);
-    if (e == hipSuccess && gemm_fp6_enabled()) e = hipMalloc((void **)&a->q6, a->q_bytes / 2 * 3);
     if (e == hipSuccess) e = hipMalloc((void **)&a->h16, xh16_bytes(a->cap_N16, K));
     if (e == hipSuccess) e = hipMemset(a->h16, 0, xh16_bytes(a->cap_N16, K));
     if (e != hipSuccess) {
@@ -468,7 +447,6 @@ void fl_qact_free(fl_qact *a) {
     if (a->q) (void)hipFree(a->q);
     if (a->d) (void)hipFree(a->d);
     if (a->s) (void)hipFree(a->s);
-    if (a->q6) (void)hipFree(a->q6);
     if (a->h16) (void)hipFree(a->h16);
     delete static_cast<fl_qact_impl *>(a);
 }
@@ -506,7 +484,6 @@ extern int g_debug_exact, g_debug_pair1;   // model.cpp
 int fl_debug_set(int what, int value) {
     if (what == 0) fl::g_gemm_force_cfg = value;
     if (what == 1) fl::g_gemv_force_waves = value;   // 0 = automatic, else 4 / 8 / 16 waves per 16-row group
-    if (what == 3) fl::g_gemm_fp6 = value != 0;      // prefill GEMM: fp6 block-scaled form (1) or the i8 form (0, default) of the same tiles
     if (what == 2) g_debug_exact = value;            // the single-token test hooks (fl_debug_gemv_*, fl_debug_decode_attention*) in exact mode
     if (what == 5) g_debug_pair1 = value;            // fl_debug_gemv_norm_silu in exact mode: the one-workgroup-per-feature-pair form
     if (what == 4) g_op_mode = value;                // operator-level entry points: 1 reference order, 0 fast kernels, -1 the default

@@ -495,18 +495,9 @@ __global__ __launch_bounds__(64 * WM * WN, (TYPE == FL_TYPE_Q4_1 && MINW == 4) ?
     X(13, 2, 4, 2, 2, 2, 4) /*  64x128   8 waves of 32x32, 4-block K-steps   */
 
 int g_gemm_force_cfg = -1;  // debug / autotune hook: >= 0 forces one configuration (>= 100: the 32x32x32 kernel)
-// The fp6 block-scaled operand form of the 32x32 kernel (gemm_q4_mfma32.hip, F6): identical bits, 16 + 8 fewer VALU operations
-// per tile and block -- and, measured (profiles/r03_fp6_vs_i8_kernels.txt), -15 % .. +6 % of the int8 form's kernel time (the
-// kernel is not issue-bound), less than the QA16 -> QA16F6 pass in front of it costs.  So it is OFF unless FL_FP6=1 /
-// fl_debug_set(3, 1): tensors and workspaces created while it is on carry the fp6 copies (+50 % weight bytes).
-int g_gemm_fp6 = -1;        // -1: FL_FP6 from the environment (default 0); 0 / 1: fl_debug_set(3, v)
-bool gemm_fp6_enabled() {
-    if (g_gemm_fp6 < 0) {
-        const char *e = getenv("FL_FP6");
-        g_gemm_fp6 = e && e[0] == '1' ? 1 : 0;
-    }
-    return g_gemm_fp6 != 0;
-}
+// (Round 3 also carried an fp6 block-scaled operand form of the 32x32 kernel -- v_mfma_scale_f32_32x32x64_f8f6f4 on E2M3 copies of the
+// nibbles and of the Q8_0 quants, bit-identical, 24 fewer VALU operations per tile and block.  Measured -15 % .. +6 % of the int8 form's
+// kernel time at +50 % weight bytes (profiles/r03_fp6_vs_i8_kernels.txt: the kernel is not issue-bound); removed in round 4.)
 
 // gemm_q4_mfma32.hip
 bool gemm32_supports(const fl_qtensor &W, int cfg, bool silu);
@@ -578,16 +569,6 @@ static hipError_t gemm_dispatch(const fl_qtensor &W, const fl_qact &xq, int N, f
     if ((ldy & 3) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return hipErrorInvalidValue;
     const int MGT = W.M16 / 16, NGT = fl_roundup(N, 16) / 16;
     int cfg = pick_config(MGT, NGT, W.type);
-    // the fp6 block-scaled form of the same tile configuration (identical bits, fewer VALU operations per block), when both
-    // operand copies exist: ids + 100
-    if ((cfg == 101 || cfg == 106 || cfg == 116) && g_gemm_force_cfg < 0 && gemm_fp6_enabled() && W.f6 && xq.q6 &&
-        gemm32_supports(W, cfg + 100, epi.silu_tab != nullptr))
-        cfg += 100;
-    if (cfg >= 200) {
-        if (!W.f6 || !xq.q6) return hipErrorInvalidValue;
-        const hipError_t e = qa16_to_f6(xq, N, st);
-        if (e != hipSuccess) return e;
-    }
     if (cfg >= 100) {
         if (gemm32_supports(W, cfg, epi.silu_tab != nullptr)) return gemm32_launch(cfg, W, xq, N, y, ldy, st, resid, ldr, epi);
         cfg = 12;

@@ -40,9 +40,6 @@ typedef const __attribute__((address_space(1))) void glb_void32;
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v32f __attribute__((ext_vector_type(32)));
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
-typedef unsigned int v3u __attribute__((ext_vector_type(3)));
-typedef int v2i32 __attribute__((ext_vector_type(2)));
-typedef int v8i __attribute__((ext_vector_type(8)));
 
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -52,13 +49,12 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 #endif
 
 // WM waves stacked along M, each owning 32 rows x (32 RN) columns; the workgroup tile is (32 WM) x (32 RN).
-// F6: the fp6 block-scaled MFMA form (q4_layout.h "F6 copies"): operands QW16F6 / QA16F6 instead of QW16 / QA16.
-template <int TYPE, int WM, int RN, bool F6 = false>
+template <int TYPE, int WM, int RN>
 struct G32 {
     static constexpr int KS = 4, NSTAGE = 3, NW = WM, RING = 8;
     static constexpr int NG = 2 * RN;                                // 16-column groups per tile
-    static constexpr int BLKB = F6 ? 768 : 512;                      // activation bytes of one (column group, block)
-    static constexpr int BLKA = F6 ? 384 : 256;                      // weight bytes of one (row group, block)
+    static constexpr int BLKB = 512;                                 // activation bytes of one (column group, block)
+    static constexpr int BLKA = 256;                                 // weight bytes of one (row group, block)
     static constexpr int B_BYTES = NG * KS * BLKB;                   // activations of one K-step
     static constexpr int B_PIECES = B_BYTES / 1024;                  // 1-KiB global_load_lds pieces
     static constexpr int N_PLANES = TYPE == FL_TYPE_Q4_1 ? 2 : 1;    // d_x (, s_x), one padded piece each
@@ -87,7 +83,7 @@ __device__ long long g32_dbg[4096 * 8];
 // (A launch is one region -- gemm_q4_mfma32_kernel -- or two regions with different tile shapes -- gemm_q4_mfma32_mixed_kernel.)
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the kernels' launch stubs (and loses them if it has to instantiate
                                       // the generic lambdas below, whose bodies use gfx950 builtins)
-template <int TYPE, int WM, int RN, int MINW, bool PDB, bool F6 = false>
+template <int TYPE, int WM, int RN, int MINW, bool PDB>
 __device__ __forceinline__ FL_NOPK32 void gemm32_body(
     const uint32_t *qs, const float *dW, const float *mW,   // (no __restrict__: the ring loads must stay where they are issued)
     const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs, int N, int M,
@@ -97,7 +93,7 @@ __device__ __forceinline__ FL_NOPK32 void gemm32_body(
 #ifdef G32_TIMING
     if ((threadIdx.x & 63) == 0 && threadIdx.x < 128 && blockIdx.x < 4096) g32_dbg[blockIdx.x * 8 + 5 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg((15 << 11) | 4);
 #endif
-    using C = G32<TYPE, WM, RN, F6>;
+    using C = G32<TYPE, WM, RN>;
     constexpr int KS = C::KS;
     constexpr bool Q41 = TYPE == FL_TYPE_Q4_1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -169,27 +165,22 @@ __device__ __forceinline__ FL_NOPK32 void gemm32_body(
 
     // ---- weight side: bounds-checked buffer loads (rows past M16 and bytes past the tensor read as zero) ----
     const uint32_t wbytes = (uint32_t)MGT * (uint32_t)KB * 256u;
-    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(qs), 0, (int)(F6 ? wbytes / 2 * 3 : wbytes), 0x00020000);
+    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(qs), 0, (int)wbytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dW), 0, (int)(wbytes >> 2), 0x00020000);
     __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Q41 ? mW : dW), 0, (int)(wbytes >> 2), 0x00020000);
     const uint32_t rgrp = (uint32_t)(mg0 + 2 * wave + g1);
-    // i8 form: the 8-byte half h of the row's nibbles.  F6: the 12-byte half h of the row's 24 bytes of codes; the MFMA wants all
-    // 24 in both lane halves (A = the block's weights twice, against the hi and the lo plane of B) and gets them by
-    // v_permlane32_swap at use -- the ring holds 3 VGPRs per block, not 6.
-    const uint32_t voffA = F6 ? (rgrp * (uint32_t)KB * 16u + (uint32_t)c15_k) * 24u + (uint32_t)h_k * 12u
-                              : (rgrp * (uint32_t)KB * 16u + (uint32_t)c15_k) * 16u + (uint32_t)((h_k ^ (c15_k >> 3)) << 3);
+    // the 8-byte half h of the row's nibbles
+    const uint32_t voffA = (rgrp * (uint32_t)KB * 16u + (uint32_t)c15_k) * 16u + (uint32_t)((h_k ^ (c15_k >> 3)) << 3);
     const uint32_t voffD = (rgrp * (uint32_t)KB * 16u + (uint32_t)c15_k) * 4u;
 
     v2u araw[C::RING];
-    v3u araw6[C::RING];
     float saw[C::RING], maw[C::RING];
     // block kb of this wave's rows into ring slot `slot` (compile-time).  Blocks past the end re-read the last one: its
     // scales are finite, and the activation side is zero there.
     auto load_w = [&](auto SLOT, int kb) FL_NOPK32 __attribute__((always_inline)) {
         constexpr int slot = decltype(SLOT)::value;
         const int kba = kb < KB ? kb : KB - 1;
-        if (F6) araw6[slot] = __builtin_bit_cast(v3u, __builtin_amdgcn_raw_buffer_load_b96(rA, voffA, kba * 384, 0));
-        else araw[slot] = __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(rA, voffA, kba * 256, 0));
+        araw[slot] = __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(rA, voffA, kba * 256, 0));
         if (RN == 2) {
             saw[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, voffD, kba * 64, 0));
             if (Q41) maw[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, voffD, kba * 64, 0));
@@ -203,9 +194,7 @@ __device__ __forceinline__ FL_NOPK32 void gemm32_body(
     };
 
     // ---- per-lane_k LDS offsets of the B fragments and the activation scales ----
-    // (F6: bytes 0..15 of plane h at b_off, the same place as the i8 form's half h; bytes 16..23 at b_off6)
     const int b_off = (g1 * KS) * C::BLKB + c15_k * 32 + ((h_k ^ (c15_k >> 3)) << 4);           // + jt * 2 KS BLKB + u * BLKB
-    const int b_off6 = (g1 * KS) * C::BLKB + 512 + c15_k * 16 + ((h_k ^ g1) << 3);
     const int sb_off = C::OFF_PL + (RN == 2 ? ((2 * h_k + g1) * KS) * 64 : (g1 * KS + h_k) * 64) + c15_k * 4;   // + u * 64
 
     v16f acc[RN];
@@ -229,24 +218,13 @@ __device__ __forceinline__ FL_NOPK32 void gemm32_body(
     for (int e = 0; e < 32; ++e) zero32[e] = 0.f;
 
     v4i afr[2], bfr[2][RN];
-    v8i afr6[1], bfr6[1][RN];     // (one buffer: the fragments of block b are dead once its last MFMA has issued, before b+1's are written)
     float sbw[2] = {0.f, 0.f}, mbw[2] = {0.f, 0.f};
     v32f P[2];
     v16i D[2];
-    // F6: E8M0 block scales of the operands (byte 0 of the lane's scale register): A 2^5 (Q4_0: the product is 16 isum, as in the
-    // i8 form) or 2^1; B 2^5 for the hi plane (lanes h = 0), 2^1 for the lo plane
-    int sc_a = Q41 ? 128 : 132, sc_b = h_k ? 128 : 132;
-    asm volatile("" : "+v"(sc_a), "+v"(sc_b));
-    v16f zero16;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
-    // one 32x32 tile of exact block dots into D[dst] (as f32 bits in the F6 form, as magic + isum in the i8 form)
+    // one 32x32 tile of exact block dots into D[dst] (as magic + isum)
     auto tile_dot = [&](auto DST, auto BUF, auto JJ) FL_NOPK32 __attribute__((always_inline)) {
         constexpr int dst = decltype(DST)::value, buf = decltype(BUF)::value, j = decltype(JJ)::value;
-        if (F6)
-            D[dst] = __builtin_bit_cast(v16i, __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(afr6[0], bfr6[0][j], zero16, 2, 2, 0, sc_a, 0, sc_b));
-        else
-            D[dst] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[buf], bfr[buf][j], magic, 0, 0, 0);
+        D[dst] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[buf], bfr[buf][j], magic, 0, 0, 0);
     };
 
     auto read_b = [&](auto BUF, const unsigned char *base, auto UU) FL_NOPK32 __attribute__((always_inline)) {
@@ -254,13 +232,7 @@ __device__ __forceinline__ FL_NOPK32 void gemm32_body(
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
             const unsigned char *bp = base + b_off + j * (2 * KS * C::BLKB) + u * C::BLKB;
-            if (F6) {
-                const v4i b0 = *reinterpret_cast<const v4i *>(bp);
-                const v2i32 b1 = *reinterpret_cast<const v2i32 *>(bp - b_off + b_off6);
-                bfr6[0][j] = v8i{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, 0, 0};
-            } else {
-                bfr[buf][j] = *reinterpret_cast<const v4i *>(bp);
-            }
+            bfr[buf][j] = *reinterpret_cast<const v4i *>(bp);
         }
         if (RN == 2) {
             sbw[buf] = *reinterpret_cast<const float *>(base + sb_off + u * 64);
@@ -272,20 +244,6 @@ __device__ __forceinline__ FL_NOPK32 void gemm32_body(
     };
     auto unpack = [&](auto BUF, auto SLOT) FL_NOPK32 __attribute__((always_inline)) {
         constexpr int buf = decltype(BUF)::value, slot = decltype(SLOT)::value;
-        if (F6) {
-            // (x, y) <- (own 12 bytes, own 12 bytes); v_permlane32_swap(x, y): upper lanes of x <-> lower lanes of y  =>  x = bytes
-            // 0..11 of the row in every lane, y = bytes 12..23.  In asm with fresh destinations: through the builtin the allocator
-            // ties the ring slot to its 6-register operand tuple, eight tuples instead of one (17 VGPRs spilled).  Each swap has two
-            // VALU operations between it and the write of its second operand (the wait states the instruction asks for).
-            int x0, x1, x2, y0, y1, y2;
-            asm volatile("v_mov_b32 %0, %6\n\tv_mov_b32 %1, %7\n\tv_mov_b32 %2, %8\n\t"
-                         "v_mov_b32 %3, %6\n\tv_mov_b32 %4, %7\n\tv_mov_b32 %5, %8\n\t"
-                         "v_permlane32_swap_b32 %0, %3\n\tv_permlane32_swap_b32 %1, %4\n\tv_permlane32_swap_b32 %2, %5"
-                         : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(y0), "=&v"(y1), "=&v"(y2)
-                         : "v"(araw6[slot].x), "v"(araw6[slot].y), "v"(araw6[slot].z));
-            afr6[0] = v8i{x0, x1, x2, y0, y1, y2, 0, 0};
-            return;
-        }
         uint32_t l0, h0, l1, h1;
         unpack_nibbles<TYPE>(araw[slot].x, l0, h0);
         unpack_nibbles<TYPE>(araw[slot].y, l1, h1);
@@ -297,7 +255,7 @@ __device__ __forceinline__ FL_NOPK32 void gemm32_body(
         const v16f df = __builtin_bit_cast(v16f, d);     // (bit_cast of a single vector ELEMENT lvalue reads element 0: clang bug)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const float f = F6 ? df[e] : df[e] + negmagic;
+            const float f = df[e] + negmagic;
             a[e] = __builtin_fmaf(f, p[half * 16 + e], a[e]);
         }
     };
@@ -339,12 +297,7 @@ __device__ __forceinline__ FL_NOPK32 void gemm32_body(
     // done with this stage (barrier), the stage is refilled with K-step t+3, and the wave moves on with MFMAs in flight.
     auto block = [&](auto SS, int kb, int t) FL_NOPK32 __attribute__((always_inline)) {
         constexpr int S = decltype(SS)::value, u = S & 3, nb = (S + 1) & 1, cb = S & 1, ns = (S + 1) & 7, nu = (u + 1) & 3;
-        constexpr bool ONE_D = F6 && RN == 2;     // F6, 32x64 wave tiles: ONE D buffer (the register budget of three waves per SIMD)
-        if (ONE_D) {                              //   E(D(b, tile 0)) | D(b, tile 1) | operands of b+1 | E(D(b, tile 1)) | P(b+1) D(b+1, tile 0)
-            scale_acc(acc[0], D[0], P[0], IC(0));
-            __builtin_amdgcn_sched_barrier(0);
-            tile_dot(IC(0), IC(cb), IC(RN - 1));
-        } else if (RN == 2) tile_dot(IC(1), IC(cb), IC(RN - 1));
+        if (RN == 2) tile_dot(IC(1), IC(cb), IC(RN - 1));
         __builtin_amdgcn_sched_barrier(0);
         if (u == 3) {
 #ifdef FL_G32_SAFE
@@ -362,14 +315,7 @@ __device__ __forceinline__ FL_NOPK32 void gemm32_body(
         unpack(IC(nb), IC(ns));
         load_w(SS, kb + C::RING);
         __builtin_amdgcn_sched_barrier(0);
-        if (ONE_D) {
-            static_assert(!(F6 && RN == 2 && PDB), "the F6 32x64 form keeps one P buffer");
-            scale_acc(acc[RN - 1], D[0], P[0], IC(1));
-            __builtin_amdgcn_sched_barrier(0);
-            P[0] = __builtin_amdgcn_mfma_f32_32x32x1f32(saw[ns], sbw[nb], zero32, 0, 0, 0);
-            if (Q41) ms2 = __builtin_amdgcn_mfma_f32_32x32x1f32(maw[ns], mbw[nb], ms2, 0, 0, 0);
-            tile_dot(IC(0), IC(nb), IC(0));
-        } else if (RN == 2 && PDB) {
+        if (RN == 2 && PDB) {
             scale_acc(acc[0], D[0], P[cb], IC(0));
             __builtin_amdgcn_sched_barrier(0);
             P[nb] = __builtin_amdgcn_mfma_f32_32x32x1f32(saw[ns], sbw[nb], zero32, 0, 0, 0);
@@ -534,13 +480,13 @@ __device__ __forceinline__ FL_NOPK32 void gemm32_body(
 }
 #endif   // __HIP_DEVICE_COMPILE__
 
-template <int TYPE, int WM, int RN, int MINW, bool PDB, bool F6>
+template <int TYPE, int WM, int RN, int MINW, bool PDB>
 __global__ __launch_bounds__(64 * WM, TYPE == FL_TYPE_Q4_1 ? 2 : MINW) FL_NOPK32 void gemm_q4_mfma32_kernel(
     const uint32_t *qs, const float *dW, const float *mW, const int8_t *__restrict__ xq, const float *__restrict__ xd,
     const float *__restrict__ xs, int N, int M, int MGT, int NGT, int KB, float *__restrict__ y, int ldy,
     const float *__restrict__ resid, int ldr, GemmSiluEpi epi) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    gemm32_body<TYPE, WM, RN, MINW, PDB, F6>(qs, dW, mW, xq, xd, xs, N, M, MGT, NGT, KB, y, ldy, resid, ldr, epi, (int)blockIdx.x, 0, MGT);
+    gemm32_body<TYPE, WM, RN, MINW, PDB>(qs, dW, mW, xq, xd, xs, N, M, MGT, NGT, KB, y, ldy, resid, ldr, epi, (int)blockIdx.x, 0, MGT);
 #endif
 }
 
@@ -550,16 +496,16 @@ __global__ __launch_bounds__(64 * WM, TYPE == FL_TYPE_Q4_1 ? 2 : MINW) FL_NOPK32
 // multiples of 256 workgroups -- and the rest covers the remaining row groups with 128 x 32 tiles: twice as many workgroups of
 // half the work each, which fill the slots the last full round frees.  Same arithmetic per output in both regions (every tile
 // configuration returns identical bits), so the result does not depend on where the split falls.
-template <int TYPE, bool F6>
+template <int TYPE>
 __global__ __launch_bounds__(256, TYPE == FL_TYPE_Q4_1 ? 2 : 3) FL_NOPK32 void gemm_q4_mfma32_mixed_kernel(
     const uint32_t *qs, const float *dW, const float *mW, const int8_t *__restrict__ xq, const float *__restrict__ xd,
     const float *__restrict__ xs, int N, int M, int MGT, int NGT, int KB, float *__restrict__ y, int ldy,
     const float *__restrict__ resid, int ldr, GemmSiluEpi epi, int n_a, int mg_split) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if ((int)blockIdx.x < n_a)
-        gemm32_body<TYPE, 4, 2, 3, false, F6>(qs, dW, mW, xq, xd, xs, N, M, MGT, NGT, KB, y, ldy, resid, ldr, epi, (int)blockIdx.x, 0, mg_split);
+        gemm32_body<TYPE, 4, 2, 3, false>(qs, dW, mW, xq, xd, xs, N, M, MGT, NGT, KB, y, ldy, resid, ldr, epi, (int)blockIdx.x, 0, mg_split);
     else
-        gemm32_body<TYPE, 4, 1, 3, true, F6>(qs, dW, mW, xq, xd, xs, N, M, MGT, NGT, KB, y, ldy, resid, ldr, epi, (int)blockIdx.x - n_a, mg_split,
+        gemm32_body<TYPE, 4, 1, 3, true>(qs, dW, mW, xq, xd, xs, N, M, MGT, NGT, KB, y, ldy, resid, ldr, epi, (int)blockIdx.x - n_a, mg_split,
                                          MGT - mg_split);
 #endif
 }
@@ -578,16 +524,15 @@ __global__ __launch_bounds__(256, TYPE == FL_TYPE_Q4_1 ? 2 : 3) FL_NOPK32 void g
     X(106, 4, 2, 3, false)  /* 128 x 64   4 waves of 32x64, three waves per SIMD    */ \
     X(108, 8, 2, 3, false)  /* 256 x 64   8 waves of 32x64, three waves per SIMD    */
 
-template <int TYPE, int WM, int RN, int MINW, bool PDB, bool F6 = false>
+template <int TYPE, int WM, int RN, int MINW, bool PDB>
 static hipError_t launch_gemm32(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                                 const float *resid, int ldr, const GemmSiluEpi &epi) {
-    using C = G32<TYPE, WM, RN, F6>;
-    if (F6 && (!W.f6 || !xq.q6)) return hipErrorInvalidValue;
+    using C = G32<TYPE, WM, RN>;
     const int MGT = W.M16 / 16, NGT = fl_roundup(N, 16) / 16;
     const int tiles = ((MGT + 2 * WM - 1) / (2 * WM)) * ((NGT + C::NG - 1) / C::NG);
     static_assert(C::LDS_BYTES <= 65536, "no dynamic-LDS attribute needed");
-    hipLaunchKernelGGL((gemm_q4_mfma32_kernel<TYPE, WM, RN, MINW, PDB, F6>), dim3(tiles), dim3(64 * WM), C::LDS_BYTES, st,
-                       F6 ? reinterpret_cast<const uint32_t *>(W.f6) : W.qs, W.d, W.m, F6 ? reinterpret_cast<const int8_t *>(xq.q6) : xq.q,
+    hipLaunchKernelGGL((gemm_q4_mfma32_kernel<TYPE, WM, RN, MINW, PDB>), dim3(tiles), dim3(64 * WM), C::LDS_BYTES, st,
+                       W.qs, W.d, W.m, xq.q,
                        xq.d, xq.s, N, W.M, MGT, NGT, W.KB, y, ldy, resid, ldr, epi);
     return hipGetLastError();
 }
@@ -604,25 +549,24 @@ void gemm32_mixed_split(int MGT, int NGT, int *n_a, int *mg_split, int *n_b) {
     *n_b = ((MGT - *mg_split + 7) / 8) * tn_b;
 }
 
-template <int TYPE, bool F6 = false>
+template <int TYPE>
 static hipError_t launch_gemm32_mixed(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                                       const float *resid, int ldr, const GemmSiluEpi &epi) {
-    using CA = G32<TYPE, 4, 2, F6>;
-    using CB = G32<TYPE, 4, 1, F6>;
-    if (F6 && (!W.f6 || !xq.q6)) return hipErrorInvalidValue;
+    using CA = G32<TYPE, 4, 2>;
+    using CB = G32<TYPE, 4, 1>;
     const int MGT = W.M16 / 16, NGT = fl_roundup(N, 16) / 16;
     int n_a, mg_split, n_b;
     gemm32_mixed_split(MGT, NGT, &n_a, &mg_split, &n_b);
     constexpr int lds = CA::LDS_BYTES > CB::LDS_BYTES ? CA::LDS_BYTES : CB::LDS_BYTES;
     static_assert(lds <= 65536, "no dynamic-LDS attribute needed");
-    hipLaunchKernelGGL((gemm_q4_mfma32_mixed_kernel<TYPE, F6>), dim3(n_a + n_b), dim3(256), lds, st,
-                       F6 ? reinterpret_cast<const uint32_t *>(W.f6) : W.qs, W.d, W.m, F6 ? reinterpret_cast<const int8_t *>(xq.q6) : xq.q,
+    hipLaunchKernelGGL((gemm_q4_mfma32_mixed_kernel<TYPE>), dim3(n_a + n_b), dim3(256), lds, st,
+                       W.qs, W.d, W.m, xq.q,
                        xq.d, xq.s, N, W.M, MGT, NGT, W.KB, y, ldy, resid, ldr, epi, n_a, mg_split);
     return hipGetLastError();
 }
 
 bool gemm32_supports(const fl_qtensor &W, int cfg, bool silu) {
-    if ((uint64_t)(W.M16 / 16 + 16) * (uint64_t)W.KB * (cfg >= 200 ? 384u : 256u) >= (1ull << 31)) return false;   // 32-bit buffer offsets
+    if ((uint64_t)(W.M16 / 16 + 16) * (uint64_t)W.KB * 256u >= (1ull << 31)) return false;   // 32-bit buffer offsets
     (void)cfg; (void)silu;
     return W.KB >= 1;
 }
@@ -638,17 +582,6 @@ hipError_t gemm32_launch(int cfg, const fl_qtensor &W, const fl_qact &xq, int N,
     if (cfg == 116)
         return W.type == FL_TYPE_Q4_0 ? launch_gemm32_mixed<FL_TYPE_Q4_0>(W, xq, N, y, ldy, st, resid, ldr, epi)
                                       : launch_gemm32_mixed<FL_TYPE_Q4_1>(W, xq, N, y, ldy, st, resid, ldr, epi);
-    // F6 forms (ids + 100) of the three configurations pick_config returns
-#define XF(ID, WM, RN, MINW, PDB)                                                                                                 \
-    if (cfg == ID)                                                                                                                \
-        return W.type == FL_TYPE_Q4_0 ? launch_gemm32<FL_TYPE_Q4_0, WM, RN, MINW, PDB, true>(W, xq, N, y, ldy, st, resid, ldr, epi) \
-                                      : launch_gemm32<FL_TYPE_Q4_1, WM, RN, MINW, PDB, true>(W, xq, N, y, ldy, st, resid, ldr, epi);
-    XF(201, 4, 1, 3, true)
-    XF(206, 4, 2, 3, false)
-#undef XF
-    if (cfg == 216)
-        return W.type == FL_TYPE_Q4_0 ? launch_gemm32_mixed<FL_TYPE_Q4_0, true>(W, xq, N, y, ldy, st, resid, ldr, epi)
-                                      : launch_gemm32_mixed<FL_TYPE_Q4_1, true>(W, xq, N, y, ldy, st, resid, ldr, epi);
     return hipErrorInvalidValue;
 }
 

@@ -145,7 +145,6 @@ static int dev_alloc(fl_model *m, void **p, size_t bytes) {
 static int qact_alloc(fl_model *m, fl_qact *a, int maxN, int K) {
     memset(a, 0, sizeof *a);
     int rc = dev_alloc(m, (void **)&a->q, qact_bytes_q(maxN, K));
-    if (rc == FL_OK && gemm_fp6_enabled()) rc = dev_alloc(m, (void **)&a->q6, qact_bytes_q(maxN, K) / 2 * 3);
     if (rc == FL_OK) rc = dev_alloc(m, (void **)&a->d, qact_bytes_scale(maxN, K));
     if (rc == FL_OK) rc = dev_alloc(m, (void **)&a->s, qact_bytes_scale(maxN, K));
     if (rc == FL_OK && maxN >= 9) {      // XH16 operand of the reference-order prefill GEMM (q4_layout.h)
@@ -180,7 +179,7 @@ static int act_alloc(fl_model *m, Act &a) {      // the work buffers of one eval
 static void act_free(Act &a) {
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(a.tok_dev); fr(a.x); fr(a.x2); fr(a.xn); fr(a.part); fr(a.qkv); fr(a.att); fr(a.ao); fr(a.h13); fr(a.logits); fr(a.pair_ws);
-    for (fl_qact *q : {&a.qE, &a.qEl, &a.qF}) { fr(q->q); fr(q->d); fr(q->s); fr(q->q6); fr(q->h16); }
+    for (fl_qact *q : {&a.qE, &a.qEl, &a.qF}) { fr(q->q); fr(q->d); fr(q->s); fr(q->h16); }
     a = Act{};
 }
 
@@ -248,7 +247,6 @@ static int stage_rows(const void *host, int bs, int KB_full, int row0, int rows,
 static int make_qtensor(fl_model *m, fl_qtensor **out, const void *aos_dev, int M, int K) {
     *out = fl_qtensor_from_device(m->qtype, aos_dev, M, K, nullptr);
     if (!*out) return FL_EHIP;
-    if (out == &m->tok_emb) fl_qtensor_drop_f6(*out);      // only ever a get_rows source
     m->dev_bytes += fl_qtensor_device_bytes(*out);
     return FL_OK;
 }
@@ -1254,7 +1252,6 @@ extern "C" int fl_model_lora_apply(fl_model *m, const char *base_name, const flo
     cleanup();
     if (e != hipSuccess) return hip_fail(e, "fl_model_lora_apply");
     if (bad) return set_error(FL_EINVAL, "lora: a merged Q4_0 block scale fell below 2^-122");
-    if (t->f6 && (rc = fl_qtensor_build_f6(t, m->stream)) != FL_OK) return rc;    // the prefill paths' copies follow the merged nibbles
     if (t->h16 && (rc = fl_qtensor_build_h16(t, m->stream)) != FL_OK) return rc;
     if (t->qwd) return fl_qtensor_build_qwd(t, m->stream);
     return FL_OK;
@@ -1270,10 +1267,6 @@ extern "C" int fl_model_lora_restore(fl_model *m) {
         M_HIP(hipMemcpyAsync(bk.t->qs, bk.qs, nblk * 16, hipMemcpyDeviceToDevice, m->stream));
         M_HIP(hipMemcpyAsync(bk.t->d, bk.d, nblk * 4, hipMemcpyDeviceToDevice, m->stream));
         if (bk.mm) M_HIP(hipMemcpyAsync(bk.t->m, bk.mm, nblk * 4, hipMemcpyDeviceToDevice, m->stream));
-        if (bk.t->f6) {
-            const int rc = fl_qtensor_build_f6(bk.t, m->stream);
-            if (rc != FL_OK) return rc;
-        }
         if (bk.t->h16) {
             const int rc = fl_qtensor_build_h16(bk.t, m->stream);
             if (rc != FL_OK) return rc;

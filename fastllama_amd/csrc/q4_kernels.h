@@ -89,10 +89,6 @@ hipError_t gemm_q4_exact_valu(const fl_qtensor &W, const fl_qact &xq, int N, flo
                               const float *resid = nullptr, int ldr = 0);   // v_dot4 form (exact_kernels.hip), cross-check
 hipError_t gemm_q4_naive(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st);
 
-// fp6 operand copies of the prefill path (fp6_convert.hip; layouts: q4_layout.h "F6 copies")
-hipError_t qw16_to_f6(const fl_qtensor &W, uint8_t *f6, hipStream_t st);
-hipError_t qa16_to_f6(const fl_qact &xq, int N, hipStream_t st);      // xq.q (QA16) -> xq.q6
-bool gemm_fp6_enabled();                                              // FL_FP6=1 (default off) / fl_debug_set(3, v)
 
 size_t qact_bytes_q(int N, int K);      // bytes of the q plane for N columns (padded to 16)
 size_t qact_bytes_scale(int N, int K);  // bytes of one scale plane

@@ -42,30 +42,6 @@
 // so none of this changes a result bit.
 //
 // ---------------------------------------------------------------------------------------------
-// F6 copies -- operands of the block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4 in its fp6 (E2M3) x fp6 form, the
-// OPTIONAL second operand form of the prefill kernel (gemm_q4_mfma32.hip, F6 configurations; FL_FP6=1 -- off by default,
-// see gemm_q4_mfma.hip g_gemm_fp6 for the measurement).  K = 64 of that instruction is ONE
-// quant block taken twice: with q = 16 hi + lo (hi = q >> 4 in -8..7, lo = q & 15),
-//
-//   sum_k w_k q_k  =  sum_k (w_k/2 * 2^a) * (hi_k/2 * 2^5)  +  sum_k (w_k/2 * 2^a) * (lo_k/2 * 2^1)
-//
-// every factor x/2 (x an integer, |x| <= 15) is an E2M3 value, the powers of two are the instruction's per-lane E8M0
-// block scales, and every partial sum is an integer below 2^24: the f32 result IS the integer block dot (the Q4_0 form
-// with a = 5 returns 16 * isum, which the stored d_w/16 takes back, exactly like the i8 form above; Q4_1: a = 1).
-// Derived data: the int8 / nibble forms above stay the ones of record (download, decode path, state).
-//
-//   QW16F6 : uint8 [M16/16][KB][16 rows][24]      32 fp6 codes of w/2 (Q4_0: w = nib - 8; Q4_1: w = nib)
-//   QA16F6 : uint8 [N16/16][KB][768]              per (column group G, block): plane 0 = the 24 bytes of codes of hi/2,
-//                                                 plane 1 = those of lo/2, of each of the 16 columns c, stored as
-//            X : [16 cols][2 slots][16]   bytes  0..15 of plane p at slot p ^ ((c >> 3) & 1)   (the place QA16 gives half p)
-//            Y : [16 cols][2 slots][8]    bytes 16..23 of plane p at slot p ^ (G & 1), from byte 512
-//                                                 (one conflict-free ds_read_b128 + ds_read_b64 per MFMA B fragment)
-//
-//   * code k occupies bits [6k, 6k+6) of the 24-byte string; element order inside a block is the one of QA16
-//     (position 8g + t = byte t of group g), on both sides.
-//   * fp6 E2M3 code of x/2, m = |x|: m < 4: 4m; m < 8: 8 + 2m; else 16 + m; sign in bit 5.
-//
-// ---------------------------------------------------------------------------------------------
 // H16 copies -- operands of the reference-order ("exact") prefill GEMM (gemm_q4_exact_h16.hip).  That kernel needs the EIGHT
 // 4-element sums of every (output, block) separately, as floats (the AVX2 lanes of ggml_vec_dot_q4_{0,1}_q8_0,
 // /root/reference/lib/ggml.c:2445-2487); v_mfma_f32_32x32x4_2b_f16 delivers two of them per instruction from f16 operands.
@@ -104,7 +80,6 @@ struct fl_qtensor {
     float *d;            // device
     float *m;            // device (Q4_1) or nullptr
     int owns;            // 1: qs/d/m were hipMalloc'ed by the library
-    uint8_t *f6;         // device, QW16F6 copy (always library-owned) or nullptr: the prefill path then takes the i8 form
     uint16_t *h16;       // device, WH16 copy (always library-owned) or nullptr: operand of the reference-order prefill GEMM
     uint32_t *qwd;       // device, QWD copy (always library-owned) or nullptr: nibbles as the reference-order decode kernel reads them
 };
@@ -115,7 +90,6 @@ struct fl_qact {
     float *d;
     float *s;
     int N, N16, KB;
-    uint8_t *q6;         // QA16F6 workspace (1.5 x the bytes of q) or nullptr
     uint16_t *h16;       // XH16 workspace (2 x the bytes of q, columns padded to 32) or nullptr
 };
 

@@ -67,8 +67,6 @@ _PROTOS = {
     "fl_qtensor_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "fl_qtensor_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "fl_qtensor_device_bytes": (C.c_size_t, [C.c_void_p]),
-    "fl_qtensor_build_f6": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "fl_qtensor_drop_f6": (None, [C.c_void_p]),
     "fl_qtensor_build_h16": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fl_qtensor_drop_h16": (None, [C.c_void_p]),
     "fl_qtensor_build_qwd": (C.c_int, [C.c_void_p, C.c_void_p]),

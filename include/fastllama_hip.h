@@ -75,15 +75,10 @@ int fl_qtensor_download(const fl_qtensor *W, void *blocks_host, void *stream);
 int fl_qtensor_info(const fl_qtensor *W, int *type, int *M, int *K);
 size_t fl_qtensor_device_bytes(const fl_qtensor *W);
 void fl_qtensor_free(fl_qtensor *W);
-/* The prefill path's fp6 (E2M3) operand copy of the weights (q4_layout.h "F6 copies"): built by upload / from_device when
- * FL_FP6=1 (default off: measured -15 % .. +6 % per kernel, profiles/r03_fp6_vs_i8_kernels.txt); a caller that rewrites a tensor's blocks in place rebuilds it.  Derived data -- download, decode and state files
- * only ever see the nibbles.  No reference counterpart (ggml keeps one host copy: lib/llama.cpp:223-258). */
-int fl_qtensor_build_f6(fl_qtensor *W, void *stream);
-void fl_qtensor_drop_f6(fl_qtensor *W);
 /* The reference-order prefill GEMM's f16 fragment copy of the weights (q4_layout.h "H16 copies", 64 bytes per row and block):
  * the integers of the nibbles, laid out as the v_mfma_f32_32x32x4_2b_f16 A fragments whose results ARE the AVX2 lane sums of
  * ggml_vec_dot_q4_{0,1}_q8_0 (lib/ggml.c:2445-2487).  A model builds the copies of its tensors on the first reference-order eval
- * with N >= 9 (fl_model_eval); a caller that rewrites a tensor's blocks in place rebuilds it.  Derived data, like the fp6 copy. */
+ * with N >= 9 (fl_model_eval); a caller that rewrites a tensor's blocks in place rebuilds it.  Derived data -- download, decode and state files never see it. */
 int fl_qtensor_build_h16(fl_qtensor *W, void *stream);
 void fl_qtensor_drop_h16(fl_qtensor *W);
 /* The reference-order DECODE kernel's copy of the nibbles (q4_layout.h "QWD", 16 bytes per row and block once more): a lane owns two of
@@ -312,7 +307,7 @@ int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a, float *y_dev, int 
                        void *stream);
 int fl_debug_qact_layout(const fl_qact *a); /* 16 = QA16, 1 = QA1 */
 int fl_debug_gemm_mixed_split(int row_groups, int col_groups, int *n_a, int *mg_split, int *n_b);  /* host logic of the two-tile-shape launch */
-int fl_debug_set(int what, int value);      /* what 0: force GEMM tile configuration id (-1 = automatic); 1: GEMV waves per row group (0 = automatic); 2: the single-token hooks run the exact-mode kernels; 3: prefill GEMM operand form, 1 = fp6 block-scaled MFMA (FL_FP6=1), 0 = int8 MFMA (default) -- same bits */
+int fl_debug_set(int what, int value);      /* what 0: force GEMM tile configuration id (-1 = automatic); 1: GEMV waves per row group (0 = automatic); 2: the single-token hooks run the exact-mode kernels */
 int fl_quantize_q8_layout(fl_qact *a, const float *x_dev, int ldx, int N, int K, int layout, void *stream);
 
 #ifdef __cplusplus

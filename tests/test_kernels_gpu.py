@@ -487,103 +487,3 @@ def test_mul_mat_argument_errors(torch, ops, port):
     L = hip.load()
     assert L.fl_mul_mat_q_f32(W.handle, None, 64, None, 16, 1, None) == hip.FL_EINVAL
     assert L.fl_quantize_row_q8_0(dev(torch, make_x(1, 64, 1)[0]).data_ptr(), 1, 48, None) == hip.FL_EINVAL
-
-
-# ---- the fp6 block-scaled operand form of the prefill kernel (FL_FP6=1) returns the bits of the int8 form ----------------
-F6_PAIRS = [(101, 201), (106, 206), (116, 216)]
-
-
-@pytest.fixture
-def fp6(torch):
-    """tensors / workspaces created inside carry the fp6 copies (q4_layout.h "F6 copies")"""
-    from fastllama_amd import hip
-    L = hip.load()
-    L.fl_debug_set(3, 1)
-    yield L
-    L.fl_debug_set(3, 0)
-    L.fl_debug_set(0, -1)
-
-
-@pytest.mark.parametrize("nm,qt", Q4)
-@pytest.mark.parametrize("M,K,N", [(4096, 4096, 512), (12288, 4096, 512), (22016, 4096, 512), (4096, 11008, 512), (5120, 13824, 96),
-                                   (200, 1408, 17), (1000, 4096, 100), (33, 32, 16), (264, 320, 33)])
-def test_fp6_form_is_bit_identical_to_int8_form(torch, ops, port, fp6, nm, qt, M, K, N):
-    """v_mfma_scale_f32_32x32x64_f8f6f4 on fp6 copies of the nibbles and of the Q8_0 quants (q = 16 hi + lo) yields the integer
-    block dots exactly, so the three F6 configurations must return the words of their int8 twins -- LLaMA shapes, row / column /
-    K tails, and operands at the ends of their ranges (nibbles 0 and 15, quants -127 and 127 in every position of a block)."""
-    from harness import synth
-    L = fp6
-    blocks = synth.synth_q4(M, K, qt, 3 + M % 7)
-    bs = 20 if qt == oracle.Q4_0 else 24
-    flat = blocks.view(-1, bs)                                  # (device tensor of reference AoS blocks; the 16 nibble bytes come last)
-    nq = bs - 16
-    flat[0::5, nq:] = 0x00          # every nibble 0  (Q4_0: -8)
-    flat[1::5, nq:] = 0xFF          # every nibble 15
-    flat[2::5, nq:] = 0xF0
-    W = ops.QTensor(qt, blocks, M, K)
-    x = make_x(N, K, 6 + N)
-    x[0::3] = np.where(np.arange(K) % 2 == 0, 3.0, -3.0)      # quants +-127 everywhere
-    x[1::3, ::32] = 1000.0                                      # one 127 per block, the rest near 0
-    a = ops.QAct(N, K).quantize(dev(torch, x))
-    for i8, f6 in F6_PAIRS:
-        L.fl_debug_set(0, i8)
-        want = ops.mul_mat_q(W, a).clone()
-        L.fl_debug_set(0, f6)
-        y = torch.full((N, (M + 3) // 4 * 4), 7.0, device="cuda")[:, :M]
-        ops.mul_mat_q(W, a, out=y)
-        assert torch.equal(y.view(torch.int32), want.view(torch.int32)), (M, K, N, f6, int((y != want).sum()))
-    L.fl_debug_set(0, -1)                                       # automatic choice, fp6 on
-    assert torch.equal(ops.mul_mat_q(W, a), want)
-    sel = np.sort(np.random.default_rng(M).choice(M, size=min(M, 8), replace=False))
-    ref = port.mul_mat_q(qt, blocks[torch.from_numpy(sel).cuda()].cpu().numpy(), x[: min(N, 6)], strict=False)
-    assert rel_max_err(want.cpu().numpy()[: min(N, 6)][:, sel], ref) <= TOL
-    W.free()
-
-
-@pytest.mark.parametrize("nm,qt", Q4)
-def test_fp6_form_epilogues_and_rebuild(torch, ops, port, fp6, nm, qt):
-    """residual / rope + KV-cache / silu -> Q8_0 epilogues of the F6 configurations == those of the int8 ones; a tensor whose
-    fp6 copy was dropped falls back to the int8 form and fl_qtensor_build_f6 brings it back."""
-    from fastllama_amd import hip
-    from harness import synth
-    L = fp6
-    E, D, N, n_past, n_ctx, F = 1024, 128, 70, 5, 128, 1408
-    Wq = ops.QTensor(qt, synth.synth_q4(3 * E, E, qt, 3), 3 * E, E)
-    W13 = ops.QTensor(qt, synth.synth_q4(2 * F, E, qt, 8), 2 * F, E)
-    a = ops.QAct(N, E).quantize(dev(torch, make_x(N, E, 4)))
-    r = dev(torch, make_x(N, 3 * E, 5))
-    rt = np.empty((n_ctx, D // 2, 2), np.float32)
-    L.fl_debug_rope_table(rt.ctypes.data_as(C.c_void_p), n_ctx, D)
-    rd = dev(torch, rt)
-    s = np.empty(1 << 16, np.uint16)
-    L.fl_debug_tables(None, s.ctypes.data_as(C.c_void_p))
-    sd = dev(torch, s.view(np.int16))
-
-    def run(cfg):
-        L.fl_debug_set(0, cfg)
-        y = torch.empty((N, 3 * E), device="cuda")
-        hip.check(L.fl_debug_mul_mat_q_resid(Wq.handle, a.handle, y.data_ptr(), 3 * E, r.data_ptr(), 3 * E, None))
-        yq = torch.zeros((N, 3 * E), device="cuda")
-        kc, vc = torch.zeros((n_ctx, E), device="cuda"), torch.zeros((E, n_ctx), device="cuda")
-        hip.check(L.fl_debug_gemm_qkv(Wq.handle, a.handle, yq.data_ptr(), 3 * E, rd.data_ptr(), kc.data_ptr(), vc.data_ptr(), E, D,
-                                      n_past, n_ctx, None))
-        out = ops.QAct(N, F)
-        hip.check(L.fl_debug_gemm_silu(W13.handle, a.handle, sd.data_ptr(), out.handle, None))
-        out.N, out.K = N, F
-        return y, yq, kc, vc, out.export().cpu().numpy()
-
-    for i8, f6 in F6_PAIRS:
-        w, g = run(i8), run(f6)
-        for t0, t1 in zip(w[:4], g[:4]):
-            assert torch.equal(t0.view(torch.int32), t1.view(torch.int32)), f6
-        assert np.array_equal(w[4], g[4]), f6
-    L.fl_debug_set(0, 206)
-    L.fl_qtensor_drop_f6(Wq.handle)
-    with pytest.raises(Exception):
-        ops.mul_mat_q(Wq, a)                                    # a forced F6 configuration without the copy is an error ...
-    L.fl_debug_set(0, -1)
-    base = ops.mul_mat_q(Wq, a).clone()                         # ... the automatic choice takes the int8 form
-    hip.check(L.fl_qtensor_build_f6(Wq.handle, None))
-    assert torch.equal(ops.mul_mat_q(Wq, a), base)
-    Wq.free()
-    W13.free()
