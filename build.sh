@@ -1,9 +1,14 @@
 #!/bin/bash
-# build.sh -- compile libfastllama_hip.so for gfx950 (cross-compiles without a GPU).
+# build.sh -- compile libfastllama_hip.so (the product: the llama_* boundary and the fl_* operator API) and libfastllama_hip_hooks.so (the
+# fl_debug_* test hooks, linked against it) for gfx950.  Cross-compiles without a GPU.
 set -e
 cd "$(dirname "$0")"
-SRCS=$(ls fastllama_amd/csrc/*.hip fastllama_amd/csrc/*.cpp)
+OUT="${OUT:-fastllama_amd/libfastllama_hip.so}"
+HOOKS="$(dirname "$OUT")/$(basename "$OUT" .so)_hooks.so"
+SRCS=$(ls fastllama_amd/csrc/*.hip fastllama_amd/csrc/*.cpp | grep -v test_hooks.cpp)
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC ${KPRE--mllvm -amdgpu-kernarg-preload-count=16} -shared -Iinclude \
-      -o "${OUT:-fastllama_amd/libfastllama_hip.so}" $SRCS -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib "$@"
+      -o "$OUT" $SRCS -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -Wl,-soname,"$(basename "$OUT")" "$@"
+hipcc -O2 -std=c++17 -fPIC -shared -Iinclude -x hip --offload-arch=gfx950 -o "$HOOKS" fastllama_amd/csrc/test_hooks.cpp \
+      -L"$(dirname "$OUT")" -l:"$(basename "$OUT")" -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 # every symbol must resolve at load time (works without a GPU)
 FASTLLAMA_HIP_LIB="${OUT:+$(realpath "$OUT")}" python3 -c "import sys; sys.path.insert(0, '.'); from fastllama_amd import hip; hip.load()"

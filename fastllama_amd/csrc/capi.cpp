@@ -12,6 +12,7 @@
 #include "q4_kernels.h"
 #include "eval_kernels.h"
 #include "runtime.h"
+#include "internal.h"
 
 namespace fl {
 
@@ -55,18 +56,13 @@ using namespace fl;
 
 static inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
-struct fl_qact_impl : fl_qact {
-    int cap_N16, K;
-    int layout;  // 16 or 1
-    size_t q_bytes, s_bytes;
-    int h16_valid;   // the XH16 copy (q4_layout.h) matches q: written by fl_quantize_q8* in reference-order mode, a fused epilogue, or on demand
-};
-
+// (struct fl_qact_impl, op_exact, ensure_h16, check_mm, mul_mat_q_which: internal.h -- shared with test_hooks.cpp)
+namespace fl {
 // Which arithmetic the operator-level entry points (fl_mul_mat_q, fl_mul_mat_q_f32) run: the reference's summation order (default, as
-// for models: fl_default_exact()) or the fast kernels.  fl_debug_set(4, 1 | 0) pins it for a process, -1 returns to the default.
-static int g_op_mode = -1;
-static bool op_exact() { return g_op_mode < 0 ? fl_default_exact() != 0 : g_op_mode != 0; }
-static int ensure_h16(const fl_qtensor *W, fl_qact_impl *a, void *st) {
+// for models: fl_default_exact()) or the fast kernels.  fl_set_op_mode(1 | 0) pins it for a process, -1 returns to the default.
+int g_op_mode = -1;
+bool op_exact() { return g_op_mode < 0 ? fl_default_exact() != 0 : g_op_mode != 0; }
+int ensure_h16(const fl_qtensor *W, fl_qact_impl *a, void *st) {
     if (!W->h16) {
         const int rc = fl_qtensor_build_h16(const_cast<fl_qtensor *>(W), st);      // (a derived copy: logically const)
         if (rc != FL_OK) return rc;
@@ -77,8 +73,8 @@ static int ensure_h16(const fl_qtensor *W, fl_qact_impl *a, void *st) {
     }
     return FL_OK;
 }
+}  // namespace fl
 
-namespace fl { void gemm32_mixed_split(int MGT, int NGT, int *n_a, int *mg_split, int *n_b); }   // gemm_q4_mfma32.hip
 
 extern "C" {
 
@@ -473,24 +469,11 @@ int fl_quantize_q8(fl_qact *a, const float *x, int ldx, int N, int K, void *st) 
     return fl_quantize_q8_layout(a, x, ldx, N, K, N <= 8 ? 1 : 16, st);
 }
 
-/* host logic of the mixed-tile GEMM launch (gemm_q4_mfma32.hip, cfg 116): how M16/16 row groups x ceil(N/16) column groups are
- * split into workgroups of 128 x 64 tiles (row groups [0, mg_split)) and of 128 x 32 tiles (the rest) */
-int fl_debug_gemm_mixed_split(int row_groups, int col_groups, int *n_a, int *mg_split, int *n_b) {
-    if (row_groups < 1 || col_groups < 1 || !n_a || !mg_split || !n_b) return set_error(FL_EINVAL, "fl_debug_gemm_mixed_split: bad arguments");
-    fl::gemm32_mixed_split(row_groups, col_groups, n_a, mg_split, n_b);
+int fl_set_op_mode(int mode) {
+    if (mode < -1 || mode > 1) return set_error(FL_EINVAL, "fl_set_op_mode: mode %d", mode);
+    g_op_mode = mode;
     return FL_OK;
 }
-extern int g_debug_exact, g_debug_pair1;   // model.cpp
-int fl_debug_set(int what, int value) {
-    if (what == 0) fl::g_gemm_force_cfg = value;
-    if (what == 1) fl::g_gemv_force_waves = value;   // 0 = automatic, else 4 / 8 / 16 waves per 16-row group
-    if (what == 2) g_debug_exact = value;            // the single-token test hooks (fl_debug_gemv_*, fl_debug_decode_attention*) in exact mode
-    if (what == 5) g_debug_pair1 = value;            // fl_debug_gemv_norm_silu in exact mode: the one-workgroup-per-feature-pair form
-    if (what == 4) g_op_mode = value;                // operator-level entry points: 1 reference order, 0 fast kernels, -1 the default
-    return FL_OK;
-}
-
-int fl_debug_qact_layout(const fl_qact *a) { return a ? static_cast<const fl_qact_impl *>(a)->layout : 0; }
 
 int fl_qact_export(const fl_qact *a_, void *blocks_dev, void *st) {
     const fl_qact_impl *a = static_cast<const fl_qact_impl *>(a_);
@@ -501,19 +484,23 @@ int fl_qact_export(const fl_qact *a_, void *blocks_dev, void *st) {
     return FL_OK;
 }
 
-static int check_mm(const fl_qtensor *W, const fl_qact_impl *a, const float *y, int ldy) {
+}  // extern "C"
+namespace fl {
+int check_mm(const fl_qtensor *W, const fl_qact_impl *a, const float *y, int ldy) {
     if (!W || !a || !y) return set_error(FL_EINVAL, "null argument");
     if (a->N <= 0) return set_error(FL_EINVAL, "activation workspace is empty (call fl_quantize_q8 first)");
     if (a->KB != W->KB) return set_error(FL_EINVAL, "K mismatch: W has %d, activations %d", W->K, a->KB * FL_QK);
     if (ldy < W->M) return set_error(FL_EINVAL, "ldy=%d < M=%d", ldy, W->M);
     return FL_OK;
 }
+}  // namespace fl
+extern "C" {
 
 int fl_mul_mat_q(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy, void *st) {
     const fl_qact_impl *a = static_cast<const fl_qact_impl *>(a_);
     int rc = check_mm(W, a, y, ldy);
     if (rc != FL_OK) return rc;
-    if (op_exact()) return fl_debug_mul_mat_q(W, a_, y, ldy, 3, st);
+    if (op_exact()) return mul_mat_q_which(W, a_, y, ldy, 3, st);
     if (a->layout == 1) {
         FL_HIP(gemv_q4(*W, *a, a->N, y, ldy, S(st)));
     } else {
@@ -523,7 +510,11 @@ int fl_mul_mat_q(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy, void
     return FL_OK;
 }
 
-int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy, int which, void *st) {
+}  // extern "C"
+namespace fl {
+// which: 3 = the reference-order kernel of record for the workspace's layout and N; the other values pin one kernel family (tests, A/B):
+// 0 naive, 1 fast MFMA GEMM, 2 fast GEMV, 4 reference-order VALU tiles, 5 reference-order H16 tiles, 6 round 3's reference-order tiles
+int mul_mat_q_which(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy, int which, void *st) {
     fl_qact_impl *a = const_cast<fl_qact_impl *>(static_cast<const fl_qact_impl *>(a_));
     int rc = check_mm(W, a, y, ldy);
     if (rc != FL_OK) return rc;
@@ -553,66 +544,8 @@ int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy
     }
     return FL_OK;
 }
-
-/* test hooks: the fused forms of the prefill GEMM (model.cpp run_eval_kernels) on caller-provided buffers */
-int fl_debug_mul_mat_q_resid(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy, const float *resid, int ldr, void *st) {
-    const fl_qact_impl *a = static_cast<const fl_qact_impl *>(a_);
-    int rc = check_mm(W, a, y, ldy);
-    if (rc != FL_OK) return rc;
-    if (a->layout != 16) return set_error(FL_EINVAL, "gemm needs the QA16 layout");
-    if (op_exact()) {
-        fl_qact_impl *am = const_cast<fl_qact_impl *>(a);
-        if ((rc = ensure_h16(W, am, st)) != FL_OK) return rc;
-        FL_HIP(gemm_q4_exact_h16(*W, *a, a->N, y, ldy, S(st), resid, ldr));
-        return FL_OK;
-    }
-    FL_HIP(gemm_q4_mfma(*W, *a, a->N, y, ldy, S(st), resid, ldr));
-    return FL_OK;
-}
-int fl_debug_gemm_qkv(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy, const float *rope_tab_dev, float *kc, float *vc,
-                      int El, int D, int n_past, int n_ctx, void *st) {
-    const fl_qact_impl *a = static_cast<const fl_qact_impl *>(a_);
-    int rc = check_mm(W, a, y, ldy);
-    if (rc != FL_OK) return rc;
-    if (a->layout != 16) return set_error(FL_EINVAL, "gemm needs the QA16 layout");
-    if (op_exact()) {
-        fl_qact_impl *am = const_cast<fl_qact_impl *>(a);
-        if ((rc = ensure_h16(W, am, st)) != FL_OK) return rc;
-        FL_HIP(gemm_q4_exact_h16_qkv(*W, *a, a->N, y, ldy, rope_tab_dev, kc, vc, El, D, n_past, n_ctx, S(st)));
-        return FL_OK;
-    }
-    FL_HIP(gemm_q4_mfma_qkv(*W, *a, a->N, y, ldy, rope_tab_dev, kc, vc, El, D, n_past, n_ctx, S(st)));
-    return FL_OK;
-}
-int fl_debug_gemm_silu(const fl_qtensor *W, const fl_qact *a_, const uint16_t *silu_tab_dev, fl_qact *out_, void *st) {
-    const fl_qact_impl *a = static_cast<const fl_qact_impl *>(a_);
-    fl_qact_impl *out = static_cast<fl_qact_impl *>(out_);
-    if (!W || !a || !out || !silu_tab_dev) return set_error(FL_EINVAL, "null argument");
-    if (a->layout != 16 || a->KB != W->KB) return set_error(FL_EINVAL, "gemm_silu: bad activation workspace");
-    if ((size_t)a->N16 * (size_t)(W->M / 2) > out->q_bytes) return set_error(FL_EINVAL, "gemm_silu: output workspace too small");
-    out->N = a->N; out->N16 = a->N16; out->KB = W->M / 64; out->layout = 16;
-    out->h16_valid = 0;
-    if (op_exact()) {
-        const int rc = ensure_h16(W, const_cast<fl_qact_impl *>(a), st);
-        if (rc != FL_OK) return rc;
-        FL_HIP(gemm_q4_exact_h16_silu(*W, *a, a->N, silu_tab_dev, *out, S(st)));
-        out->h16_valid = 1;
-        return FL_OK;
-    }
-    FL_HIP(gemm_q4_mfma_silu(*W, *a, a->N, silu_tab_dev, *out, S(st)));
-    return FL_OK;
-}
-/* test hook: the P.V product of the reference-order prefill attention with its Q8_0 epilogue: att = soft_max'ed probabilities [H][N][n_ctx]
- * (as fl_debug_attn_exact leaves them) -> out = Q8_0 of the merged [N, E] rows (QA16 + the XH16 copy) */
-int fl_debug_attn_pv_exact_q8(const float *att, int n_ctx, int D, int H, int N, int n_past, const float *vc, int E, fl_qact *out_, void *st) {
-    fl_qact_impl *out = static_cast<fl_qact_impl *>(out_);
-    if (!att || !vc || !out) return set_error(FL_EINVAL, "null argument");
-    if (E != out->K || N > out->cap_N16 || E != H * D) return set_error(FL_EINVAL, "attn_pv_exact_q8: bad output workspace");
-    out->N = N; out->N16 = fl_roundup(N, 16); out->KB = E / 32; out->layout = 16;
-    FL_HIP(attn_pv_exact(att, n_ctx, (int64_t)N * n_ctx, D, H, N, n_past, vc, n_ctx, nullptr, E, S(st), out, true));
-    out->h16_valid = 1;
-    return FL_OK;
-}
+}  // namespace fl
+extern "C" {
 
 /* grow-on-demand workspace of the one-call op */
 static fl_qact *g_ws = nullptr;

@@ -30,6 +30,7 @@
 #include "eval_kernels.h"
 #include "q4_kernels.h"
 #include "runtime.h"
+#include "internal.h"
 
 using namespace fl;
 
@@ -194,6 +195,36 @@ static float f16_bits_to_f32(uint16_t u) {
     memcpy(&h, &u, 2);
     return (float)h;
 }
+
+namespace fl {
+// the two 65536-entry fp16 tables of ggml_init (exp and silu of every fp16 value, host libm -- lib/ggml.c:3676-3693; either pointer may
+// be NULL) -> the number of entries of exp's [-0, -inf] half up to where it becomes (and stays) zero, rounded up to 8
+int build_f16_tables(uint16_t *te, uint16_t *ts) {
+    int last_nz = 0;
+    for (int i = 0; i < (1 << 16); ++i) {
+        const float f = f16_bits_to_f32((uint16_t)i);
+        const uint16_t e = f32_to_f16_bits(expf(f));
+        if (te) te[i] = e;
+        if (ts) ts[i] = f32_to_f16_bits(f / (1.0f + expf(-f)));   // ggml_silu_f32, lib/ggml.c:3196-3198
+        if (i >= 0x8000 && i <= 0xFC00 && e != 0) last_nz = i - 0x8000;
+    }
+    return (last_nz + 1 + 7) & ~7;
+}
+// [n_ctx][D/2][2] {cos, sin}: theta = p, then theta *= theta_scale per pair -- lib/ggml.c:8655-8667
+void build_rope_table(float *rt, int n_ctx, int D) {
+    const float theta_scale = powf(10000.0f, -2.0f / (float)D);
+    for (int p = 0; p < n_ctx; ++p) {
+        float theta = (float)p;
+        for (int i = 0; i < D / 2; ++i) {
+            float sn, cs;
+            sincosf(theta, &sn, &cs);   // the reference's gcc build calls sincosf (merged cosf/sinf)
+            rt[((size_t)p * (D / 2) + i) * 2 + 0] = cs;
+            rt[((size_t)p * (D / 2) + i) * 2 + 1] = sn;
+            theta *= theta_scale;
+        }
+    }
+}
+}  // namespace fl
 
 extern "C" {
 
@@ -381,16 +412,7 @@ int fl_model_finalize(fl_model *m) {
     // fp16 tables, host libm -- lib/ggml.c:3676-3693
     {
         std::vector<uint16_t> te(1 << 16), ts(1 << 16);
-        for (int i = 0; i < (1 << 16); ++i) {
-            const float f = f16_bits_to_f32((uint16_t)i);
-            te[i] = f32_to_f16_bits(expf(f));
-            ts[i] = f32_to_f16_bits(f / (1.0f + expf(-f)));   // ggml_silu_f32, lib/ggml.c:3196-3198
-        }
-        {   // exp(x) for fp16 x in [-0, -inf]: find where the table becomes (and stays) zero
-            int last_nz = 0;
-            for (int i = 0x8000; i <= 0xFC00; ++i) if (te[i] != 0) last_nz = i - 0x8000;
-            m->exp_tab_n = (last_nz + 1 + 7) & ~7;
-        }
+        m->exp_tab_n = build_f16_tables(te.data(), ts.data());
         if ((rc = dev_alloc(m, (void **)&m->exp_tab, 2 << 16)) != FL_OK) return rc;
         if ((rc = dev_alloc(m, (void **)&m->silu_tab, 2 << 16)) != FL_OK) return rc;
         M_HIP(hipMemcpy(m->exp_tab, te.data(), 2 << 16, hipMemcpyHostToDevice));
@@ -399,17 +421,7 @@ int fl_model_finalize(fl_model *m) {
     // rope table: theta = p, then theta *= theta_scale per pair -- lib/ggml.c:8655-8667
     {
         std::vector<float> rt((size_t)n_ctx * (D / 2) * 2);
-        const float theta_scale = powf(10000.0f, -2.0f / (float)D);
-        for (int p = 0; p < n_ctx; ++p) {
-            float theta = (float)p;
-            for (int i = 0; i < D / 2; ++i) {
-                float sn, cs;
-                sincosf(theta, &sn, &cs);   // the reference's gcc build calls sincosf (merged cosf/sinf)
-                rt[((size_t)p * (D / 2) + i) * 2 + 0] = cs;
-                rt[((size_t)p * (D / 2) + i) * 2 + 1] = sn;
-                theta *= theta_scale;
-            }
-        }
+        build_rope_table(rt.data(), n_ctx, D);
         if ((rc = dev_alloc(m, (void **)&m->rope_tab, rt.size() * 4)) != FL_OK) return rc;
         M_HIP(hipMemcpy(m->rope_tab, rt.data(), rt.size() * 4, hipMemcpyHostToDevice));
     }
@@ -1343,159 +1355,3 @@ void fl_model_free(fl_model *m) {
 
 }  // extern "C"
 
-/* ------------------------------------------------------------------------------------------------
- * test hooks: the individual eval kernels on caller-provided device buffers (per-op parity tests)
- * ---------------------------------------------------------------------------------------------- */
-extern "C" {
-
-int fl_debug_tables(uint16_t *exp_host, uint16_t *silu_host) {   /* the two 65536-entry fp16 tables, as built for a model */
-    for (int i = 0; i < (1 << 16); ++i) {
-        const float f = f16_bits_to_f32((uint16_t)i);
-        if (exp_host) exp_host[i] = f32_to_f16_bits(expf(f));
-        if (silu_host) silu_host[i] = f32_to_f16_bits(f / (1.0f + expf(-f)));
-    }
-    return FL_OK;
-}
-
-int fl_debug_rope_table(float *out_host, int n_ctx, int D) {     /* [n_ctx][D/2][2] {cos, sin} */
-    const float theta_scale = powf(10000.0f, -2.0f / (float)D);
-    for (int p = 0; p < n_ctx; ++p) {
-        float theta = (float)p;
-        for (int i = 0; i < D / 2; ++i) {
-            float sn, cs;
-            sincosf(theta, &sn, &cs);
-            out_host[((size_t)p * (D / 2) + i) * 2 + 0] = cs;
-            out_host[((size_t)p * (D / 2) + i) * 2 + 1] = sn;
-            theta *= theta_scale;
-        }
-    }
-    return FL_OK;
-}
-
-int fl_debug_rmsnorm_quant(const float *x, int ldx, const float *w, int N, int E, float *y_f32, int ldy, fl_qact *out,
-                           int layout, void *stream) {
-    M_HIP(rmsnorm_quant(x, ldx, w, N, E, y_f32, ldy, out, layout, (hipStream_t)stream));
-    return FL_OK;
-}
-int g_debug_pair1 = 0;      // fl_debug_set(5, 1): fl_debug_gemv_norm_silu runs the one-workgroup-per-pair form of the reference-order kernel
-int g_debug_exact = 0;      // fl_debug_set(2, 1): the single-token test hooks below run the reference-order kernels
-// (the reference-order single-token hooks run the kernel of record: it reads the tensor's QWD copy)
-static int dbg_qwd(const fl_qtensor *W, void *stream) {
-    if (!g_debug_exact || !W || W->qwd || getenv("FL_EXACT_R3")) return FL_OK;
-    return fl_qtensor_build_qwd(const_cast<fl_qtensor *>(W), stream);
-}
-int fl_debug_gemv_norm(const fl_qtensor *W, const float *x, const float *norm_w, float *ynorm, float *y, void *stream) {
-    if (int rc = dbg_qwd(W, stream)) return rc;
-    M_HIP((g_debug_exact ? gemv_q4_norm_exact : gemv_q4_norm)(*W, x, norm_w, ynorm, y, (hipStream_t)stream));
-    return FL_OK;
-}
-int fl_debug_gemv_silu(const fl_qtensor *W, const float *h13, const uint16_t *silu_tab, float *y, const float *resid,
-                       void *stream) {
-    if (int rc = dbg_qwd(W, stream)) return rc;
-    M_HIP((g_debug_exact ? gemv_q4_silu_exact : gemv_q4_silu)(*W, h13, silu_tab, y, resid, (hipStream_t)stream, false));
-    return FL_OK;
-}
-static float *g_pa_scratch = nullptr;
-static int g_pa_ld = 0;
-static long g_pa_head = 0;
-int fl_debug_prefill_attention(const float *qkv, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc,
-                               const float *vc, const uint16_t *exp_tab_dev, float scale, float *ao, int ldo, fl_qact *qout,
-                               void *stream) {
-    static int tab_n = -1;
-    if (tab_n < 0) {                                   // same bound as fl_model_finalize computes
-        int last_nz = 0;
-        for (int i = 0x8000; i <= 0xFC00; ++i)
-            if (f32_to_f16_bits(expf(f16_bits_to_f32((uint16_t)i))) != 0) last_nz = i - 0x8000;
-        tab_n = (last_nz + 1 + 7) & ~7;
-    }
-    M_HIP(prefill_attention(qkv, ldq, D, H, N, n_past, n_ctx, E, kc, vc, exp_tab_dev, tab_n, scale, ao, ldo, (hipStream_t)stream, qout,
-                            g_pa_scratch, g_pa_ld, g_pa_head, g_pa_scratch ? 1 : 0));
-    return FL_OK;
-}
-// the next fl_debug_prefill_attention calls run the key-tiled (deep-context) form with this scratch ([H][N][ld] floats); NULL: back
-int fl_debug_prefill_attention_scratch(float *scratch, int ld, long head_stride) {
-    g_pa_scratch = scratch; g_pa_ld = ld; g_pa_head = head_stride;
-    return FL_OK;
-}
-int fl_debug_gemv_norm_silu(const fl_qtensor *W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act,
-                            void *stream) {
-    if (int rc = dbg_qwd(W, stream)) return rc;
-    if (!g_debug_exact) {
-        M_HIP(gemv_q4_norm_silu(*W, x, norm_w, silu_tab, act, (hipStream_t)stream));
-        return FL_OK;
-    }
-    static float *ws = nullptr;                      // (test hook: one workspace, grown as needed, calls one at a time)
-    static size_t ws_bytes = 0;
-    const size_t need = gemv1_llc_pair_ws_bytes(W->M);
-    if (need > ws_bytes) {
-        if (ws) (void)hipFree(ws);
-        ws = nullptr; ws_bytes = 0;
-        M_HIP(hipMalloc((void **)&ws, need));
-        M_HIP(hipMemset(ws, 0, need));
-        ws_bytes = need;
-    }
-    M_HIP(gemv_q4_norm_silu_exact(*W, x, norm_w, silu_tab, act, (hipStream_t)stream, g_debug_pair1 ? nullptr : ws));
-    return FL_OK;
-}
-int fl_debug_gemv_quant(const fl_qtensor *W, const float *x, float *y, const float *resid, void *stream) {
-    if (int rc = dbg_qwd(W, stream)) return rc;
-    M_HIP((g_debug_exact ? gemv_q4_quant_exact : gemv_q4_quant)(*W, x, y, resid, (hipStream_t)stream));
-    return FL_OK;
-}
-int fl_debug_decode_attention(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab_dev,
-                              float *kc, float *vc, const uint16_t *exp_tab_dev, float scale, fl_qact *out, void *stream) {
-    M_HIP(decode_attention(qkv, E, D, H, n_past, n_ctx, rope_tab_dev, kc, vc, exp_tab_dev, scale, out, (hipStream_t)stream, nullptr, g_debug_exact != 0));
-    return FL_OK;
-}
-int fl_debug_decode_attention_split(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab_dev,
-                                    float *kc, float *vc, const uint16_t *exp_tab_dev, float scale, float *scores,
-                                    fl_qact *out, const int *dyn_past, void *stream) {
-    M_HIP(decode_attention_split(qkv, E, D, H, n_past, n_ctx, rope_tab_dev, kc, vc, exp_tab_dev, scale, scores, out,
-                                 (hipStream_t)stream, dyn_past, g_debug_exact != 0));
-    return FL_OK;
-}
-int fl_debug_silu_mul_quant(const float *h13, int ld, int N, int F, const uint16_t *silu_tab_dev, fl_qact *out, int layout,
-                            void *stream) {
-    M_HIP(silu_mul_quant(h13, ld, N, F, silu_tab_dev, out, layout, (hipStream_t)stream, false));
-    return FL_OK;
-}
-int fl_debug_silu_mul_quant_woven(const float *h13, int ld, int N, int F, const uint16_t *silu_tab_dev, fl_qact *out, int layout,
-                                  void *stream) {   /* h13 = [w1 x 16 | w3 x 16 | ...]: the woven w1|w3 matmul's output */
-    M_HIP(silu_mul_quant(h13, ld, N, F, silu_tab_dev, out, layout, (hipStream_t)stream, true));
-    return FL_OK;
-}
-int fl_debug_rope_kv(float *qkv, int ld, int N, int E, int D, int n_past, int n_ctx, const float *rope_tab_dev, float *kc,
-                     float *vc, void *stream) {
-    M_HIP(rope_kv(qkv, ld, N, E, D, n_past, n_ctx, rope_tab_dev, kc, vc, (hipStream_t)stream));
-    return FL_OK;
-}
-int fl_debug_gemm_f32_abt(const float *A, int lda, long sAz, const float *B, int ldb, long sBz, float *Cc, int ldc, long sCz,
-                          int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past, void *stream) {
-    M_HIP(gemm_f32_abt(A, lda, sAz, B, ldb, sBz, Cc, ldc, sCz, M, Nn, K, batch, alpha, causal_mode, n_past, (hipStream_t)stream));
-    return FL_OK;
-}
-int fl_debug_gemm_f32_abt_exact(const float *A, int lda, long sAz, const float *B, int ldb, long sBz, float *Cc, int ldc, long sCz,
-                                int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past, void *stream) {
-    M_HIP(dot_f32_abt_exact(A, lda, sAz, B, ldb, sBz, Cc, ldc, sCz, M, Nn, K, batch, alpha, causal_mode, n_past, (hipStream_t)stream));
-    return FL_OK;
-}
-/* test hook: exact-mode prefill attention on caller-provided buffers: scores (MFMA form when which = 1, one half-wave per dot when 0)
- * -> soft_max -> P.V; att: [H][N][n_ctx] scratch, ao: [N][E] f32 result */
-int fl_debug_attn_exact(const float *qkv, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc, const float *vc,
-                        const uint16_t *exp_tab_dev, float scale, float *att, float *ao, int which, void *stream) {
-    hipStream_t st = (hipStream_t)stream;
-    const int P = n_past + N;
-    if (which) M_HIP(attn_scores_exact(qkv, ldq, D, H, N, n_past, kc, E, scale, att, n_ctx, (int64_t)N * n_ctx, st));
-    else M_HIP(dot_f32_abt_exact(qkv, ldq, D, kc, E, D, att, n_ctx, (int64_t)N * n_ctx, N, P, D, H, scale, 1, n_past, st));
-    M_HIP(softmax_rows(att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, H, exp_tab_dev, st));
-    if (which) M_HIP(attn_pv_exact(att, n_ctx, (int64_t)N * n_ctx, D, H, N, n_past, vc, n_ctx, ao, E, st));
-    else M_HIP(dot_f32_abt_exact(att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, ao, E, D, N, D, P, H, 1.0f, 2, n_past, st));
-    return FL_OK;
-}
-int fl_debug_softmax_rows(float *S, int ld, long sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab_dev,
-                          void *stream) {
-    M_HIP(softmax_rows(S, ld, sz, N, P, n_past, batch, exp_tab_dev, (hipStream_t)stream));
-    return FL_OK;
-}
-
-}  // extern "C"

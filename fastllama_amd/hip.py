@@ -151,6 +151,7 @@ _PROTOS = {
     "fl_model_set_exact": (C.c_int, [C.c_void_p, C.c_int]),
     "fl_model_get_exact": (C.c_int, [C.c_void_p]),
     "fl_default_exact": (C.c_int, []),
+    "fl_set_op_mode": (C.c_int, [C.c_int]),
     "fl_debug_attn_exact": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "fl_debug_softmax_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -175,8 +176,41 @@ _PROTOS = {
 _lib = None
 
 
-def load(path: str | None = None) -> C.CDLL:
-    """Load libfastllama_hip.so (once) and declare every prototype of include/fastllama_hip.h."""
+def hooks_path(lib_path: str) -> str:
+    """libX.so -> libX_hooks.so next to it (build.sh)"""
+    return lib_path[:-3] + "_hooks.so" if lib_path.endswith(".so") else lib_path + "_hooks"
+
+
+class _Libs:
+    """The product library plus, on first use of an fl_debug_* name, the test-hook library that is linked against it
+    (include/fastllama_hip_test.h).  Attribute access goes to whichever exports the name."""
+
+    def __init__(self, main: C.CDLL, path: str):
+        self._main, self._path, self._hooks = main, path, None
+
+    def _load_hooks(self) -> C.CDLL:
+        if self._hooks is None:
+            hp = hooks_path(self._path)
+            if not os.path.exists(hp):
+                raise FastLlamaHipError(f"{hp} is missing: run ./build.sh (the fl_debug_* test hooks live there)")
+            lib = C.CDLL(hp)
+            for name, (res, args) in _PROTOS.items():
+                if name.startswith("fl_debug_"):
+                    fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+                    fn.restype = res
+                    fn.argtypes = args
+            self._hooks = lib
+        return self._hooks
+
+    def __getattr__(self, name):
+        if name.startswith("fl_debug_"):
+            return getattr(self._load_hooks(), name)
+        return getattr(self._main, name)
+
+
+def load(path: str | None = None) -> "_Libs":
+    """Load libfastllama_hip.so (once) and declare every prototype of include/fastllama_hip.h; fl_debug_* names resolve in
+    libfastllama_hip_hooks.so (include/fastllama_hip_test.h), loaded on first use."""
     global _lib
     if _lib is not None and path is None:
         return _lib
@@ -185,14 +219,17 @@ def load(path: str | None = None) -> C.CDLL:
         raise FastLlamaHipError(
             f"{p} is missing: run ./build.sh (or __graft_entry__.build()). "
             "fastllama_amd has no CPU fallback.")
-    lib = C.CDLL(p)
+    lib = C.CDLL(p, mode=C.RTLD_GLOBAL)      # (the hook library resolves its references against this one)
     for name, (res, args) in _PROTOS.items():
+        if name.startswith("fl_debug_"):
+            continue
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    libs = _Libs(lib, p)
     if path is None:
-        _lib = lib
-    return lib
+        _lib = libs
+    return libs
 
 
 def check(rc: int, what: str = "") -> None:

@@ -11,7 +11,7 @@ for (M, K) in [(4096, 4096), (4096, 11008), (12288, 4096)]:
     x = torch.randn(1, K, device="cuda"); a = ops.QAct(1, K).quantize(x)
     y = torch.empty(1, M, device="cuda")
     for which, name in ((3, "reference order"), (None, "fast")):
-        L.fl_debug_set(4, 0 if which is None else -1)
+        L.fl_set_op_mode(0 if which is None else -1)
         def timed(seq, reps=96):
             g = torch.cuda.CUDAGraph()
             for W in seq: ops.mul_mat_q(W, a, which=which, out=y)       # (derived copies are built on first use: not inside the capture)
@@ -26,5 +26,5 @@ for (M, K) in [(4096, 4096), (4096, 11008), (12288, 4096)]:
             return e0.elapsed_time(e1) / reps * 1e3
         cold, warm = timed(Ws), timed(Ws[:1])
         print(f"GEMV {M}x{K} {name}: round-robin over 24 tensors {cold:.2f} us   same tensor {warm:.2f} us", flush=True)
-    L.fl_debug_set(4, -1)
+    L.fl_set_op_mode(-1)
     for W in Ws: W.free()

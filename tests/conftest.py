@@ -38,11 +38,11 @@ def pytest_collection_modifyitems(config, items):
 def fast_mode(monkeypatch):
     """The library's default is the reference-order ("exact") arithmetic (fl_default_exact() == 1).  Modules that characterise the
     FAST kernels -- their tile configurations, fused forms and tolerances -- opt in with this fixture: models created inside start
-    in fast mode (FL_FAST=1) and the operator-level entry points run the fast kernels (fl_debug_set(4, 0))."""
+    in fast mode (FL_FAST=1) and the operator-level entry points run the fast kernels (fl_set_op_mode(0))."""
     from fastllama_amd import hip
     L = hip.load()
     monkeypatch.setenv("FL_FAST", "1")
     monkeypatch.delenv("FL_EXACT", raising=False)
-    L.fl_debug_set(4, 0)
+    L.fl_set_op_mode(0)
     yield
-    L.fl_debug_set(4, -1)
+    L.fl_set_op_mode(-1)

@@ -10,6 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "fastllama_amd", "libfastllama_hip.so")
+HOOKS = os.path.join(ROOT, "fastllama_amd", "libfastllama_hip_hooks.so")
 
 
 def _declared(header, prefix):
@@ -22,16 +23,30 @@ def _declared(header, prefix):
 
 @pytest.fixture(scope="module")
 def lib():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(HOOKS):
         subprocess.check_call([os.path.join(ROOT, "build.sh")])
-    return ctypes.CDLL(LIB)
+    return ctypes.CDLL(LIB, mode=ctypes.RTLD_GLOBAL)
 
 
 def test_kernel_abi_symbols_exported(lib):
     names = _declared("fastllama_hip.h", "fl_")
-    assert len(names) >= 30
+    assert len(names) >= 30 and not any(n.startswith("fl_debug_") for n in names)
     missing = [n for n in sorted(names) if not hasattr(lib, n)]
     assert not missing, missing
+
+
+def test_test_hooks_live_in_their_own_library(lib):
+    """The fl_debug_* hooks (include/fastllama_hip_test.h) are exported by libfastllama_hip_hooks.so, which is linked against the
+    product library; the product library exports none of them."""
+    names = _declared("fastllama_hip_test.h", "fl_debug_")
+    assert len(names) >= 20
+    hooks = ctypes.CDLL(HOOKS)
+    missing = [n for n in sorted(names) if not hasattr(hooks, n)]
+    assert not missing, missing
+    out = subprocess.run(["nm", "-D", "--defined-only", LIB], capture_output=True, text=True, check=True).stdout
+    assert "fl_debug_" not in out
+    needed = subprocess.run(["readelf", "-d", HOOKS], capture_output=True, text=True, check=True).stdout
+    assert "libfastllama_hip.so" in needed
 
 
 def test_primary_llama_abi_symbols_exported(lib):
@@ -61,9 +76,10 @@ def test_llama_context_args_layout_matches_reference_python_binding(lib):
 
 def test_python_binding_covers_header():
     from fastllama_amd import hip
-    names = _declared("fastllama_hip.h", "fl_")
+    names = _declared("fastllama_hip.h", "fl_") | _declared("fastllama_hip_test.h", "fl_debug_")
     assert names == set(hip._PROTOS), names ^ set(hip._PROTOS)
-    hip.load()
+    L = hip.load()
+    L.fl_debug_set                        # (the hook library loads and declares its prototypes on first use)
 
 
 def test_no_device_means_loud_failure(lib):

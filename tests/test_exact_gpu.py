@@ -490,9 +490,9 @@ def test_exact_prefill_attention_mfma_forms(torch, ops, port, D, H, N, n_past):
         wq = port.quantize_q4(oracle.Q4_0, (rng.standard_normal((80, E)) * 0.05).astype(np.float32))
         W = ops.QTensor(oracle.Q4_0, wq, 80, E)
         y = torch.empty((N, 80), device="cuda")
-        L.fl_debug_set(4, 1)
+        L.fl_set_op_mode(1)
         try:
             hip.check(L.fl_mul_mat_q(W.handle, a.handle, y.data_ptr(), 80, None))
         finally:
-            L.fl_debug_set(4, -1)
+            L.fl_set_op_mode(-1)
         assert np.array_equal(bits(y.cpu().numpy()), bits(port.mul_mat_q(oracle.Q4_0, wq, want, strict=False)))
