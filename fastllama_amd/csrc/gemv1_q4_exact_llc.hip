@@ -286,6 +286,9 @@ static bool launch_llc(const fl_qtensor &W, const fl_qact *xq, float *y, hipStre
 #define FL_LLC(NK, QPW)                                                                                                                   \
     hipLaunchKernelGGL((gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW>), dim3(units), dim3(64 * NK), lds, st, W.M, units, KB, woven, \
                        W.qwd, W.d, xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid, ynorm, aux2, pair_ws)
+    if constexpr (TYPE == FL_TYPE_Q4_1) {             // Q4_1 carries m_w as well: 4 x 8 needs 174 registers = two waves per SIMD; 8 x 4 needs <= 126
+        if (NQ <= 32) { FL_LLC(8, 4); return true; }   // (four): LLaMA-7B Q4_1 decode 412 -> 424 tok/s.  (Q4_0, 139 registers at 4 x 8: no gain)
+    }
     if (NQ <= 32) FL_LLC(4, 8);
     else if (NQ <= 44) FL_LLC(4, 11);
     else FL_LLC(8, 11);
