@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <cstdlib>
 #include "q4_device.h"
 #include "q4_kernels.h"
 #include <type_traits>
@@ -77,14 +78,18 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
 
     // ---- XCD-aware bijective remap of the tile id (as gemm_q4_mfma32.hip): workgroup b runs on XCD b % 8; the column tiles that
     //      share a weight row panel get consecutive ids on ONE XCD, so the panel comes from HBM once and is re-read from that L2.
-    const int tiles_m = (MT32 + 1) >> 1, tiles_n = (NT32 + 1) >> 1;
-    int bid = blockIdx.x;
-    {
-        const int nwg = tiles_m * tiles_n;
-        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, k = bid >> 3;
-        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
-    }
-    const int tn = bid % tiles_n, tm = bid / tiles_n;
+    //      A workgroup is PERSISTENT when the launch has fewer workgroups than tiles (launch_xh: one per residency slot): it takes the
+    //      tiles vb = blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x a multiple of 8: vb & 7 stays the XCD it runs on), and the DMA of
+    //      a tile's LAST K-step, which used to fetch a K-step past the row, fetches the first K-step of the NEXT tile instead -- that
+    //      tile starts with its operands in LDS, and the ramp of every tile but the first is gone.
+    const int tiles_m = (MT32 + 1) >> 1, tiles_n = (NT32 + 1) >> 1, nwg = tiles_m * tiles_n;
+    auto remap = [&](int vb) XH_ATTR __attribute__((always_inline)) {
+        const int q = nwg >> 3, rem = nwg & 7, xcd = vb & 7, k = vb >> 3;
+        return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
+    };
+    int vbid = blockIdx.x;
+    int bid = remap(vbid);
+    int tn = bid % tiles_n, tm = bid / tiles_n;
 
     // ---- DMA plan.  Per K-step (4 blocks) a wave moves 8 fragment pieces of 1 KiB (piece p = wave + 4 j of 32: side p >> 4, tile
     //      (p >> 3) & 1, block (p >> 1) & 3, part p & 1) and one scale piece of 1 KiB (Q4_0: waves 0 / 1 d_w / d_x, waves 2 / 3 the same
@@ -94,7 +99,6 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
     //      one (their outputs are never stored); blocks past K re-read block K - 1 for the fragments and read ZERO scales on the
     //      activation side (bounds check of the descriptor): d_x = s_x = 0, the block contributes nothing.
     uint32_t lane16 = (uint32_t)lane * 16u;
-    int tileA0 = min(tm * 2, MT32 - 1), tileA1 = min(tm * 2 + 1, MT32 - 1), tileB0 = min(tn * 2, NT32 - 1), tileB1 = min(tn * 2 + 1, NT32 - 1);
     const uint64_t wbp = (uint64_t)(uintptr_t)wh, xbp = (uint64_t)(uintptr_t)xh;
     v4i rA = v4i{(int)(uint32_t)wbp, (int)((wbp >> 32) & 0xFFFF), (int)((uint32_t)MT32 * (uint32_t)KB * 2048u), 0x00020000};
     v4i rB = v4i{(int)(uint32_t)xbp, (int)((xbp >> 32) & 0xFFFF), (int)((uint32_t)NT32 * (uint32_t)KB * 2048u), 0x00020000};
@@ -106,46 +110,46 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
     v4i rS = v4i{__builtin_amdgcn_readfirstlane((int)(uint32_t)sbp), __builtin_amdgcn_readfirstlane((int)((sbp >> 32) & 0xFFFF)),
                        __builtin_amdgcn_readfirstlane((int)((uint32_t)sc_ng * (uint32_t)KB * 64u)), 0x00020000};
     // lane -> (group lane >> 4, 16-byte chunk lane & 15 of the group's 4 blocks x 16 rows): byte offset relative to block kb0 of group 0
-    int sc_g = min((sc_act ? tn : tm) * 4 + (lane >> 4), sc_ng - 1), sc_blk = (lane & 15) >> 2;
-    uint32_t sc_voff = ((uint32_t)sc_g * (uint32_t)KB + (uint32_t)sc_blk) * 64u + (uint32_t)(lane & 3) * 16u;
+    const int sc_blk = (lane & 15) >> 2;
+    auto sc_voff_of = [&](int tn_, int tm_) XH_ATTR __attribute__((always_inline)) {
+        const int sc_g = min((sc_act ? tn_ : tm_) * 4 + (lane >> 4), sc_ng - 1);
+        return ((uint32_t)sc_g * (uint32_t)KB + (uint32_t)sc_blk) * 64u + (uint32_t)(lane & 3) * 16u;
+    };
     int sc_loff = C::OFF_SC + (Q41 ? ((sc_kind & 1) * 1024 + (sc_kind >> 1) * 2048) : sc_kind * 1024);
     uint32_t lds0 = (uint32_t)(uintptr_t)smem;
     // fragment piece j (0..7) of this wave for the K-step starting at block kb0, into stage st.  With p = wave + 4 j: side = j >> 2,
     // tile = (j >> 1) & 1 are compile-time, block = (wave >> 1) + 2 (j & 1), part = wave & 1 -- scalars.
     const int wb = __builtin_amdgcn_readfirstlane(wave >> 1), wp = __builtin_amdgcn_readfirstlane(wave & 1);
-    uint32_t tbase[4];                                                         // byte offset of block 0, part wp of tiles A0, A1, B0, B1
-    tbase[0] = (uint32_t)__builtin_amdgcn_readfirstlane(tileA0 * KB * 2048 + wp * 1024);
-    tbase[1] = (uint32_t)__builtin_amdgcn_readfirstlane(tileA1 * KB * 2048 + wp * 1024);
-    tbase[2] = (uint32_t)__builtin_amdgcn_readfirstlane(tileB0 * KB * 2048 + wp * 1024);
-    tbase[3] = (uint32_t)__builtin_amdgcn_readfirstlane(tileB1 * KB * 2048 + wp * 1024);
+    // byte offset of block 0, part wp of tiles A0, A1, B0, B1 of a workgroup tile
+    auto tbase_of = [&](int tn_, int tm_, uint32_t (&tb)[4]) XH_ATTR __attribute__((always_inline)) {
+        tb[0] = (uint32_t)__builtin_amdgcn_readfirstlane(min(tm_ * 2, MT32 - 1) * KB * 2048 + wp * 1024);
+        tb[1] = (uint32_t)__builtin_amdgcn_readfirstlane(min(tm_ * 2 + 1, MT32 - 1) * KB * 2048 + wp * 1024);
+        tb[2] = (uint32_t)__builtin_amdgcn_readfirstlane(min(tn_ * 2, NT32 - 1) * KB * 2048 + wp * 1024);
+        tb[3] = (uint32_t)__builtin_amdgcn_readfirstlane(min(tn_ * 2 + 1, NT32 - 1) * KB * 2048 + wp * 1024);
+    };
+    uint32_t tbase[4];
+    tbase_of(tn, tm, tbase);
+    uint32_t sc_voff = sc_voff_of(tn, tm);
     uint32_t dstw = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds0 + (wb * 2 + wp) * 1024);
-    auto fill_frag = [&](auto JJ, int st, int kb0) XH_ATTR __attribute__((always_inline)) {
+    auto fill_frag = [&](auto JJ, int st, int kb0, const uint32_t (&ftb)[4]) XH_ATTR __attribute__((always_inline)) {
         constexpr int j = decltype(JJ)::value, side = j >> 2, t = (j >> 1) & 1;
         const int kb = min(kb0 + wb + 2 * (j & 1), KB - 1);
-        const uint32_t soff = tbase[side * 2 + t] + (uint32_t)kb * 2048u;
+        const uint32_t soff = ftb[side * 2 + t] + (uint32_t)kb * 2048u;
         const uint32_t dst = dstw + (uint32_t)(st * C::STAGE + side * C::OFF_B + (t * 4 + 2 * (j & 1)) * 2048);
         const uint32_t vo = lane16;                                            // (named copies: a generic lambda does not capture a
         const v4i rs = side ? rB : rA;                                         //  variable that only an asm operand mentions)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory", "m0");
     };
-    auto fill_scale = [&](int st, int kb0) XH_ATTR __attribute__((always_inline)) {
-        uint32_t vo = sc_voff;
+    auto fill_scale = [&](int st, int kb0, uint32_t fsc_voff) XH_ATTR __attribute__((always_inline)) {
+        uint32_t vo = fsc_voff;
         if (sc_act && kb0 + sc_blk >= KB) vo = 0x80000000u;                     // activation scales of a block past K: zero
-        else if (kb0 + sc_blk >= KB) vo = sc_voff - (uint32_t)(kb0 + sc_blk - (KB - 1)) * 64u;   // weight scales: block K - 1 again (finite)
+        else if (kb0 + sc_blk >= KB) vo = fsc_voff - (uint32_t)(kb0 + sc_blk - (KB - 1)) * 64u;  // weight scales: block K - 1 again (finite)
         const uint32_t dst = lds0 + (uint32_t)(st * C::STAGE + sc_loff);
         const v4i rs = rS;
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(dst), "v"(vo), "s"(rs), "s"(kb0 * 64) : "memory", "m0");
     };
 
     v16f acc[8], summs;
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) summs[e] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(acc[j]));    // (opaque zeros: no peeled first trip)
     const v32f zero32 = {};
 
     // per-lane LDS offsets inside a stage: fragments of block u at + u * 2048 (+ 1024 for the second part); scales of block u
@@ -154,10 +158,28 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
     const int sx_off = C::OFF_SC + 1024 + ((2 * wc + (i >> 4)) * 4 + h) * 64 + (i & 15) * 4;   // + 2048: s_x
 
     const int nsteps = (KB + KS - 1) / KS;
-    fill_frag(XIC(0), 0, 0); fill_frag(XIC(1), 0, 0); fill_frag(XIC(2), 0, 0); fill_frag(XIC(3), 0, 0);
-    fill_frag(XIC(4), 0, 0); fill_frag(XIC(5), 0, 0); fill_frag(XIC(6), 0, 0); fill_frag(XIC(7), 0, 0);
-    fill_scale(0, 0);
+    fill_frag(XIC(0), 0, 0, tbase); fill_frag(XIC(1), 0, 0, tbase); fill_frag(XIC(2), 0, 0, tbase); fill_frag(XIC(3), 0, 0, tbase);
+    fill_frag(XIC(4), 0, 0, tbase); fill_frag(XIC(5), 0, 0, tbase); fill_frag(XIC(6), 0, 0, tbase); fill_frag(XIC(7), 0, 0, tbase);
+    fill_scale(0, 0, sc_voff);
     int cur = 0;
+#pragma unroll 1
+  for (;;) {                                                                   // ---- tiles of this workgroup
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) summs[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(acc[j]));    // (opaque zeros: no peeled first trip)
+    // the tile after this one: its bases replace this tile's for the DMA issued during the LAST K-step (no next tile: this tile's again --
+    // a K-step nobody reads, as before)
+    const int nvb = vbid + (int)gridDim.x;
+    const bool has_next = nvb < nwg;
+    const int nbid = remap(has_next ? nvb : vbid), ntn = nbid % tiles_n, ntm = nbid / tiles_n;
+    uint32_t ntbase[4];
+    tbase_of(ntn, ntm, ntbase);
+    const uint32_t nsc_voff = sc_voff_of(ntn, ntm);
 #pragma unroll 1
     for (int t = 0; t < nsteps; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's pieces of K-step t have landed
@@ -168,7 +190,12 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
         if (t == 1) XH_STAMP(2);
         if (t == 2) XH_STAMP(3);
         const unsigned char *base = smem + cur * C::STAGE;
-        const int nst = cur ^ 1, nkb = (t + 1) * KS;                           // K-step t + 1 goes into the stage step t - 1 occupied
+        const bool last = t + 1 == nsteps;
+        const int nst = cur ^ 1, nkb = last ? 0 : (t + 1) * KS;                // K-step t + 1 (the next tile's step 0) goes into the stage step t - 1 occupied
+        uint32_t ftb[4];                                                       // (wave-uniform selects: SGPRs)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ftb[q] = last ? ntbase[q] : tbase[q];
+        const uint32_t fsc_voff = last ? nsc_voff : sc_voff;
         // Software pipeline inside the wave: the lane-sum MFMA of group g + 1 is issued BEFORE the 32 fma of group g (two D tiles),
         // so a wave alone on its SIMD (its neighbour waiting at a barrier) still keeps both pipes fed: coexec5, 277 vs 529 ns.
         // fragments: 8 bytes per lane and MFMA (steps 2p, 2p + 1 of a block sit side by side in a 16-byte slot), read one group ahead
@@ -220,8 +247,8 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
                 dx = *reinterpret_cast<const float *>(base + sx_off + 128);
             }
 #ifndef XH_NODMA
-            if (g < 8) fill_frag(XIC(g < 8 ? g : 0), nst, nkb);          // ... and the DMA of K-step t + 1
-            if (g == 8) fill_scale(nst, nkb);
+            if (g < 8) fill_frag(XIC(g < 8 ? g : 0), nst, nkb, ftb);     // ... and the DMA of K-step t + 1
+            if (g == 8) fill_scale(nst, nkb, fsc_voff);
 #endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -248,7 +275,7 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
         cur ^= 1;
     }
     XH_STAMP(4);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // the fills past the last pair (zeros / unused)
+    auto epilogue = [&]() XH_ATTR __attribute__((always_inline)) {
 
     // ---- ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)) [+ summs]: C layout col = i, row = (e & 3) + 8 (e >> 2) + 4 h ----
     v16f out;
@@ -266,8 +293,11 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
         // ---- silu(w1 x) * (w3 x) -> Q8_0 (ggml_silu + ggml_mul, lib/llama.cpp:428-431, then quantize_row_q8_0 of the w2 matmul's
         //      INIT phase).  W is woven by 16-row groups: rows 0..15 of a wave's 32 are w1 of 16 features, rows 16..31 w3 of the same;
         //      the workgroup's 64 rows are ONE 32-feature block of every column.
-        float *act = reinterpret_cast<float *>(smem);                          // [32 features][64 columns] f32
-        __syncthreads();                                                       // every wave is done with the operand ring
+        // [32 features][64 columns] f32 in the stage the last K-step was read from (the other one is receiving the next tile's first
+        // K-step).  Barriers without a vmcnt wait: that DMA stays in flight under the epilogue.
+        float *act = reinterpret_cast<float *>(smem + (cur ^ 1) * C::STAGE);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                          // every wave is done with that stage
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -277,7 +307,8 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
                 const float sl = __half2float(__ushort_as_half(epi.silu_tab[hx]));              // table_silu_f16
                 act[(wr * 16 + 8 * g + 4 * h + e) * 64 + wc * 32 + i] = __fmul_rn(sl, a3);     // ggml_mul(silu, tmp)
             }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         // four threads per column, 8 features each; amax and the integer sum meet through DPP quad reductions
         const int tid = threadIdx.x, nl = tid >> 2, part = tid & 3;
         const int nn = tn * 64 + nl, gfb = tm;                                 // column, 32-feature block
@@ -367,7 +398,17 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
             for (int k = 0; k < 4 && row + k < M; ++k) yp[k] = rp ? __fadd_rn(ov[k], rp[k]) : ov[k];
         }
     }
+    };      // epilogue
+    epilogue();
     XH_STAMP(5);
+    if (!has_next) break;
+    vbid = nvb; tn = ntn; tm = ntm;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tbase[q] = ntbase[q];
+    sc_voff = nsc_voff;
+    // (this tile's first K-step is in flight or landed; the loop's first wait covers it -- and the epilogue's stores)
+  }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // the K-step fetched past the last tile (unused) must have landed before the LDS is released
 }
 #else
 template <int TYPE, int EPI>
@@ -491,7 +532,17 @@ static hipError_t launch_xh(const fl_qtensor &W, const fl_qact &xq, int N, float
     }
     const int MT32 = (W.M16 + 31) / 32, NT32 = (N + 31) / 32;
     const int tiles = ((MT32 + 1) / 2) * ((NT32 + 1) / 2);
-    hipLaunchKernelGGL((gemm_q4_exact_h16_kernel<TYPE, EPI>), dim3(tiles), dim3(256), C::LDS_BYTES, st, W.h16, W.d, W.m, xq.h16, xq.d, xq.s, N,
+    // one workgroup per residency slot (two per CU), each walking its tiles with the next tile's first K-step requested ahead
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+            cus = 256;
+        slots = 2 * cus / 8 * 8;                                               // (a multiple of the 8 XCDs: a workgroup's tiles stay on its XCD)
+        if (getenv("FL_XH_NOPERSIST")) slots = 1 << 30;                        // A/B: one workgroup per tile, as before
+    }
+    const int grid = tiles < slots ? tiles : slots;
+    hipLaunchKernelGGL((gemm_q4_exact_h16_kernel<TYPE, EPI>), dim3(grid), dim3(256), C::LDS_BYTES, st, W.h16, W.d, W.m, xq.h16, xq.d, xq.s, N,
                        W.M, MT32, W.M16 / 16, NT32, fl_roundup(N, 16) / 16, W.KB, y, ldy, resid, ldr, epi);
     return hipGetLastError();
 }

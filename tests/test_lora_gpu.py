@@ -80,41 +80,51 @@ def test_lora_merge_bit_exact_vs_oracle(port, qtype, r):
 
 
 @pytest.mark.parametrize("qtype", [ggjt.Q4_0, ggjt.Q4_1])
-def test_fp6_operand_copies_follow_the_weights_through_merge_and_restore(port, qtype):
-    """A model created with FL_FP6 on (fl_debug_set(3, 1)) evaluates its prefill GEMMs on fp6 copies of the weights (q4_layout.h
-    "F6 copies"): same logit bits as the int8 form -- before a LoRA merge, after it (the copy is rebuilt from the merged
-    nibbles) and after the restore."""
+def test_derived_weight_copies_follow_the_weights_through_merge_and_restore(port, qtype):
+    """The reference-order kernels read DERIVED copies of the nibbles (q4_layout.h: the f16 fragment copy H16 for N >= 9, the QWD copy for
+    N = 1), built on first use.  A LoRA merge rewrites the nibbles of record; the copies must follow: after the merge the model's logits
+    (a 96-token batch and a decode step) equal, bit for bit, those of a FRESH model created from the merged tensor -- and after the restore
+    those of the original."""
     import torch
     from fastllama_amd import hip
-    from harness import synth
     from harness.flmodel import FlModel
     L = hip.load()
-    cfg = dict(n_vocab=512, n_embd=1024, n_head=8, n_layer=2, n_ff=2816)
-    N, r = 96, 8
-    toks = np.random.default_rng(2).integers(3, 259, N).astype(np.int32)
+    cfg = ggjt.SMALL
     E = cfg["n_embd"]
+    N, r, name = 96, 8, "layers.1.attention.wo.weight"
+    tensors = ggjt.synth_tensors(cfg, qtype, port.quantize_q4, seed=4)
+    toks = np.random.default_rng(2).integers(3, 259, N).astype(np.int32)
     rng = np.random.default_rng(qtype)
     a = (rng.standard_normal((E, r)) * 0.05).astype(np.float32)
     b = (rng.standard_normal((E, r)) * 0.05).astype(np.float32)
-    L.fl_debug_set(3, 1)
-    try:
-        m = FlModel(cfg, qtype, synth.synth_model_tensors(cfg, qtype, seed=4), n_ctx=128, max_batch=N)
-        seen = []
-        for step in ("base", "merged", "restored"):
-            if step == "merged":
-                hip.check(L.fl_model_lora_apply(m.h, b"layers.1.attention.wo.weight", None, ptr(a), ptr(b), r, 1.0, 1), "lora_apply")
-            if step == "restored":
-                hip.check(L.fl_model_lora_restore(m.h), "restore")
-            L.fl_debug_set(3, 1)
-            got6 = m.eval(toks, all_logits=True).copy()
-            L.fl_debug_set(3, 0)
-            got8 = m.eval(toks, all_logits=True).copy()
-            assert np.array_equal(got6.view(np.int32), got8.view(np.int32)), step
-            seen.append(got8)
-        assert not np.array_equal(seen[0], seen[1]) and np.array_equal(seen[0], seen[2])
-        m.free()
-    finally:
-        L.fl_debug_set(3, 0)
+
+    def run(model):
+        pre = model.eval(toks, all_logits=True).copy()
+        dec = model.eval([int(toks[5])], n_past=N).copy()
+        return pre, dec
+
+    m = FlModel(cfg, qtype, tensors, n_ctx=128, max_batch=N)
+    m.set_exact(True)
+    base = run(m)                                               # (builds both derived copies)
+    hip.check(L.fl_model_lora_apply(m.h, name.encode(), None, ptr(a), ptr(b), r, 1.0, 1), "lora_apply")
+    merged = run(m)
+    merged_blocks = download(L, m, name, E, E, qtype)
+    hip.check(L.fl_model_lora_restore(m.h), "restore")
+    restored = run(m)
+    m.free()
+    t2 = dict(tensors)
+    ent = list(t2[name])
+    ent[2] = merged_blocks.reshape(np.asarray(ent[2]).shape)
+    t2[name] = tuple(ent)
+    m2 = FlModel(cfg, qtype, t2, n_ctx=128, max_batch=N)
+    m2.set_exact(True)
+    fresh = run(m2)
+    m2.free()
+    for got, want in zip(merged, fresh):
+        assert np.array_equal(got.view(np.int32), want.view(np.int32))
+    for got, want in zip(restored, base):
+        assert np.array_equal(got.view(np.int32), want.view(np.int32))
+    assert not np.array_equal(base[0], merged[0])
     torch.cuda.empty_cache()
 
 
