@@ -97,6 +97,24 @@ def test_exact_tile_kernel_at_llama_shapes(torch, ops, port, nm, qt, M, K):
 
 
 @pytest.mark.parametrize("nm,qt", Q4)
+@pytest.mark.parametrize("M,K,N", [(8200, 320, 300), (33000, 96, 75)])
+def test_exact_tile_kernel_persistent_workgroups_on_ragged_shapes(torch, ops, port, nm, qt, M, K, N):
+    """More 64 x 64 tiles than residency slots (645 / 1032 against 512: workgroups walk several tiles, the next tile's first K-step
+    requested during the last one of the current tile) with ragged last row and column tiles and an odd number of K-steps: the whole
+    output equals the oracle's, bit for bit."""
+    wq = make_weights(port, qt, M, K, 3 + M)
+    W = ops.QTensor(qt, wq, M, K)
+    x = make_x(N, K, 9 + N)
+    a = ops.QAct(N, K).quantize(dev(torch, x))
+    want = port.mul_mat_q(qt, wq, x, strict=False)
+    y = torch.full((N, (M + 3) // 4 * 4), 7.0, device="cuda")[:, :M]
+    ops.mul_mat_q(W, a, which=3, out=y)
+    got = y.cpu().numpy()
+    assert np.array_equal(bits(got), bits(want)), (int((bits(got) != bits(want)).sum()), float(np.abs(got - want).max()))
+    W.free()
+
+
+@pytest.mark.parametrize("nm,qt", Q4)
 def test_mul_mat_q_exact_large_scales_and_signs(torch, ops, port, nm, qt):
     """Weights and activations spanning many orders of magnitude: the 16x / (1/16) bookkeeping of the Q4_0 layout (q4_layout.h)
     must stay exact, and the residual add must be the plain f32 add that follows the matmul (lib/llama.cpp:407)."""
