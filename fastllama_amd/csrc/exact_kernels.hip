@@ -784,6 +784,22 @@ __global__ __launch_bounds__(512) void attn_scores_exact_kernel(const float *__r
     }
 }
 
+#ifdef XA_TIMING   // development build only: per-workgroup clocks of the V.P launch (scripts/dev/xa_timeline.py)
+__device__ long long xa_dbg[1024 * 16];
+#define XA_STAMP(k) do { if (threadIdx.x == 0) xa_dbg[((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) % 1024 * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define XA_STAMP(k) do {} while (0)
+#endif
+// a barrier that orders LDS traffic only: __syncthreads() also waits for every global load and store of the wave (s_waitcnt vmcnt(0)) -- here
+// that is the V block requested ahead and the Q8_0 / f32 stores of the previous feature block, a round trip each
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// ONE: the whole context is one piece for every query block (n_past + N <= 512): its own kernel, because the two forms want different
+// registers (a V block in flight + four chain tiles here; eight chain tiles carried across pieces there)
+template <bool ONE>
 __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restrict__ att, int ld_att, int64_t head_stride, int D, int N,
                                                             int n_past, const float *__restrict__ vc, int n_ctx, float *__restrict__ ao,
                                                             int ldo, int8_t *__restrict__ oq, float *__restrict__ od,
@@ -830,141 +846,182 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
     };
     // The whole context in one piece (<= 512 keys): load and store are separate steps, so that the next feature block's V rows are
     // requested BEFORE the current block's MFMAs and written to LDS after them -- their round trip used to stand between every two
-    // blocks (profiles/r04_attn_exact.md).  Thread -> keys 4 (tid & 127) .. + 3 of rows 2 u + (tid >> 7), u = 0 .. 15: one 32-bit
-    // offset per thread next to a wave-uniform row base.
-    const int sk = (threadIdx.x & 127) * 4, srow = threadIdx.x >> 7;
+    // blocks (profiles/r04_attn_exact.md).  Thread -> 16 float4: lane (rr = lane >> 3, kk = lane & 7) of wave w takes, for u = 0 .. 15,
+    // row 8 (u & 3) + rr, keys 32 (4 w + (u >> 2)) + 4 kk .. + 3: a wave-load is 8 rows x one 128-byte line, and a wave-store of one
+    // component lands on bank (rr + 4 kk + const) % 32 -- all 32 lanes of a half wave on different banks (keys along the lanes put a
+    // whole wave on 8 banks: 4-way conflicts on 64 stores per thread and block).
+    const int s_rr = lane >> 3, s_kk = lane & 7;
     auto wide_load = [&](float4 (&v)[16], const float *src, int row_stride, int rows_valid, int kt) {
-        const unsigned col = (unsigned)max(0, min(min(sk, kt - 4), n_ctx - 4));        // (a thread past the piece: a cache-hot address, never stored)
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const unsigned off = (unsigned)min(2 * u + srow, rows_valid - 1) * (unsigned)row_stride + col;
+            const int row = 8 * (u & 3) + s_rr, col = 32 * (4 * wave + (u >> 2)) + 4 * s_kk;
+            // (a piece past the context: a cache-hot address, never stored)
+            const unsigned off = (unsigned)min(row, rows_valid - 1) * (unsigned)row_stride + (unsigned)max(0, min(min(col, kt - 4), n_ctx - 4));
             v[u] = *reinterpret_cast<const float4 *>(src + off);
         }
     };
     auto wide_store = [&](float *dst, const float4 (&v)[16], int rows_valid, int kt) {
-        if (sk < kt) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int r = 2 * u + srow;
-                float *d = dst + r * XA_LD + sk;
-                const bool rv = r < rows_valid;
-                d[0] = rv && sk < kend ? v[u].x : 0.f;
-                d[1] = rv && sk + 1 < kend ? v[u].y : 0.f;
-                d[2] = rv && sk + 2 < kend ? v[u].z : 0.f;
-                d[3] = rv && sk + 3 < kend ? v[u].w : 0.f;
+        for (int u = 0; u < 16; ++u) {
+            const int row = 8 * (u & 3) + s_rr, col = 32 * (4 * wave + (u >> 2)) + 4 * s_kk;
+            if (col < kt) {                                  // (wave-uniform: kt is a multiple of 64, a wave-store covers 32 keys)
+                float *d = dst + row * XA_LD + col;
+                const bool rv = row < rows_valid;
+                d[0] = rv && col < kend ? v[u].x : 0.f;
+                d[1] = rv && col + 1 < kend ? v[u].y : 0.f;
+                d[2] = rv && col + 2 < kend ? v[u].z : 0.f;
+                d[3] = rv && col + 3 < kend ? v[u].w : 0.f;
             }
         }
     };
     auto chunk_len = [&](int c) { return min(XA_KT, ((nbody - c * XA_KT) + 63) & ~63); };   // zero padded to whole MFMA pairs
     const int rows_q = min(32, N - q0);
-    const bool one_piece = nchunk == 1;                      // short contexts: P staged once, V blocks requested one ahead
+    constexpr bool one_piece = ONE;                          // short contexts: P staged once, V blocks requested one ahead
     float4 vnext[16];
-    if (one_piece) {
+    XA_STAMP(0);
+    if constexpr (one_piece) {
         float4 pfirst[16];
         wide_load(pfirst, prow + (int64_t)q0 * ld_att, ld_att, rows_q, chunk_len(0));
         wide_load(vnext, vc + (int64_t)(hd * D) * n_ctx, n_ctx, 32, chunk_len(0));
         wide_store(Ps, pfirst, rows_q, chunk_len(0));
         wide_store(Vs, vnext, 32, chunk_len(0));
     }
-    float *Ts = xs_ + 64 * XA_LD;                            // the waves' t tiles meet here: [4][64][16]
+    XA_STAMP(1);
+    float *Ts = xs_ + 64 * XA_LD;                            // the waves' t tiles meet here: [4 waves][16 e][64 lanes]
     float *Os = Ts + 4 * 64 * 16;                            // oq: the finished [32 queries][33] tile of a feature block, on its way to Q8_0
     const int nleft = P - np;                                // < 32 keys behind the body, taken in order
     const bool left_visible = nleft > 0 && kend > np;
     for (int d0 = 0; d0 < D; d0 += 32) {
-        // wave w: partial sums l = w and l = w + 4, all four jj: chains over ALL 32-key steps of the body, two steps per MFMA
-        v16f tl[2][4] = {{{}, {}, {}, {}}, {{}, {}, {}, {}}};
-        for (int c = 0; c < nchunk; ++c) {
-            const int k0 = c * XA_KT, kt = chunk_len(c);
-            __syncthreads();                                 // P, V staged / the previous piece is done with Ps, Vs and Ts
-            if (one_piece) {
-                if (d0 + 32 < D) wide_load(vnext, vc + (int64_t)(hd * D + d0 + 32) * n_ctx, n_ctx, 32, kt);
-            } else {
-                stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, rows_q, k0, kt);
-                stage(Vs, vc + (int64_t)(hd * D + d0) * n_ctx, n_ctx, 32, k0, kt);
-                __syncthreads();
+        // wave w: partial sums l = w and l = w + 4, all four jj: chains over ALL 32-key steps of the body, two steps per MFMA.
+        // chain(acc, l, k0, cend): the four jj chains of partial sum l over the staged keys [k0, cend)
+        auto chain = [&](v16f (&acc)[4], int l, int k0, int cend) __attribute__((always_inline)) {
+            for (int cs = k0; cs < cend; cs += 128) {         // two MFMAs (four 32-key steps) per chain and trip: 16 operand reads, then 8 MFMAs
+                float a[2][4], b[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c0 = cs + 64 * u + 32 * h;      // (a step past the body: zeros -- fma(0, 0, c) = c)
+                    const bool ok = c0 < cend;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int e = (ok ? c0 - k0 : 0) + 8 * jj + l;
+                        const float av = Ps[i * XA_LD + e], bv = Vs[i * XA_LD + e];
+                        a[u][jj] = ok ? av : 0.f;
+                        b[u][jj] = ok ? bv : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][jj], b[u][jj], acc[jj], 0, 0, 0);
             }
-            const int cend = min(nbody, k0 + XA_KT);
+        };
+        v16f tw;
+        if constexpr (one_piece) {
+            // one partial sum at a time: its four chain tiles (64 registers) are folded to v_l = (s0+s1)+(s2+s3) before the other starts
+            // -- with both alive (128) next to the 64 registers of the V block in flight the kernel shuffled ~600 values between the
+            // two register files per feature block (profiles/r04_attn_exact.md)
+            lds_barrier();                                    // P, V staged / the previous block is done with Ps, Vs and Ts
+            const int kt = chunk_len(0);
+            if (d0 + 32 < D) wide_load(vnext, vc + (int64_t)(hd * D + d0 + 32) * n_ctx, n_ctx, 32, kt);
+            v16f v0;
 #pragma unroll
             for (int li = 0; li < 2; ++li) {
-                const int l = wave + 4 * li;
-                for (int cs = k0; cs < cend; cs += 128) {     // two MFMAs (four 32-key steps) per chain and trip: 16 operand reads, then 8 MFMAs
-                    float a[2][4], b[2][4];
+                v16f t4[4] = {{}, {}, {}, {}};
+                chain(t4, wave + 4 * li, 0, nbody);
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int c0 = cs + 64 * u + 32 * h;  // (a step past the body: zeros -- fma(0, 0, c) = c)
-                        const bool ok = c0 < cend;
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            const int e = (ok ? c0 - k0 : 0) + 8 * jj + l;
-                            const float av = Ps[i * XA_LD + e], bv = Vs[i * XA_LD + e];
-                            a[u][jj] = ok ? av : 0.f;
-                            b[u][jj] = ok ? bv : 0.f;
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj)
-                            tl[li][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][jj], b[u][jj], tl[li][jj], 0, 0, 0);
+                for (int e = 0; e < 16; ++e) {
+                    const float v = __fadd_rn(__fadd_rn(t4[0][e], t4[1][e]), __fadd_rn(t4[2][e], t4[3][e]));   // (s0+s1)+(s2+s3)
+                    if (li == 0) v0[e] = v;
+                    else tw[e] = __fadd_rn(v0[e], v);                                                            // t_w = v_w + v_{w+4} (lo128 + hi128)
                 }
+                if (li == 0) asm volatile("" : "+v"(v0));     // (folded before the second partial sum's MFMAs are issued)
+            }
+        } else {
+            v16f tl[2][4] = {{{}, {}, {}, {}}, {{}, {}, {}, {}}};
+            for (int c = 0; c < nchunk; ++c) {
+                const int k0 = c * XA_KT, kt = chunk_len(c);
+                lds_barrier();                                // the previous piece is done with Ps, Vs and Ts
+                stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, rows_q, k0, kt);
+                stage(Vs, vc + (int64_t)(hd * D + d0) * n_ctx, n_ctx, 32, k0, kt);
+                lds_barrier();   
+                const int cend = min(nbody, k0 + XA_KT);
+                chain(tl[0], wave, k0, cend);
+                chain(tl[1], wave + 4, k0, cend);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float v0 = __fadd_rn(__fadd_rn(tl[0][0][e], tl[0][1][e]), __fadd_rn(tl[0][2][e], tl[0][3][e]));   // (s0+s1)+(s2+s3)
+                const float v1 = __fadd_rn(__fadd_rn(tl[1][0][e], tl[1][1][e]), __fadd_rn(tl[1][2][e], tl[1][3][e]));
+                tw[e] = __fadd_rn(v0, v1);                                                                              // t_w = v_w + v_{w+4} (lo128 + hi128)
             }
         }
-        v16f tw;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float v0 = __fadd_rn(__fadd_rn(tl[0][0][e], tl[0][1][e]), __fadd_rn(tl[0][2][e], tl[0][3][e]));   // (s0+s1)+(s2+s3)
-            const float v1 = __fadd_rn(__fadd_rn(tl[1][0][e], tl[1][1][e]), __fadd_rn(tl[1][2][e], tl[1][3][e]));
-            tw[e] = __fadd_rn(v0, v1);                                                                              // t_w = v_w + v_{w+4} (lo128 + hi128)
-        }
-        __syncthreads();                                     // every wave is done with Ps / Vs
+        if (d0 == 0) XA_STAMP(2); else if (d0 == 32) XA_STAMP(6);
+        lds_barrier();                                        // every wave is done with Ps / Vs
         if (left_visible) {                                  // the leftover keys [np, P) to columns 0.. of both tiles
             stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, rows_q, np, 32);
             stage(Vs, vc + (int64_t)(hd * D + d0) * n_ctx, n_ctx, 32, np, 32);
         }
         {
-            float *dst = Ts + (wave * 64 + lane) * 16;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) dst[e] = tw[e];
+            float *dst = Ts + wave * 1024 + lane;            // [wave][e][lane]: a wave's store / load of one e is 64 consecutive floats
+#pragma unroll                                               // ([wave][lane][e] put every lane of a load on two banks: 32-way conflicts)
+            for (int e = 0; e < 16; ++e) dst[e * 64] = tw[e];
         }
-        __syncthreads();
-        if (wave == 0) {
-            const float *t0 = Ts + (0 * 64 + lane) * 16, *t1 = Ts + (1 * 64 + lane) * 16, *t2 = Ts + (2 * 64 + lane) * 16,
-                        *t3 = Ts + (3 * 64 + lane) * 16;
+        lds_barrier();   
+        {
+            // every wave finishes four of the sixteen query rows a lane holds (e = 4 wave .. 4 wave + 3): the four t tiles are read first
+            // (one LDS round trip), then -- contexts with P % 32 != 0 only -- the leftover keys in the reference's order, then the stores.
+            // (Wave 0 alone, row by row, each behind the branches of the leftover code: 2.2 us per feature block, profiles/r04_attn_exact.md.)
+            const float *t0 = Ts + lane, *t1 = Ts + 1024 + lane, *t2 = Ts + 2048 + lane, *t3 = Ts + 3072 + lane;
             // C layout: col = lane & 31 = feature, row = (e & 3) + 8 (e >> 2) + 4 h = query
             const float *vr = Vs + i * XA_LD;
+            float sv[4];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float s = __fadd_rn(__fadd_rn(t0[e], t1[e]), __fadd_rn(t2[e], t3[e]));       // (t0+t1) + (t2+t3) (hadd, hadd)
-                const int ql = (e & 3) + 8 * (e >> 2) + 4 * h, q = q0 + ql;
-                const float *pr = Ps + ql * XA_LD;
-                // the n % 32 leftovers as the reference's build compiled them (chunks of 8, one of 4: rounded products added in
-                // order; the last n % 4: FMAs); keys past this block's last visible one carry p = +0 and change nothing
-                int k = 0;
-                for (; k + 8 <= nleft; k += 8)
-                    for (int u = 0; u < 8; ++u)
-                        if (np + k + u < kend) {
-                            const float prd = pr[k + u] * vr[k + u];
-                            s = s + prd;
-                        }
-                if (nleft - k >= 4) {
-                    for (int u = 0; u < 4; ++u)
-                        if (np + k + u < kend) {
-                            const float prd = pr[k + u] * vr[k + u];
-                            s = s + prd;
-                        }
-                    k += 4;
+            for (int j = 0; j < 4; ++j) {
+                const int e = 4 * wave + j;
+                sv[j] = __fadd_rn(__fadd_rn(t0[e * 64], t1[e * 64]), __fadd_rn(t2[e * 64], t3[e * 64]));   // (t0+t1) + (t2+t3) (hadd, hadd)
+            }
+            if (nleft > 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ql = j + 8 * wave + 4 * h;             // (e & 3) + 8 (e >> 2) + 4 h with e = 4 wave + j
+                    const float *pr = Ps + ql * XA_LD;
+                    float s = sv[j];
+                    // the n % 32 leftovers as the reference's build compiled them (chunks of 8, one of 4: rounded products added in
+                    // order; the last n % 4: FMAs); keys past this block's last visible one carry p = +0 and change nothing
+                    int k = 0;
+                    for (; k + 8 <= nleft; k += 8)
+                        for (int u = 0; u < 8; ++u)
+                            if (np + k + u < kend) {
+                                const float prd = pr[k + u] * vr[k + u];
+                                s = s + prd;
+                            }
+                    if (nleft - k >= 4) {
+                        for (int u = 0; u < 4; ++u)
+                            if (np + k + u < kend) {
+                                const float prd = pr[k + u] * vr[k + u];
+                                s = s + prd;
+                            }
+                        k += 4;
+                    }
+                    for (; k < nleft; ++k)
+                        if (np + k < kend) s = __fmaf_rn(pr[k], vr[k], s);
+                    sv[j] = s;
                 }
-                for (; k < nleft; ++k)
-                    if (np + k < kend) s = __fmaf_rn(pr[k], vr[k], s);
-                if (oq) Os[ql * 33 + i] = s;
-                else if (q < N) ao[(int64_t)q * ldo + hd * D + d0 + i] = s;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ql = j + 8 * wave + 4 * h, q = q0 + ql;
+                if (oq) Os[ql * 33 + i] = sv[j];
+                else if (q < N) ao[(int64_t)q * ldo + hd * D + d0 + i] = sv[j];
             }
         }
+        if (d0 == 0) XA_STAMP(3);
         if (oq) {
             // the Q8_0 operand of the wo matmul, written here (quantize_row_q8_0 of the merged [N, n_embd] rows, lib/ggml.c:8063-8075: a
             // block = 32 consecutive features of one query = one row of this tile): QA16 (+ its XH16 copy), 4 adjacent lanes per block,
             // the arithmetic of quantize_q8_kernel; queries past N are the layout's padding: zero blocks
-            __syncthreads();
+            lds_barrier();   
             if (threadIdx.x < 128) {
                 const int ql = threadIdx.x >> 2, part = threadIdx.x & 3, q = q0 + ql, KBo = ldo >> 5, kg = ((hd * D + d0) >> 3) + part;
                 float v[8];
@@ -979,14 +1036,20 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
                 }
             }
         }
+        if (d0 == 0) XA_STAMP(4);
         if (one_piece && d0 + 32 < D) {
-            __syncthreads();                                 // wave 0 / the quantizing threads are done with Ps, Vs and Os
+            lds_barrier();                                    // wave 0 / the quantizing threads are done with Ps, Vs and Os
             if (left_visible)                                // the single staged P piece was overwritten by the leftovers: stage it again
                 stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, rows_q, 0, chunk_len(0));
             wide_store(Vs, vnext, 32, chunk_len(0));
         }
+        if (d0 == 0) XA_STAMP(5);
     }
+    XA_STAMP(7);
 }
+#ifdef XA_TIMING
+extern "C" int fl_debug_xa_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(xa_dbg), sizeof(long long) * 1024 * 16); }
+#endif
 
 // hipErrorInvalidValue: shape outside these kernels' reach (head_dim not a multiple of 32 or > 128, unaligned rows): the caller
 // (run_eval_kernels, model.cpp) then takes dot_f32_abt_exact
@@ -1011,12 +1074,21 @@ hipError_t attn_pv_exact(const float *att, int ld_att, int64_t head_stride, int 
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_pv_exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_pv_exact_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_pv_exact_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(attn_pv_exact_kernel, dim3(H, (N + 31) / 32), dim3(256), lds, st, att, ld_att, head_stride, D, N, n_past, vc, n_ctx,
-                       ao, ldo, out ? out->q : nullptr, out ? out->d : nullptr, out ? out->s : nullptr, out && with_h16 ? out->h16 : nullptr);
+    int8_t *oq = out ? out->q : nullptr;
+    float *od = out ? out->d : nullptr, *os = out ? out->s : nullptr;
+    uint16_t *oh = out && with_h16 ? out->h16 : nullptr;
+    if (n_past + N <= XA_KT)
+        hipLaunchKernelGGL(attn_pv_exact_kernel<true>, dim3(H, (N + 31) / 32), dim3(256), lds, st, att, ld_att, head_stride, D, N, n_past, vc, n_ctx, ao, ldo,
+                           oq, od, os, oh);
+    else
+        hipLaunchKernelGGL(attn_pv_exact_kernel<false>, dim3(H, (N + 31) / 32), dim3(256), lds, st, att, ld_att, head_stride, D, N, n_past, vc, n_ctx, ao, ldo,
+                           oq, od, os, oh);
     return hipGetLastError();
 }
 
