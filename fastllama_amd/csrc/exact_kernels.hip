@@ -443,9 +443,9 @@ hipError_t gemv_q4_silu_exact(const fl_qtensor &W, const float *h13, const uint1
     return ok ? hipGetLastError() : hipErrorInvalidValue;
 }
 hipError_t gemv_q4_norm_silu_exact(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act,
-                                   hipStream_t st, float *pair_ws) {
+                                   hipStream_t st, float *pair_ws, int form) {
     if (W.K % 32 != 0 || W.K > 8192 || W.M % 32 != 0) return hipErrorInvalidValue;
-    if (!llc_off() && gemv1_llc_norm_silu(W, x, norm_w, silu_tab, act, st, pair_ws)) return hipGetLastError();
+    if (!llc_off() && gemv1_llc_norm_silu(W, x, norm_w, silu_tab, act, st, pair_ws, form)) return hipGetLastError();
     const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab)),
                              (launch_gemv1_exact<FL_TYPE_Q4_1, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab)));
     return ok ? hipGetLastError() : hipErrorInvalidValue;

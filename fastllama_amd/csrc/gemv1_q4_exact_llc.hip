@@ -87,6 +87,12 @@ __device__ __forceinline__ float quad_bcast(float v) {
     return dpp_f32<SRC | (SRC << 2) | (SRC << 4) | (SRC << 6)>(v);
 }
 
+#ifdef LLC_TIMING   // development build only: per-workgroup clocks of a launch (scripts/dev/llc_timeline.py)
+__device__ long long llc_dbg[2048 * 8];
+#define LLC_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) llc_dbg[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define LLC_STAMP(k) do {} while (0)
+#endif
 // NK waves share a 16-row group along K (wave k: quads [k NQ / NK, (k+1) NQ / NK)); PAIR = 1: the workgroup takes the w1 group and then
 // the w3 group of the same 16 features (one after the other: three workgroups per CU cover each other's round trips).  QPW: most quads a wave can hold (its lane sums stay in registers until its turn in the chain).
 template <int TYPE, int NK, int PRO, int PAIR, int QPW>
@@ -109,6 +115,7 @@ __global__ __launch_bounds__(64 * NK, (PAIR == 1 && QPW <= 8 && NK == 4) ? 3 : 1
     float *ls_ = ld_ + 4 * NQ;                                                  //  zero, so a block past K has dd = 0 and adds nothing)
     unsigned char *lx = reinterpret_cast<unsigned char *>(ls_ + 4 * NQ);
 
+    LLC_STAMP(0);
     GP_DECL(PRO);
     GemvPrologue<PRO, NT>::issue(pv, pw, psl, psb, xf, aux, KB, woven);
 
@@ -130,6 +137,7 @@ __global__ __launch_bounds__(64 * NK, (PAIR == 1 && QPW <= 8 && NK == 4) ? 3 : 1
         }
     };
     load_group(unit * G2);
+    LLC_STAMP(1);
 
     if constexpr (PRO != 0) {
         GemvPrologue<PRO, NT>::finish(pv, pw, psl, psb, xf, aux, KB, woven, lq, ld_, ls_, sh, ynorm, blockIdx.x == 0);
@@ -157,6 +165,7 @@ __global__ __launch_bounds__(64 * NK, (PAIR == 1 && QPW <= 8 && NK == 4) ? 3 : 1
         ls_[KB + threadIdx.x] = 0.f;
     }
     __syncthreads();
+    LLC_STAMP(2);
 
     const uint32_t m8 = 0xF0F0F0F0u;
     float y1 = 0.f;
@@ -187,6 +196,7 @@ __global__ __launch_bounds__(64 * NK, (PAIR == 1 && QPW <= 8 && NK == 4) ? 3 : 1
                 if (Q41) { ms[i][0] = quad_bcast<0>(mw[i]); ms[i][1] = quad_bcast<1>(mw[i]); ms[i][2] = quad_bcast<2>(mw[i]); ms[i][3] = quad_bcast<3>(mw[i]); }
             }
         }
+        if (gi == 0) LLC_STAMP(3);
         // ---- the chains, slice after slice: wave k continues from the state wave k - 1 left in LDS
         float a0 = 0.f, a1 = 0.f, summs = 0.f;
 #pragma unroll 1
@@ -213,6 +223,7 @@ __global__ __launch_bounds__(64 * NK, (PAIR == 1 && QPW <= 8 && NK == 4) ? 3 : 1
             }
             if (ph < NK - 1) __syncthreads();
         }
+        if (gi == 0) LLC_STAMP(4);
         // ---- the row group is complete in its last wave: ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)) over the quad of lanes that holds the
         // row (lane g holds accumulators 2g, 2g+1; every lane of the quad ends with the same bits), then the store / the PAIR epilogue
         if (k == NK - 1) {
@@ -266,7 +277,11 @@ __global__ __launch_bounds__(64 * NK, (PAIR == 1 && QPW <= 8 && NK == 4) ? 3 : 1
     };
     do_group(std::integral_constant<int, 0>{});
     if constexpr (PAIR == 1) do_group(std::integral_constant<int, 1>{});
+    LLC_STAMP(5);
 }
+#ifdef LLC_TIMING
+extern "C" int fl_debug_llc_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(llc_dbg), sizeof(long long) * 2048 * 8); }
+#endif
 
 // false: no QWD copy, or a shape outside the kernel's reach (rows too long for the slices' registers, activation beyond LDS)
 // -> the caller takes round 3's kernel
@@ -311,8 +326,8 @@ bool gemv1_llc_silu(const fl_qtensor &W, const float *h13, const uint16_t *silu_
 }
 size_t gemv1_llc_pair_ws_bytes(int M) { return (size_t)(M + 31) / 32 * 16 * 8; }
 bool gemv1_llc_norm_silu(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act, hipStream_t st,
-                         float *pair_ws) {
-    if (pair_ws && (W.M16 / 16) % 2 == 0)         // (pair_ws: gemv1_llc_pair_ws_bytes(W.M) bytes, zero before its first use)
+                         float *pair_ws, int form /* 0: automatic; 1 / 2 pins a form (tests, A/B: profiles/r04_decode_exact.md) */) {
+    if (pair_ws && (W.M16 / 16) % 2 == 0 && form != 1)   // (pair_ws: gemv1_llc_pair_ws_bytes(W.M) bytes, zero before its first use)
         return FL_TYPED((launch_llc<FL_TYPE_Q4_0, 1, 2>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab, pair_ws)),
                         (launch_llc<FL_TYPE_Q4_1, 1, 2>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab, pair_ws)));
     return FL_TYPED((launch_llc<FL_TYPE_Q4_0, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab)),

@@ -517,8 +517,8 @@ static hipError_t mm_norm_silu(fl_model *m, const fl_qtensor *W, const float *x,
     hipEvent_t e1;
     hipError_t r = prof_begin(m, &e1);
     if (r != hipSuccess) return r;
-    static const bool one_wg = getenv("FL_EXACT_PAIR1") != nullptr;     // A/B: profiles/r04_decode_exact.md
-    if (m->exact) r = gemv_q4_norm_silu_exact(*W, x, norm_w, m->silu_tab, act, m->stream, one_wg ? nullptr : m->pair_ws);
+    static const int form = getenv("FL_EXACT_PAIR") ? atoi(getenv("FL_EXACT_PAIR")) : 0;     // A/B: 1 / 2 pins a form (profiles/r04_decode_exact.md)
+    if (m->exact) r = gemv_q4_norm_silu_exact(*W, x, norm_w, m->silu_tab, act, m->stream, m->pair_ws, form);
     else r = gemv_q4_norm_silu(*W, x, norm_w, m->silu_tab, act, m->stream);
     prof_end(m, e1);
     return r;

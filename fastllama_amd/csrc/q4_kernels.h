@@ -55,8 +55,9 @@ hipError_t gemv_q4_silu_exact(const fl_qtensor &W, const float *h13, const uint1
                               hipStream_t st, bool woven = false);
 // pair_ws: gemv1_llc_pair_ws_bytes(W.M) bytes of zeroed device memory owned by the caller's eval (one launch at a time per workspace): the
 // w1 / w3 groups of a feature then run as separate workgroups and the second to finish forms silu * mul; NULL: one workgroup per pair
+// form: 0 automatic; 1 one workgroup per feature pair, groups in turn; 2 two workgroups meeting in pair_ws
 hipError_t gemv_q4_norm_silu_exact(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act,
-                                   hipStream_t st, float *pair_ws = nullptr);
+                                   hipStream_t st, float *pair_ws = nullptr, int form = 0);
 size_t gemv1_llc_pair_ws_bytes(int M);
 hipError_t gemv_q4_quant_exact(const fl_qtensor &W, const float *x, float *y, const float *resid, hipStream_t st);
 hipError_t gemm_q4_exact(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
@@ -83,7 +84,7 @@ bool gemv1_llc(const fl_qtensor &W, const fl_qact &xq, float *y, hipStream_t st,
 bool gemv1_llc_norm(const fl_qtensor &W, const float *x, const float *norm_w, float *ynorm, float *y, hipStream_t st);
 bool gemv1_llc_silu(const fl_qtensor &W, const float *h13, const uint16_t *silu_tab, float *y, const float *resid, hipStream_t st, bool woven);
 bool gemv1_llc_norm_silu(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act, hipStream_t st,
-                         float *pair_ws);
+                         float *pair_ws, int form);
 bool gemv1_llc_quant(const fl_qtensor &W, const float *x, float *y, const float *resid, hipStream_t st);
 hipError_t gemm_q4_exact_valu(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                               const float *resid = nullptr, int ldr = 0);   // v_dot4 form (exact_kernels.hip), cross-check

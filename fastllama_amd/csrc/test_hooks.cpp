@@ -24,7 +24,7 @@ extern "C" {
 /* ------------------------------------------------------------------------------------------------
  * switches
  * ---------------------------------------------------------------------------------------------- */
-static int g_debug_pair1 = 0;      // fl_debug_set(5, 1): fl_debug_gemv_norm_silu runs the one-workgroup-per-pair form of the reference-order kernel
+static int g_debug_pair1 = 0;      // fl_debug_set(5, form): the form of the reference-order w1|w3 kernel fl_debug_gemv_norm_silu runs (q4_kernels.h; 0 automatic)
 static int g_debug_exact = 0;      // fl_debug_set(2, 1): the single-token hooks below run the reference-order kernels
 
 /* host logic of the mixed-tile GEMM launch (gemm_q4_mfma32.hip, cfg 116): how M16/16 row groups x ceil(N/16) column groups are
@@ -38,7 +38,7 @@ int fl_debug_set(int what, int value) {
     if (what == 0) fl::g_gemm_force_cfg = value;
     if (what == 1) fl::g_gemv_force_waves = value;   // 0 = automatic, else 4 / 8 / 16 waves per 16-row group
     if (what == 2) g_debug_exact = value;            // the single-token test hooks (fl_debug_gemv_*, fl_debug_decode_attention*) in exact mode
-    if (what == 5) g_debug_pair1 = value;            // fl_debug_gemv_norm_silu in exact mode: the one-workgroup-per-feature-pair form
+    if (what == 5) g_debug_pair1 = value;            // fl_debug_gemv_norm_silu in exact mode: 1 / 2 pins a form of the w1|w3 kernel, 0 automatic
     if (what == 4) fl::g_op_mode = value;            // (= fl_set_op_mode: kept for the sweep scripts)
     return FL_OK;
 }
@@ -179,7 +179,7 @@ int fl_debug_gemv_norm_silu(const fl_qtensor *W, const float *x, const float *no
         M_HIP(hipMemset(ws, 0, need));
         ws_bytes = need;
     }
-    M_HIP(gemv_q4_norm_silu_exact(*W, x, norm_w, silu_tab, act, (hipStream_t)stream, g_debug_pair1 ? nullptr : ws));
+    M_HIP(gemv_q4_norm_silu_exact(*W, x, norm_w, silu_tab, act, (hipStream_t)stream, ws, g_debug_pair1));      // (fl_debug_set(5, form): 0 automatic)
     return FL_OK;
 }
 int fl_debug_gemv_quant(const fl_qtensor *W, const float *x, float *y, const float *resid, void *stream) {

@@ -1,5 +1,5 @@
 """Stress of the two-workgroup w1|w3 pairing (gemv1_q4_exact_llc.hip, PAIR = 2): T decode steps of LLaMA-7B (hipGraph replay), logits of
-every step written to argv[1].  Run once as is and once with FL_EXACT_PAIR1=1 (the one-workgroup form), then compare the files bit for bit:
+every step written to argv[1].  Run once as is and once with FL_EXACT_PAIR=1 (the one-workgroup form; 2 = two workgroups per pair), then compare the files bit for bit:
 python scripts/dev/pair_stress.py out.npy [T] [qtype]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -388,9 +388,9 @@ def test_exact_feed_forward_pair_and_quant_prologue(torch, ops, port, exact_hook
     cur = le.rms_norm_mul(x, nw)
     h1, h3 = port.mul_mat_q(qt, w1, cur, strict=False), port.mul_mat_q(qt, w3, cur, strict=False)
     want_act = (le.silu(h1) * h3).astype(np.float32)
-    # two forms of (a): the w1 / w3 groups of a feature as two workgroups meeting in a workspace (the default; launched three times:
-    # its flags must be back at zero after every launch) and as one workgroup (fl_debug_set(5, 1))
-    for form, reps in [(0, 3), (1, 1)]:
+    # the forms of (a) (q4_kernels.h): automatic; 2 = the two groups of a feature as two workgroups meeting in a workspace (launched three
+    # times: its slots must be back at zero after every launch); 1 = one workgroup per feature pair, groups in turn
+    for form, reps in [(0, 2), (2, 3), (1, 1)]:
         L.fl_debug_set(5, form)
         for _ in range(reps):
             act = torch.full((F,), 9.0, device="cuda")
