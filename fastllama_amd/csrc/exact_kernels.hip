@@ -851,26 +851,27 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
     // component lands on bank (rr + 4 kk + const) % 32 -- all 32 lanes of a half wave on different banks (keys along the lanes put a
     // whole wave on 8 banks: 4-way conflicts on 64 stores per thread and block).
     const int s_rr = lane >> 3, s_kk = lane & 7;
-    auto wide_load = [&](float4 (&v)[16], const float *src, int row_stride, int rows_valid, int kt) {
+    // (k0: first key of the piece -- 0 when the context is one piece)
+    auto wide_load = [&](float4 (&v)[16], const float *src, int row_stride, int rows_valid, int kt, int k0 = 0) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int row = 8 * (u & 3) + s_rr, col = 32 * (4 * wave + (u >> 2)) + 4 * s_kk;
             // (a piece past the context: a cache-hot address, never stored)
-            const unsigned off = (unsigned)min(row, rows_valid - 1) * (unsigned)row_stride + (unsigned)max(0, min(min(col, kt - 4), n_ctx - 4));
+            const unsigned off = (unsigned)min(row, rows_valid - 1) * (unsigned)row_stride + (unsigned)max(0, min(k0 + min(col, kt - 4), n_ctx - 4));
             v[u] = *reinterpret_cast<const float4 *>(src + off);
         }
     };
-    auto wide_store = [&](float *dst, const float4 (&v)[16], int rows_valid, int kt) {
+    auto wide_store = [&](float *dst, const float4 (&v)[16], int rows_valid, int kt, int k0 = 0) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int row = 8 * (u & 3) + s_rr, col = 32 * (4 * wave + (u >> 2)) + 4 * s_kk;
             if (col < kt) {                                  // (wave-uniform: kt is a multiple of 64, a wave-store covers 32 keys)
                 float *d = dst + row * XA_LD + col;
                 const bool rv = row < rows_valid;
-                d[0] = rv && col < kend ? v[u].x : 0.f;
-                d[1] = rv && col + 1 < kend ? v[u].y : 0.f;
-                d[2] = rv && col + 2 < kend ? v[u].z : 0.f;
-                d[3] = rv && col + 3 < kend ? v[u].w : 0.f;
+                d[0] = rv && k0 + col < kend ? v[u].x : 0.f;
+                d[1] = rv && k0 + col + 1 < kend ? v[u].y : 0.f;
+                d[2] = rv && k0 + col + 2 < kend ? v[u].z : 0.f;
+                d[3] = rv && k0 + col + 3 < kend ? v[u].w : 0.f;
             }
         }
     };
@@ -942,8 +943,13 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
             for (int c = 0; c < nchunk; ++c) {
                 const int k0 = c * XA_KT, kt = chunk_len(c);
                 lds_barrier();                                // the previous piece is done with Ps, Vs and Ts
-                stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, rows_q, k0, kt);
-                stage(Vs, vc + (int64_t)(hd * D + d0) * n_ctx, n_ctx, 32, k0, kt);
+                {   // both tiles of the piece: all 32 loads in flight, then the (bank-conflict free) stores
+                    float4 pp[16], vv[16];
+                    wide_load(pp, prow + (int64_t)q0 * ld_att, ld_att, rows_q, kt, k0);
+                    wide_load(vv, vc + (int64_t)(hd * D + d0) * n_ctx, n_ctx, 32, kt, k0);
+                    wide_store(Ps, pp, rows_q, kt, k0);
+                    wide_store(Vs, vv, 32, kt, k0);
+                }
                 lds_barrier();   
                 const int cend = min(nbody, k0 + XA_KT);
                 chain(tl[0], wave, k0, cend);
