@@ -379,6 +379,14 @@ def main():
                 "launches_per_step": n_launch // evals, "avg_launch_us": mm_ms * 1e3 / max(1, n_launch),
                 "algorithmic_flops_per_launch": wk["flops"] / shard / (n_launch / evals), "note": note,
             }
+            if mode == "exact":
+                # the ceiling the reference's summation order has on this chip: 247 ns per 32x32 tile and block on each of the 1024 SIMDs
+                # (8 lane sums at the matrix pipe's output rate + 8 fma per output + the d_w x d_x outer product, the two pipes of a SIMD not
+                # overlapping: DESIGN.md 3.7, profiles/r04_ubench_coexec5.txt) = 65536 ops / 247 ns x 1024
+                floor_tops = 65536.0 / 247e-9 * 1024 / 1e12
+                m["roofline"]["order_floor"] = {"ns_per_tile_block": 247.0, "tops": floor_tops, "frac": tops / floor_tops,
+                                                "note": "event-timed launches (ramp, epilogue and partial rounds included) against the measured floor "
+                                                        "of the instruction mix the reference's accumulation order needs on gfx950"}
             model.profile(1)
             for i in range(8):
                 dec(i)
