@@ -82,6 +82,20 @@ def test_python_binding_covers_header():
     L.fl_debug_set                        # (the hook library loads and declares its prototypes on first use)
 
 
+def test_operator_mode_switch_checks_its_argument():
+    """fl_set_op_mode(1 | 0 | -1): reference order / fast kernels / the library default for fl_mul_mat_q*; anything else is refused.
+    The default itself follows FL_FAST / FL_EXACT (fl_default_exact)."""
+    from fastllama_amd import hip
+    L = hip.load()
+    assert L.fl_set_op_mode(2) == hip.FL_EINVAL and L.fl_set_op_mode(-2) == hip.FL_EINVAL
+    assert b"fl_set_op_mode" in L.fl_last_error()
+    for mode in (1, 0, -1):
+        assert L.fl_set_op_mode(mode) == hip.FL_OK
+    e, f = os.environ.get("FL_EXACT"), os.environ.get("FL_FAST")          # (FL_EXACT wins over FL_FAST; neither: reference order)
+    want = (int(e) != 0) if e else (int(f) == 0) if f else 1
+    assert L.fl_default_exact() == int(want)
+
+
 def test_no_device_means_loud_failure(lib):
     """Without a GPU the product refuses to compute (FL_ENODEV) -- it never falls back to a CPU path."""
     import torch
