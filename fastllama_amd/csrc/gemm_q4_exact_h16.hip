@@ -50,6 +50,9 @@ struct XH {
 };
 
 enum { EPI_PLAIN = 0, EPI_ROPE = 1, EPI_SILU = 2 };
+#ifndef XH_PIPE
+#define XH_PIPE 0
+#endif
 
 #ifdef XH_TIMING   // development build only: per-workgroup clocks of the launch phases (scripts/dev/xh_timeline.py)
 __device__ long long xh_dbg[8192 * 8];
@@ -207,12 +210,24 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
             constexpr int g = decltype(G)::value, u = g >> 2, s = g & 3;
             return *reinterpret_cast<const v2u32 *>(base + b_off + u * 2048 + (s >> 1) * 1024 + (s & 1) * 8);
         };
-        v2u32 fa = frag_a(XIC(0)), fb = frag_b(XIC(0)), fan = frag_a(XIC(1)), fbn = frag_b(XIC(1));
+        // B128 (Q4_0): a lane's two MFMA steps of a 16-byte slot in ONE ds_read_b128 (two ds_read_b64 put lanes l and l + 8 on the same
+        // banks: half of the kernel's LDS cycles were conflicts), one slot ahead; Q4_1 has no registers left for it
+        constexpr bool B128 = !Q41 && !XH_PIPE;
+        typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+        auto slot_a = [&](auto P) XH_ATTR __attribute__((always_inline)) -> v4u32 {
+            constexpr int p = decltype(P)::value;
+            return *reinterpret_cast<const v4u32 *>(base + a_off + (p >> 1) * 2048 + (p & 1) * 1024);
+        };
+        auto slot_b = [&](auto P) XH_ATTR __attribute__((always_inline)) -> v4u32 {
+            constexpr int p = decltype(P)::value;
+            return *reinterpret_cast<const v4u32 *>(base + b_off + (p >> 1) * 2048 + (p & 1) * 1024);
+        };
+        v4u32 sa = {}, sb = {}, san = {}, sbn = {};
+        v2u32 fa = {}, fb = {}, fan = {}, fbn = {};
+        if (B128) { sa = slot_a(XIC(0)); sb = slot_b(XIC(0)); san = slot_a(XIC(1)); sbn = slot_b(XIC(1)); }
+        else { fa = frag_a(XIC(0)); fb = frag_b(XIC(0)); fan = frag_a(XIC(1)); fbn = frag_b(XIC(1)); }
         float dw = *reinterpret_cast<const float *>(base + sw_off), dx = *reinterpret_cast<const float *>(base + sx_off);
         v32f P = __builtin_amdgcn_mfma_f32_32x32x1f32(dw, dx, zero32, 0, 0, 0);             // rn(d_w d_x) of blocks 0 (regs 0..15), 1
-#ifndef XH_PIPE
-#define XH_PIPE 0
-#endif
         v32f D0, D1;
         if (XH_PIPE) D0 = __builtin_amdgcn_mfma_f32_32x32x4f16(__builtin_bit_cast(v4h, fa), __builtin_bit_cast(v4h, fb), zero32, 0, 0, 0);
         auto group = [&](auto G) XH_ATTR __attribute__((always_inline)) {
@@ -226,6 +241,17 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
                     if (g + 2 < 4 * KS) {            // operands of the group after next, in the shadow of that MFMA
                         fan = frag_a(XIC(g + 2 < 4 * KS ? g + 2 : 0));
                         fbn = frag_b(XIC(g + 2 < 4 * KS ? g + 2 : 0));
+                    }
+                }
+            } else if (B128) {
+                const v2u32 ga = (g & 1) ? v2u32{sa.z, sa.w} : v2u32{sa.x, sa.y}, gb = (g & 1) ? v2u32{sb.z, sb.w} : v2u32{sb.x, sb.y};
+                D0 = __builtin_amdgcn_mfma_f32_32x32x4f16(__builtin_bit_cast(v4h, ga), __builtin_bit_cast(v4h, gb), zero32, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g & 1) {                         // the slot is used up: the next one moves in, the one after it is requested
+                    sa = san; sb = sbn;
+                    if ((g >> 1) + 2 < 2 * KS) {
+                        san = slot_a(XIC((g >> 1) + 2 < 2 * KS ? (g >> 1) + 2 : 0));
+                        sbn = slot_b(XIC((g >> 1) + 2 < 2 * KS ? (g >> 1) + 2 : 0));
                     }
                 }
             } else {
