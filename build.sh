@@ -6,9 +6,13 @@ cd "$(dirname "$0")"
 OUT="${OUT:-fastllama_amd/libfastllama_hip.so}"
 HOOKS="$(dirname "$OUT")/$(basename "$OUT" .so)_hooks.so"
 SRCS=$(ls fastllama_amd/csrc/*.hip fastllama_amd/csrc/*.cpp | grep -v test_hooks.cpp)
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC ${KPRE--mllvm -amdgpu-kernarg-preload-count=16} -shared -Iinclude \
-      -o "$OUT" $SRCS -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -Wl,-soname,"$(basename "$OUT")" "$@"
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden ${KPRE--mllvm -amdgpu-kernarg-preload-count=16} -shared -Iinclude \
+      -o "$OUT" $SRCS -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -Wl,-soname,"$(basename "$OUT")" -Wl,--version-script=fastllama_amd/csrc/exports.map "$@"
 hipcc -O2 -std=c++17 -fPIC -shared -Iinclude -x hip --offload-arch=gfx950 -o "$HOOKS" fastllama_amd/csrc/test_hooks.cpp \
       -L"$(dirname "$OUT")" -l:"$(basename "$OUT")" -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+# the dynamic symbol table is the C API and nothing else: 17 llama_* + fl_* (incl. fl_internal_table, the hook library's one way in)
+if nm -D --defined-only "$OUT" | awk '$2 ~ /^[TDB]$/ {print $3}' | grep -v -E '^(llama_|fl_)' | grep -q .; then
+    echo "build.sh: $OUT exports symbols outside its C API:"; nm -D --defined-only "$OUT" | awk '$2 ~ /^[TDB]$/ {print $3}' | grep -v -E '^(llama_|fl_)' | head; exit 1
+fi
 # every symbol must resolve at load time (works without a GPU)
 FASTLLAMA_HIP_LIB="${OUT:+$(realpath "$OUT")}" python3 -c "import sys; sys.path.insert(0, '.'); from fastllama_amd import hip; hip.load()"

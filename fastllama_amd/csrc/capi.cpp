@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "../../include/fastllama_hip.h"
@@ -24,6 +25,20 @@ int set_error(int code, const char *fmt, ...) {
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
     return code;
+}
+
+// Warnings: things a caller should know about but that are not errors (a derived operand copy that did not fit and the slower kernel
+// family that runs instead).  One line per event to the handler of fl_set_warn_handler -- stderr unless the embedder installs its own
+// (llama_api.cpp routes them to the session's logger).
+static void (*g_warn_cb)(const char *) = nullptr;
+void warn(const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (g_warn_cb) g_warn_cb(buf);
+    else fprintf(stderr, "fastllama_hip: warning: %s\n", buf);
 }
 
 int hip_fail(hipError_t e, const char *what) {
@@ -62,9 +77,15 @@ namespace fl {
 // for models: fl_default_exact()) or the fast kernels.  fl_set_op_mode(1 | 0) pins it for a process, -1 returns to the default.
 int g_op_mode = -1;
 bool op_exact() { return g_op_mode < 0 ? fl_default_exact() != 0 : g_op_mode != 0; }
+// The derived weight copies are built on first use by the operator-level entry points (fl_mul_mat_q takes a const tensor: the copies are
+// logically const).  The build allocates, launches on the caller's stream and synchronises it ONCE per tensor; the mutex makes a tensor
+// shared between host threads safe.  Callers that cannot take the one-time synchronisation (stream capture) build the copies first:
+// fl_qtensor_build_h16 / fl_qtensor_build_qwd, or fl_model_prepare for a model.
+static std::mutex g_lazy_mu;
 int ensure_h16(const fl_qtensor *W, fl_qact_impl *a, void *st) {
     if (!W->h16) {
-        const int rc = fl_qtensor_build_h16(const_cast<fl_qtensor *>(W), st);      // (a derived copy: logically const)
+        std::lock_guard<std::mutex> lk(g_lazy_mu);
+        const int rc = W->h16 ? FL_OK : fl_qtensor_build_h16(const_cast<fl_qtensor *>(W), st);      // (a derived copy: logically const)
         if (rc != FL_OK) return rc;
     }
     if (!a->h16_valid) {
@@ -80,6 +101,7 @@ extern "C" {
 
 const char *fl_version(void) { return "fastllama_hip 0.1 (gfx950)"; }
 const char *fl_last_error(void) { return g_err; }
+void fl_set_warn_handler(void (*cb)(const char *line)) { g_warn_cb = cb; }
 
 int fl_device_count(void) {
     int n = 0;
@@ -428,8 +450,9 @@ fl_qact *fl_qact_create(int max_N, int K) {
     hipError_t e = hipMalloc((void **)&a->q, a->q_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&a->d, a->s_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&a->s, a->s_bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&a->h16, xh16_bytes(a->cap_N16, K));
-    if (e == hipSuccess) e = hipMemset(a->h16, 0, xh16_bytes(a->cap_N16, K));
+    a->h16_bytes = xh16_bytes(a->cap_N16, K);
+    if (e == hipSuccess) e = hipMalloc((void **)&a->h16, a->h16_bytes);
+    if (e == hipSuccess) e = hipMemset(a->h16, 0, a->h16_bytes);
     if (e != hipSuccess) {
         hip_fail(e, "fl_qact_create");
         fl_qact_free(a);
@@ -453,6 +476,10 @@ int fl_quantize_q8_layout(fl_qact *a_, const float *x, int ldx, int N, int K, in
     if (K <= 0 || K % FL_QK != 0) return set_error(FL_EINVAL, "K=%d is not a positive multiple of 32", K);
     if (N <= 0 || (size_t)fl_roundup(N, 16) * (size_t)K > a->q_bytes)
         return set_error(FL_EINVAL, "N=%d K=%d exceeds the workspace (%zu bytes)", N, K, a->q_bytes);
+    // the XH16 copy holds WHOLE 32-column tiles: a workspace reused with a longer K and fewer columns can pass the q_bytes check and
+    // still be too small for it (created N = 64, K = 4096; reused N = 16, K = 11008)
+    if (layout == 16 && xh16_bytes(N, K) > a->h16_bytes)
+        return set_error(FL_EINVAL, "N=%d K=%d exceeds the workspace's XH16 copy (%zu bytes)", N, K, a->h16_bytes);
     if ((ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return set_error(FL_EINVAL, "x rows must be 16-byte aligned");
     if (layout != 1 && layout != 16) return set_error(FL_EINVAL, "layout must be 1 or 16");
     a->N = N;
@@ -531,7 +558,10 @@ int mul_mat_q_which(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy, i
         if (a->layout != 16) return set_error(FL_EINVAL, "gemm needs the QA16 layout");
         FL_HIP(gemm_q4_exact_valu(*W, *a, a->N, y, ldy, S(st)));
     } else if (which == 3) {               // reference-order kernels, whichever the layout says
-        if (a->layout == 1 && a->N == 1 && !W->qwd && (rc = fl_qtensor_build_qwd(const_cast<fl_qtensor *>(W), st)) != FL_OK) return rc;
+        if (a->layout == 1 && a->N == 1 && !W->qwd) {
+            std::lock_guard<std::mutex> lk(g_lazy_mu);
+            if (!W->qwd && (rc = fl_qtensor_build_qwd(const_cast<fl_qtensor *>(W), st)) != FL_OK) return rc;
+        }
         if (a->layout == 1) FL_HIP(gemv_q4_exact(*W, *a, a->N, y, ldy, S(st)));
         else FL_HIP(gemm_q4_exact(*W, *a, a->N, y, ldy, S(st)));
     } else if (which == 2) {
@@ -557,13 +587,13 @@ int fl_mul_mat_q_f32(const fl_qtensor *W, const float *x, int ldx, float *y, int
     if (!W || !x || !y) return set_error(FL_EINVAL, "null argument");
     if (N <= 0) return set_error(FL_EINVAL, "N=%d", N);
     if (ldx < W->K) return set_error(FL_EINVAL, "ldx=%d < K=%d", ldx, W->K);
-    const size_t need = (size_t)fl_roundup(N, 16) * W->K;
-    if (!g_ws || need > g_ws_elems) {
+    const size_t need = (size_t)fl_roundup(N, 32) * W->K;      // (whole 32-column tiles: the XH16 copy of the reference-order GEMM)
+    if (!g_ws || need > g_ws_elems || xh16_bytes(N, W->K) > static_cast<fl_qact_impl *>(g_ws)->h16_bytes) {
         if (g_ws) {
             (void)hipDeviceSynchronize();
             fl_qact_free(g_ws);
         }
-        g_ws = fl_qact_create(fl_roundup(N, 16), W->K);
+        g_ws = fl_qact_create(fl_roundup(N, 32), W->K);
         g_ws_elems = g_ws ? need : 0;
         if (!g_ws) return FL_ENOMEM;
     }
@@ -573,3 +603,13 @@ int fl_mul_mat_q_f32(const fl_qtensor *W, const float *x, int ldx, float *y, int
 }
 
 }  // extern "C"
+
+/* the one entry point of the test-hook library into this one (internal.h) */
+extern "C" const fl::InternalTable *fl_internal_table(void) {
+    static const fl::InternalTable t = {
+#define X(name) &fl::name,
+        FL_INTERNAL_FUNCS(X)
+#undef X
+        &fl::g_gemm_force_cfg, &fl::g_gemv_force_waves, &fl::g_op_mode};
+    return &t;
+}

@@ -617,8 +617,8 @@ __global__ __launch_bounds__(PA_T) void prefill_attention_kernel(const float *__
     PA_STAMP(6);
 }
 #ifdef PA_TIMING
-extern "C" int fl_debug_pa_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pa_dbg), sizeof(long long) * 64 * 8); }
-extern "C" int fl_debug_pd_timing(long long *out);
+extern "C" __attribute__((visibility("default"))) int fl_debug_pa_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pa_dbg), sizeof(long long) * 64 * 8); }
+extern "C" __attribute__((visibility("default"))) int fl_debug_pd_timing(long long *out);
 #endif
 
 #undef PA_SEL
@@ -963,7 +963,7 @@ __global__ __launch_bounds__(PD_T, 2) void prefill_attention_deep_kernel(const f
 }
 
 #ifdef PA_TIMING
-extern "C" int fl_debug_pd_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pd_dbg), sizeof(long long) * 64 * 8); }
+extern "C" __attribute__((visibility("default"))) int fl_debug_pd_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pd_dbg), sizeof(long long) * 64 * 8); }
 #endif
 hipError_t prefill_attention_deep(const float *qkv, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc,
                                   const float *vc, const uint16_t *exp_tab, int tab_n, float scale, float *scratch, int ld_s,
@@ -1417,7 +1417,7 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const int *__res
     DA_STAMP(6);
 }
 #ifdef PA_TIMING
-extern "C" int fl_debug_da_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(da_dbg), sizeof(long long) * 8); }
+extern "C" __attribute__((visibility("default"))) int fl_debug_da_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(da_dbg), sizeof(long long) * 8); }
 #endif
 
 hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab, float *kc,

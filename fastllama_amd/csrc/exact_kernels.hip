@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
     XA_STAMP(7);
 }
 #ifdef XA_TIMING
-extern "C" int fl_debug_xa_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(xa_dbg), sizeof(long long) * 1024 * 16); }
+extern "C" __attribute__((visibility("default"))) int fl_debug_xa_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(xa_dbg), sizeof(long long) * 1024 * 16); }
 #endif
 
 // hipErrorInvalidValue: shape outside these kernels' reach (head_dim not a multiple of 32 or > 128, unaligned rows): the caller

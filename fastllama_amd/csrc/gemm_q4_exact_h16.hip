@@ -606,5 +606,5 @@ hipError_t gemm_q4_exact_h16_silu(const fl_qtensor &W, const fl_qact &xq, int N,
 
 }  // namespace fl
 #ifdef XH_TIMING
-extern "C" int fl_debug_xh_timing(long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fl::xh_dbg), sizeof(long long) * (size_t)n * 8); }
+extern "C" __attribute__((visibility("default"))) int fl_debug_xh_timing(long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fl::xh_dbg), sizeof(long long) * (size_t)n * 8); }
 #endif

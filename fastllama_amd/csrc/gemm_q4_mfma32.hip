@@ -587,5 +587,5 @@ hipError_t gemm32_launch(int cfg, const fl_qtensor &W, const fl_qact &xq, int N,
 
 }  // namespace fl
 #ifdef G32_TIMING
-extern "C" int fl_debug_g32_timing(long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fl::g32_dbg), sizeof(long long) * (size_t)n * 8); }
+extern "C" __attribute__((visibility("default"))) int fl_debug_g32_timing(long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fl::g32_dbg), sizeof(long long) * (size_t)n * 8); }
 #endif

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64 * NK, (PAIR == 1 && QPW <= 8 && NK == 4) ? 3 : 1
     LLC_STAMP(5);
 }
 #ifdef LLC_TIMING
-extern "C" int fl_debug_llc_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(llc_dbg), sizeof(long long) * 2048 * 8); }
+extern "C" __attribute__((visibility("default"))) int fl_debug_llc_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(llc_dbg), sizeof(long long) * 2048 * 8); }
 #endif
 
 // false: no QWD copy, or a shape outside the kernel's reach (rows too long for the slices' registers, activation beyond LDS)

@@ -61,6 +61,10 @@ void def_log_err(const char *fn, int fl, const char *m, int ml) { fprintf(stderr
 void def_log_warn(const char *fn, int fl, const char *m, int ml) { printf("\x1b[93;1m[Warn]:\x1b[0m Func('%.*s') %.*s", fl, fn, ml, m); fflush(stdout); }
 void def_log_reset() { printf("\x1b[0m"); fflush(stdout); }
 void def_log_progress(progress_type_tag, size_t, size_t) {}
+// the operator library's warnings (a derived operand copy that did not fit: fl_set_warn_handler) go to the logger of the most recently
+// loaded session, as the reference's own warnings do
+Log g_warn_log;
+void forward_warning(const char *line) { g_warn_log.warn("fastllama_hip", std::string(line) + "\n"); }
 
 // ------------------------------------------------------------------------------------------------ vocabulary
 struct Vocab {
@@ -941,6 +945,8 @@ bool llama_load_model(struct llama_model_context *c, char const *filepath) {
     auto s = std::make_unique<Session>();
     s->args = c->args;
     s->log.cb = c->args.logger;
+    g_warn_log.cb = c->args.logger;
+    fl_set_warn_handler(forward_warning);
     s->seed = c->args.seed;
     s->keep = c->args.n_keep;
     s->rng = std::mt19937((uint32_t)c->args.seed);

@@ -432,7 +432,8 @@ int fl_model_finalize(fl_model *m) {
     if (m->tp_rows) {
         if ((rc = qact_alloc(m, &m->qFf, m->B, m->F)) != FL_OK) return rc;
         const size_t B16 = (size_t)fl_roundup(B, 16);
-        const size_t msg = B16 * (size_t)Fl + 2 * B16 * (size_t)(Fl / FL_QK) * 4;           // the largest Q8_0 message (operand of w2)
+        const size_t Km = (size_t)std::max(El, Fl);                                           // the larger Q8_0 message (operand of w2, or of wo when n_embd > n_ff)
+        const size_t msg = B16 * Km + 2 * B16 * (Km / FL_QK) * 4;
         const size_t all = std::max((size_t)m->G * msg, std::max((size_t)B * E * 4, (size_t)m->F * 4));
         if ((rc = dev_alloc(m, (void **)&m->ag_send, msg)) != FL_OK) return rc;
         if ((rc = dev_alloc(m, (void **)&m->ag_tmp, all)) != FL_OK) return rc;
@@ -552,14 +553,20 @@ static void ensure_h16(fl_model *m) {
     for (Layer &ly : m->layers) for (fl_qtensor *t : {ly.wqkv, ly.wo, ly.w13, ly.w2}) ts.push_back(t);
     ts.push_back(m->output);
     m->h16_state = 1;
+    size_t need = 0, built = 0;
+    for (fl_qtensor *t : ts) if (!t->h16) need += wh16_bytes(*t);
     for (fl_qtensor *t : ts) {
         if (t->h16) continue;
         if (fl_qtensor_build_h16(t, m->stream) != FL_OK) { m->h16_state = -1; break; }
         m->dev_bytes += wh16_bytes(*t);
+        built += wh16_bytes(*t);
     }
     if (m->h16_state < 0) {
         (void)hipGetLastError();
         for (fl_qtensor *t : ts) if (t->h16) { m->dev_bytes -= wh16_bytes(*t); fl_qtensor_drop_h16(t); }
+        // same bits, slower kernel: say so (no silent cliffs)
+        warn("no device memory for the f16 operand copies of the reference-order prefill GEMM (%.1f GB needed, %.1f GB fit): "
+             "prefill runs the nibble-operand kernel (gemm_q4_exact_mfma, same results, ~1.45x the time)", need / 1e9, built / 1e9);
     }
 }
 
@@ -571,14 +578,19 @@ static void ensure_qwd(fl_model *m) {
     for (Layer &ly : m->layers) for (fl_qtensor *t : {ly.wqkv, ly.wo, ly.w13, ly.w2}) ts.push_back(t);
     ts.push_back(m->output);
     m->qwd_state = 1;
+    size_t need = 0, built = 0;
+    for (fl_qtensor *t : ts) if (!t->qwd) need += qwd_bytes(*t);
     for (fl_qtensor *t : ts) {
         if (t->qwd) continue;
         if (fl_qtensor_build_qwd(t, m->stream) != FL_OK) { m->qwd_state = -1; break; }
         m->dev_bytes += qwd_bytes(*t);
+        built += qwd_bytes(*t);
     }
     if (m->qwd_state < 0) {
         (void)hipGetLastError();
         for (fl_qtensor *t : ts) if (t->qwd) { m->dev_bytes -= qwd_bytes(*t); fl_qtensor_drop_qwd(t); }
+        warn("no device memory for the decode copies of the weights (%.1f GB needed, %.1f GB fit): single-token evals run the "
+             "producer / chain-wave kernel on the primary layout (same results, ~1.3x the time)", need / 1e9, built / 1e9);
     }
 }
 
@@ -636,7 +648,10 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
     if (exact && N >= 9 && !dyn) ensure_h16(m);
     // reference-order prefill: the H16 form of the GEMM (gemm_q4_exact_h16.hip) with rope / K-V stores and silu * mul -> Q8_0 as its
     // epilogues; every Q8_0 operand gets its XH16 copy
-    const bool xh = exact && N >= 9 && !dyn && m->h16_state > 0 && m->qE.h16 && m->qEl.h16 && m->qF.h16 && !getenv("FL_EXACT_R3");
+    // (the fused launchers' own preconditions are part of the decision: a shape they refuse takes the unfused reference-order sequence)
+    const bool xh = exact && N >= 9 && !dyn && m->h16_state > 0 && m->qE.h16 && m->qEl.h16 && m->qF.h16 && !getenv("FL_EXACT_R3") &&
+                    D % 4 == 0 && El % 4 == 0 && l0 < m->L && gemm_q4_exact_h16_supports(*m->layers[l0].wqkv, m->qE, N) &&
+                    gemm_q4_exact_h16_supports(*m->layers[l0].w13, m->qE, N) && m->layers[l0].w13->M % 64 == 0;
     m->xh = xh;
     if (!body_only) M_HIP(get_rows_qw16(*m->tok_emb, m->tok_dev, N, m->x, E, st));      // inpL = get_rows  llama.cpp:304
     float *inp = m->x, *mid = m->x2;
@@ -1039,6 +1054,16 @@ int fl_model_set_exact(fl_model *m, int on) {
     return FL_OK;
 }
 int fl_model_get_exact(const fl_model *m) { return m && m->exact ? 1 : 0; }
+/* build the derived weight copies of the reference-order kernels now instead of inside the first eval that needs them (fastllama_hip.h) */
+int fl_model_prepare(fl_model *m, int flags) {
+    if (!m) return set_error(FL_EINVAL, "null model");
+    if (!m->finalized) return set_error(FL_EINVAL, "fl_model_prepare: model not finalized");
+    if (flags & 1) ensure_h16(m);
+    if (flags & 2) ensure_qwd(m);
+    M_HIP(hipStreamSynchronize(m->stream));
+    return FL_OK;
+}
+int fl_model_prepared(const fl_model *m) { return m ? (m->h16_state > 0 ? 1 : 0) | (m->qwd_state > 0 ? 2 : 0) : 0; }
 /* the mode new models start in: FL_FAST=1 (or FL_EXACT=0) in the environment selects the fast kernels, FL_EXACT=1 the reference
  * order; else the built-in default (reference order) */
 int fl_default_exact(void) {
@@ -1333,6 +1358,7 @@ void fl_model_free(fl_model *m) {
     }
     fr(m->kc); fr(m->vc); fr(m->exp_tab); fr(m->silu_tab); fr(m->rope_tab);
     fr(m->logits_part); fr(m->gather_tmp);
+    fr(m->qFf.q); fr(m->qFf.d); fr(m->qFf.s); fr(m->qFf.h16); fr(m->ag_send); fr(m->ag_tmp);      // (row-split tensor parallelism)
     {
         hipStream_t st0 = m->stream, st1 = m->alt.stream;
         act_free(*m);

@@ -10,6 +10,47 @@
 
 using namespace fl;
 
+// everything this library calls inside libfastllama_hip.so goes through the table of internal.h (the product library exports its C API only)
+static const fl::InternalTable *const IT = fl_internal_table();
+#define attn_pv_exact (IT->attn_pv_exact)
+#define attn_scores_exact (IT->attn_scores_exact)
+#define build_f16_tables (IT->build_f16_tables)
+#define build_rope_table (IT->build_rope_table)
+#define check_mm (IT->check_mm)
+#define decode_attention (IT->decode_attention)
+#define decode_attention_split (IT->decode_attention_split)
+#define dot_f32_abt_exact (IT->dot_f32_abt_exact)
+#define ensure_h16 (IT->ensure_h16)
+#define gemm32_mixed_split (IT->gemm32_mixed_split)
+#define gemm_f32_abt (IT->gemm_f32_abt)
+#define gemm_q4_exact_h16 (IT->gemm_q4_exact_h16)
+#define gemm_q4_exact_h16_qkv (IT->gemm_q4_exact_h16_qkv)
+#define gemm_q4_exact_h16_silu (IT->gemm_q4_exact_h16_silu)
+#define gemm_q4_mfma (IT->gemm_q4_mfma)
+#define gemm_q4_mfma_qkv (IT->gemm_q4_mfma_qkv)
+#define gemm_q4_mfma_silu (IT->gemm_q4_mfma_silu)
+#define gemv1_llc_pair_ws_bytes (IT->gemv1_llc_pair_ws_bytes)
+#define gemv_q4_norm (IT->gemv_q4_norm)
+#define gemv_q4_norm_exact (IT->gemv_q4_norm_exact)
+#define gemv_q4_norm_silu (IT->gemv_q4_norm_silu)
+#define gemv_q4_norm_silu_exact (IT->gemv_q4_norm_silu_exact)
+#define gemv_q4_quant (IT->gemv_q4_quant)
+#define gemv_q4_quant_exact (IT->gemv_q4_quant_exact)
+#define gemv_q4_silu (IT->gemv_q4_silu)
+#define gemv_q4_silu_exact (IT->gemv_q4_silu_exact)
+#define hip_fail (IT->hip_fail)
+#define mul_mat_q_which (IT->mul_mat_q_which)
+#define op_exact (IT->op_exact)
+#define prefill_attention (IT->prefill_attention)
+#define rmsnorm_quant (IT->rmsnorm_quant)
+#define rope_kv (IT->rope_kv)
+#define set_error (IT->set_error)
+#define silu_mul_quant (IT->silu_mul_quant)
+#define softmax_rows (IT->softmax_rows)
+#define g_gemm_force_cfg (*IT->g_gemm_force_cfg)
+#define g_gemv_force_waves (*IT->g_gemv_force_waves)
+#define g_op_mode (*IT->g_op_mode)
+
 #define FL_HIP(call)                                   \
     do {                                               \
         hipError_t e_ = (call);                        \
@@ -31,15 +72,15 @@ static int g_debug_exact = 0;      // fl_debug_set(2, 1): the single-token hooks
  * split into workgroups of 128 x 64 tiles (row groups [0, mg_split)) and of 128 x 32 tiles (the rest) */
 int fl_debug_gemm_mixed_split(int row_groups, int col_groups, int *n_a, int *mg_split, int *n_b) {
     if (row_groups < 1 || col_groups < 1 || !n_a || !mg_split || !n_b) return set_error(FL_EINVAL, "fl_debug_gemm_mixed_split: bad arguments");
-    fl::gemm32_mixed_split(row_groups, col_groups, n_a, mg_split, n_b);
+    gemm32_mixed_split(row_groups, col_groups, n_a, mg_split, n_b);
     return FL_OK;
 }
 int fl_debug_set(int what, int value) {
-    if (what == 0) fl::g_gemm_force_cfg = value;
-    if (what == 1) fl::g_gemv_force_waves = value;   // 0 = automatic, else 4 / 8 / 16 waves per 16-row group
+    if (what == 0) g_gemm_force_cfg = value;
+    if (what == 1) g_gemv_force_waves = value;   // 0 = automatic, else 4 / 8 / 16 waves per 16-row group
     if (what == 2) g_debug_exact = value;            // the single-token test hooks (fl_debug_gemv_*, fl_debug_decode_attention*) in exact mode
     if (what == 5) g_debug_pair1 = value;            // fl_debug_gemv_norm_silu in exact mode: 1 / 2 pins a form of the w1|w3 kernel, 0 automatic
-    if (what == 4) fl::g_op_mode = value;            // (= fl_set_op_mode: kept for the sweep scripts)
+    if (what == 4) g_op_mode = value;            // (= fl_set_op_mode: kept for the sweep scripts)
     return FL_OK;
 }
 
@@ -127,7 +168,7 @@ int fl_debug_rope_table(float *out_host, int n_ctx, int D) {     /* [n_ctx][D/2]
 
 int fl_debug_rmsnorm_quant(const float *x, int ldx, const float *w, int N, int E, float *y_f32, int ldy, fl_qact *out,
                            int layout, void *stream) {
-    M_HIP(rmsnorm_quant(x, ldx, w, N, E, y_f32, ldy, out, layout, (hipStream_t)stream));
+    M_HIP(rmsnorm_quant(x, ldx, w, N, E, y_f32, ldy, out, layout, (hipStream_t)stream, false));
     return FL_OK;
 }
 // (the reference-order single-token hooks run the kernel of record: it reads the tensor's QWD copy)
@@ -201,27 +242,27 @@ int fl_debug_decode_attention_split(const float *qkv, int E, int D, int H, int n
 }
 int fl_debug_silu_mul_quant(const float *h13, int ld, int N, int F, const uint16_t *silu_tab_dev, fl_qact *out, int layout,
                             void *stream) {
-    M_HIP(silu_mul_quant(h13, ld, N, F, silu_tab_dev, out, layout, (hipStream_t)stream, false));
+    M_HIP(silu_mul_quant(h13, ld, N, F, silu_tab_dev, out, layout, (hipStream_t)stream, false, false));
     return FL_OK;
 }
 int fl_debug_silu_mul_quant_woven(const float *h13, int ld, int N, int F, const uint16_t *silu_tab_dev, fl_qact *out, int layout,
                                   void *stream) {   /* h13 = [w1 x 16 | w3 x 16 | ...]: the woven w1|w3 matmul's output */
-    M_HIP(silu_mul_quant(h13, ld, N, F, silu_tab_dev, out, layout, (hipStream_t)stream, true));
+    M_HIP(silu_mul_quant(h13, ld, N, F, silu_tab_dev, out, layout, (hipStream_t)stream, true, false));
     return FL_OK;
 }
 int fl_debug_rope_kv(float *qkv, int ld, int N, int E, int D, int n_past, int n_ctx, const float *rope_tab_dev, float *kc,
                      float *vc, void *stream) {
-    M_HIP(rope_kv(qkv, ld, N, E, D, n_past, n_ctx, rope_tab_dev, kc, vc, (hipStream_t)stream));
+    M_HIP(rope_kv(qkv, ld, N, E, D, n_past, n_ctx, rope_tab_dev, kc, vc, (hipStream_t)stream, nullptr));
     return FL_OK;
 }
 int fl_debug_gemm_f32_abt(const float *A, int lda, long sAz, const float *B, int ldb, long sBz, float *Cc, int ldc, long sCz,
                           int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past, void *stream) {
-    M_HIP(gemm_f32_abt(A, lda, sAz, B, ldb, sBz, Cc, ldc, sCz, M, Nn, K, batch, alpha, causal_mode, n_past, (hipStream_t)stream));
+    M_HIP(gemm_f32_abt(A, lda, sAz, B, ldb, sBz, Cc, ldc, sCz, M, Nn, K, batch, alpha, causal_mode, n_past, (hipStream_t)stream, nullptr, 0));
     return FL_OK;
 }
 int fl_debug_gemm_f32_abt_exact(const float *A, int lda, long sAz, const float *B, int ldb, long sBz, float *Cc, int ldc, long sCz,
                                 int M, int Nn, int K, int batch, float alpha, int causal_mode, int n_past, void *stream) {
-    M_HIP(dot_f32_abt_exact(A, lda, sAz, B, ldb, sBz, Cc, ldc, sCz, M, Nn, K, batch, alpha, causal_mode, n_past, (hipStream_t)stream));
+    M_HIP(dot_f32_abt_exact(A, lda, sAz, B, ldb, sBz, Cc, ldc, sCz, M, Nn, K, batch, alpha, causal_mode, n_past, (hipStream_t)stream, nullptr, 0));
     return FL_OK;
 }
 /* test hook: exact-mode prefill attention on caller-provided buffers: scores (MFMA form when which = 1, one half-wave per dot when 0)
@@ -231,15 +272,15 @@ int fl_debug_attn_exact(const float *qkv, int ldq, int D, int H, int N, int n_pa
     hipStream_t st = (hipStream_t)stream;
     const int P = n_past + N;
     if (which) M_HIP(attn_scores_exact(qkv, ldq, D, H, N, n_past, kc, E, scale, att, n_ctx, (int64_t)N * n_ctx, st));
-    else M_HIP(dot_f32_abt_exact(qkv, ldq, D, kc, E, D, att, n_ctx, (int64_t)N * n_ctx, N, P, D, H, scale, 1, n_past, st));
-    M_HIP(softmax_rows(att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, H, exp_tab_dev, st));
-    if (which) M_HIP(attn_pv_exact(att, n_ctx, (int64_t)N * n_ctx, D, H, N, n_past, vc, n_ctx, ao, E, st));
-    else M_HIP(dot_f32_abt_exact(att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, ao, E, D, N, D, P, H, 1.0f, 2, n_past, st));
+    else M_HIP(dot_f32_abt_exact(qkv, ldq, D, kc, E, D, att, n_ctx, (int64_t)N * n_ctx, N, P, D, H, scale, 1, n_past, st, nullptr, 0));
+    M_HIP(softmax_rows(att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, H, exp_tab_dev, st, nullptr));
+    if (which) M_HIP(attn_pv_exact(att, n_ctx, (int64_t)N * n_ctx, D, H, N, n_past, vc, n_ctx, ao, E, st, nullptr, false));
+    else M_HIP(dot_f32_abt_exact(att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, ao, E, D, N, D, P, H, 1.0f, 2, n_past, st, nullptr, 0));
     return FL_OK;
 }
 int fl_debug_softmax_rows(float *S, int ld, long sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab_dev,
                           void *stream) {
-    M_HIP(softmax_rows(S, ld, sz, N, P, n_past, batch, exp_tab_dev, (hipStream_t)stream));
+    M_HIP(softmax_rows(S, ld, sz, N, P, n_past, batch, exp_tab_dev, (hipStream_t)stream, nullptr));
     return FL_OK;
 }
 

@@ -47,6 +47,7 @@ _PROTOS = {
     "fl_device_count": (C.c_int, []),
     "fl_init": (C.c_int, [C.c_int]),
     "fl_last_error": (C.c_char_p, []),
+    "fl_set_warn_handler": (None, [C.c_void_p]),
     "fl_device_name": (C.c_int, [C.c_char_p, C.c_size_t]),
     "fl_version": (C.c_char_p, []),
     "fl_malloc": (C.c_void_p, [C.c_size_t]),
@@ -151,6 +152,8 @@ _PROTOS = {
     "fl_model_set_exact": (C.c_int, [C.c_void_p, C.c_int]),
     "fl_model_get_exact": (C.c_int, [C.c_void_p]),
     "fl_default_exact": (C.c_int, []),
+    "fl_model_prepare": (C.c_int, [C.c_void_p, C.c_int]),
+    "fl_model_prepared": (C.c_int, [C.c_void_p]),
     "fl_set_op_mode": (C.c_int, [C.c_int]),
     "fl_debug_attn_exact": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -40,6 +40,17 @@ class FlModel:
         """reference-order matmuls (logits bit-identical to the reference) / the fast kernels"""
         hip.check(self.L.fl_model_set_exact(self.h, 1 if on else 0), "fl_model_set_exact")
 
+    def prepare(self, flags: int = 3) -> int:
+        """build the derived weight copies of the reference-order kernels now (bit 0: WH16, prefill; bit 1: QWD, decode) instead of
+        inside the first eval that needs them; returns which are resident (fl_model_prepared)"""
+        hip.check(self.L.fl_model_prepare(self.h, flags), "fl_model_prepare")
+        return self.L.fl_model_prepared(self.h)
+
+    def eval_last_logits(self, toks_i32: np.ndarray, n_past: int, out: np.ndarray):
+        """eval that hands the LAST token's logits back to the host (what llama_eval() callers get): the bench's timed call."""
+        hip.check(self.L.fl_model_eval(self.h, toks_i32.ctypes.data_as(C.c_void_p), toks_i32.size, n_past,
+                                       out.ctypes.data_as(C.c_void_p), 0, None), "fl_model_eval")
+
     def set_comm(self, comm):
         hip.check(self.L.fl_model_set_comm(self.h, comm), "fl_model_set_comm")
 

@@ -22,6 +22,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: these declarations ARE its export list */
 
 /* reference: `enum progress_type_tag : uint8_t`, fastllama.h:12-20 (passed as one byte) */
 typedef uint8_t progress_type_tag;
@@ -95,6 +96,7 @@ bool llama_reset_model(struct llama_model_context *ctx);                        
 void llama_free_context(struct llama_model_context *ctx);                                /* fastllama.h:218 */
 void llama_handle_signal(int);                        /* exported but undeclared in the reference, c/main.cpp:229 */
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: these declarations ARE its export list */
 
 #define FL_OK 0
 #define FL_EINVAL (-1)  /* bad argument (shape, alignment, type)                        */
@@ -43,6 +44,9 @@ extern "C" {
 int fl_device_count(void);
 int fl_init(int device);                 /* hipSetDevice + sanity check that the device is gfx950 */
 const char *fl_last_error(void);
+/* Warnings -- events that are not errors but that a caller should hear about (a derived operand copy that did not fit in device memory and the
+ * slower kernel family that runs instead): one line each to `cb`; NULL (the default) prints them to stderr. */
+void fl_set_warn_handler(void (*cb)(const char *line));
 int fl_device_name(char *buf, size_t n);
 const char *fl_version(void);
 
@@ -224,6 +228,13 @@ int fl_model_set_graph(fl_model *m, int mode); /* bit0: hipGraph replay for deco
 int fl_model_set_exact(fl_model *m, int on);
 int fl_model_get_exact(const fl_model *m);
 int fl_default_exact(void); /* the mode new models start in: environment FL_EXACT=1|0, else the library default */
+/* The reference-order kernels read derived copies of the weights (q4_layout.h): WH16 for evals with N >= 9 (4 x the nibble bytes: 13 GB at 7B,
+ * 130 GB at 65B) and QWD for single-token evals (1 x).  By default they are built inside the first eval that needs them; fl_model_prepare
+ * builds them NOW (flags bit 0: WH16, bit 1: QWD), so that no timed or latency-sensitive eval pays for it.  Returns FL_OK also when a copy does
+ * not fit: the warning handler is told how many bytes were missing and the kernel family that reads the primary layout runs instead (same bits,
+ * ~1.3-1.45 x the time).  fl_model_prepared: which copies are resident (same bits; a negative state = tried and dropped reads as 0). */
+int fl_model_prepare(fl_model *m, int flags);
+int fl_model_prepared(const fl_model *m);
 /* LoRA on the resident Q4 weights -- replaces Model::attach_lora / detach_lora (lib/llama.cpp:697-944) and its
  * ggml_compute_forward_add_q_f32 (lib/ggml.c:6414-6520): W <- quantize_row_q(dequantize_row_q(W) + sign * BA), with the
  * reference's SIMD quantizer arithmetic.  base_name is the base tensor ("layers.3.attention.wq.weight"); pass either
@@ -258,6 +269,7 @@ int fl_set_op_mode(int mode);
 /* fl_quantize_q8 with the workspace layout chosen by the caller (16 = QA16, the GEMM's; 1 = QA1, the GEMV's) instead of by N */
 int fl_quantize_q8_layout(fl_qact *a, const float *x_dev, int ldx, int N, int K, int layout, void *stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

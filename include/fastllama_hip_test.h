@@ -9,6 +9,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)
 
 /* test hooks: the individual non-matmul eval kernels (fastllama_amd/csrc/eval_kernels.hip) and their tables */
 int fl_debug_tables(uint16_t *exp_host, uint16_t *silu_host);
@@ -67,6 +68,7 @@ int fl_debug_qact_layout(const fl_qact *a); /* 16 = QA16, 1 = QA1 */
 int fl_debug_gemm_mixed_split(int row_groups, int col_groups, int *n_a, int *mg_split, int *n_b);  /* host logic of the two-tile-shape launch */
 int fl_debug_set(int what, int value);      /* what 0: force GEMM tile configuration id (-1 = automatic); 1: GEMV waves per row group (0 = automatic); 2: the single-token hooks run the reference-order kernels; 4: = fl_set_op_mode; 5: the form of the reference-order w1|w3 kernel fl_debug_gemv_norm_silu runs (1 / 2, 0 automatic) */
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

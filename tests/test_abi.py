@@ -49,6 +49,19 @@ def test_test_hooks_live_in_their_own_library(lib):
     assert "libfastllama_hip.so" in needed
 
 
+def test_product_library_exports_its_c_api_and_nothing_else(lib):
+    """-fvisibility=hidden + fastllama_amd/csrc/exports.map: the dynamic symbol table holds the 17 llama_* symbols, the fl_* API and
+    fl_internal_table (the hook library's one way in) -- no C++ launcher, no kernel handle."""
+    out = subprocess.run(["nm", "-D", "--defined-only", LIB], capture_output=True, text=True, check=True).stdout
+    syms = [l.split()[-1] for l in out.splitlines() if len(l.split()) >= 3 and l.split()[-2] in "TDBVWRi"]
+    stray = [s for s in syms if not (s.startswith("llama_") or s.startswith("fl_"))]
+    assert not stray, stray[:10]
+    assert sum(s.startswith("llama_") for s in syms) == 17
+    assert "fl_internal_table" in syms and "fl_model_prepare" in syms and "fl_set_warn_handler" in syms
+    und = subprocess.run(["nm", "-D", "--undefined-only", HOOKS], capture_output=True, text=True, check=True).stdout
+    assert "_ZN2fl" not in und, "the hook library must reach the product library through fl_internal_table only"
+
+
 def test_primary_llama_abi_symbols_exported(lib):
     """include/fastllama.h = the reference's interfaces/c/fastllama.h: all 17 llama_* symbols are exported."""
     names = _declared("fastllama.h", "llama_")
