@@ -222,7 +222,7 @@ def main():
     qtype = synth.Q4_0 if args.qtype == "q4_0" else synth.Q4_1
     cfg = dict(synth.MODELS[args.model])
     N = args.n_batch
-    n_ctx = max(args.n_ctx, 1024, 2 * N)
+    n_ctx = max(args.n_ctx, 2048, 2 * N)      # (2048: the deep-context legs -- prefill at n_past 1536, decode at the end of the context)
     L = hip.load()
     hip.require_device(local)
     # development: FL_BENCH_P2P_ONLY=1 builds the tensor-parallel communicator from the peer exchange alone (no RCCL), which lets
@@ -337,8 +337,10 @@ def main():
             """prefill + decode (+ roofline legs when `full`) of `model` in `mode`"""
             model.set_exact(mode == "exact")
             m = {}
-            prefill = lambda i: model.eval_nocopy(toks, 0)
-            dec = lambda i: model.eval_nocopy(tok1, min(128, N) + i)
+            # what a llama_eval() caller gets: token ids in, the LAST token's logits back on the host -- inside the timed region
+            lg_host = np.empty(cfg["n_vocab"], dtype=np.float32)
+            prefill = lambda i: model.eval_last_logits(toks, 0, lg_host)
+            dec = lambda i: model.eval_last_logits(tok1, min(128, N) + i, lg_host)
             nst = steps if mode == "exact" or short else max(2, steps // 2)
             # ---- prefill: K timed evals after W warm-ups (the first exact eval also builds the f16 fragment copies of the weights)
             for i in range(max(1, args.warmup)):
@@ -351,8 +353,33 @@ def main():
                 dec(i)
             m["decode_ms"] = timed(dec, dsteps) / dsteps * 1e3
             m["decode_tokens_per_s"] = seqs / (m["decode_ms"] * 1e-3)
+            # the same steps with the logits left in HBM (no host round trip per token): what the kernels alone sustain
+            dec_nc = lambda i: model.eval_nocopy(tok1, min(128, N) + i)
+            m["decode_ms_device_resident"] = timed(dec_nc, dsteps) / dsteps * 1e3
+            # ---- decode at the end of the context (p ~ n_ctx - 1; the K/V stream of n_past positions per layer, split attention)
+            lsteps_ = min(32 if not short else 12, args.decode_steps)
+            m["long_past"] = n_ctx - lsteps_ - 4
+            decl = lambda i: model.eval_last_logits(tok1, m["long_past"] + i, lg_host)
+            for i in range(3):
+                decl(i)
+            m["decode_long_ms"] = timed(decl, lsteps_) / lsteps_ * 1e3
             if not full:
                 return m
+            # ---- a later chunk of a long prompt: the same N tokens behind n_ctx - N cached positions (the reference-order attention over
+            #      1536 .. 2047 keys: the piece-by-piece V.P loop; positions beyond the first eval hold zeros: fine for timing)
+            deep_past = n_ctx - N
+            if deep_past >= N:
+                deep = lambda i: model.eval_last_logits(toks, deep_past, lg_host)
+                deep(0)
+                dsteps_ = max(2, nst // 2)
+                dtd = timed(deep, dsteps_)
+                m["prefill_deep"] = {"n_past": deep_past, "ms_per_step": dtd / dsteps_ * 1e3, "tokens_per_s": N * seqs / (dtd / dsteps_)}
+            # ---- decode in the middle of the context (round 4's long-context point, n_past 988)
+            if n_ctx >= 1100:
+                decm = lambda i: model.eval_last_logits(tok1, 988 + i, lg_host)
+                for i in range(3):
+                    decm(i)
+                m["decode_988_ms"] = timed(decm, 24) / 24 * 1e3
             # ---- roofline of the dominant kernels: HIP events around every matmul launch on the eval stream
             gemm, gemv = KERNELS[mode]
             model.profile(1)
@@ -391,13 +418,19 @@ def main():
             for i in range(8):
                 dec(i)
             mm1_ms, n1 = model.profile(0)
-            gbs = wk1["bytes"] / shard * 8 / (mm1_ms * 1e-3) / 1e9
+            gbs_ev = wk1["bytes"] / shard * 8 / (mm1_ms * 1e-3) / 1e9
+            # achieved = ALGORITHMIC bytes of a token / the graph-replayed time per token with the logits left in HBM (every kernel of the
+            # token, attention included: plain event-bracketed launches are SLOWER than the replayed graph they would be compared with)
+            gbs = wk1["bytes"] / shard / (m["decode_ms_device_resident"] * 1e-3) / 1e9
             traffic1, tsrc1 = pmc_traffic(gemv, tp)
             m["roofline_decode"] = {
                 "kernel": "%s<Q4_%d,...>" % (gemv, qtype - 2), "bound": "hbm",
                 "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                "timing": "hipGraph replay of the whole token (logits left in HBM), all kernels",
+                "event_timed_plain_launches": {"achieved": gbs_ev, "frac": gbs_ev / PEAK_HBM_GBS, "avg_launch_us": mm1_ms * 1e3 / max(1, n1),
+                                               "note": "HIP events around every matmul launch outside the graph: matmul kernels only, each paying a plain launch"},
                 "traffic": traffic1, "traffic_source": tsrc1,
-                "launches_per_step": n1 // 8, "avg_launch_us": mm1_ms * 1e3 / max(1, n1),
+                "launches_per_step": n1 // 8,
                 "algorithmic_bytes_per_launch": wk1["bytes"] / shard / (n1 / 8),
             }
             return m
@@ -405,13 +438,8 @@ def main():
         model, comm = make_model("exact")
         r["exact"] = time_mode(model, "exact", not short)
         if not short:
-            # ---- decode at the end of the context (K/V stream of n_past positions per layer; two-launch attention)
-            long_steps = min(32, args.decode_steps)
-            r["long_past"] = n_ctx - long_steps - 4
-            decl = lambda i: model.eval_nocopy(tok1, r["long_past"] + i)
-            for i in range(3):
-                decl(i)
-            r["decode_long_ms"] = timed(decl, long_steps) / long_steps * 1e3
+            r["long_past"] = r["exact"]["long_past"]
+            r["decode_long_ms"] = r["exact"]["decode_long_ms"]
             r["model_device_bytes"] = hip.load().fl_model_device_bytes(model.h)
             # ---- a prompt longer than n_batch: the session's ingest loop evaluates it n_batch tokens at a time; fl_model_ingest keeps
             #      two of those evals in flight (same results).  Reported beside the headline, which stays the single n_batch eval.
@@ -441,10 +469,12 @@ def main():
         x = leg["exact"]
         o = {"config": name, "prefill_tokens_per_s": x["prefill_tokens_per_s"], "ms_per_step": x["ms_per_step"],
              "decode_tokens_per_s": x["decode_tokens_per_s"],
+             "decode_long_context": {"n_past": x["long_past"], "tokens_per_s": leg["seqs"] / (x["decode_long_ms"] * 1e-3), "ms_per_token": x["decode_long_ms"]},
              "hbm_roofline_frac": {"prefill": t_hbm / x["ms_per_step"], "decode": t_hbm1 / x["decode_ms"]}}
         if "fast" in leg:
             f = leg["fast"]
             o["fast_mode"] = {"prefill_tokens_per_s": f["prefill_tokens_per_s"], "decode_tokens_per_s": f["decode_tokens_per_s"],
+                              "decode_long_context_tokens_per_s": leg["seqs"] / (f["decode_long_ms"] * 1e-3),
                               "hbm_roofline_frac": {"prefill": t_hbm / f["ms_per_step"], "decode": t_hbm1 / f["decode_ms"]}}
         return o
 
@@ -478,6 +508,9 @@ def main():
                           "integer block dots, per-block f32 terms added in the kernels' own order (1e-7 per matmul; ~1e-2 on 7B logits after 32 layers)"),
             "prefill_tokens_per_s": head["prefill_tokens_per_s"],
             "decode_tokens_per_s": head["decode_tokens_per_s"], "decode_ms_per_token": head["decode_ms"],
+            "decode_device_resident": {"tokens_per_s": leg["seqs"] / (head["decode_ms_device_resident"] * 1e-3), "ms_per_token": head["decode_ms_device_resident"],
+                                       "note": "the same steps with the logits left in HBM (no host round trip per token)"},
+            "timed_region": "token ids in (host), the last token's logits back on the host, per eval: prefill and decode alike",
             "decode_long_context": {"n_past": leg["long_past"], "tokens_per_s": leg["seqs"] / (leg["decode_long_ms"] * 1e-3),
                                     "ms_per_token": leg["decode_long_ms"]},
             "hbm_roofline": {"peak_GBs": PEAK_HBM_GBS,
@@ -486,6 +519,8 @@ def main():
                              "decode": {"algorithmic_bytes_per_token": wk1["bytes"] / shard, "t_hbm_ms": t_hbm_decode_ms,
                                         "frac": t_hbm_decode_ms / head["decode_ms"]},
                              "note": "whole-step fractions (every kernel of the eval, not only the matmuls); BASELINE.json's target is 0.40 for prefill"},
+            "prefill_deep_context": head.get("prefill_deep"),
+            "decode_n_past_988": ({"tokens_per_s": leg["seqs"] / (head["decode_988_ms"] * 1e-3), "ms_per_token": head["decode_988_ms"]} if "decode_988_ms" in head else None),
             "prefill_long_prompt": leg.get("long_prompt"),
             "roofline": head["roofline"], "roofline_decode": head["roofline_decode"],
             "model_device_bytes": leg["model_device_bytes"],
@@ -497,7 +532,7 @@ def main():
             out["fast_mode"] = {"prefill_tokens_per_s": f["prefill_tokens_per_s"], "ms_per_step": f["ms_per_step"],
                                 "decode_tokens_per_s": f["decode_tokens_per_s"], "decode_ms_per_token": f["decode_ms"],
                                 "hbm_roofline_frac": {"prefill": t_hbm_prefill_ms / f["ms_per_step"], "decode": t_hbm_decode_ms / f["decode_ms"]},
-                                "roofline": f["roofline"], "roofline_decode": f["roofline_decode"],
+                                "roofline": f["roofline"], "roofline_decode": f["roofline_decode"], "prefill_deep_context": f.get("prefill_deep"),
                                 "parity": "logits ~1e-2 from the reference on this configuration (profiles/r03_parity_7b.json): opt-in, not the contract"}
             if tp:
                 out["fast_mode"]["parallelism"] = f"tp{world}: wo / w2 by K blocks, 2 RCCL all-reduces of the [N, n_embd] partial sums per layer"

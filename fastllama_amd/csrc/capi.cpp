@@ -233,7 +233,8 @@ fl_qtensor *fl_qtensor_from_device(int type, const void *blocks_dev, int M, int 
         return nullptr;
     }
     if (bad) {
-        set_error(FL_EINVAL, "Q4_0 block scale below 2^-122: d/16 would be subnormal (not a valid model)");
+        set_error(FL_EINVAL, (bad & 2) ? "non-finite block scale (not a valid model)"
+                                       : "Q4_0 block scale below 2^-122: d/16 would be subnormal (not a valid model)");
         fl_qtensor_free(W);
         return nullptr;
     }

@@ -1157,8 +1157,29 @@ hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, 
 #ifdef PA_TIMING
 __device__ long long da_dbg[8];
 #define DA_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) da_dbg[k] = wall_clock64(); } while (0)
+#define DA_COMMIT() do {} while (0)
+#elif defined(LLC_TIMING)   // every workgroup of every launch since the last reset, on the wall clock the GEMV ring uses (scripts/dev/decode_timeline.py)
+constexpr unsigned DA_TL_CAP = 1u << 14;
+__device__ long long da_tl[DA_TL_CAP * 8];
+__device__ unsigned da_tl_cur;
+#define DA_T_DECL long long tl_[7] = {0, 0, 0, 0, 0, 0, 0}
+#define DA_STAMP(k) do { tl_[k] = wall_clock64(); } while (0)
+#define DA_COMMIT()                                                                            \
+    do {                                                                                       \
+        if (threadIdx.x == 0) {                                                                \
+            const unsigned s_ = atomicAdd(&da_tl_cur, 1u);                                     \
+            if (s_ < DA_TL_CAP) {                                                              \
+                for (int k_ = 0; k_ < 7; ++k_) da_tl[(size_t)s_ * 8 + k_] = tl_[k_];           \
+                da_tl[(size_t)s_ * 8 + 7] = (900ll << 32) | blockIdx.x;                        \
+            }                                                                                  \
+        }                                                                                      \
+    } while (0)
 #else
 #define DA_STAMP(k) do {} while (0)
+#define DA_COMMIT() do {} while (0)
+#endif
+#ifndef DA_T_DECL
+#define DA_T_DECL do {} while (0)
 #endif
 // Dots of the decode attention: 8 lanes per row, lane l8 holds the float4 pieces at element offsets 32 j + 4 l8 (+ c).
 // ORD = 0: the fast order -- one accumulator per lane, pieces ascending, group8_sum_f32.
@@ -1236,6 +1257,7 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const int *__res
                                                                 int8_t *__restrict__ oq, float *__restrict__ od,
                                                                 float *__restrict__ os) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    DA_T_DECL;
     DA_STAMP(0);
     if (dyn_past) n_past = *dyn_past;
     const int h = blockIdx.x, tid = threadIdx.x, pos = n_past, P = n_past + 1;
@@ -1415,7 +1437,20 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const int *__res
         quantize_store_group(o8, 0, (h * D >> 3) + tid, E >> 5, 1, oq, od, os);
     }
     DA_STAMP(6);
+    DA_COMMIT();
 }
+#if defined(LLC_TIMING) && !defined(PA_TIMING)
+// stamps: t0 entry, t1 requests issued, t2 rope + K/V stores, t3 scores + max, t4 soft_max, t5 K.Q.V, t6 Q8_0 stored
+extern "C" __attribute__((visibility("default"))) int fl_debug_da_timeline(long long *out, int max_rec, int reset) {
+    unsigned n = 0;
+    if (reset) return (int)hipMemcpyToSymbol(HIP_SYMBOL(da_tl_cur), &n, sizeof n);
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(da_tl_cur), sizeof n) != hipSuccess) return -1;
+    if (n > DA_TL_CAP) n = DA_TL_CAP;
+    if ((int)n > max_rec) n = (unsigned)max_rec;
+    if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(da_tl), sizeof(long long) * 8 * (size_t)n) != hipSuccess) return -1;
+    return (int)n;
+}
+#endif
 #ifdef PA_TIMING
 extern "C" __attribute__((visibility("default"))) int fl_debug_da_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(da_dbg), sizeof(long long) * 8); }
 #endif

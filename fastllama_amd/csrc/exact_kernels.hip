@@ -852,13 +852,21 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
     // whole wave on 8 banks: 4-way conflicts on 64 stores per thread and block).
     const int s_rr = lane >> 3, s_kk = lane & 7;
     // (k0: first key of the piece -- 0 when the context is one piece)
-    auto wide_load = [&](float4 (&v)[16], const float *src, int row_stride, int rows_valid, int kt, int k0 = 0) {
+    // Buffer loads (round 5): the wave-uniform part of the address (the piece's first key) travels in the scalar offset, the lane's part is
+    // one 32-bit register per load, and bytes past the tile's rows read as zero (descriptor bounds; keys past the row's end are the next
+    // row's -- every such value is dropped or zeroed by wide_store).  As flat loads the sixteen 64-bit addresses of a tile lived in
+    // registers (or, with a second tile in flight, in scratch memory).
+    auto tile_rsrc = [&](const float *base, int rows, int row_stride) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)((unsigned)rows * (unsigned)row_stride * 4u), 0x00020000);
+    };
+    auto wide_load = [&](float4 (&v)[16], __amdgpu_buffer_rsrc_t rs, int row_stride, int rows_valid, int k0 = 0) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int row = 8 * (u & 3) + s_rr, col = 32 * (4 * wave + (u >> 2)) + 4 * s_kk;
-            // (a piece past the context: a cache-hot address, never stored)
-            const unsigned off = (unsigned)min(row, rows_valid - 1) * (unsigned)row_stride + (unsigned)max(0, min(k0 + min(col, kt - 4), n_ctx - 4));
-            v[u] = *reinterpret_cast<const float4 *>(src + off);
+            const int voff = (min(row, rows_valid - 1) * row_stride + col) * 4;
+            typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
+            const v4u_ r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, k0 * 4, 0);
+            v[u] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
         }
     };
     auto wide_store = [&](float *dst, const float4 (&v)[16], int rows_valid, int kt, int k0 = 0) {
@@ -878,12 +886,14 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
     auto chunk_len = [&](int c) { return min(XA_KT, ((nbody - c * XA_KT) + 63) & ~63); };   // zero padded to whole MFMA pairs
     const int rows_q = min(32, N - q0);
     constexpr bool one_piece = ONE;                          // short contexts: P staged once, V blocks requested one ahead
+    const __amdgpu_buffer_rsrc_t rsP = tile_rsrc(prow + (int64_t)q0 * ld_att, rows_q, ld_att);
     float4 vnext[16];
+    float4 pnext[ONE ? 1 : 16];                              // (multi-piece form: the next piece's probabilities in flight)
     XA_STAMP(0);
     if constexpr (one_piece) {
         float4 pfirst[16];
-        wide_load(pfirst, prow + (int64_t)q0 * ld_att, ld_att, rows_q, chunk_len(0));
-        wide_load(vnext, vc + (int64_t)(hd * D) * n_ctx, n_ctx, 32, chunk_len(0));
+        wide_load(pfirst, rsP, ld_att, rows_q);
+        wide_load(vnext, tile_rsrc(vc + (int64_t)(hd * D) * n_ctx, 32, n_ctx), n_ctx, 32);
         wide_store(Ps, pfirst, rows_q, chunk_len(0));
         wide_store(Vs, vnext, 32, chunk_len(0));
     }
@@ -924,7 +934,7 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
             // two register files per feature block (profiles/r04_attn_exact.md)
             lds_barrier();                                    // P, V staged / the previous block is done with Ps, Vs and Ts
             const int kt = chunk_len(0);
-            if (d0 + 32 < D) wide_load(vnext, vc + (int64_t)(hd * D + d0 + 32) * n_ctx, n_ctx, 32, kt);
+            if (d0 + 32 < D) wide_load(vnext, tile_rsrc(vc + (int64_t)(hd * D + d0 + 32) * n_ctx, 32, n_ctx), n_ctx, 32);
             v16f v0;
 #pragma unroll
             for (int li = 0; li < 2; ++li) {
@@ -939,18 +949,28 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
                 if (li == 0) asm volatile("" : "+v"(v0));     // (folded before the second partial sum's MFMAs are issued)
             }
         } else {
+            // Software pipeline over the 512-key pieces (round 5): the NEXT piece's P and V tiles are requested right after this piece's tiles
+            // have been stored to LDS and travel under this piece's MFMA chains (~4000 cycles); round 4 requested a piece behind the barrier that
+            // ended the previous one and waited out the round trip every time (90 us per layer at 1024-2048 keys).  The 32 float4 in flight sit
+            // next to the 128 accumulator registers: a wave alone on its SIMD (one workgroup per CU) has the unified 512-register file.
             v16f tl[2][4] = {{{}, {}, {}, {}}, {{}, {}, {}, {}}};
+            if (d0 == 0) {                                    // (later feature blocks: requested during the previous block's last chains)
+                wide_load(pnext, rsP, ld_att, rows_q, 0);
+                wide_load(vnext, tile_rsrc(vc + (int64_t)(hd * D) * n_ctx, 32, n_ctx), n_ctx, 32, 0);
+            }
             for (int c = 0; c < nchunk; ++c) {
                 const int k0 = c * XA_KT, kt = chunk_len(c);
                 lds_barrier();                                // the previous piece is done with Ps, Vs and Ts
-                {   // both tiles of the piece: all 32 loads in flight, then the (bank-conflict free) stores
-                    float4 pp[16], vv[16];
-                    wide_load(pp, prow + (int64_t)q0 * ld_att, ld_att, rows_q, kt, k0);
-                    wide_load(vv, vc + (int64_t)(hd * D + d0) * n_ctx, n_ctx, 32, kt, k0);
-                    wide_store(Ps, pp, rows_q, kt, k0);
-                    wide_store(Vs, vv, 32, kt, k0);
+                wide_store(Ps, pnext, rows_q, kt, k0);
+                wide_store(Vs, vnext, 32, kt, k0);
+                lds_barrier();
+                if (c + 1 < nchunk) {
+                    wide_load(pnext, rsP, ld_att, rows_q, k0 + XA_KT);
+                    wide_load(vnext, tile_rsrc(vc + (int64_t)(hd * D + d0) * n_ctx, 32, n_ctx), n_ctx, 32, k0 + XA_KT);
+                } else if (d0 + 32 < D) {
+                    wide_load(pnext, rsP, ld_att, rows_q, 0);
+                    wide_load(vnext, tile_rsrc(vc + (int64_t)(hd * D + d0 + 32) * n_ctx, 32, n_ctx), n_ctx, 32, 0);
                 }
-                lds_barrier();   
                 const int cend = min(nbody, k0 + XA_KT);
                 chain(tl[0], wave, k0, cend);
                 chain(tl[1], wave + 4, k0, cend);

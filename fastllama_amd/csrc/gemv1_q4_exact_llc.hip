@@ -31,6 +31,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <cstdlib>
+#include <algorithm>
 #include "q4_device.h"
 #include "q4_kernels.h"
 #include <type_traits>
@@ -87,16 +89,34 @@ __device__ __forceinline__ float quad_bcast(float v) {
     return dpp_f32<SRC | (SRC << 2) | (SRC << 4) | (SRC << 6)>(v);
 }
 
-#ifdef LLC_TIMING   // development build only: per-workgroup clocks of a launch (scripts/dev/llc_timeline.py)
-__device__ long long llc_dbg[2048 * 8];
-#define LLC_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) llc_dbg[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#ifdef LLC_TIMING   // development build only: per-workgroup clocks of EVERY launch since the last reset, in one ring (scripts/dev/decode_timeline.py):
+                    // the 100 MHz wall clock is common to all launches, so the records of a token's kernels line up on one time axis
+constexpr unsigned LLC_TL_CAP = 1u << 17;
+__device__ long long llc_tl[LLC_TL_CAP * 8];
+__device__ unsigned llc_tl_cur;
+#define LLC_T_DECL long long tl_[7] = {0, 0, 0, 0, 0, 0, 0}
+#define LLC_STAMP(k) do { tl_[k] = wall_clock64(); } while (0)
+#define LLC_COMMIT(kid)                                                                        \
+    do {                                                                                       \
+        if (threadIdx.x == 0) {                                                                \
+            const unsigned s_ = atomicAdd(&llc_tl_cur, 1u);                                    \
+            if (s_ < LLC_TL_CAP) {                                                             \
+                for (int k_ = 0; k_ < 7; ++k_) llc_tl[(size_t)s_ * 8 + k_] = tl_[k_];          \
+                llc_tl[(size_t)s_ * 8 + 7] = ((long long)(kid) << 32) | blockIdx.x;            \
+            }                                                                                  \
+        }                                                                                      \
+    } while (0)
 #else
+#define LLC_T_DECL do {} while (0)
 #define LLC_STAMP(k) do {} while (0)
+#define LLC_COMMIT(kid) do {} while (0)
 #endif
 // NK waves share a 16-row group along K (wave k: quads [k NQ / NK, (k+1) NQ / NK)); PAIR = 1: the workgroup takes the w1 group and then
 // the w3 group of the same 16 features (one after the other: three workgroups per CU cover each other's round trips).  QPW: most quads a wave can hold (its lane sums stay in registers until its turn in the chain).
-template <int TYPE, int NK, int PRO, int PAIR, int QPW>
-__global__ __launch_bounds__(64 * NK, (PAIR == 1 && QPW <= 8 && NK == 4) ? 3 : 1) void gemv1_q4_exact_llc_kernel(
+// PERSIST = 1: the row-group loop (a launch with fewer workgroups than row groups).  Its own instantiation: the loop costs ~45 registers
+// (200: two workgroups per CU instead of three), which a launch whose row groups all fit on the chip at once need not pay.
+template <int TYPE, int NK, int PRO, int PAIR, int QPW, int PERSIST>
+__global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1) void gemv1_q4_exact_llc_kernel(
     int M, int units, int KB, int woven,
     const uint32_t *__restrict__ qwd, const float *__restrict__ dW, const float *__restrict__ xf, const void *__restrict__ aux,
     const float *__restrict__ mW, const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs,
@@ -106,71 +126,130 @@ __global__ __launch_bounds__(64 * NK, (PAIR == 1 && QPW <= 8 && NK == 4) ? 3 : 1
     constexpr int G2 = PAIR == 1 ? 2 : 1, NT = 64 * NK;
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     __shared__ double sh[4];
-    __shared__ float accs[64][3];                                               // the chains' state between the K slices: a_2g, a_2g+1, summs
-    const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+    __shared__ float accs[2][64][3];                                            // the chains' state between the K slices: a_2g, a_2g+1, summs
+                                                                                // (two copies: consecutive row groups of a persistent workgroup alternate)
+    const int lane = threadIdx.x & 63, k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (the slice index in an SGPR: the `i < nq` tests below are scalar branches)
     const int NQ = (KB + 3) >> 2;
-    // LDS: [Q8_0 activation, QA1 layout: q [KB][32], d [4 NQ], s [4 NQ]] [LX: the lanes' view, [NQ][4 k-groups][4 blocks][8 B]]
-    int8_t *lq = reinterpret_cast<int8_t *>(gsm);
-    float *ld_ = reinterpret_cast<float *>(gsm + (size_t)KB * 32);              // (d and s padded to whole quads: 16-byte reads; the padding is
+    // LDS: [LX: the Q8_0 activation as the lanes read it, [NQ][4 k-groups][4 blocks][8 B: e0..e3 | e4..e7]] [d [4 NQ]] [s [4 NQ]]
+    // (round 5: the prologues write LX directly -- round 4 built the QA1 layout first and re-laid it in a second pass behind a barrier)
+    unsigned char *lx = gsm;
+    float *ld_ = reinterpret_cast<float *>(gsm + (size_t)NQ * 128);             // (d and s padded to whole quads: 16-byte reads; the padding is
     float *ls_ = ld_ + 4 * NQ;                                                  //  zero, so a block past K has dd = 0 and adds nothing)
-    unsigned char *lx = reinterpret_cast<unsigned char *>(ls_ + 4 * NQ);
 
+    LLC_T_DECL;
     LLC_STAMP(0);
     GP_DECL(PRO);
-    GemvPrologue<PRO, NT>::issue(pv, pw, psl, psb, xf, aux, KB, woven);
+    GemvPrologue<PRO, NT, true>::issue(pv, pw, psl, psb, xf, aux, KB, woven);
+#ifdef LLC_LATE_WEIGHTS   // experiment (profiles/r05_decode_exact.md): the weight stream is requested only once the activation has arrived
+    if constexpr (PRO != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 
     // ---- this wave's slice of the weight stream: every load goes out before anything waits (nontemporal: read once per token)
-    const int unit = blockIdx.x;
+    // PERSISTENT workgroups (round 5): a launch has at most one workgroup per residency slot; a workgroup takes the row groups
+    // blockIdx.x, blockIdx.x + gridDim.x, ... -- the prologue (the activation's Q8_0 form in LDS) is paid once, and the next row group's
+    // weights are requested as soon as this one's lane sums have freed their registers, i.e. they travel under the chains and the store.
+    // (LLaMA-7B's woven w1|w3 is 1376 row groups on 768 slots: as one workgroup per row group the second round's workgroups were
+    //  dispatched 7-10 us into the launch, each redoing the 5 us prologue before it could use its bytes: profiles/r05_decode_timeline.md.)
+    int unit = blockIdx.x;
     const int qlo = (k * NQ) / NK, nq = ((k + 1) * NQ) / NK - qlo;              // (wave-uniform; nq <= QPW by the launcher's choice of NK)
     const int r = lane >> 2, g = lane & 3;
     ntv4u w[QPW];
     float dw[QPW], mw[QPW];
+    // Addresses: buffer loads with the wave-uniform part (row group, quad) in the SCALAR offset and one lane offset register per plane
+    // (round 5).  The flat 64-bit addresses of round 4 cost two VGPRs per load -- kept alive across the row-group loop they were 45
+    // registers, the difference between three workgroups per CU and two.  Bytes past a plane read as zero (descriptor bounds).
+    const int groups = units * G2;
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(qwd), 0, (int)((uint32_t)groups * (uint32_t)NQ * 1024u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dW), 0, (int)((uint32_t)groups * (uint32_t)KB * 64u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Q41 ? mW : dW), 0, (int)((uint32_t)groups * (uint32_t)KB * 64u), 0x00020000);
+    const int voff_w = lane * 16;
+    const int voff_d = (g * 16 + r) * 4;                                         // lane (row, g) fetches the scale of block 4q + g of its row
+    // (a partial last quad reads past the row's blocks: the next row group's first scales, or zeros behind the plane -- FINITE numbers
+    //  (fl_qtensor_upload rejects anything else) that meet d_x = 0 and zero nibbles: the block adds +0 to a chain that can never hold -0)
+    // The scales go out FIRST, then the nibbles, quad by quad: loads return in order, so a quad can be summed as soon as ITS sixteen bytes per
+    // lane are there.  (Issued quad by quad -- nibbles, scale, nibbles, scale -- the compiler's scheduler moved all the scale loads behind
+    // all the nibble loads, and the first quad's sums waited for the wave's whole slice: round 5, seen in the ISA.)
     auto load_group = [&](int grp) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < QPW; ++i) {
             const int q = qlo + (i < nq ? i : 0);                               // (past the slice: a cache-hot dummy, never used -- unconditional
-            const int64_t gq = (int64_t)grp * NQ + q;                           //  loads let the compiler count the ones in flight)
-            w[i] = __builtin_nontemporal_load(reinterpret_cast<const ntv4u *>(qwd) + gq * 64 + lane);
-            const int b = min(4 * q + g, KB - 1);                               // lane (row, g) fetches the scale of block 4q + g of its row
-            dw[i] = __builtin_nontemporal_load(dW + ((int64_t)grp * KB + b) * 16 + r);
-            if (Q41) mw[i] = __builtin_nontemporal_load(mW + ((int64_t)grp * KB + b) * 16 + r);
+            const int sd = (grp * KB + 4 * q) * 64;                             //  loads let the compiler count the ones in flight)
+            dw[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, voff_d, sd, 2));
+            if (Q41) mw[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, voff_d, sd, 2));
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < QPW; ++i) {
+            const int q = qlo + (i < nq ? i : 0);
+            const int gq = grp * NQ + q;
+            w[i] = __builtin_bit_cast(ntv4u, __builtin_amdgcn_raw_buffer_load_b128(rW, voff_w, gq * 1024, 2 /* nt */));
+        }
+        __builtin_amdgcn_sched_barrier(0);
     };
+    // PRO = 0: the Q8_0 activation (QA1 in HBM) is requested BEFORE the weight stream as well (round 5): behind it -- loads return in order --
+    // its copy to LDS waited for the wave's whole slice, and every lane sum of the launch was computed after the last byte had arrived
+    constexpr int XIT = 4;                                                      // 8-byte k-group entries per thread held in registers
+    uint2 xa_[PRO == 0 ? XIT : 1];
+    float xd_[PRO == 0 ? 2 : 1], xs_[PRO == 0 ? 2 : 1];
+    if constexpr (PRO == 0) {
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int i = threadIdx.x + it * NT;
+            xa_[it] = reinterpret_cast<const uint2 *>(xq)[i < KB * 4 ? i : 0];
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = threadIdx.x + it * NT;
+            xd_[it] = xd[i < KB ? i : 0];
+            xs_[it] = Q41 ? xs[i < KB ? i : 0] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     load_group(unit * G2);
     LLC_STAMP(1);
 
+    // blocks past K in a partial last quad: zero quants, d_x = s_x = 0 (written before the prologue's closing barrier)
+    if ((int)threadIdx.x < (4 * NQ - KB) * 4) {
+        const int b = KB + ((int)threadIdx.x >> 2), gg = threadIdx.x & 3;
+        *reinterpret_cast<uint2 *>(lx + (((b >> 2) * 4 + gg) * 4 + (b & 3)) * 8) = make_uint2(0, 0);
+        if (gg == 0) { ld_[b] = 0.f; ls_[b] = 0.f; }
+    }
     if constexpr (PRO != 0) {
-        GemvPrologue<PRO, NT>::finish(pv, pw, psl, psb, xf, aux, KB, woven, lq, ld_, ls_, sh, ynorm, blockIdx.x == 0);
-    } else {                                          // the activation is already Q8_0 (QA1 in HBM): copy it
-        for (int i = threadIdx.x; i < KB * 2; i += NT) reinterpret_cast<uint4 *>(lq)[i] = reinterpret_cast<const uint4 *>(xq)[i];
-        for (int i = threadIdx.x; i < KB; i += NT) {
-            ld_[i] = xd[i];
-            ls_[i] = Q41 ? xs[i] : 0.f;
+        GemvPrologue<PRO, NT, true>::finish(pv, pw, psl, psb, xf, aux, KB, woven, reinterpret_cast<int8_t *>(lx), ld_, ls_, sh, ynorm, blockIdx.x == 0);
+    } else {                                          // the activation is already Q8_0 (QA1 in HBM: k-group bytes e0,e2,e4,e6 | e1,e3,e5,e7): re-lay it on the way
+        auto put = [&](int i, uint2 lh) __attribute__((always_inline)) {
+            const int b = i >> 2, gg = i & 3;
+            *reinterpret_cast<uint2 *>(lx + (((b >> 2) * 4 + gg) * 4 + (b & 3)) * 8) =
+                make_uint2(__builtin_amdgcn_perm(lh.y, lh.x, 0x05010400u), __builtin_amdgcn_perm(lh.y, lh.x, 0x07030602u));
+        };
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int i = threadIdx.x + it * NT;
+            if (i < KB * 4) put(i, xa_[it]);
         }
+        for (int i = threadIdx.x + XIT * NT; i < KB * 4; i += NT) put(i, reinterpret_cast<const uint2 *>(xq)[i]);      // (very long rows: the rest)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = threadIdx.x + it * NT;
+            if (i < KB) { ld_[i] = xd_[it]; ls_[i] = xs_[it]; }
+        }
+        for (int i = threadIdx.x + 2 * NT; i < KB; i += NT) { ld_[i] = xd[i]; ls_[i] = Q41 ? xs[i] : 0.f; }
         __syncthreads();
     }
-    // the lanes' view of the activation, once per workgroup: k-group g of block b, bytes (e0,e2,e4,e6 | e1,e3,e5,e7) -> (e0..e3 | e4..e7),
-    // at LX[b >> 2][g][b & 3]: a lane reads the 32 bytes of its four blocks as two ds_read_b128 (four addresses per wave: broadcasts)
-    for (int i = threadIdx.x; i < NQ * 16; i += NT) {
-        const int q = i >> 4, gg = (i >> 2) & 3, blk = i & 3, b = 4 * q + blk;
-        uint2 o = make_uint2(0, 0);
-        if (b < KB) {
-            const uint2 lh = *reinterpret_cast<const uint2 *>(lq + b * 32 + gg * 8);
-            o = make_uint2(__builtin_amdgcn_perm(lh.y, lh.x, 0x05010400u), __builtin_amdgcn_perm(lh.y, lh.x, 0x07030602u));
-        }
-        *reinterpret_cast<uint2 *>(lx + (size_t)i * 8) = o;
-    }
-    if ((int)threadIdx.x < 4 * NQ - KB) {             // d_x / s_x of the blocks past K in a partial last quad: zero
-        ld_[KB + threadIdx.x] = 0.f;
-        ls_[KB + threadIdx.x] = 0.f;
-    }
-    __syncthreads();
     LLC_STAMP(2);
 
     const uint32_t m8 = 0xF0F0F0F0u;
     float y1 = 0.f;
+    int par = 0;                                                                // which copy of the chain state this row group uses
     auto do_group = [&](auto GI) __attribute__((always_inline)) {
         constexpr int gi = decltype(GI)::value;
+        // the residual of this lane's row is requested NOW (PAIR = 0): asked for in the epilogue it was a dependent round trip of ~0.6 us at
+        // the very end of every wo / w2 launch, behind the last chain (round 5)
+        float rsd = 0.f;
+        if constexpr (PAIR == 0) {
+            const int row_ = unit * 16 + r;
+            if (resid && k == NK - 1) rsd = resid[min(row_, M - 1)];      // (wave-uniform condition, clamped address: a load behind a lane-dependent branch makes the compiler drain every load in flight)
+        }
         // ---- order-free part, all waves at once: per block the two lane sums of this lane's k-group as floats, rn(d_w d_x), m_w
         float f0[QPW][4], f1[QPW][4], dd[QPW][4], ms[Q41 ? QPW : 1][4];
 #pragma unroll
@@ -194,6 +273,9 @@ __global__ __launch_bounds__(64 * NK, (PAIR == 1 && QPW <= 8 && NK == 4) ? 3 : 1
                     dd[i][blk] = __fmul_rn(dwb[blk], dxv[blk]);                 // rn(d_w d_x); a block past K: d_x = 0
                 }
                 if (Q41) { ms[i][0] = quad_bcast<0>(mw[i]); ms[i][1] = quad_bcast<1>(mw[i]); ms[i][2] = quad_bcast<2>(mw[i]); ms[i][3] = quad_bcast<3>(mw[i]); }
+#ifdef LLC_TIMING
+                if (gi == 0 && i == 0) { asm volatile("" :: "v"(f0[0][0]), "v"(f1[0][3])); LLC_STAMP(6); }      // the first quad has arrived and is summed
+#endif
             }
         }
         if (gi == 0) LLC_STAMP(3);
@@ -202,7 +284,7 @@ __global__ __launch_bounds__(64 * NK, (PAIR == 1 && QPW <= 8 && NK == 4) ? 3 : 1
 #pragma unroll 1
         for (int ph = 0; ph < NK; ++ph) {
             if (k == ph) {                                                      // (wave-uniform)
-                if (ph > 0) { a0 = accs[lane][0]; a1 = accs[lane][1]; if (Q41) summs = accs[lane][2]; }
+                if (ph > 0) { a0 = accs[par][lane][0]; a1 = accs[par][lane][1]; if (Q41) summs = accs[par][lane][2]; }
 #pragma unroll
                 for (int i = 0; i < QPW; ++i) {
                     if (i < nq) {
@@ -219,7 +301,7 @@ __global__ __launch_bounds__(64 * NK, (PAIR == 1 && QPW <= 8 && NK == 4) ? 3 : 1
                         }
                     }
                 }
-                if (ph < NK - 1) { accs[lane][0] = a0; accs[lane][1] = a1; if (Q41) accs[lane][2] = summs; }
+                if (ph < NK - 1) { accs[par][lane][0] = a0; accs[par][lane][1] = a1; if (Q41) accs[par][lane][2] = summs; }
             }
             if (ph < NK - 1) __syncthreads();
         }
@@ -262,9 +344,16 @@ __global__ __launch_bounds__(64 * NK, (PAIR == 1 && QPW <= 8 && NK == 4) ? 3 : 1
                     y[unit * 16 + r] = __fmul_rn(sl, v);                                      // ggml_mul(silu, tmp)
                 }
             } else if (g == 0 && row < M) {
-                if (resid) v = __fadd_rn(v, resid[row]);
+                if (resid) v = __fadd_rn(v, rsd);
                 y[row] = v;
             }
+        }
+        if constexpr (PAIR != 1 && PERSIST) {
+            // the next row group's bytes start now -- behind this wave's chain and, for the last wave, behind the store (a load issued before the
+            // residual's round trip would make the store wait for the whole prefetch: the compiler counts loads, it does not tell them apart).
+            // Requested right after the lane sums (when w / dw / mw die) they would keep 40 registers busy next to the 96 of the lane sums.
+            const int next_unit = unit + (int)gridDim.x;
+            if (next_unit < units) load_group(next_unit);
         }
         if (PAIR == 1 && gi == 0) {
             // the w3 group's slice is requested only now.  Requested before the w1 chains it keeps both groups' registers alive: 214
@@ -275,13 +364,50 @@ __global__ __launch_bounds__(64 * NK, (PAIR == 1 && QPW <= 8 && NK == 4) ? 3 : 1
             __syncthreads();                            // (the chain state in LDS is free again for the second group)
         }
     };
-    do_group(std::integral_constant<int, 0>{});
-    if constexpr (PAIR == 1) do_group(std::integral_constant<int, 1>{});
+    if constexpr (PAIR == 1) {
+        do_group(std::integral_constant<int, 0>{});
+        do_group(std::integral_constant<int, 1>{});
+    } else if constexpr (!PERSIST) {
+        do_group(std::integral_constant<int, 0>{});
+    } else {
+#pragma unroll 1
+        for (;;) {
+            // (compiler barrier: the activation's LDS reads do not depend on the row group, and hoisted out of this loop they cost 96 registers)
+            asm volatile("" ::: "memory");
+            do_group(std::integral_constant<int, 0>{});
+            unit += (int)gridDim.x;
+            if (unit >= units) break;
+            par ^= 1;
+        }
+    }
     LLC_STAMP(5);
+    LLC_COMMIT(PRO * 100 + PAIR * 10 + NK);
 }
 #ifdef LLC_TIMING
-extern "C" __attribute__((visibility("default"))) int fl_debug_llc_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(llc_dbg), sizeof(long long) * 2048 * 8); }
+// reset != 0: empty the ring; else copy up to max_rec records of 8 x int64 {t0 entry, t1 loads issued, t2 prologue done, t3 lane sums of the
+// wave's slice done (= its last byte has arrived), t4 chains handed through, t5 end, t6 first quad summed, (kernel id << 32) | workgroup}
+// and return how many there are
+extern "C" __attribute__((visibility("default"))) int fl_debug_llc_timeline(long long *out, int max_rec, int reset) {
+    unsigned n = 0;
+    if (reset) return (int)hipMemcpyToSymbol(HIP_SYMBOL(llc_tl_cur), &n, sizeof n);
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(llc_tl_cur), sizeof n) != hipSuccess) return -1;
+    if (n > LLC_TL_CAP) n = LLC_TL_CAP;
+    if ((int)n > max_rec) n = (unsigned)max_rec;
+    if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(llc_tl), sizeof(long long) * 8 * (size_t)n) != hipSuccess) return -1;
+    return (int)n;
+}
 #endif
+
+// residency slots of a kernel instantiation on this device: workgroups per CU (occupancy query with the launch's dynamic LDS) x CUs, rounded
+// down to an even number (the two workgroups of a w1|w3 feature pair are neighbours)
+static int llc_slots(const void *fn, int threads, size_t lds) {
+    if (!getenv("FL_LLC_PERSIST") && !getenv("FL_LLC_SLOTS")) return 1 << 30;
+    if (const char *e = getenv("FL_LLC_SLOTS")) return std::max(2, atoi(e) & ~1);      // tests: persistent workgroups on small matrices
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+    return (per_cu * cus) & ~1;
+}
 
 // false: no QWD copy, or a shape outside the kernel's reach (rows too long for the slices' registers, activation beyond LDS)
 // -> the caller takes round 3's kernel
@@ -291,16 +417,31 @@ static bool launch_llc(const fl_qtensor &W, const fl_qact *xq, float *y, hipStre
     if (!W.qwd) return false;
     constexpr int G2 = PAIR == 1 ? 2 : 1;
     const int KB = W.KB, NQ = (KB + 3) / 4, units = W.M16 / 16 / G2;
-    const size_t lds = (size_t)KB * 32 + (size_t)NQ * 32 + (size_t)NQ * 16 * 8;
+    const size_t lds = (size_t)NQ * 128 + (size_t)NQ * 32;                   // LX + d_x + s_x
     if (lds > 60 * 1024 || units < 1 || NQ > 88) return false;
     // (waves along K, quads a wave holds): 4 x 8 covers K <= 4096 with the fewest registers (three waves per SIMD), 4 x 11 K <= 5632,
     // 8 x 11 K <= 11264 -- but an 8-wave workgroup at 186 registers is ONE per CU: good for a matrix of <= 256 row groups (LLaMA-7B's w2:
     // 12.5 us against round 3's 15.1), bad for many groups of long rows (65B width, K = 8192: 57 / 93 us against 35 / 63 for
     // wq|wk|wv / w1|w3, scripts/dev/dec_ab.sh) -- those, and rows beyond 11264 (13B / 65B w2), stay on round 3's kernel
     if (NQ > 44 && units > 256) return false;
+    // grid: one workgroup per row group.  FL_LLC_PERSIST=1 (opt-in): when the row groups do not all fit on the chip at once, the PERSIST
+    // instantiation with one workgroup per ITS residency slot (see the kernel) -- built, bit-identical, and measured 2 % SLOWER on LLaMA-7B's
+    // decode (564.8-567.8 against 577.5 tok/s in one gpurun call, profiles/r05_decode_exact.md): the loop costs 45 registers = two workgroups per CU
+    // instead of three, and a row group's bytes are requested one chain phase, not one row group, ahead.
+#define FL_LLC_GO(NK, QPW, PS, GRID)                                                                                                      \
+    hipLaunchKernelGGL((gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, PS>), dim3(GRID), dim3(64 * NK), lds, st, W.M, units, KB,     \
+                       woven, W.qwd, W.d, xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid,       \
+                       ynorm, aux2, pair_ws)
 #define FL_LLC(NK, QPW)                                                                                                                   \
-    hipLaunchKernelGGL((gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW>), dim3(units), dim3(64 * NK), lds, st, W.M, units, KB, woven, \
-                       W.qwd, W.d, xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid, ynorm, aux2, pair_ws)
+    do {                                                                                                                                  \
+        static int slots0 = 0, slots1 = 0;                                                                                                \
+        if (!slots0) {                                                                                                                    \
+            slots0 = llc_slots(reinterpret_cast<const void *>(&gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, 0>), 64 * NK, lds);    \
+            slots1 = llc_slots(reinterpret_cast<const void *>(&gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, 1>), 64 * NK, lds);    \
+        }                                                                                                                                 \
+        if (PAIR == 1 || units <= slots0) FL_LLC_GO(NK, QPW, 0, units);                                                                   \
+        else FL_LLC_GO(NK, QPW, 1, (units < slots1 ? units : slots1));                                                                    \
+    } while (0)
     if constexpr (TYPE == FL_TYPE_Q4_1) {             // Q4_1 carries m_w as well: 4 x 8 needs 174 registers = two waves per SIMD; 8 x 4 needs <= 126
         if (NQ <= 32) { FL_LLC(8, 4); return true; }   // (four): LLaMA-7B Q4_1 decode 412 -> 424 tok/s.  (Q4_0, 139 registers at 4 x 8: no gain)
     }
@@ -308,6 +449,7 @@ static bool launch_llc(const fl_qtensor &W, const fl_qact *xq, float *y, hipStre
     else if (NQ <= 44) FL_LLC(4, 11);
     else FL_LLC(8, 11);
 #undef FL_LLC
+#undef FL_LLC_GO
     return true;
 }
 

@@ -19,6 +19,9 @@
 namespace fl {
 
 // quantize_row_q8_0 of one 8-element group (4 adjacent lanes = one block) into an LDS copy of the QA1 layout
+// LXF: write the group straight into the lane view of gemv1_q4_exact_llc.hip instead -- LX [block >> 2][k-group][block & 3] 8-byte entries,
+// bytes (e0..e3 | e4..e7) -- which saves that kernel a pass over LDS and a barrier (round 5)
+template <bool LXF = false>
 __device__ __forceinline__ void quantize_group_lds_x(const float o[8], int kg, int8_t *lq, float *ld_, float *ls_) {
     float amax = 0.f;
 #pragma unroll
@@ -37,7 +40,12 @@ __device__ __forceinline__ void quantize_group_lds_x(const float o[8], int kg, i
         return (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(c & 0xFF) << 16) |
                ((uint32_t)(e & 0xFF) << 24);
     };
-    *reinterpret_cast<uint2 *>(lq + kg * 8) = make_uint2(pk(qi[0], qi[2], qi[4], qi[6]), pk(qi[1], qi[3], qi[5], qi[7]));
+    if (LXF) {
+        const int b = kg >> 2, gg = kg & 3;
+        *reinterpret_cast<uint2 *>(lq + (((b >> 2) * 4 + gg) * 4 + (b & 3)) * 8) = make_uint2(pk(qi[0], qi[1], qi[2], qi[3]), pk(qi[4], qi[5], qi[6], qi[7]));
+    } else {
+        *reinterpret_cast<uint2 *>(lq + kg * 8) = make_uint2(pk(qi[0], qi[2], qi[4], qi[6]), pk(qi[1], qi[3], qi[5], qi[7]));
+    }
     if ((kg & 3) == 0) {
         ld_[kg >> 2] = dd;
         ls_[kg >> 2] = __fmul_rn(dd, (float)isum);
@@ -49,13 +57,14 @@ __device__ __forceinline__ void quantize_group_lds_x(const float o[8], int kg, i
 //   float pv[GP_MAXIT1][8], pw[GP_MAXIT1][8], psl[GP_SIT2][8], psb[GP_SIT2][8];   with the sizes below
 #define GP_MAXIT 4               /* PRO == 1: 8-element groups per thread (256 threads: K <= 8192) */
 #define GP_SIT 2                 /* PRO == 2: group-iterations whose loads precede the weight stream */
-#define GP_DECL(PRO) float pv[(PRO) == 1 ? GP_MAXIT : 1][8], pw[(PRO) == 1 ? GP_MAXIT : 1][8], psl[(PRO) == 2 ? GP_SIT : 1][8], psb[(PRO) == 2 ? GP_SIT : 1][8]
+#define GP_QIT 4                 /* PRO == 3: group-iterations whose loads precede the weight stream (NT = 512: K <= 16384) */
+#define GP_DECL(PRO) float pv[(PRO) == 1 ? GP_MAXIT : (PRO) == 3 ? GP_QIT : 1][8], pw[(PRO) == 1 ? GP_MAXIT : 1][8], psl[(PRO) == 2 ? GP_SIT : 1][8], psb[(PRO) == 2 ? GP_SIT : 1][8]
 
-template <int PRO, int NT>
+template <int PRO, int NT, bool LXF = false>
 struct GemvPrologue {
-    static constexpr int MAXIT = GP_MAXIT, SIT = GP_SIT;
-    template <typename A1, typename A2>
-    static __device__ __forceinline__ void issue(A1 &v, A1 &ww, A2 &sl_, A2 &sb_, const float *__restrict__ xf,
+    static constexpr int MAXIT = GP_MAXIT, SIT = GP_SIT, QIT = GP_QIT;
+    template <typename A1, typename A1w, typename A2>
+    static __device__ __forceinline__ void issue(A1 &v, A1w &ww, A2 &sl_, A2 &sb_, const float *__restrict__ xf,
                                                  const void *__restrict__ aux, int KB, int woven) {
         if constexpr (PRO == 1) {
             const float *nw = static_cast<const float *>(aux);
@@ -77,6 +86,21 @@ struct GemvPrologue {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) v[it][i] = 0.f, ww[it][i] = 0.f;
                     }
+                }
+            }
+        }
+        if constexpr (PRO == 3) {
+            // round 5: the f32 vector's loads go out HERE, in front of the weight stream.  They used to be issued in finish(), behind it --
+            // and vector-memory loads return in order: the prologue of the w2 matmul sat behind its whole 110 KB of weights
+            // (6.1 us from entry to "prologue done" of a 11 us launch, profiles/r05_decode_timeline.md).
+            const int gpr = KB * 4;
+#pragma unroll
+            for (int it = 0; it < QIT; ++it) {
+                const int kg = threadIdx.x + it * NT;
+                if (kg < gpr) {
+                    const float4 a = *reinterpret_cast<const float4 *>(xf + kg * 8), c = *reinterpret_cast<const float4 *>(xf + kg * 8 + 4);
+                    v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
+                    v[it][4] = c.x; v[it][5] = c.y; v[it][6] = c.z; v[it][7] = c.w;
                 }
             }
         }
@@ -115,8 +139,8 @@ struct GemvPrologue {
 
     // lq [KB][32], ld_ [KB], ls_ [KB] in LDS; sh: 4 doubles of LDS scratch (PRO == 1).  ynorm (PRO == 1, optional): the f32
     // normalised vector, stored by the workgroup for which store_ynorm is set.
-    template <typename A1, typename A2>
-    static __device__ __forceinline__ void finish(A1 &v, A1 &ww, A2 &sl_, A2 &sb_, const float *__restrict__ xf,
+    template <typename A1, typename A1w, typename A2>
+    static __device__ __forceinline__ void finish(A1 &v, A1w &ww, A2 &sl_, A2 &sb_, const float *__restrict__ xf,
                                                   const void *__restrict__ aux, int KB, int woven, int8_t *lq, float *ld_, float *ls_,
                                                   double *sh, float *__restrict__ ynorm, bool store_ynorm) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -150,7 +174,7 @@ struct GemvPrologue {
                         yp[0] = make_float4(o[0], o[1], o[2], o[3]);
                         yp[1] = make_float4(o[4], o[5], o[6], o[7]);
                     }
-                    quantize_group_lds_x(o, kg, lq, ld_, ls_);
+                    quantize_group_lds_x<LXF>(o, kg, lq, ld_, ls_);
                 }
             }
             __syncthreads();
@@ -164,7 +188,7 @@ struct GemvPrologue {
                 float o[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = __fmul_rn(sl_[it][i], sb_[it][i]);
-                quantize_group_lds_x(o, kg, lq, ld_, ls_);
+                quantize_group_lds_x<LXF>(o, kg, lq, ld_, ls_);
             }
             for (int kg = threadIdx.x + SIT * NT; kg < gpr; kg += NT) {   // very wide rows: the rest
                 const float *pa = xf + (woven ? ((kg >> 1) << 5) + ((kg & 1) << 3) : kg * 8);
@@ -180,15 +204,24 @@ struct GemvPrologue {
                     const float sl = __half2float(__ushort_as_half(silu_tab[hx]));
                     o[i] = __fmul_rn(sl, b[i]);
                 }
-                quantize_group_lds_x(o, kg, lq, ld_, ls_);
+                quantize_group_lds_x<LXF>(o, kg, lq, ld_, ls_);
             }
             __syncthreads();
         } else if constexpr (PRO == 3) {
             const int gpr = KB * 4;
-            for (int kg = threadIdx.x; kg < gpr; kg += NT) {   // gpr % 4 == 0: quads stay together
+#pragma unroll
+            for (int it = 0; it < QIT; ++it) {
+                const int kg = threadIdx.x + it * NT;
+                if (kg >= gpr) continue;                                   // gpr % 4 == 0: quads stay together
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = v[it][i];
+                quantize_group_lds_x<LXF>(o, kg, lq, ld_, ls_);
+            }
+            for (int kg = threadIdx.x + QIT * NT; kg < gpr; kg += NT) {   // very wide rows: the rest, behind the weights
                 const float4 a0 = *reinterpret_cast<const float4 *>(xf + kg * 8), a1 = *reinterpret_cast<const float4 *>(xf + kg * 8 + 4);
                 const float o[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                quantize_group_lds_x(o, kg, lq, ld_, ls_);
+                quantize_group_lds_x<LXF>(o, kg, lq, ld_, ls_);
             }
             __syncthreads();
         }

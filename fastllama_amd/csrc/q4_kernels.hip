@@ -41,6 +41,9 @@ __global__ void repack_qw16_kernel(const uint32_t *__restrict__ aos, int M, int 
         const uint32_t *p = aos + ((int64_t)row * KB + b) * WPB;
         dv = __uint_as_float(p[0]);
         if (TYPE == FL_TYPE_Q4_1) mv = __uint_as_float(p[1]);
+        // (a non-finite block scale is no model -- and the single-token kernels rely on finite scales where a partial last quad reads
+        //  one scale past its row against d_x = 0, gemv1_q4_exact_llc.hip)
+        if (!isfinite(dv) || (TYPE == FL_TYPE_Q4_1 && !isfinite(mv))) atomicOr(bad, 2);
 #pragma unroll
         for (int g = 0; g < 4; ++g) w[g] = p[WPB - 4 + g];
         if (TYPE == FL_TYPE_Q4_0) {

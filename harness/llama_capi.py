@@ -61,7 +61,7 @@ class Session:
     """One llama_model_context (the reference's fastllama.Model, interfaces/python/fastllama.py:194-479)."""
 
     def __init__(self, lib: LlamaLib, path: str, n_ctx=512, n_batch=16, n_threads=4, all_logits=False,
-                 embeddings=False, seed=0, n_keep=200, last_n_tokens=64, quiet=True, use_mmap=False):
+                 embeddings=False, seed=0, n_keep=200, last_n_tokens=64, quiet=True, use_mmap=False, extra_mem=0):
         self.L = lib.lib
         args = self.L.llama_create_default_context_args()
         args.embedding_eval_enabled = embeddings
@@ -71,6 +71,7 @@ class Session:
         args.load_parallel = False
         args.seed, args.n_keep, args.n_ctx, args.n_threads, args.n_batch = seed, n_keep, n_ctx, n_threads, n_batch
         args.last_n_tokens = last_n_tokens
+        args.allocate_extra_mem = extra_mem      # the reference's own knob: bytes added to the eval context's memory pool (lib/llama.cpp:173)
         self.log = []
         self._cbs = (LOG_FN(lambda f, fl, m, ml: self.log.append(("I", m[:ml]))),
                      LOG_FN(lambda f, fl, m, ml: self.log.append(("E", m[:ml]))),

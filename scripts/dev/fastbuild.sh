@@ -1,7 +1,7 @@
 #!/bin/bash
 # Development build: per-file objects under build/obj (rebuilt only when the source or a header changed), compiled in parallel,
 # linked into $OUT (default fastllama_amd/libfastllama_hip.so) and its test-hook library ($OUT with _hooks.so, from test_hooks.cpp).
-# Extra flags for ONE source: X_SRC=exact_kernels.hip X_FLAGS="-DFOO".
+# Extra flags for ONE source: X_SRC=exact_kernels.hip X_FLAGS="-DFOO"; for every source: ALL_FLAGS="-DFOO".
 # The release build is ./build.sh (what __graft_entry__.build() runs).
 set -e
 cd "$(dirname "$0")/../.."
@@ -17,7 +17,7 @@ for src in fastllama_amd/csrc/*.hip fastllama_amd/csrc/*.cpp; do
     extra=""
     [ "$(basename "$src")" = "${X_SRC:-}" ] && extra="${X_FLAGS:-}"
     if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ "$newest_hdr" -nt "$o" ]; then
-        hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden ${KPRE--mllvm -amdgpu-kernarg-preload-count=16} -Iinclude -x hip $extra -c "$src" -o "$o" 2> "$o.log" &
+        hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden ${KPRE--mllvm -amdgpu-kernarg-preload-count=16} -Iinclude -x hip $extra ${ALL_FLAGS:-} -c "$src" -o "$o" 2> "$o.log" &
         pids+=($!)
     fi
 done
