@@ -958,6 +958,22 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
                 wide_load(pnext, rsP, ld_att, rows_q, 0);
                 wide_load(vnext, tile_rsrc(vc + (int64_t)(hd * D) * n_ctx, 32, n_ctx), n_ctx, 32, 0);
             }
+#ifdef XA_NOPIPE   // A/B build (profiles/r05_attn_exact.md): round 4's order -- a piece is requested behind the barrier that ended the previous one
+            for (int c = 0; c < nchunk; ++c) {
+                const int k0 = c * XA_KT, kt = chunk_len(c);
+                lds_barrier();
+                if (c > 0 || d0 > 0) {
+                    wide_load(pnext, rsP, ld_att, rows_q, k0);
+                    wide_load(vnext, tile_rsrc(vc + (int64_t)(hd * D + d0) * n_ctx, 32, n_ctx), n_ctx, 32, k0);
+                }
+                wide_store(Ps, pnext, rows_q, kt, k0);
+                wide_store(Vs, vnext, 32, kt, k0);
+                lds_barrier();
+                const int cend = min(nbody, k0 + XA_KT);
+                chain(tl[0], wave, k0, cend);
+                chain(tl[1], wave + 4, k0, cend);
+            }
+#else
             for (int c = 0; c < nchunk; ++c) {
                 const int k0 = c * XA_KT, kt = chunk_len(c);
                 lds_barrier();                                // the previous piece is done with Ps, Vs and Ts
@@ -975,6 +991,7 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
                 chain(tl[0], wave, k0, cend);
                 chain(tl[1], wave + 4, k0, cend);
             }
+#endif
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float v0 = __fadd_rn(__fadd_rn(tl[0][0][e], tl[0][1][e]), __fadd_rn(tl[0][2][e], tl[0][3][e]));   // (s0+s1)+(s2+s3)

@@ -245,7 +245,14 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
                 }
             } else if (B128) {
                 const v2u32 ga = (g & 1) ? v2u32{sa.z, sa.w} : v2u32{sa.x, sa.y}, gb = (g & 1) ? v2u32{sb.z, sb.w} : v2u32{sb.x, sb.y};
+#ifdef XH_SETPRIO   // experiment: coexec6 gives 229 -> 223 ns per tile and block at two waves per SIMD with the MFMA issued at raised priority; in the
+                    // kernel it is a loss (33.15 / 33.16 -> 33.41 / 33.28 ms per eval, one gpurun call, profiles/r05_gemm_exact.md)
+                __builtin_amdgcn_s_setprio(1);
+#endif
                 D0 = __builtin_amdgcn_mfma_f32_32x32x4f16(__builtin_bit_cast(v4h, ga), __builtin_bit_cast(v4h, gb), zero32, 0, 0, 0);
+#ifdef XH_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (g & 1) {                         // the slot is used up: the next one moves in, the one after it is requested
                     sa = san; sb = sbn;

@@ -92,17 +92,19 @@ __device__ __forceinline__ float quad_bcast(float v) {
 #ifdef LLC_TIMING   // development build only: per-workgroup clocks of EVERY launch since the last reset, in one ring (scripts/dev/decode_timeline.py):
                     // the 100 MHz wall clock is common to all launches, so the records of a token's kernels line up on one time axis
 constexpr unsigned LLC_TL_CAP = 1u << 17;
-__device__ long long llc_tl[LLC_TL_CAP * 8];
+constexpr int LLC_TL_W = 12;      // int64 per record: 7 stamps, id, 3 prologue stamps, spare
+__device__ long long llc_tl[(size_t)LLC_TL_CAP * LLC_TL_W];
 __device__ unsigned llc_tl_cur;
-#define LLC_T_DECL long long tl_[7] = {0, 0, 0, 0, 0, 0, 0}
+#define LLC_T_DECL long long tl_[7] = {0, 0, 0, 0, 0, 0, 0}, tlp_[4] = {0, 0, 0, 0}
 #define LLC_STAMP(k) do { tl_[k] = wall_clock64(); } while (0)
 #define LLC_COMMIT(kid)                                                                        \
     do {                                                                                       \
         if (threadIdx.x == 0) {                                                                \
             const unsigned s_ = atomicAdd(&llc_tl_cur, 1u);                                    \
             if (s_ < LLC_TL_CAP) {                                                             \
-                for (int k_ = 0; k_ < 7; ++k_) llc_tl[(size_t)s_ * 8 + k_] = tl_[k_];          \
-                llc_tl[(size_t)s_ * 8 + 7] = ((long long)(kid) << 32) | blockIdx.x;            \
+                for (int k_ = 0; k_ < 7; ++k_) llc_tl[(size_t)s_ * LLC_TL_W + k_] = tl_[k_];   \
+                llc_tl[(size_t)s_ * LLC_TL_W + 7] = ((long long)(kid) << 32) | blockIdx.x;     \
+                for (int k_ = 0; k_ < 4; ++k_) llc_tl[(size_t)s_ * LLC_TL_W + 8 + k_] = tlp_[k_]; \
             }                                                                                  \
         }                                                                                      \
     } while (0)
@@ -115,20 +117,30 @@ __device__ unsigned llc_tl_cur;
 // the w3 group of the same 16 features (one after the other: three workgroups per CU cover each other's round trips).  QPW: most quads a wave can hold (its lane sums stay in registers until its turn in the chain).
 // PERSIST = 1: the row-group loop (a launch with fewer workgroups than row groups).  Its own instantiation: the loop costs ~45 registers
 // (200: two workgroups per CU instead of three), which a launch whose row groups all fit on the chip at once need not pay.
-template <int TYPE, int NK, int PRO, int PAIR, int QPW, int PERSIST>
-__global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1) void gemv1_q4_exact_llc_kernel(
+// TEAMS > 1 (round 5): one workgroup = TEAMS row groups side by side (TEAMS x NK waves, e.g. 3 x 4 = the 12 waves a CU holds at 136 registers) that
+// SHARE the prologue: the activation is read, normalised and quantized once per CU instead of once per row group -- a launch's lane sums wait for
+// the prologue, not for their bytes (profiles/r05_decode_timeline.md), and three workgroups per CU ran three of them at once behind each other's
+// weight requests.  Same arithmetic per row group; the chain hand-offs of the teams share the workgroup's barriers.
+template <int TYPE, int NK, int PRO, int PAIR, int QPW, int PERSIST, int TEAMS = 1>
+__global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1) void gemv1_q4_exact_llc_kernel(
     int M, int units, int KB, int woven,
     const uint32_t *__restrict__ qwd, const float *__restrict__ dW, const float *__restrict__ xf, const void *__restrict__ aux,
     const float *__restrict__ mW, const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs,
     float *__restrict__ y, const float *__restrict__ resid, float *__restrict__ ynorm, const uint16_t *__restrict__ aux2,
     float *pair_ws /* PAIR = 2: [units / 2][16] 64-bit slots (zero between launches) */) {
     constexpr bool Q41 = TYPE == FL_TYPE_Q4_1;
-    constexpr int G2 = PAIR == 1 ? 2 : 1, NT = 64 * NK;
+    static_assert(TEAMS == 1 || (PERSIST == 0 && PAIR != 1), "teams: one row group per team");
+    constexpr int G2 = PAIR == 1 ? 2 : 1, NT = 64 * NK * TEAMS;
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     __shared__ double sh[4];
-    __shared__ float accs[2][64][3];                                            // the chains' state between the K slices: a_2g, a_2g+1, summs
+    __shared__ float accs_[TEAMS][2][64][3];                                    // the chains' state between the K slices: a_2g, a_2g+1, summs
                                                                                 // (two copies: consecutive row groups of a persistent workgroup alternate)
-    const int lane = threadIdx.x & 63, k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (the slice index in an SGPR: the `i < nq` tests below are scalar branches)
+    const int lane = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // (the slice index in an SGPR: the `i < nq` tests below are scalar branches.  Teams: slice k of team t is wave t NK + (k - t) mod NK, so that
+    //  the waves working in one chain phase -- slice ph of every team -- sit on DIFFERENT SIMDs (wave w runs on SIMD w mod 4); with k = w mod NK they
+    //  shared one and the chain phase of three teams took three times as long, profiles/r05_decode_exact.md)
+    const int team = wave_ / NK, k = TEAMS == 1 ? wave_ % NK : (wave_ + team) % NK;
+    float (*accs)[64][3] = accs_[team];
     const int NQ = (KB + 3) >> 2;
     // LDS: [LX: the Q8_0 activation as the lanes read it, [NQ][4 k-groups][4 blocks][8 B: e0..e3 | e4..e7]] [d [4 NQ]] [s [4 NQ]]
     // (round 5: the prologues write LX directly -- round 4 built the QA1 layout first and re-laid it in a second pass behind a barrier)
@@ -150,7 +162,8 @@ __global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1)
     // weights are requested as soon as this one's lane sums have freed their registers, i.e. they travel under the chains and the store.
     // (LLaMA-7B's woven w1|w3 is 1376 row groups on 768 slots: as one workgroup per row group the second round's workgroups were
     //  dispatched 7-10 us into the launch, each redoing the 5 us prologue before it could use its bytes: profiles/r05_decode_timeline.md.)
-    int unit = blockIdx.x;
+    int unit = TEAMS == 1 ? (int)blockIdx.x : min((int)blockIdx.x * TEAMS + team, units - 1);
+    const bool live = TEAMS == 1 || (int)blockIdx.x * TEAMS + team < units;      // (a team past the last row group redoes it and stores nothing)
     const int qlo = (k * NQ) / NK, nq = ((k + 1) * NQ) / NK - qlo;              // (wave-uniform; nq <= QPW by the launcher's choice of NK)
     const int r = lane >> 2, g = lane & 3;
     ntv4u w[QPW];
@@ -215,7 +228,11 @@ __global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1)
         if (gg == 0) { ld_[b] = 0.f; ls_[b] = 0.f; }
     }
     if constexpr (PRO != 0) {
+#ifdef LLC_TIMING
+        GemvPrologue<PRO, NT, true>::finish(pv, pw, psl, psb, xf, aux, KB, woven, reinterpret_cast<int8_t *>(lx), ld_, ls_, sh, ynorm, blockIdx.x == 0, tlp_);
+#else
         GemvPrologue<PRO, NT, true>::finish(pv, pw, psl, psb, xf, aux, KB, woven, reinterpret_cast<int8_t *>(lx), ld_, ls_, sh, ynorm, blockIdx.x == 0);
+#endif
     } else {                                          // the activation is already Q8_0 (QA1 in HBM: k-group bytes e0,e2,e4,e6 | e1,e3,e5,e7): re-lay it on the way
         auto put = [&](int i, uint2 lh) __attribute__((always_inline)) {
             const int b = i >> 2, gg = i & 3;
@@ -251,7 +268,7 @@ __global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1)
             if (resid && k == NK - 1) rsd = resid[min(row_, M - 1)];      // (wave-uniform condition, clamped address: a load behind a lane-dependent branch makes the compiler drain every load in flight)
         }
         // ---- order-free part, all waves at once: per block the two lane sums of this lane's k-group as floats, rn(d_w d_x), m_w
-        float f0[QPW][4], f1[QPW][4], dd[QPW][4], ms[Q41 ? QPW : 1][4];
+        float f0[QPW][4], f1[QPW][4], dd[QPW][4];
 #pragma unroll
         for (int i = 0; i < QPW; ++i) {
             if (i < nq) {                                                       // (wave-uniform)
@@ -272,7 +289,6 @@ __global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1)
                     f1[i][blk] = (float)__builtin_amdgcn_sdot4((int)wb, (int)xb[blk], 0, false);
                     dd[i][blk] = __fmul_rn(dwb[blk], dxv[blk]);                 // rn(d_w d_x); a block past K: d_x = 0
                 }
-                if (Q41) { ms[i][0] = quad_bcast<0>(mw[i]); ms[i][1] = quad_bcast<1>(mw[i]); ms[i][2] = quad_bcast<2>(mw[i]); ms[i][3] = quad_bcast<3>(mw[i]); }
 #ifdef LLC_TIMING
                 if (gi == 0 && i == 0) { asm volatile("" :: "v"(f0[0][0]), "v"(f1[0][3])); LLC_STAMP(6); }      // the first quad has arrived and is summed
 #endif
@@ -288,8 +304,11 @@ __global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1)
 #pragma unroll
                 for (int i = 0; i < QPW; ++i) {
                     if (i < nq) {
-                        float sxv[4] = {0.f, 0.f, 0.f, 0.f};
+                        float sxv[4] = {0.f, 0.f, 0.f, 0.f}, msb[4] = {0.f, 0.f, 0.f, 0.f};
                         if (Q41) {
+                            // (m_w of a block sits in one lane of the row's quad, as d_w does; broadcast here, in the chain -- kept as four registers
+                            //  per quad since the order-free part it cost Q4_1 its third workgroup per CU: round 5)
+                            msb[0] = quad_bcast<0>(mw[i]); msb[1] = quad_bcast<1>(mw[i]); msb[2] = quad_bcast<2>(mw[i]); msb[3] = quad_bcast<3>(mw[i]);
                             const float4 sx4 = *reinterpret_cast<const float4 *>(ls_ + 4 * (qlo + i));
                             sxv[0] = sx4.x; sxv[1] = sx4.y; sxv[2] = sx4.z; sxv[3] = sx4.w;
                         }
@@ -297,7 +316,7 @@ __global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1)
                         for (int blk = 0; blk < 4; ++blk) {
                             a0 = __fmaf_rn(dd[i][blk], f0[i][blk], a0);
                             a1 = __fmaf_rn(dd[i][blk], f1[i][blk], a1);
-                            if (Q41) summs = __fmaf_rn(ms[i][blk], sxv[blk], summs);      // (a block past K: s_x = 0, m_w finite)
+                            if (Q41) summs = __fmaf_rn(msb[blk], sxv[blk], summs);      // (a block past K: s_x = 0, m_w finite)
                         }
                     }
                 }
@@ -322,7 +341,7 @@ __global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1)
                 // (1 << 32 | its dot product) into it; the side that gets the other's word back arrived second and finishes the
                 // feature, then clears the slot -- one agent-scope atomic round trip per workgroup, no fence (a release / acquire
                 // fence writes back / invalidates the whole L2 of the XCD: 58 us for this launch), no order between the sides.
-                if (g == 0 && row < M) {
+                if (g == 0 && row < M && live) {
                     unsigned long long *slot = reinterpret_cast<unsigned long long *>(pair_ws) + (size_t)(unit >> 1) * 16 + r;
                     const unsigned long long mine = (1ull << 32) | (unsigned long long)__float_as_uint(v);
                     const unsigned long long old = __hip_atomic_exchange(slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -343,7 +362,7 @@ __global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1)
                     const float sl = __half2float(__ushort_as_half(aux2[hx]));               // table_silu_f16
                     y[unit * 16 + r] = __fmul_rn(sl, v);                                      // ggml_mul(silu, tmp)
                 }
-            } else if (g == 0 && row < M) {
+            } else if (g == 0 && row < M && live) {
                 if (resid) v = __fadd_rn(v, rsd);
                 y[row] = v;
             }
@@ -393,7 +412,7 @@ extern "C" __attribute__((visibility("default"))) int fl_debug_llc_timeline(long
     if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(llc_tl_cur), sizeof n) != hipSuccess) return -1;
     if (n > LLC_TL_CAP) n = LLC_TL_CAP;
     if ((int)n > max_rec) n = (unsigned)max_rec;
-    if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(llc_tl), sizeof(long long) * 8 * (size_t)n) != hipSuccess) return -1;
+    if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(llc_tl), sizeof(long long) * LLC_TL_W * (size_t)n) != hipSuccess) return -1;
     return (int)n;
 }
 #endif
@@ -419,6 +438,7 @@ static bool launch_llc(const fl_qtensor &W, const fl_qact *xq, float *y, hipStre
     const int KB = W.KB, NQ = (KB + 3) / 4, units = W.M16 / 16 / G2;
     const size_t lds = (size_t)NQ * 128 + (size_t)NQ * 32;                   // LX + d_x + s_x
     if (lds > 60 * 1024 || units < 1 || NQ > 88) return false;
+    if (qwd_bytes(W) >= (1ull << 31) || (size_t)W.M16 * (size_t)KB * 4 >= (1ull << 31)) return false;      // 32-bit buffer offsets (no LLaMA tensor comes close)
     // (waves along K, quads a wave holds): 4 x 8 covers K <= 4096 with the fewest registers (three waves per SIMD), 4 x 11 K <= 5632,
     // 8 x 11 K <= 11264 -- but an 8-wave workgroup at 186 registers is ONE per CU: good for a matrix of <= 256 row groups (LLaMA-7B's w2:
     // 12.5 us against round 3's 15.1), bad for many groups of long rows (65B width, K = 8192: 57 / 93 us against 35 / 63 for
@@ -428,10 +448,17 @@ static bool launch_llc(const fl_qtensor &W, const fl_qact *xq, float *y, hipStre
     // instantiation with one workgroup per ITS residency slot (see the kernel) -- built, bit-identical, and measured 2 % SLOWER on LLaMA-7B's
     // decode (564.8-567.8 against 577.5 tok/s in one gpurun call, profiles/r05_decode_exact.md): the loop costs 45 registers = two workgroups per CU
     // instead of three, and a row group's bytes are requested one chain phase, not one row group, ahead.
-#define FL_LLC_GO(NK, QPW, PS, GRID)                                                                                                      \
-    hipLaunchKernelGGL((gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, PS>), dim3(GRID), dim3(64 * NK), lds, st, W.M, units, KB,     \
+#define FL_LLC_GO(NK, QPW, PS, TM, GRID)                                                                                                  \
+    hipLaunchKernelGGL((gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, PS, TM>), dim3(GRID), dim3(64 * NK * TM), lds, st, W.M, units, KB, \
                        woven, W.qwd, W.d, xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid,       \
                        ynorm, aux2, pair_ws)
+    // FL_LLC_TEAMS=1 (opt-in): three row groups per workgroup (TEAMS = 3, the 4 x 8 form: 12 waves = one CU's worth at 136 registers; Q4_1's 8 x 4 form: two)
+    // when a launch has more than two row groups per CU -- the prologue once per CU.  Built, bit-identical, and measured SLOWER: 551 against 594 tok/s
+    // (Q4_1 402 against 455), profiles/r05_decode_exact.md -- the prologue takes the same 4.6 us whether one or three run on a CU (it waits for the
+    // norm weights' and the activation's round trips, not for the VALU), and twelve waves behind one barrier stretch the chain phase from 0.8 to 2.4 us.
+    static const bool teams_on = getenv("FL_LLC_TEAMS") && atoi(getenv("FL_LLC_TEAMS")) != 0 || getenv("FL_LLC_TEAMS_MIN");
+    static const int teams_min = getenv("FL_LLC_TEAMS_MIN") ? atoi(getenv("FL_LLC_TEAMS_MIN")) : -1;      // tests: teams on small matrices
+    static const int n_cus = [] { int d = 0, c = 0; return (hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && c > 0) ? c : 256; }();
 #define FL_LLC(NK, QPW)                                                                                                                   \
     do {                                                                                                                                  \
         static int slots0 = 0, slots1 = 0;                                                                                                \
@@ -439,11 +466,18 @@ static bool launch_llc(const fl_qtensor &W, const fl_qact *xq, float *y, hipStre
             slots0 = llc_slots(reinterpret_cast<const void *>(&gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, 0>), 64 * NK, lds);    \
             slots1 = llc_slots(reinterpret_cast<const void *>(&gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, 1>), 64 * NK, lds);    \
         }                                                                                                                                 \
-        if (PAIR == 1 || units <= slots0) FL_LLC_GO(NK, QPW, 0, units);                                                                   \
-        else FL_LLC_GO(NK, QPW, 1, (units < slots1 ? units : slots1));                                                                    \
+        if constexpr (NK == 4 && QPW == 8 && PAIR != 1) {                                                                                 \
+            if (teams_on && units > (teams_min >= 0 ? teams_min : 2 * n_cus)) { FL_LLC_GO(NK, QPW, 0, 3, (units + 2) / 3); break; }       \
+        }                                                                                                                                 \
+        if constexpr (NK == 8 && QPW == 4 && PAIR != 1) {      /* (Q4_1: 8 x 4 at <= 128 registers: two teams = 16 waves = one CU's worth) */ \
+            if (teams_on && units > (teams_min >= 0 ? teams_min : n_cus)) { FL_LLC_GO(NK, QPW, 0, 2, (units + 1) / 2); break; }           \
+        }                                                                                                                                 \
+        if (PAIR == 1 || units <= slots0) FL_LLC_GO(NK, QPW, 0, 1, units);                                                                \
+        else FL_LLC_GO(NK, QPW, 1, 1, (units < slots1 ? units : slots1));                                                                 \
     } while (0)
     if constexpr (TYPE == FL_TYPE_Q4_1) {             // Q4_1 carries m_w as well: 4 x 8 needs 174 registers = two waves per SIMD; 8 x 4 needs <= 126
-        if (NQ <= 32) { FL_LLC(8, 4); return true; }   // (four): LLaMA-7B Q4_1 decode 412 -> 424 tok/s.  (Q4_0, 139 registers at 4 x 8: no gain)
+        static const bool q41_48 = getenv("FL_Q41_48") != nullptr;      // A/B: the 4 x 8 form for Q4_1 as well
+        if (NQ <= 32 && !q41_48) { FL_LLC(8, 4); return true; }   // (four): LLaMA-7B Q4_1 decode 412 -> 424 tok/s.  (Q4_0, 139 registers at 4 x 8: no gain)
     }
     if (NQ <= 32) FL_LLC(4, 8);
     else if (NQ <= 44) FL_LLC(4, 11);

@@ -142,8 +142,24 @@ struct GemvPrologue {
     template <typename A1, typename A1w, typename A2>
     static __device__ __forceinline__ void finish(A1 &v, A1w &ww, A2 &sl_, A2 &sb_, const float *__restrict__ xf,
                                                   const void *__restrict__ aux, int KB, int woven, int8_t *lq, float *ld_, float *ls_,
-                                                  double *sh, float *__restrict__ ynorm, bool store_ynorm) {
+                                                  double *sh, float *__restrict__ ynorm, bool store_ynorm, long long *dbg = nullptr) {
+        // (dbg: development builds only -- wall-clock stamps of the prologue's steps, scripts/dev/decode_timeline.py)
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef GP_DIAG_SKIP   // timing-only diagnostic build (WRONG results): the prologue's arithmetic replaced by a constant fill of the LDS copy --
+                      // what the norm / quantize COMPUTE costs a decode token end to end (profiles/r05_decode_exact.md)
+        {
+            const int n8 = KB * 4;
+            for (int kg = threadIdx.x; kg < n8; kg += NT) {
+                *reinterpret_cast<uint2 *>(lq + kg * 8) = make_uint2(0x01010101u, 0x01010101u);
+                if ((kg & 3) == 0) { ld_[kg >> 2] = 1.f; ls_[kg >> 2] = 32.f; }
+            }
+            if (PRO == 1 && ynorm && store_ynorm)
+                for (int i = threadIdx.x; i < KB * 32; i += NT) ynorm[i] = xf[i];
+            asm volatile("" :: "v"(v[0][0]), "v"(ww[0][0]), "v"(sl_[0][0]), "v"(sb_[0][0]));      // (the loads stay: their round trips are still waited for)
+            __syncthreads();
+            return;
+        }
+#endif
         if constexpr (PRO == 1) {
             const int E = KB * 32, gpr = E >> 3;
             double sum = 0.0;
@@ -153,15 +169,18 @@ struct GemvPrologue {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) sum += (double)__fmul_rn(v[it][i], v[it][i]);
                 }
+                if (dbg) { asm volatile("" :: "v"(sum)); dbg[0] = wall_clock64(); }      // x has arrived and is squared
                 sum = wave_sum_f64(sum);                          // same order as block_sum_f64 (eval_kernels.hip)
                 if (lane == 0) sh[wave] = sum;
             }
             __syncthreads();
+            if (dbg) dbg[1] = wall_clock64();
             if (threadIdx.x < 256) {
                 double t = 0.0;
                 for (int i = 0; i < 4; ++i) t += sh[i];
                 const float mean = (float)(t / (double)E);
                 const float scale = __fdiv_rn(1.0f, sqrtf(mean + 1e-6f));
+                if (dbg) { asm volatile("" :: "v"(scale), "v"(ww[0][0])); dbg[2] = wall_clock64(); }      // scale known, the norm weights have arrived
 #pragma unroll
                 for (int it = 0; it < MAXIT; ++it) {
                     const int kg = threadIdx.x + it * 256;

@@ -12,7 +12,8 @@ pasts = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [128]
 name = sys.argv[5] if len(sys.argv) > 5 else "7B"
 cfg = dict(synth.MODELS[name])
 n_ctx = int(os.environ.get("FL_NCTX", 0)) or max(1024, (max(pasts) + steps + 8 + 511) // 512 * 512)
-m = FlModel(cfg, 2, synth.synth_model_tensors(cfg, 2), n_ctx=n_ctx, max_batch=512)
+QT = int(os.environ.get("FL_QTYPE", "2"))
+m = FlModel(cfg, QT, synth.synth_model_tensors(cfg, QT), n_ctx=n_ctx, max_batch=512)
 hip.load().fl_model_set_graph(m.h, graph)
 if waves:
     hip.load().fl_debug_set(1, waves)                 # force GEMV waves per row group

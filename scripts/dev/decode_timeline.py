@@ -29,11 +29,13 @@ KNAME = {104: "wq|wk|wv + rms_norm prologue", 900: "attention (one launch)", 4: 
          304: "w2 + Q8_0 prologue (+ residual), 4 slices"}
 
 
-def fetch(fn, cap):
-    buf = np.zeros((cap, 8), np.int64)
+def fetch(fn, cap, w=8):
+    buf = np.zeros((cap, w), np.int64)
     n = fn(buf.ctypes.data_as(C.c_void_p), cap, 0)
     assert n >= 0
-    return buf[:n]
+    out = np.zeros((n, 12), np.int64)
+    out[:, :w] = buf[:n]
+    return out
 
 
 def one_token(graph):
@@ -44,7 +46,7 @@ def one_token(graph):
     lib.fl_debug_llc_timeline(None, 0, 1); lib.fl_debug_da_timeline(None, 0, 1)
     m.eval_nocopy(t1, past + 4)
     torch.cuda.synchronize()
-    rec = np.concatenate([fetch(lib.fl_debug_llc_timeline, 1 << 17), fetch(lib.fl_debug_da_timeline, 1 << 14)])
+    rec = np.concatenate([fetch(lib.fl_debug_llc_timeline, 1 << 17, 12), fetch(lib.fl_debug_da_timeline, 1 << 14, 8)])
     rec = rec[np.argsort(rec[:, 0], kind="stable")]
     kid = rec[:, 7] >> 32
     # launches run one after the other on the stream: a launch = a maximal run of one kernel id on the time axis (the lm-head, also 104, follows a 308)
@@ -64,6 +66,9 @@ def one_token(graph):
             d.update(issue=float(np.median(t[:, 1] - t[:, 0])), prologue=float(np.median(t[:, 2] - t[:, 0])), first_data=float(np.median(t[:, 6] - t[:, 0])),
                      last_data_med=float(np.median(t[:, 3] - t[:, 0])), last_data=float(t[:, 3].max() - first), chains=float(np.median(t[:, 4] - t[:, 3])),
                      tail=float(end - t[:, 3].max()), life_med=float(np.median(t[:, 5] - t[:, 0])), life_max=float((t[:, 5] - t[:, 0]).max()))
+            tp = rec[r][:, 8:11].astype(np.float64) * 0.01
+            if tp[:, 0].max() > 0:                            # rms_norm prologue: x squared | first barrier | scale + norm weights there (from entry)
+                d["pro"] = [float(np.median(tp[:, j] - t[:, 0])) for j in range(3)]
         out.append(d)
     for a, b in zip(out, out[1:]):
         a["gap"] = b["first"] - a["end"]
@@ -86,6 +91,9 @@ for graph, what in ((1, "hipGraph replay"), (0, "plain stream launches")):
             ph = np.median(np.array([r["phases"] for r in rs]), axis=0)
             print(f"| {KNAME[k]} | {rs[0]['wgs']} | {med('dur'):.2f} | {med('ramp'):.2f} | requests issued {ph[0]:.2f} | rope + K/V stores {ph[1]:.2f} | scores + max {ph[2]:.2f} | soft_max {ph[3]:.2f} | P.V {ph[4]:.2f} | Q8_0 store {ph[5]:.2f} | - | {med('gap'):.2f} |")
         else:
+            if "pro" in rs[0]:
+                pm = np.median(np.array([r["pro"] for r in rs]), axis=0)
+                print(f"|   ... its rms_norm prologue, from entry: x arrived and squared {pm[0]:.2f}, first barrier passed {pm[1]:.2f}, scale known + norm weights arrived {pm[2]:.2f} | | | | | | | | | | | |")
             print(f"| {KNAME.get(k, k)} | {rs[0]['wgs']} | {med('dur'):.2f} | {med('ramp'):.2f} | {med('issue'):.2f} | {med('prologue'):.2f} | {med('first_data'):.2f} | {med('last_data_med'):.2f} / {med('last_data'):.2f} | {med('chains'):.2f} | {med('tail'):.2f} | {med('life_med'):.2f} / {med('life_max'):.2f} | {med('gap'):.2f} |")
     lay = [r for r in runs if r["kid"] == 104]
     if len(lay) > 3:
