@@ -443,6 +443,8 @@ static bool launch_llc(const fl_qtensor &W, const fl_qact *xq, float *y, hipStre
     // 8 x 11 K <= 11264 -- but an 8-wave workgroup at 186 registers is ONE per CU: good for a matrix of <= 256 row groups (LLaMA-7B's w2:
     // 12.5 us against round 3's 15.1), bad for many groups of long rows (65B width, K = 8192: 57 / 93 us against 35 / 63 for
     // wq|wk|wv / w1|w3, scripts/dev/dec_ab.sh) -- those, and rows beyond 11264 (13B / 65B w2), stay on round 3's kernel
+    // (round 5 tried an 8 x 8 form for K <= 8192 compiled for <= 128 registers -- two workgroups per CU -- : 23-35 scratch spills, LLaMA-65B decode 58.8
+    //  against round 3's kernel's 78.6 tok/s in one gpurun call; removed)
     if (NQ > 44 && units > 256) return false;
     // grid: one workgroup per row group.  FL_LLC_PERSIST=1 (opt-in): when the row groups do not all fit on the chip at once, the PERSIST
     // instantiation with one workgroup per ITS residency slot (see the kernel) -- built, bit-identical, and measured 2 % SLOWER on LLaMA-7B's

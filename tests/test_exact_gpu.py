@@ -344,7 +344,7 @@ def exact_hooks():
 
 
 @pytest.mark.parametrize("nm,qt", Q4)
-@pytest.mark.parametrize("M,K", [(48, 64), (300, 256), (4096, 4096), (12288, 4096), (1024, 8192), (32, 2560)])
+@pytest.mark.parametrize("M,K", [(48, 64), (300, 256), (4096, 4096), (12288, 4096), (1024, 8192), (4608, 8192), (32, 2560)])
 def test_exact_gemv_with_norm_prologue(torch, ops, port, exact_hooks, nm, qt, M, K):
     """rms_norm * w -> Q8_0 -> mul_mat in one launch (producer / chain waves): the oracle's bits."""
     from fastllama_amd import hip
@@ -365,7 +365,7 @@ def test_exact_gemv_with_norm_prologue(torch, ops, port, exact_hooks, nm, qt, M,
 
 
 @pytest.mark.parametrize("nm,qt", Q4)
-@pytest.mark.parametrize("F,K,E", [(64, 64, 48), (704, 256, 256), (11008, 4096, 4096), (13824, 5120, 512)])
+@pytest.mark.parametrize("F,K,E", [(64, 64, 48), (704, 256, 256), (11008, 4096, 4096), (13824, 5120, 512), (4608, 8192, 8192)])
 def test_exact_feed_forward_pair_and_quant_prologue(torch, ops, port, exact_hooks, nm, qt, F, K, E):
     """(a) woven w1|w3: norm prologue + the two dots + silu*mul epilogue in one launch; (b) w2 with the Q8_0 prologue
     (+ residual); (c) w2 with the silu*mul prologue on an f32 [w1 x | w3 x] vector -- each the oracle's bits."""
