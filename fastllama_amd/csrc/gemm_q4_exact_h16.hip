@@ -3,7 +3,8 @@
 // What must be reproduced (ggml_vec_dot_q4_{0,1}_q8_0, AVX2 branch, /root/reference/lib/ggml.c:2445-2487, :2639-2689): per output
 // 8 f32 accumulators, accumulator j taking  acc_j = fma(d_w * d_x, float(sum of the products of elements 4j..4j+3), acc_j)
 // block after block, then ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)) [+ the scalar chain summs = fma(m_w, s_x, summs) for Q4_1].
-// The 8 fma per (output, block) are VALU work nothing can remove (64 v_pk_fma_f32 per 32x32 tile and block = 256 cycles) and the
+// The 8 fma per (output, block) are VALU work nothing can remove (128 v_fma_f32 per 32x32 tile and block = 256+ cycles; the kernel is compiled
+// with packed f32 OFF: beside MFMAs v_pk_fma_f32 costs twice what two v_fma_f32 do, profiles/r04_ubench_coexec5.txt) and the
 // 8 lane sums cost four v_mfma_f32_32x32x4_2b_f16 (two lane sums of a 32x32 tile each, 64 cycles: the matrix pipe delivers 32
 // results per cycle whatever the shape) = 256 cycles; on gfx950 the two pipes of a SIMD do not overlap, so 512 + 32 (the d_w x d_x
 // outer product, one MFMA per block PAIR) is the floor of the reference's order.  Round 3's kernel (gemm_q4_exact_mfma.hip)
@@ -12,7 +13,8 @@
 //   * both operands are read as ready-made f16 MFMA fragments (q4_layout.h "H16 copies": WH16 built once per tensor, XH16 by
 //     whoever produces the Q8_0 activations), 2 KiB per (32-row tile, block), moved HBM/L2 -> LDS by buffer_load ... lds;
 //   * a workgroup = 4 waves = 64 x 64 outputs (2 x 2 wave tiles): every fragment staged in LDS is read by two waves;
-//     3-stage ring of block PAIRS, one barrier per pair, DMA counted with s_waitcnt vmcnt (never 0 inside the loop);
+//     K-steps of 4 blocks, TWO LDS stages of 34-36 KiB, one barrier per K-step; a K-step's nine DMA pieces per wave are issued one by one in
+//     the shadow of the previous step's first MFMAs and have landed (s_waitcnt vmcnt(0) at the top of the step: nothing else is in flight) by then;
 //   * the scales reach LDS by the same DMA (gathered per lane from the QW16 / QA16 planes); d_w x d_x of a block pair is ONE
 //     v_mfma_f32_32x32x1_2b_f32 (exact products, rounded once: rn(d_w d_x));
 //   * the order-free tails of the reference graph run as epilogues on the accumulators, bit-identical to the separate
