@@ -242,8 +242,16 @@ fl_qtensor *fl_qtensor_from_device(int type, const void *blocks_dev, int M, int 
 }
 
 /* (re)build the f16 fragment copy the reference-order prefill GEMM reads (q4_layout.h "H16 copies"; 4 x the nibble bytes) */
+// FL_TEST_FAIL_DERIVED=1|2|3 (tests only): the WH16 (bit 0) / QWD (bit 1) allocation fails as if device memory had run out -- the fallback and
+// its warning cannot be exercised otherwise without filling 288 GB
+static bool test_fail_derived(int bit) {
+    const char *e = getenv("FL_TEST_FAIL_DERIVED");
+    return e && (atoi(e) & bit) != 0;
+}
+
 int fl_qtensor_build_h16(fl_qtensor *W, void *stream) {
     if (!W) return set_error(FL_EINVAL, "null tensor");
+    if (!W->h16 && test_fail_derived(1)) return set_error(FL_ENOMEM, "hipMalloc(WH16): out of memory (FL_TEST_FAIL_DERIVED)");
     if (!W->h16) {
         hipError_t ea = hipMalloc((void **)&W->h16, wh16_bytes(*W));
         if (ea != hipSuccess) {
@@ -260,6 +268,7 @@ int fl_qtensor_build_h16(fl_qtensor *W, void *stream) {
 /* (re)build the nibble copy the reference-order decode kernel reads (q4_layout.h "QWD"; the size of the nibbles again) */
 int fl_qtensor_build_qwd(fl_qtensor *W, void *stream) {
     if (!W) return set_error(FL_EINVAL, "null tensor");
+    if (!W->qwd && test_fail_derived(2)) return set_error(FL_ENOMEM, "hipMalloc(QWD): out of memory (FL_TEST_FAIL_DERIVED)");
     if (!W->qwd) {
         hipError_t ea = hipMalloc((void **)&W->qwd, qwd_bytes(*W));
         if (ea != hipSuccess) {

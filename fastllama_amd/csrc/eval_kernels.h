@@ -31,6 +31,8 @@ hipError_t dot_f32_abt_exact(const float *A, int lda, int64_t sAz, const float *
 // fma chain (exact_kernels.hip); hipErrorInvalidValue: shape outside their reach -> dot_f32_abt_exact
 hipError_t attn_scores_exact(const float *qkv, int ldq, int D, int H, int N, int n_past, const float *kc, int ldk, float scale,
                              float *att, int ld_att, int64_t head_stride, hipStream_t st);
+hipError_t attn_scores_softmax_exact(const float *qkv, int ldq, int D, int H, int N, int n_past, const float *kc, int ldk, float scale,
+                                     float *att, int ld_att, int64_t head_stride, const uint16_t *exp_tab, hipStream_t st);   // + soft_max in the same launch (<= 1024 keys)
 // out != NULL: the result leaves as the Q8_0 operand of the wo matmul (QA16, K = ldo; with_h16: + its XH16 copy) instead of f32 rows in ao
 hipError_t attn_pv_exact(const float *att, int ld_att, int64_t head_stride, int D, int H, int N, int n_past, const float *vc, int n_ctx,
                          float *ao, int ldo, hipStream_t st, const fl_qact *out = nullptr, bool with_h16 = false);

@@ -688,10 +688,16 @@ constexpr int XA_LD = XA_KT + 1;
 // lane (i, h) of an MFMA supplies, for the 32-element step st = 2 m + h, element 8 jj + l of row i.  The key row of a tile is kept in
 // registers (the 32 elements of each of the lane's MS = ceil(NST / 2) steps, zeros for a step past the row; straight from HBM/L2
 // as 128-byte pieces), the 32 query rows of the workgroup in LDS.
-template <int NST>
+// SM (round 5): soft_max of the workgroup's 32 score rows in the same launch -- the workgroup computes every key tile of its query block, so
+// the complete rows can wait in LDS ([32][PLD] floats, contexts of up to 1024 keys) instead of making the trip through HBM to a separate
+// kernel and back: ggml_soft_max's arithmetic as softmax_rows_reg_kernel (eval_kernels.hip) has it -- row max, fp16 exp table, f64 sum (exact in
+// any order), rn(t * rn_f32(1 / sum)), zeros past each row's last visible key.
+template <int NST, bool SM>
 __global__ __launch_bounds__(512) void attn_scores_exact_kernel(const float *__restrict__ qkv, int ldq, int N, int n_past,
                                                                 const float *__restrict__ kc, int ldk, float scale,
-                                                                float *__restrict__ att, int ld_att, int64_t head_stride) {
+                                                                float *__restrict__ att, int ld_att, int64_t head_stride,
+                                                                const uint16_t *__restrict__ exp_tab, int PLD) {
+    extern __shared__ float sm_rows[];                        // SM: [32][PLD] scaled scores
     constexpr int D = 32 * NST, MS = (NST + 1) / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // heaviest query blocks first (block i sees (i + 1) 32-key steps): with one or two workgroups resident per CU the launch runs in
@@ -778,8 +784,49 @@ __global__ __launch_bounds__(512) void attn_scores_exact_kernel(const float *__r
         float *out = att + hd * head_stride;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int q = q0 + (e & 3) + 8 * (e >> 2) + 4 * h, key = k0 + i;
-            if (q < N && key <= n_past + q) out[(int64_t)q * ld_att + key] = __fmul_rn(total[e], scale);
+            const int ql = (e & 3) + 8 * (e >> 2) + 4 * h, q = q0 + ql, key = k0 + i;
+            if (q < N && key <= n_past + q) {
+                if (SM) sm_rows[ql * PLD + key] = __fmul_rn(total[e], scale);
+                else out[(int64_t)q * ld_att + key] = __fmul_rn(total[e], scale);
+            }
+        }
+    }
+    if constexpr (SM) {
+        __syncthreads();
+        const int P = n_past + N;
+        constexpr int IT = 16;                                // 64 x 16 = 1024 keys at most (the launcher checks)
+#pragma unroll 1
+        for (int rr = 0; rr < 4; ++rr) {
+            const int ql = wave * 4 + rr, q = q0 + ql;
+            if (q >= N) break;                                // (wave-uniform)
+            const int L = min(P, n_past + q + 1);
+            const float *srow = sm_rows + ql * PLD;
+            float x[IT];
+#pragma unroll
+            for (int u = 0; u < IT; ++u) {
+                const int c = lane + 64 * u;
+                x[u] = c < L ? srow[c] : -INFINITY;
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < IT; ++u) mx = fmaxf(mx, x[u]);
+            mx = wave_max_f32(mx);
+#pragma unroll
+            for (int u = 0; u < IT; ++u) {                    // (-inf - mx rounds to fp16 -inf: a valid table index, entry 0)
+                const float t = __half2float(__ushort_as_half(exp_tab[__half_as_ushort(__float2half_rn(x[u] - mx))]));
+                x[u] = x[u] != -INFINITY ? t : 0.f;
+            }
+            double sum = 0.0;
+#pragma unroll
+            for (int u = 0; u < IT; ++u) sum += (double)x[u];
+            sum = wave_sum_f64(sum);
+            const float inv = (float)(1.0 / sum);
+            float *prow = att + hd * head_stride + (int64_t)q * ld_att;
+#pragma unroll
+            for (int u = 0; u < IT; ++u) {
+                const int c = lane + 64 * u;
+                if (c < P) prow[c] = c < L ? __fmul_rn(x[u], inv) : 0.f;
+            }
         }
     }
 }
@@ -1100,7 +1147,38 @@ hipError_t attn_scores_exact(const float *qkv, int ldq, int D, int H, int N, int
                              float *att, int ld_att, int64_t head_stride, hipStream_t st) {
     if (D % 32 != 0 || D > 128 || N < 1 || (ldq & 3) || (ldk & 3)) return hipErrorInvalidValue;
     const dim3 grid(H, (N + 31) / 32);
-#define FL_XS(NST) hipLaunchKernelGGL(attn_scores_exact_kernel<NST>, grid, dim3(512), 0, st, qkv, ldq, N, n_past, kc, ldk, scale, att, ld_att, head_stride)
+#define FL_XS(NST) hipLaunchKernelGGL((attn_scores_exact_kernel<NST, false>), grid, dim3(512), 0, st, qkv, ldq, N, n_past, kc, ldk, scale, att, ld_att, head_stride, nullptr, 0)
+    if (D == 32) FL_XS(1);
+    else if (D == 64) FL_XS(2);
+    else if (D == 96) FL_XS(3);
+    else FL_XS(4);
+#undef FL_XS
+    return hipGetLastError();
+}
+// K.Q, scale, mask AND soft_max in one launch (contexts of up to 1024 keys: the 32 score rows of a workgroup wait in LDS); hipErrorInvalidValue:
+// outside its reach -- the caller runs attn_scores_exact + softmax_rows
+hipError_t attn_scores_softmax_exact(const float *qkv, int ldq, int D, int H, int N, int n_past, const float *kc, int ldk, float scale,
+                                     float *att, int ld_att, int64_t head_stride, const uint16_t *exp_tab, hipStream_t st) {
+    static const bool off = getenv("FL_XA_NOFUSE") != nullptr;                 // A/B (profiles/r05_attn_exact.md)
+    const int P = n_past + N;
+    if (off || !exp_tab || D % 32 != 0 || D > 128 || N < 1 || (ldq & 3) || (ldk & 3) || P > 1024) return hipErrorInvalidValue;
+    const int PLD = ((P + 31) & ~31) + 1;
+    const size_t lds = (size_t)32 * PLD * 4;
+    static bool attr_set[64] = {false};      // (per device)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        const size_t mx = (size_t)32 * 1025 * 4;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_scores_exact_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_scores_exact_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_scores_exact_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_scores_exact_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    const dim3 grid(H, (N + 31) / 32);
+#define FL_XS(NST) hipLaunchKernelGGL((attn_scores_exact_kernel<NST, true>), grid, dim3(512), lds, st, qkv, ldq, N, n_past, kc, ldk, scale, att, ld_att, head_stride, exp_tab, PLD)
     if (D == 32) FL_XS(1);
     else if (D == 64) FL_XS(2);
     else if (D == 96) FL_XS(3);

@@ -692,15 +692,22 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
                 (void)hipGetLastError();
                 // KQ, scale, mask, soft_max                                                            :364-379
                 const bool xa = exact && !dyn && N >= 2 && D % 32 == 0 && D <= 128;   // the MFMA forms of the exact products
-                hipError_t xe = xa ? attn_scores_exact(m->qkv, 3 * El, D, Hl, N, n_past, kc, El, kq_scale, m->att, n_ctx, (int64_t)N * n_ctx, st)
+                // (contexts of up to 1024 keys: K.Q and soft_max in one launch, the score rows waiting in LDS)
+                bool softmaxed = false;
+                hipError_t xe = xa ? attn_scores_softmax_exact(m->qkv, 3 * El, D, Hl, N, n_past, kc, El, kq_scale, m->att, n_ctx, (int64_t)N * n_ctx, m->exp_tab, st)
                                    : hipErrorInvalidValue;
+                if (xe == hipSuccess) softmaxed = true;
+                else if (xa) {
+                    (void)hipGetLastError();
+                    xe = attn_scores_exact(m->qkv, 3 * El, D, Hl, N, n_past, kc, El, kq_scale, m->att, n_ctx, (int64_t)N * n_ctx, st);
+                }
                 if (xe == hipErrorInvalidValue) {                   // (a shape or alignment outside the MFMA form's reach: the half-wave-per-dot kernel)
                     (void)hipGetLastError();
                     xe = (exact ? dot_f32_abt_exact : gemm_f32_abt)(m->qkv, 3 * El, D, kc, El, D, m->att, n_ctx, (int64_t)N * n_ctx, N, P, D, Hl,
                                                                     kq_scale, 1, n_past, st, dyn, n_ctx);
                 }
                 M_HIP(xe);
-                M_HIP(softmax_rows(m->att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, Hl, m->exp_tab, st, dyn));
+                if (!softmaxed) M_HIP(softmax_rows(m->att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, Hl, m->exp_tab, st, dyn));
                 // KQV, merged back to [N, n_embd]                                                      :389-398
                 bool quantized = xa && layout == 16 && El % 32 == 0;        // the MFMA form writes the Q8_0 operand of wo itself
                 xe = xa ? attn_pv_exact(m->att, n_ctx, (int64_t)N * n_ctx, D, Hl, N, n_past, vc, n_ctx, m->ao, El, st, quantized ? &m->qEl : nullptr,

@@ -329,6 +329,41 @@ def test_exact_decode_forms_agree_with_each_other_and_the_reference(tmp_path, to
     m.free()
 
 
+def test_prepare_builds_the_operand_copies_and_a_failed_copy_warns(torch, port, monkeypatch):
+    """fl_model_prepare builds the derived weight copies of the reference-order kernels up front (fl_model_prepared says which are
+    resident); when a copy cannot be allocated the kernel family that reads the primary layout runs -- the SAME bits -- and the warning
+    handler is told once per kind, with the bytes that were missing (no silent cliffs)."""
+    import ctypes as C
+    from fastllama_amd import hip
+    from harness.flmodel import FlModel
+    L = hip.load()
+    cfg, qt = ggjt.SMALL, oracle.Q4_0
+    tensors = ggjt.synth_tensors(cfg, qt, port.quantize_q4, seed=3)
+    toks = np.random.default_rng(2).integers(3, 259, 40).astype(np.int32)
+    lines = []
+    CB = C.CFUNCTYPE(None, C.c_char_p)
+    cb = CB(lambda s: lines.append(s.decode()))
+    L.fl_set_warn_handler(C.cast(cb, C.c_void_p))
+    try:
+        m = FlModel(cfg, qt, tensors, n_ctx=64, max_batch=40)
+        assert L.fl_model_prepared(m.h) == 0
+        assert m.prepare(3) == 3 and not lines
+        want = m.eval(toks, all_logits=True)
+        want1 = m.eval([int(toks[7])], n_past=40)
+        m.free()
+        monkeypatch.setenv("FL_TEST_FAIL_DERIVED", "3")
+        m = FlModel(cfg, qt, tensors, n_ctx=64, max_batch=40)
+        assert m.prepare(3) == 0
+        assert len(lines) == 2 and "f16 operand copies" in lines[0] and "decode copies" in lines[1], lines
+        got = m.eval(toks, all_logits=True)
+        got1 = m.eval([int(toks[7])], n_past=40)
+        assert len(lines) == 2                                        # told once, not per eval
+        m.free()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and np.array_equal(got1.view(np.uint32), want1.view(np.uint32))
+    finally:
+        L.fl_set_warn_handler(None)
+
+
 # ------------------------------------------------------------------ the single-token (decode) kernels, op by op ------------
 from oracle import llama_eval as le  # noqa: E402
 
