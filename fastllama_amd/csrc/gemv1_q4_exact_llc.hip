@@ -157,11 +157,10 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
 #endif
 
     // ---- this wave's slice of the weight stream: every load goes out before anything waits (nontemporal: read once per token)
-    // PERSISTENT workgroups (round 5): a launch has at most one workgroup per residency slot; a workgroup takes the row groups
-    // blockIdx.x, blockIdx.x + gridDim.x, ... -- the prologue (the activation's Q8_0 form in LDS) is paid once, and the next row group's
-    // weights are requested as soon as this one's lane sums have freed their registers, i.e. they travel under the chains and the store.
-    // (LLaMA-7B's woven w1|w3 is 1376 row groups on 768 slots: as one workgroup per row group the second round's workgroups were
-    //  dispatched 7-10 us into the launch, each redoing the 5 us prologue before it could use its bytes: profiles/r05_decode_timeline.md.)
+    // PERSIST = 1 (round 5, opt-in): a launch has at most one workgroup per residency slot; a workgroup takes the row groups blockIdx.x,
+    // blockIdx.x + gridDim.x, ... -- the prologue (the activation's Q8_0 form in LDS) is paid once, and the next row group's weights are requested
+    // behind this one's chains (do_group, below).  (LLaMA-7B's woven w1|w3 is 1376 row groups on 768 slots: as one workgroup per row group the second
+    // round's workgroups are dispatched 7-10 us into the launch, each redoing the prologue: profiles/r05_decode_timeline.md -- and still the faster form.)
     int unit = TEAMS == 1 ? (int)blockIdx.x : min((int)blockIdx.x * TEAMS + team, units - 1);
     const bool live = TEAMS == 1 || (int)blockIdx.x * TEAMS + team < units;      // (a team past the last row group redoes it and stores nothing)
     const int qlo = (k * NQ) / NK, nq = ((k + 1) * NQ) / NK - qlo;              // (wave-uniform; nq <= QPW by the launcher's choice of NK)
