@@ -358,6 +358,9 @@ def main():
             # the same steps with the logits left in HBM (no host round trip per token): what the kernels alone sustain
             dec_nc = lambda i: model.eval_nocopy(tok1, min(128, N) + i)
             m["decode_ms_device_resident"] = min(timed(dec_nc, dsteps), timed(dec_nc, dsteps)) / dsteps * 1e3
+            # launches of a decode token = kernel nodes of the replayed hipGraph (under the row split: are the exchanges tails of the producers?)
+            m["decode_graph_nodes"] = int(hip.load().fl_model_graph_nodes(model.h))
+            m["tp_decode_folded"] = bool(hip.load().fl_model_tp_folded(model.h))
             # ---- decode at the end of the context (p ~ n_ctx - 1; the K/V stream of n_past positions per layer, split attention)
             lsteps_ = min(32 if not short else 12, args.decode_steps)
             m["long_past"] = n_ctx - lsteps_ - 4
@@ -556,6 +559,13 @@ def main():
                                        "sample": f"failed: {e!r}"}
         if tp:
             out["tp_small_message_path"] = "peer-mapped buffers (hipIpc), one kernel per rank" if leg.get("peer_exchange") else "RCCL"
+            nl = int(cfg["n_layer"])
+            out["tp_decode"] = {
+                "exchanges_folded_into_producers": head["tp_decode_folded"], "graph_nodes_per_token": head["decode_graph_nodes"],
+                "launches_per_layer": (head["decode_graph_nodes"] - 4) / nl if head["decode_graph_nodes"] else None,
+                "note": ("kernel nodes of the replayed decode hipGraph; -4: token lookup, lm-head, the logits' gather (exchange + permute).  Folded: the "
+                         "four exchanges of a layer are the tails of the launches that produce the data (peer-mapped fold regions, tp_tail.h): "
+                         "wq|wk|wv, attention, wo, w1|w3, w2 and no collective launch; otherwise pack -> all-gather -> unpack (-> add) per exchange")}
         if tp_error:
             out["tp_error"] = tp_error + " -- the headline above is the replica leg"
         if rank == 0:

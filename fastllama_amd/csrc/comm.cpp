@@ -14,6 +14,7 @@
 
 #include "comm.h"
 #include "runtime.h"
+#include "tp_tail.h"
 
 using namespace fl;
 
@@ -36,7 +37,11 @@ struct LocalGroup {
 // One-shot exchange of small messages through peer-mapped buffers (hipIpc; p2p_exchange_kernel, eval_kernels.hip): what a decode
 // token's 16-32 KB all-reduces and its logits all-gather take instead of a ring collective.  Set up next to the RCCL
 // communicator when every step of the handle exchange succeeds; otherwise the communicator simply stays RCCL-only.
-constexpr size_t P2P_CAP = 64 * 1024;          // floats per slot (256 KB): the exchange buffer of a rank is two slots
+constexpr size_t P2P_CAP = 64 * 1024;          // floats per slot (256 KB): the exchange buffer of a rank is two slots + the fold region (tp_tail.h)
+// flag page (4096 B, exported): words [0..1] the slots' flags, [16] this rank's epoch, [17] timeouts; the fold exchanges: [64 + kind * 8 + source rank]
+// the flags peers write, [128 + kind] tickets, [144 + kind] epochs (local)
+constexpr int FOLD_FLAG0 = 64, FOLD_TICKET0 = 128, FOLD_EPOCH0 = 144;
+static_assert(FL_COMM_MAX_LOCAL <= 8 && TP_FOLD_KINDS <= 8, "flag page layout");
 constexpr size_t P2P_MAX_COUNT = 16 * 1024;    // messages up to 64 KB go this way (one workgroup moves them)
 struct P2PState {
     P2PPeers peers{};
@@ -65,7 +70,7 @@ static int p2p_alloc(fl_comm *c) {
         if (r != hipSuccess) { (void)hipGetLastError(); r = hipMalloc(ptr, bytes); }
         return r;
     };
-    hipError_t e = alloc(&p.own_buf, 2 * P2P_CAP * sizeof(float));
+    hipError_t e = alloc(&p.own_buf, 2 * P2P_CAP * sizeof(float) + TP_FOLD_BYTES);
     if (e == hipSuccess) e = alloc(&p.own_flag, 4096);               // [0..1] flags (exported), [16] this rank's epoch
     if (e == hipSuccess) e = hipMemset(p.own_flag, 0, 4096);
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -91,10 +96,18 @@ static void p2p_free(fl_comm *c) {
     p = P2PState{};
 }
 static_assert(2 * sizeof(hipIpcMemHandle_t) == FL_COMM_P2P_HANDLE_BYTES, "hipIpcMemHandle_t size");
+static bool p2p_selftest(fl_comm *c);
 
 static_assert(sizeof(ncclUniqueId) == FL_COMM_ID_BYTES, "ncclUniqueId size");
 
 extern "C" {
+
+/* The check fl_comm_create runs before it keeps the exchange, for hosts that moved the handles themselves (fl_comm_create_p2p): COLLECTIVE --
+ * every rank calls it after fl_comm_p2p_import; patterned slices travel between all ranks through the exchange's tail kernel within 2 s. */
+int fl_comm_p2p_selftest(fl_comm *c) {
+    if (!c || !c->p2p.ready) return set_error(FL_EINVAL, "fl_comm_p2p_selftest: no peer-mapped exchange behind this communicator");
+    return p2p_selftest(c) ? FL_OK : set_error(FL_EHIP, "peer exchange self-test failed on rank %d (a slice did not arrive, or a peer did not within 2 s)", c->rank);
+}
 
 int fl_comm_unique_id(void *out) {
     if (!out) return set_error(FL_EINVAL, "null id buffer");
@@ -114,10 +127,11 @@ fl_comm *fl_comm_create(const void *id_bytes, int rank, int world) {
     fl_comm *c = new (std::nothrow) fl_comm();
     if (!c) return nullptr;
     // peer-mapped exchange buffers for the small messages: handles travel through the communicator itself
-    // (opt-in, FL_P2P=1: the exchange has run between processes on one GPU only -- no multi-GPU node was available to this
-    //  project -- and a communicator that every multi-GPU run depends on should not default to an untried path)
+    // ON by default since round 5 (FL_P2P=0: RCCL only).  The exchange has run between processes on ONE GPU only -- no multi-GPU node was
+    // available to this project -- so a communicator keeps it only if (a) every step of the handle exchange worked on every rank and (b)
+    // the self-test below moved patterned slices between all ranks within its 2 s; anything else leaves the communicator on RCCL alone.
     const char *want_p2p_env = getenv("FL_P2P");
-    const bool want_p2p = world >= 2 && world <= FL_COMM_MAX_LOCAL && want_p2p_env && want_p2p_env[0] == '1';
+    const bool want_p2p = world >= 2 && world <= FL_COMM_MAX_LOCAL && !(want_p2p_env && want_p2p_env[0] == '0');
     // The handshake's staging buffer is allocated BEFORE the communicator exists: once ncclCommInitRank has returned, every rank
     // must execute both collectives below whatever happens locally (a local ncclCommAbort does not reliably unblock peers already
     // inside ncclAllGather), so nothing that can fail may sit between the init and them.  Device memory first, pinned host memory
@@ -171,12 +185,17 @@ fl_comm *fl_comm_create(const void *id_bytes, int rank, int world) {
         // every rank must take the same path for a given message: the exchange is used only if it came up on ALL ranks
         // (the agreement word lives in the staging buffer: no allocation that could fail between the two collectives)
         int *agree = static_cast<int *>(stage);
-        int mine_ok = c->p2p.ready ? 1 : 0, all_ok = 0;
-        const bool sent = hipMemcpy(agree, &mine_ok, sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
-        if (!sent) (void)hipMemset(agree, 0, sizeof(int));
-        if (ncclAllReduce(agree, agree, 1, ncclInt32, ncclMin, c->comm, nullptr) == ncclSuccess && hipDeviceSynchronize() == hipSuccess &&
-            hipMemcpy(&all_ok, agree, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && all_ok == 1) {
-            // keep it
+        auto all_agree = [&](bool mine) {
+            int mine_ok = mine ? 1 : 0, all_ok = 0;
+            const bool sent = hipMemcpy(agree, &mine_ok, sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+            if (!sent) (void)hipMemset(agree, 0, sizeof(int));
+            return ncclAllReduce(agree, agree, 1, ncclInt32, ncclMin, c->comm, nullptr) == ncclSuccess && hipDeviceSynchronize() == hipSuccess &&
+                   hipMemcpy(&all_ok, agree, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && all_ok == 1;
+        };
+        // ... and only if it then WORKS between these devices (every rank has the mappings: the self-test is collective), again on all ranks
+        if (all_agree(c->p2p.ready)) {
+            const bool works = getenv("FL_P2P_NO_SELFTEST") ? true : p2p_selftest(c);
+            if (!all_agree(works)) p2p_free(c);
         } else {
             p2p_free(c);
         }
@@ -237,6 +256,65 @@ int fl_comm_p2p_import(fl_comm *c, const void *handles_all) {
 }
 
 int fl_comm_has_p2p(const fl_comm *c) { return c && c->p2p.ready ? 1 : 0; }
+}  // extern "C"
+
+bool fl::comm_fold(const fl_comm *c, TpFold *out) {
+    if (!c || !c->p2p.ready || !out) return false;
+    const P2PPeers &pp = c->p2p.peers;
+    *out = TpFold{};
+    out->world = pp.world;
+    out->rank = pp.rank;
+    for (int r = 0; r < pp.world; ++r) {
+        out->region[r] = reinterpret_cast<unsigned char *>(pp.buf[r] + 2 * pp.cap);
+        out->flag[r] = pp.flag[r] + FOLD_FLAG0;
+    }
+    out->ticket = pp.flag[pp.rank] + FOLD_TICKET0;
+    out->epoch = pp.flag[pp.rank] + FOLD_EPOCH0;
+    out->timeouts = pp.epoch + 1;
+    return true;
+}
+
+// One exchange kind's record for a slice [off, off + bytes) of the fold region
+static TpTail fold_tail(const TpFold &f, int kind, unsigned off, unsigned bytes, unsigned long long timeout_ticks) {
+    TpTail t{};
+    t.world = f.world; t.rank = f.rank;
+    t.n_ranges = 1; t.off[0] = off; t.bytes[0] = bytes;
+    for (int r = 0; r < f.world; ++r) { t.region[r] = f.region[r]; t.flag[r] = f.flag[r] + kind * FL_COMM_MAX_LOCAL; }
+    t.ticket = f.ticket + kind; t.epoch = f.epoch + kind; t.timeouts = f.timeouts;
+    t.timeout_ticks = timeout_ticks;
+    return t;
+}
+
+// Does the exchange work between THESE devices?  Every rank pushes three patterned 1 KB slices through the tail kernel (short timeout: the
+// ranks are in step, the caller has just finished a collective) and checks what arrived from every peer.  Collective: every rank of a
+// communicator whose handles were imported calls it.  A failure leaves the communicator on RCCL alone (fl_comm_create).
+static bool p2p_selftest(fl_comm *c) {
+    TpFold f;
+    if (!comm_fold(c, &f)) return false;
+    constexpr unsigned SL = 1024, W = SL / 4;
+    TpTail *td = nullptr;
+    if (hipMalloc(&td, sizeof(TpTail)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const TpTail t = fold_tail(f, TP_FOLD_KINDS - 1, (unsigned)f.rank * SL, SL, 200000000ull /* 2 s */);
+    bool ok = hipMemcpy(td, &t, sizeof t, hipMemcpyHostToDevice) == hipSuccess;
+    unsigned before = 0, after = 0;
+    ok = ok && hipMemcpy(&before, f.timeouts, 4, hipMemcpyDeviceToHost) == hipSuccess;
+    uint32_t mine[W], all[FL_COMM_MAX_LOCAL * W];
+    for (unsigned round = 1; round <= 3 && ok; ++round) {
+        for (unsigned i = 0; i < W; ++i) mine[i] = (round << 28) ^ ((unsigned)f.rank << 20) ^ (i * 2654435761u);
+        ok = hipMemcpy(f.region[f.rank] + (size_t)f.rank * SL, mine, SL, hipMemcpyHostToDevice) == hipSuccess &&
+             tp_tail_launch(td, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+             hipMemcpy(all, f.region[f.rank], (size_t)f.world * SL, hipMemcpyDeviceToHost) == hipSuccess;
+        for (int r = 0; r < f.world && ok; ++r)
+            for (unsigned i = 0; i < W && ok; ++i) ok = all[(size_t)r * W + i] == ((round << 28) ^ ((unsigned)r << 20) ^ (i * 2654435761u));
+    }
+    if (hipMemcpy(&after, f.timeouts, 4, hipMemcpyDeviceToHost) != hipSuccess || after != before) ok = false;
+    if (after != before) c->p2p.timeouts_seen = after;          // (the self-test's give-ups are not an eval's)
+    (void)hipFree(td);
+    (void)hipGetLastError();
+    return ok;
+}
+
+extern "C" {
 /* exchanges of this rank that gave up waiting for a peer (p2p_exchange_kernel's bounded spin); synchronises the device */
 int fl_comm_p2p_timeouts(const fl_comm *c) {
     if (!c || !c->p2p.ready) return 0;

@@ -16,4 +16,17 @@ struct P2PPeers {
     int world, rank;
 };
 hipError_t p2p_exchange(const P2PPeers &peers, float *data, size_t count, float *gather_out, hipStream_t st);
+
+// The fold regions of a communicator with the peer-mapped exchange behind it (tp_tail.h): per rank TP_FOLD_BYTES behind the two
+// small-message slots, and in the flag page the words of the exchange kinds -- what a model needs to build its TpTail records.
+constexpr size_t TP_FOLD_BYTES = 256 * 1024;
+constexpr int TP_FOLD_KINDS = 8;                 // 0..3: the four exchanges of a decode layer; 7: the communicator's self-test
+struct TpFold {
+    int world, rank;
+    unsigned char *region[FL_COMM_MAX_LOCAL];
+    unsigned *flag[FL_COMM_MAX_LOCAL];           // rank r's words: [TP_FOLD_KINDS][FL_COMM_MAX_LOCAL source ranks]
+    unsigned *ticket, *epoch;                    // local, [TP_FOLD_KINDS]
+    unsigned *timeouts;                          // local (the counter fl_comm_p2p_check reads)
+};
+bool comm_fold(const fl_comm *c, TpFold *out);   // false: no peer-mapped exchange behind this communicator
 }  // namespace fl

@@ -20,6 +20,7 @@
 #include <climits>
 #include "eval_kernels.h"
 #include "comm.h"
+#include "tp_tail.h"
 #include "q4_device.h"
 
 namespace fl {
@@ -1255,7 +1256,7 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const int *__res
                                                                 float *__restrict__ vc, int E, int D, int n_past, int n_ctx,
                                                                 const uint16_t *__restrict__ exp_tab, float scale,
                                                                 int8_t *__restrict__ oq, float *__restrict__ od,
-                                                                float *__restrict__ os) {
+                                                                float *__restrict__ os, const TpTail *__restrict__ tt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     DA_T_DECL;
     DA_STAMP(0);
@@ -1438,6 +1439,7 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const int *__res
     }
     DA_STAMP(6);
     DA_COMMIT();
+    if (tt) tp_tail<true>(tt);       // tensor parallel: this rank's heads -> every peer's copy of the Q8_0 planes (tp_tail.h)
 }
 #if defined(LLC_TIMING) && !defined(PA_TIMING)
 // stamps: t0 entry, t1 requests issued, t2 rope + K/V stores, t3 scores + max, t4 soft_max, t5 K.Q.V, t6 Q8_0 stored
@@ -1460,12 +1462,13 @@ hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, i
                             const int *dyn_past, bool exact) {
     if (D % 32 != 0 || D > 128 || n_ctx % 4 != 0 || E % 4 != 0) return hipErrorInvalidValue;
     const size_t lds = (size_t)(4 * D + n_ctx + 4) * 4 + 8 * 8 + 8 * 4;
+    const TpTail *tt = tp_take_tail();
     if (exact)
         hipLaunchKernelGGL(decode_attention_kernel<1>, dim3(H), dim3(DA_T), lds, st, dyn_past, qkv, reinterpret_cast<const float2 *>(rope_tab),
-                           kc, vc, E, D, n_past, n_ctx, exp_tab, scale, out->q, out->d, out->s);
+                           kc, vc, E, D, n_past, n_ctx, exp_tab, scale, out->q, out->d, out->s, tt);
     else
         hipLaunchKernelGGL(decode_attention_kernel<0>, dim3(H), dim3(DA_T), lds, st, dyn_past, qkv, reinterpret_cast<const float2 *>(rope_tab),
-                           kc, vc, E, D, n_past, n_ctx, exp_tab, scale, out->q, out->d, out->s);
+                           kc, vc, E, D, n_past, n_ctx, exp_tab, scale, out->q, out->d, out->s, tt);
     return hipGetLastError();
 }
 
@@ -1551,7 +1554,7 @@ template <int ORD>
 __global__ __launch_bounds__(DP_T) void decode_pv_kernel(const int *__restrict__ dyn_past, const float *__restrict__ scores, int E, int D,
                                                          int n_past, int n_ctx, const float *__restrict__ vc,
                                                          const uint16_t *__restrict__ exp_tab, int8_t *__restrict__ oq,
-                                                         float *__restrict__ od, float *__restrict__ os) {
+                                                         float *__restrict__ od, float *__restrict__ os, const TpTail *__restrict__ tt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     if (dyn_past) n_past = *dyn_past;
     const int h = blockIdx.x, tid = threadIdx.x, pos = n_past, P = n_past + 1;
@@ -1662,12 +1665,14 @@ __global__ __launch_bounds__(DP_T) void decode_pv_kernel(const int *__restrict__
         for (int i = 0; i < 8; ++i) o8[i] = out[tid * 8 + i];
         quantize_store_group(o8, 0, ((h * D + blockIdx.y * 32) >> 3) + tid, E >> 5, 1, oq, od, os);
     }
+    if (tt) tp_tail<true>(tt);
 }
 
 hipError_t decode_attention_split(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab,
                                   float *kc, float *vc, const uint16_t *exp_tab, float scale, float *scores,
                                   const fl_qact *out, hipStream_t st, const int *dyn_past, bool exact) {
     if (D % 32 != 0 || D > 128 || n_ctx % 4 != 0 || E % 4 != 0) return hipErrorInvalidValue;
+    const TpTail *tt = tp_take_tail();
     const int slices = dyn_past ? (n_ctx + DS_POS - 1) / DS_POS : (n_past + DS_POS) / DS_POS;
     if (exact)
         hipLaunchKernelGGL(decode_scores_kernel<1>, dim3(H, slices), dim3(DS_T), 0, st, dyn_past, qkv, E, D, n_past, n_ctx,
@@ -1680,10 +1685,10 @@ hipError_t decode_attention_split(const float *qkv, int E, int D, int H, int n_p
     const size_t lds = 4 * 8 + 4 * 4 + 32 * 4 + (size_t)((n_ctx + 511) / 512 * 512 + 512) * 4;
     if (exact)
         hipLaunchKernelGGL(decode_pv_kernel<1>, dim3(H, D / 32), dim3(DP_T), lds, st, dyn_past, scores, E, D, n_past, n_ctx, vc, exp_tab,
-                           out->q, out->d, out->s);
+                           out->q, out->d, out->s, tt);
     else
         hipLaunchKernelGGL(decode_pv_kernel<0>, dim3(H, D / 32), dim3(DP_T), lds, st, dyn_past, scores, E, D, n_past, n_ctx, vc, exp_tab,
-                           out->q, out->d, out->s);
+                           out->q, out->d, out->s, tt);
     return hipGetLastError();
 }
 
@@ -1755,6 +1760,14 @@ __global__ __launch_bounds__(1024) void p2p_exchange_kernel(P2PPeers a, float *d
 hipError_t p2p_exchange(const P2PPeers &peers, float *data, size_t count, float *gather_out, hipStream_t st) {
     if (count == 0 || count > peers.cap || peers.world < 2 || peers.world > FL_COMM_MAX_LOCAL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(p2p_exchange_kernel, dim3(1), dim3(1024), 0, st, peers, data, (unsigned)count, gather_out);
+    return hipGetLastError();
+}
+
+// the tensor-parallel exchange tail as a launch of its own (tp_tail.h): behind a producer whose kernel does not carry it
+thread_local const TpTail *tp_pending_tail = nullptr;
+__global__ __launch_bounds__(256) void tp_tail_kernel(const TpTail *__restrict__ tt) { tp_tail<false, true>(tt); }
+hipError_t tp_tail_launch(const TpTail *tt_dev, hipStream_t st) {
+    hipLaunchKernelGGL(tp_tail_kernel, dim3(1), dim3(256), 0, st, tt_dev);
     return hipGetLastError();
 }
 

@@ -37,6 +37,7 @@
 #include "q4_kernels.h"
 #include <type_traits>
 #include "gemv_prologue.h"
+#include "tp_tail.h"
 
 #pragma clang fp contract(off)
 
@@ -127,7 +128,8 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
     const uint32_t *__restrict__ qwd, const float *__restrict__ dW, const float *__restrict__ xf, const void *__restrict__ aux,
     const float *__restrict__ mW, const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs,
     float *__restrict__ y, const float *__restrict__ resid, float *__restrict__ ynorm, const uint16_t *__restrict__ aux2,
-    float *pair_ws /* PAIR = 2: [units / 2][16] 64-bit slots (zero between launches) */) {
+    float *pair_ws /* PAIR = 2: [units / 2][16] 64-bit slots (zero between launches) */,
+    const TpTail *__restrict__ tt /* tensor parallel: the exchange of this launch's rows as its tail (tp_tail.h); NULL: none */) {
     constexpr bool Q41 = TYPE == FL_TYPE_Q4_1;
     static_assert(TEAMS == 1 || (PERSIST == 0 && PAIR != 1), "teams: one row group per team");
     constexpr int G2 = PAIR == 1 ? 2 : 1, NT = 64 * NK * TEAMS;
@@ -255,6 +257,11 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
     LLC_STAMP(2);
 
     const uint32_t m8 = 0xF0F0F0F0u;
+    // (with a tail: written through to memory -- the workgroup that sends the rows to the peers runs on another XCD, tp_tail.h)
+    auto put_y = [&](float *p, float v) __attribute__((always_inline)) {
+        if (tt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *p = v;
+    };
     float y1 = 0.f;
     int par = 0;                                                                // which copy of the chain state this row group uses
     auto do_group = [&](auto GI) __attribute__((always_inline)) {
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
                         const float h1 = (unit & 1) ? other : v, h3 = (unit & 1) ? v : other;
                         const uint16_t hx = __half_as_ushort(__float2half_rn(h1));                    // GGML_FP32_TO_FP16
                         const float sl = __half2float(__ushort_as_half(aux2[hx]));                   // table_silu_f16
-                        y[(unit >> 1) * 16 + r] = __fmul_rn(sl, h3);                                  // ggml_mul(silu, tmp)
+                        put_y(y + (unit >> 1) * 16 + r, __fmul_rn(sl, h3));                           // ggml_mul(silu, tmp)
                     }
                 }
             } else if constexpr (PAIR == 1) {
@@ -359,11 +366,11 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
                 } else if (g == 0 && row < M) {
                     const uint16_t hx = __half_as_ushort(__float2half_rn(y1));                // GGML_FP32_TO_FP16
                     const float sl = __half2float(__ushort_as_half(aux2[hx]));               // table_silu_f16
-                    y[unit * 16 + r] = __fmul_rn(sl, v);                                      // ggml_mul(silu, tmp)
+                    put_y(y + unit * 16 + r, __fmul_rn(sl, v));                               // ggml_mul(silu, tmp)
                 }
             } else if (g == 0 && row < M && live) {
                 if (resid) v = __fadd_rn(v, rsd);
-                y[row] = v;
+                put_y(y + row, v);
             }
         }
         if constexpr (PAIR != 1 && PERSIST) {
@@ -400,6 +407,7 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
     }
     LLC_STAMP(5);
     LLC_COMMIT(PRO * 100 + PAIR * 10 + NK);
+    if (tt) tp_tail<false>(tt);
 }
 #ifdef LLC_TIMING
 // reset != 0: empty the ring; else copy up to max_rec records of 8 x int64 {t0 entry, t1 loads issued, t2 prologue done, t3 lane sums of the
@@ -445,6 +453,7 @@ static bool launch_llc(const fl_qtensor &W, const fl_qact *xq, float *y, hipStre
     // (round 5 tried an 8 x 8 form for K <= 8192 compiled for <= 128 registers -- two workgroups per CU -- : 23-35 scratch spills, LLaMA-65B decode 58.8
     //  against round 3's kernel's 78.6 tok/s in one gpurun call; removed)
     if (NQ > 44 && units > 256) return false;
+    const TpTail *tt = tp_take_tail();
     // grid: one workgroup per row group.  FL_LLC_PERSIST=1 (opt-in): when the row groups do not all fit on the chip at once, the PERSIST
     // instantiation with one workgroup per ITS residency slot (see the kernel) -- built, bit-identical, and measured 2 % SLOWER on LLaMA-7B's
     // decode (564.8-567.8 against 577.5 tok/s in one gpurun call, profiles/r05_decode_exact.md): the loop costs 45 registers = two workgroups per CU
@@ -452,7 +461,7 @@ static bool launch_llc(const fl_qtensor &W, const fl_qact *xq, float *y, hipStre
 #define FL_LLC_GO(NK, QPW, PS, TM, GRID)                                                                                                  \
     hipLaunchKernelGGL((gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, PS, TM>), dim3(GRID), dim3(64 * NK * TM), lds, st, W.M, units, KB, \
                        woven, W.qwd, W.d, xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid,       \
-                       ynorm, aux2, pair_ws)
+                       ynorm, aux2, pair_ws, tt)
     // FL_LLC_TEAMS=1 (opt-in): three row groups per workgroup (TEAMS = 3, the 4 x 8 form: 12 waves = one CU's worth at 136 registers; Q4_1's 8 x 4 form: two)
     // when a launch has more than two row groups per CU -- the prologue once per CU.  Built, bit-identical, and measured SLOWER: 551 against 594 tok/s
     // (Q4_1 402 against 455), profiles/r05_decode_exact.md -- the prologue takes the same 4.6 us whether one or three run on a CU (it waits for the

@@ -27,6 +27,7 @@
 
 #include "../../include/fastllama_hip.h"
 #include "comm.h"
+#include "tp_tail.h"
 #include "eval_kernels.h"
 #include "q4_kernels.h"
 #include "runtime.h"
@@ -86,6 +87,12 @@ struct fl_model : Act {
     bool tp_rows = false;
     fl_qact qFf{};              // tp_rows: the gathered Q8_0 operand of w2 (K = n_ff); the one of wo is gathered into qE
     unsigned char *ag_send = nullptr, *ag_tmp = nullptr;   // tp_rows: one rank's message / the G gathered messages
+    // tp_rows decode over the fold region of the communicator (tp_tail.h): the exchanges are the tails of the producing launches
+    int fold_state = 0;         // 0 not tried, 1 ready, -1 unavailable (no peer-mapped exchange behind the communicator, or the vectors do not fit)
+    TpTail *fold_dev = nullptr; // [4] device records: attention planes, wo rows, silu features, w2 rows
+    float *fx = nullptr, *fx2 = nullptr, *fh13 = nullptr;   // the layer input / middle rows and the silu features, full width, in this rank's region
+    fl_qact fq{}, fql{};        // the attention output's Q8_0 planes (K = n_embd) there, and the view of this rank's blocks
+    size_t graph_nodes = 0;     // kernel nodes of the last captured decode graph (fl_model_graph_nodes)
     int El = 0, Hl = 0, Fl = 0; // local (per rank) widths
     fl_qtensor *tok_emb = nullptr, *output = nullptr;
     float *norm_w = nullptr;
@@ -450,9 +457,80 @@ int fl_model_finalize(fl_model *m) {
 int fl_model_set_comm(fl_model *m, fl_comm *c) {
     if (!m) return set_error(FL_EINVAL, "null model");
     if (m->G > 1 && !c) return set_error(FL_EINVAL, "tensor-parallel model needs a communicator");
+    if (m->comm != c) {                      // (the fold records point into the old communicator's regions)
+        if (m->fold_dev) { (void)hipFree(m->fold_dev); m->fold_dev = nullptr; }
+        m->fold_state = 0;
+        if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+        if (m->graph_exec_long) { (void)hipGraphExecDestroy(m->graph_exec_long); m->graph_exec_long = nullptr; }
+    }
     m->comm = c;
     return FL_OK;
 }
+
+// Row-split tensor-parallel decode over the communicator's fold regions (tp_tail.h): lays the four exchanged vectors out in the region
+// and builds the exchange records.  Before any graph capture (it allocates).  Every rank takes the same decision: the peer-mapped exchange is
+// agreed on by all ranks when the communicator is made, the sizes are the model's.  FL_TP_FOLD=0: the collective sequence (A/B, tests).
+static void ensure_fold(fl_model *m) {
+    if (m->fold_state != 0) return;
+    m->fold_state = -1;
+    if (const char *e = getenv("FL_TP_FOLD")) if (e[0] == '0') return;
+    TpFold f;
+    if (!m->comm || !comm_fold(m->comm, &f) || f.world != m->G || f.rank != m->rank) return;
+    const size_t E = (size_t)m->E, F = (size_t)m->G * m->Fl, El = (size_t)m->El, Fl = (size_t)m->Fl, KB = E / FL_QK, KBl = El / FL_QK;
+    const size_t off_x = 0, off_x2 = E * 4, off_h = 2 * E * 4, off_q = fl_roundup((int)(off_h + F * 4), 16), off_d = off_q + E, off_s = off_d + KB * 4,
+                 total = off_s + KB * 4;
+    if (total > TP_FOLD_BYTES || El % FL_QK != 0) {
+        warn("tensor-parallel decode: the exchanged vectors (%zu B) do not fit the communicator's fold region (%zu B): the collective sequence runs "
+             "(same results, 11 kernels + 4 collectives per layer instead of 5 launches)", total, TP_FOLD_BYTES);
+        return;
+    }
+    TpTail t[4] = {};
+    for (int k = 0; k < 4; ++k) {
+        t[k].world = f.world; t[k].rank = f.rank;
+        for (int r = 0; r < f.world; ++r) { t[k].region[r] = f.region[r]; t[k].flag[r] = f.flag[r] + k * FL_COMM_MAX_LOCAL; }
+        t[k].ticket = f.ticket + k; t[k].epoch = f.epoch + k; t[k].timeouts = f.timeouts;
+        t[k].timeout_ticks = 2000000000ull;                // ~20 s of the 100 MHz wall clock: far beyond any legitimate skew between ranks
+        t[k].n_ranges = 1;
+    }
+    const unsigned r = (unsigned)m->rank;
+    t[0].n_ranges = 3;                                     // the attention's Q8_0 blocks of this rank's heads: q | d | s
+    t[0].off[0] = (unsigned)(off_q + r * El);      t[0].bytes[0] = (unsigned)El;
+    t[0].off[1] = (unsigned)(off_d + r * KBl * 4); t[0].bytes[1] = (unsigned)(KBl * 4);
+    t[0].off[2] = (unsigned)(off_s + r * KBl * 4); t[0].bytes[2] = (unsigned)(KBl * 4);
+    t[1].off[0] = (unsigned)(off_x2 + r * El * 4); t[1].bytes[0] = (unsigned)(El * 4);      // wo rows (+ residual)
+    t[2].off[0] = (unsigned)(off_h + r * Fl * 4);  t[2].bytes[0] = (unsigned)(Fl * 4);      // silu(w1 x) * (w3 x) features
+    t[3].off[0] = (unsigned)(off_x + r * El * 4);  t[3].bytes[0] = (unsigned)(El * 4);      // w2 rows (+ residual)
+    if (hipMalloc((void **)&m->fold_dev, sizeof t) != hipSuccess || hipMemcpy(m->fold_dev, t, sizeof t, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        if (m->fold_dev) { (void)hipFree(m->fold_dev); m->fold_dev = nullptr; }
+        warn("tensor-parallel decode: no device memory for the exchange records: the collective sequence runs");
+        return;
+    }
+    unsigned char *own = f.region[f.rank];
+    m->fx = reinterpret_cast<float *>(own + off_x);
+    m->fx2 = reinterpret_cast<float *>(own + off_x2);
+    m->fh13 = reinterpret_cast<float *>(own + off_h);
+    m->fq = fl_qact{reinterpret_cast<int8_t *>(own + off_q), reinterpret_cast<float *>(own + off_d), reinterpret_cast<float *>(own + off_s), 1, 16, (int)KB, nullptr};
+    m->fql = fl_qact{m->fq.q + r * El, m->fq.d + r * KBl, m->fq.s + r * KBl, 1, 16, (int)KBl, nullptr};
+    m->fold_state = 1;
+}
+
+namespace {
+// a producer launch that may carry the exchange as its tail: the record is offered to the launcher (tp_pending_tail) for exactly this call
+struct TailOffer {
+    explicit TailOffer(const TpTail *t) { tp_pending_tail = t; }
+    ~TailOffer() { tp_pending_tail = nullptr; }
+    bool taken() const { return tp_pending_tail == nullptr; }
+};
+}  // namespace
+#define M_TAILED(k, call)                                                                              \
+    do {                                                                                               \
+        bool taken_;                                                                                   \
+        hipError_t e_;                                                                                 \
+        { TailOffer offer_(m->fold_dev + (k)); e_ = (call); taken_ = offer_.taken(); }                 \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);                                              \
+        if (!taken_) M_HIP(tp_tail_launch(m->fold_dev + (k), st));      /* (a kernel without the tail: the exchange is a launch of its own) */ \
+    } while (0)
 
 // bench hook: bracket one quantized-matmul launch with HIP events on the eval stream
 static hipError_t prof_begin(fl_model *m, hipEvent_t *e1) {
@@ -653,12 +731,28 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
                     D % 4 == 0 && El % 4 == 0 && l0 < m->L && gemm_q4_exact_h16_supports(*m->layers[l0].wqkv, m->qE, N) &&
                     gemm_q4_exact_h16_supports(*m->layers[l0].w13, m->qE, N) && m->layers[l0].w13->M % 64 == 0;
     m->xh = xh;
-    if (!body_only) M_HIP(get_rows_qw16(*m->tok_emb, m->tok_dev, N, m->x, E, st));      // inpL = get_rows  llama.cpp:304
-    float *inp = m->x, *mid = m->x2;
+    // Row-split tensor-parallel decode over the fold region (tp_tail.h): the rows between the launches live in this rank's region, every
+    // producer writes its slice there, and the exchange is the tail of the producing launch -- the layer is its five decode launches.
+    const bool fold = tp && m->tp_rows && exact && fused && m->w13_il && m->fold_state > 0 && !kv_wait && !kv_rec && !body_only;
+    float *inp = fold ? m->fx : m->x, *mid = fold ? m->fx2 : m->x2;
+    if (!body_only) M_HIP(get_rows_qw16(*m->tok_emb, m->tok_dev, N, inp, E, st));       // inpL = get_rows  llama.cpp:304
     if (l1 < 0) l1 = m->L;
     for (int l = l0; l < l1; ++l) {
         const Layer &ly = m->layers[l];
         float *kc = m->kc + (size_t)l * n_ctx * El, *vc = m->vc + (size_t)l * n_ctx * El;
+        if (fold) {
+            const size_t r0 = (size_t)m->rank * El;
+            M_HIP(mm_norm(m, ly.wqkv, inp, ly.attn_norm, nullptr, m->qkv));
+            const float kq_scale = 1.0f / sqrtf((float)E / (float)m->H);
+            if (split_attn)
+                M_TAILED(0, decode_attention_split(m->qkv, El, D, Hl, n_past, n_ctx, m->rope_tab, kc, vc, m->exp_tab, kq_scale, m->att, &m->fql, st, dyn, exact));
+            else
+                M_TAILED(0, decode_attention(m->qkv, El, D, Hl, n_past, n_ctx, m->rope_tab, kc, vc, m->exp_tab, kq_scale, &m->fql, st, dyn, exact));
+            M_TAILED(1, mm(m, ly.wo, m->fq, 1, mid + r0, El, inp + r0, El));                             // this rank's rows of wo (+ its rows of the residual)
+            M_TAILED(2, mm_norm_silu(m, ly.w13, mid, ly.ffn_norm, m->fh13 + (size_t)m->rank * Fl));      // this rank's silu(w1 x) * (w3 x) features
+            M_TAILED(3, mm_quant(m, ly.w2, m->fh13, inp + r0, mid + r0));                                // this rank's rows of w2 (+ residual)
+            continue;
+        }
         if (fused) {
             // decode: norm folded into the matmul, attention in one launch per layer (rope .. KQV .. Q8_0)
             M_HIP(mm_norm(m, ly.wqkv, inp, ly.attn_norm, nullptr, m->qkv));
@@ -880,6 +974,7 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
     // sequence); the single-process group of fl_comm_create_local rendezvouses on the host and cannot be captured.
     const bool tp_capturable = m->G == 1 || (m->comm && !fl_comm_is_local(m->comm) && !m->tp_graph_failed && !getenv("FL_TP_NO_GRAPH"));
     if (N == 1 && m->exact) ensure_qwd(m);          // (before any capture: it allocates)
+    if (N == 1 && m->exact && m->G > 1 && m->tp_rows) ensure_fold(m);
     const bool use_graph = N == 1 && tp_capturable && m->graph_enabled && !m->profile;
     const bool split_attn = N == 1 && n_past >= m->split_past;
     if (use_graph) {
@@ -894,6 +989,7 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
             const int rc = run_eval_kernels(m, 1, 0, m->npast_dev, split_attn);
             const hipError_t e = hipStreamEndCapture(st, &g);
             hipError_t ei = hipSuccess;
+            if (rc == FL_OK && e == hipSuccess && hipGraphGetNodes(g, nullptr, &m->graph_nodes) != hipSuccess) { (void)hipGetLastError(); m->graph_nodes = 0; }
             if (rc == FL_OK && e == hipSuccess) ei = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
             if (g) (void)hipGraphDestroy(g);
             if (rc != FL_OK || e != hipSuccess || ei != hipSuccess) {
@@ -1070,6 +1166,10 @@ int fl_model_prepare(fl_model *m, int flags) {
     M_HIP(hipStreamSynchronize(m->stream));
     return FL_OK;
 }
+/* launches of one decode token: the nodes of the decode hipGraph captured last (0: none captured yet) */
+int fl_model_graph_nodes(const fl_model *m) { return m ? (int)m->graph_nodes : 0; }
+/* 1: a row-split tensor-parallel model whose decode exchanges run as the tails of the producing launches (tp_tail.h); decided at the first single-token eval */
+int fl_model_tp_folded(const fl_model *m) { return m && m->fold_state > 0 ? 1 : 0; }
 int fl_model_prepared(const fl_model *m) { return m ? (m->h16_state > 0 ? 1 : 0) | (m->qwd_state > 0 ? 2 : 0) : 0; }
 /* the mode new models start in: FL_FAST=1 (or FL_EXACT=0) in the environment selects the fast kernels, FL_EXACT=1 the reference
  * order; else the built-in default (reference order) */
@@ -1366,6 +1466,7 @@ void fl_model_free(fl_model *m) {
     fr(m->kc); fr(m->vc); fr(m->exp_tab); fr(m->silu_tab); fr(m->rope_tab);
     fr(m->logits_part); fr(m->gather_tmp);
     fr(m->qFf.q); fr(m->qFf.d); fr(m->qFf.s); fr(m->qFf.h16); fr(m->ag_send); fr(m->ag_tmp);      // (row-split tensor parallelism)
+    fr(m->fold_dev);
     {
         hipStream_t st0 = m->stream, st1 = m->alt.stream;
         act_free(*m);

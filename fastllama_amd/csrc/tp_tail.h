@@ -1,0 +1,104 @@
+// tp_tail.h -- the tensor-parallel exchange as the TAIL of the kernel that produced the data (round 5).
+//
+// Row-split tensor parallelism (the reference's own split across threads, lib/ggml.c:8127-8135: rank = thread with its own HBM) moves four
+// small vectors per layer and decode token between the ranks: the Q8_0 attention output, the wo rows, the silu features, the w2 rows.  As
+// collectives they were pack -> all-gather -> unpack (-> add): 11 kernels + 4 collectives per layer.  Here every rank owns a FOLD REGION
+// (comm.cpp; peer-mapped like the small-message exchange buffers) with the SAME layout on every rank -- [x row][x2 row][silu features]
+// [Q8_0 planes of the attention output] -- and the decode kernels of a tensor-parallel model read and write their operands THERE:
+//   * a producer writes its slice (its rows / features / blocks) into its own region, in place;
+//   * the LAST workgroup of the launch to finish (an agent-scope ticket) copies the slice into every peer's region (system-scope stores),
+//     publishes this rank's epoch in every peer's flag word, and waits until every peer's epoch has arrived here (bounded spin);
+//   * the launch ends => every slice of the vector is in this rank's region, and the next launch -- an ordinary kernel -- reads it.
+// One workgroup per rank waits, so ranks that share a GPU (the two-process rehearsal on the one-GPU test box) cannot starve each other.
+// No pack / unpack / add kernels and no collective launch: the layer is its five decode launches (model.cpp, run_eval_kernels).
+//
+// What keeps a slot from being overwritten while it is still read: a vector's only full-width reader is the launch that produces the NEXT
+// exchange (wo reads the attention planes and produces x2; w1|w3 reads x2 and produces the silu features; w2 reads those and produces x;
+// wq|wk|wv and the lm-head read x, and the attention -- the next producer -- follows them on the stream), and a peer can pass exchange k + 1
+// only after this rank published it, i.e. after all of this rank's workgroups of that reader have finished.  Its write into the same slot
+// comes three exchanges later.
+//
+// Visibility inside the launch: the producer's stores must have reached memory before its ticket counts (other workgroups run on other XCDs,
+// whose L2s are not coherent with each other) -- either agent-scope atomic stores (write-through; the GEMV, which has hundreds of
+// workgroups: one release fence per workgroup writes back the XCD's whole L2, 58 us per launch, profiles/r04_decode_exact.md) or plain
+// stores and ONE agent-scope release per workgroup (FENCE = true: the attention, a few dozen workgroups).
+#pragma once
+#include "../../include/fastllama_hip.h"
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace fl {
+
+constexpr int TP_TAIL_RANGES = 3;
+struct TpTail {
+    int world, rank;
+    int n_ranges;
+    unsigned off[TP_TAIL_RANGES], bytes[TP_TAIL_RANGES];      // this rank's slice: byte ranges of the fold region (multiples of 4; the same offsets on every rank)
+    unsigned char *region[FL_COMM_MAX_LOCAL];                 // fold region of every rank (own + mapped peers')
+    unsigned *flag[FL_COMM_MAX_LOCAL];                        // rank r's flag words of THIS exchange, one per source rank
+    unsigned *ticket;                                         // local: workgroups of the launch that have finished (0 between launches)
+    unsigned *epoch;                                          // local: exchanges of this kind completed
+    unsigned *timeouts;                                       // local: waits given up (fl_comm_p2p_check)
+    unsigned long long timeout_ticks;                         // of the 100 MHz wall clock
+};
+
+// the tail a launcher may fuse into the kernel it is about to launch: set by the model before the call, cleared by the launcher that took it
+// (a launcher that cannot -- round 3's fallback kernels -- leaves it, and the model launches tp_tail_kernel behind the producer)
+extern thread_local const TpTail *tp_pending_tail;
+inline const TpTail *tp_take_tail() { const TpTail *t = tp_pending_tail; tp_pending_tail = nullptr; return t; }
+hipError_t tp_tail_launch(const TpTail *tt_dev, hipStream_t st);       // eval_kernels.hip: the tail as a launch of its own (one workgroup)
+
+#ifdef __HIPCC__
+// Called by EVERY workgroup of the launch, by all of its threads, after its last global store.  STANDALONE: the launch is the tail itself
+// (one workgroup behind a producer that could not carry it: the kernel boundary made the producer's stores visible).
+template <bool FENCE, bool STANDALONE = false>
+__device__ __forceinline__ void tp_tail(const TpTail *__restrict__ tt) {
+    __shared__ unsigned tp_last_s;
+    const unsigned tid = threadIdx.x, nt = blockDim.x;
+    if constexpr (!STANDALONE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have been acknowledged
+        __syncthreads();
+        if (tid == 0) {
+            if (FENCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+            tp_last_s = __hip_atomic_fetch_add(tt->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1;
+        }
+        __syncthreads();
+        if (!tp_last_s) return;
+    }
+    const int world = tt->world, rank = tt->rank;
+    const unsigned e = __hip_atomic_load(tt->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    for (int i = 0; i < tt->n_ranges; ++i) {
+        const unsigned words = tt->bytes[i] >> 2;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(tt->region[rank] + tt->off[i]);
+        for (unsigned w = tid; w < words; w += nt) {
+            const uint32_t v = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int r = 0; r < world; ++r)
+                if (r != rank)
+                    __hip_atomic_store(reinterpret_cast<uint32_t *>(tt->region[r] + tt->off[i]) + w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < (unsigned)world && (int)tid != rank) {
+        __hip_atomic_store(tt->flag[tid] + rank, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned *f = tt->flag[rank] + tid;
+        // bounded: a peer that died must not hang this GPU's queue for ever (the host sees the count and fails the eval: fl_comm_p2p_check)
+        const unsigned long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {      // (epochs only grow)
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > tt->timeout_ticks) {
+                atomicAdd(tt->timeouts, 1u);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(tt->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(tt->epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+#endif
+
+}  // namespace fl

@@ -95,6 +95,7 @@ _PROTOS = {
     "fl_comm_p2p_export": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fl_comm_p2p_import": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fl_comm_has_p2p": (C.c_int, [C.c_void_p]),
+    "fl_comm_p2p_selftest": (C.c_int, [C.c_void_p]),
     "fl_comm_p2p_timeouts": (C.c_int, [C.c_void_p]),
     "fl_comm_p2p_check": (C.c_int, [C.c_void_p]),
     "fl_comm_debug_graph_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
@@ -154,6 +155,8 @@ _PROTOS = {
     "fl_default_exact": (C.c_int, []),
     "fl_model_prepare": (C.c_int, [C.c_void_p, C.c_int]),
     "fl_model_prepared": (C.c_int, [C.c_void_p]),
+    "fl_model_graph_nodes": (C.c_int, [C.c_void_p]),
+    "fl_model_tp_folded": (C.c_int, [C.c_void_p]),
     "fl_set_op_mode": (C.c_int, [C.c_int]),
     "fl_debug_attn_exact": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

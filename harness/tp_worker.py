@@ -17,6 +17,31 @@ import time
 import numpy as np
 
 
+def p2p_comm(L, hip, rank, world, p2p_dir):
+    """no RCCL (it refuses two ranks on one GPU): the peer-mapped exchange alone carries the collectives of a model whose messages are
+    small enough for it; the hipIpc handles travel through files in p2p_dir"""
+    comm = L.fl_comm_create_p2p(rank, world)
+    if not comm:
+        raise SystemExit("fl_comm_create_p2p: " + L.fl_last_error().decode())
+    comm = C.c_void_p(comm)
+    mine = (C.c_ubyte * 128)()
+    hip.check(L.fl_comm_p2p_export(comm, mine), "p2p_export")
+    with open(os.path.join(p2p_dir, f"h{rank}.tmp"), "wb") as f:
+        f.write(bytes(mine))
+    os.replace(os.path.join(p2p_dir, f"h{rank}.tmp"), os.path.join(p2p_dir, f"h{rank}.bin"))
+    allh, t0 = b"", time.time()
+    for r in range(world):
+        pth = os.path.join(p2p_dir, f"h{r}.bin")
+        while not os.path.exists(pth):
+            if time.time() - t0 > 120:
+                raise SystemExit("no handle from rank %d" % r)
+            time.sleep(0.02)
+        allh += open(pth, "rb").read()
+    hip.check(L.fl_comm_p2p_import(comm, (C.c_ubyte * len(allh))(*allh)), "p2p_import")
+    hip.check(L.fl_comm_p2p_selftest(comm), "p2p_selftest")          # (collective: what fl_comm_create does before it keeps the exchange)
+    return comm
+
+
 def main():
     rank, world, idfile, outfile = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,26 +57,7 @@ def main():
     hip.require_device(dev)
     raw = (C.c_ubyte * 128)()
     if p2p_dir:
-        # no RCCL (it refuses two ranks on one GPU): the peer-mapped exchange alone carries the collectives of a model whose
-        # messages are small enough for it; the hipIpc handles travel through files
-        comm = L.fl_comm_create_p2p(rank, world)
-        if not comm:
-            raise SystemExit("fl_comm_create_p2p: " + L.fl_last_error().decode())
-        comm = C.c_void_p(comm)
-        mine = (C.c_ubyte * 128)()
-        hip.check(L.fl_comm_p2p_export(comm, mine), "p2p_export")
-        with open(os.path.join(p2p_dir, f"h{rank}.tmp"), "wb") as f:
-            f.write(bytes(mine))
-        os.replace(os.path.join(p2p_dir, f"h{rank}.tmp"), os.path.join(p2p_dir, f"h{rank}.bin"))
-        allh, t0 = b"", time.time()
-        for r in range(world):
-            pth = os.path.join(p2p_dir, f"h{r}.bin")
-            while not os.path.exists(pth):
-                if time.time() - t0 > 120:
-                    raise SystemExit("no handle from rank %d" % r)
-                time.sleep(0.02)
-            allh += open(pth, "rb").read()
-        hip.check(L.fl_comm_p2p_import(comm, (C.c_ubyte * len(allh))(*allh)), "p2p_import")
+        comm = p2p_comm(L, hip, rank, world, p2p_dir)
     elif rank == 0:
         hip.check(L.fl_comm_unique_id(raw), "fl_comm_unique_id")
         with open(idfile + ".tmp", "wb") as f:
@@ -80,10 +86,37 @@ def main():
     hip.check(L.fl_model_set_graph(m.h, 0))
     dec_plain = m.eval([toks[4]], n_past=len(toks) + 1)
     out = dict(pre=pre, dec_graph=dec_graph, dec_graph2=dec_graph2, dec_plain=dec_plain)
+    # a run of decode tokens: replays of the graph, then the two-launch attention of long contexts (its own graph), then plain launches again;
+    # row-split models over the peer exchange run them with the exchanges folded into the producing launches (fl_model_tp_folded)
+    def run(mm):
+        seq, p = [], len(toks) + 2
+        hip.check(L.fl_model_set_graph(mm.h, 1))
+        for i in range(6):
+            seq.append(mm.eval([toks[5 + i]], n_past=p)); p += 1
+        nodes = L.fl_model_graph_nodes(mm.h)
+        hip.check(L.fl_model_set_graph(mm.h, 1 | 16))          # every position takes the split attention
+        for i in range(4):
+            seq.append(mm.eval([toks[11 + i]], n_past=p)); p += 1
+        nodes_split = L.fl_model_graph_nodes(mm.h)
+        hip.check(L.fl_model_set_graph(mm.h, 16))
+        for i in range(2):
+            seq.append(mm.eval([toks[15 + i]], n_past=p)); p += 1
+        hip.check(L.fl_model_set_graph(mm.h, 1))
+        return np.concatenate(seq), nodes, nodes_split
+    out["seq"], out["graph_nodes"], out["graph_nodes_split"] = run(m)
+    out["folded"] = L.fl_model_tp_folded(m.h)
+    out["n_layer"] = cfg["n_layer"]
+    t0 = time.perf_counter()
+    for i in range(32):
+        m.eval_nocopy(np.asarray([toks[3]], np.int32), len(toks) + 14 + i)
+    torch.cuda.synchronize()
+    out["us_per_token"] = (time.perf_counter() - t0) / 32 * 1e6
     if rank == 0:
         full = FlModel(cfg, qtype, tensors, n_ctx=128, max_batch=64, device=0)
         out["full_pre"] = full.eval(toks, all_logits=True)
         out["full_dec"] = full.eval([toks[3]], n_past=len(toks))
+        full.eval([toks[4]], n_past=len(toks) + 1)
+        out["full_seq"], out["full_graph_nodes"], _ = run(full)
         full.free()
     np.savez(outfile, **out)
     m.free()

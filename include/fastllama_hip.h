@@ -168,8 +168,11 @@ int fl_comm_allgather_f32(fl_comm *c, const float *send_dev, size_t count, float
 int fl_comm_is_local(const fl_comm *c);
 /* Small messages (<= 64 KB: the partial sums and logits slices of a decode token) skip the ring collective: every rank owns an
  * exchange buffer its peers map (hipIpc, xGMI), and ONE kernel per rank publishes, waits for and adds -- in rank order -- the
- * G vectors.  With FL_P2P=1 in the environment fl_comm_create sets this up by itself (the handles travel through RCCL; any
- * failure leaves a plain RCCL communicator).  Opt-in because it has only ever run between processes on ONE GPU.  A host that
+ * G vectors.  fl_comm_create sets this up by itself (round 5: on by default; FL_P2P=0 in the environment: RCCL only): the handles travel
+ * through RCCL, then a self-test moves patterned slices between all ranks -- the exchange has only ever run between processes on ONE GPU,
+ * so any failure of the hand-over or of the self-test, on any rank, leaves a plain RCCL communicator on every rank.  The same buffers carry
+ * the FOLD REGIONS of a row-split tensor-parallel model's decode: the four exchanges of a layer are the tails of the launches that produce
+ * the data (csrc/tp_tail.h, fl_model_tp_folded) -- five launches per layer and no collective launch.  A host that
  * moves the handles itself: fl_comm_create_p2p on every rank, fl_comm_p2p_export -> gather the FL_COMM_P2P_HANDLE_BYTES of all
  * ranks in rank order -> fl_comm_p2p_import.  Such a communicator has no RCCL behind it: larger messages fail. */
 #define FL_COMM_P2P_HANDLE_BYTES 128
@@ -177,6 +180,9 @@ fl_comm *fl_comm_create_p2p(int rank, int world);
 int fl_comm_p2p_export(fl_comm *c, void *handles_out /* FL_COMM_P2P_HANDLE_BYTES */);
 int fl_comm_p2p_import(fl_comm *c, const void *handles_all /* world * FL_COMM_P2P_HANDLE_BYTES, rank order */);
 int fl_comm_has_p2p(const fl_comm *c);
+/* COLLECTIVE (every rank, after the import): patterned slices through the exchange between all ranks within 2 s -- the check fl_comm_create
+ * itself runs before it keeps the exchange (a failure there leaves the communicator on RCCL alone). */
+int fl_comm_p2p_selftest(fl_comm *c);
 int fl_comm_p2p_timeouts(const fl_comm *c); /* exchanges that gave up waiting for a peer (~20 s each); 0 on a healthy group */
 int fl_comm_p2p_check(fl_comm *c);          /* FL_EHIP if that count advanced since the last check (fl_model_eval calls it after every
                                               * synchronised tensor-parallel eval: such an eval's results are invalid); caller has synchronised */
@@ -235,6 +241,12 @@ int fl_default_exact(void); /* the mode new models start in: environment FL_EXAC
  * ~1.3-1.45 x the time).  fl_model_prepared: which copies are resident (same bits; a negative state = tried and dropped reads as 0). */
 int fl_model_prepare(fl_model *m, int flags);
 int fl_model_prepared(const fl_model *m);
+/* Kernel nodes of the decode hipGraph captured last = launches per decode token (0: none captured yet). */
+int fl_model_graph_nodes(const fl_model *m);
+/* 1: the decode exchanges of this row-split tensor-parallel model are the tails of the launches that produce the data (peer-mapped
+ * fold regions of the communicator; five launches per layer and no collective launch), decided at the first single-token eval;
+ * 0: the collective sequence (no peer-mapped exchange behind the communicator, FL_TP_FOLD=0, or not a row-split model). */
+int fl_model_tp_folded(const fl_model *m);
 /* LoRA on the resident Q4 weights -- replaces Model::attach_lora / detach_lora (lib/llama.cpp:697-944) and its
  * ggml_compute_forward_add_q_f32 (lib/ggml.c:6414-6520): W <- quantize_row_q(dequantize_row_q(W) + sign * BA), with the
  * reference's SIMD quantizer arithmetic.  base_name is the base tensor ("layers.3.attention.wq.weight"); pass either

@@ -291,6 +291,56 @@ def test_two_process_tensor_parallel_over_the_peer_exchange(tmp_path):
     assert relerr(o[0]["dec_graph"], o[0]["full_dec"]) <= 5e-2
 
 
+def _run_tp_workers(tmp_path, tag, extra_env=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = tmp_path / tag
+    d.mkdir()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FL_EXACT="1", **(extra_env or {}))      # (this module's models are fast-mode ones: conftest.py)
+    env.pop("FL_FAST", None)
+    procs = [subprocess.Popen([sys.executable, "-m", "harness.tp_worker", str(r), "2", str(d / "unused"), str(d / f"out{r}.npz"), str(d)],
+                              cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=300)[0].decode(errors="replace"))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("tensor-parallel workers did not finish")
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    return [np.load(str(d / f"out{r}.npz")) for r in range(2)]
+
+
+def test_two_process_row_split_decode_with_the_exchanges_folded_into_the_producers(tmp_path):
+    """VERDICT r4 item 5.  The default (reference-order) mode shards every matmul by output rows; its decode token used to run 11 kernels + 4
+    collectives per layer.  Over a communicator with the peer-mapped exchange the four exchanges of a layer are now the TAILS of the launches
+    that produce the data (tp_tail.h): five launches per layer (six with the two-launch attention of long contexts), counted from the captured
+    hipGraph.  Two processes on this box's one GPU; every logit of the prefill and of a run of decode tokens -- graph replays, the split
+    attention's graph, plain launches -- equals the UNSHARDED model's bit for bit on both ranks, and the collective sequence (FL_TP_FOLD=0)
+    gives the same bits."""
+    o = _run_tp_workers(tmp_path, "fold")
+    L = int(o[0]["n_layer"])
+    for r in range(2):
+        assert int(o[r]["folded"]) == 1
+        assert np.array_equal(o[r]["seq"].view(np.uint32), o[0]["full_seq"].view(np.uint32)), r
+        assert np.array_equal(o[r]["pre"].view(np.uint32), o[0]["full_pre"].view(np.uint32)), r
+        assert np.array_equal(o[r]["dec_graph"].view(np.uint32), o[0]["full_dec"].view(np.uint32)), r
+        # get_rows + L x (wq|wk|wv, attention, wo, w1|w3, w2) + lm-head + the logits' gather (exchange, permute)
+        assert int(o[r]["graph_nodes"]) == 5 * L + 4, int(o[r]["graph_nodes"])
+        assert int(o[r]["graph_nodes_split"]) == 6 * L + 4, int(o[r]["graph_nodes_split"])
+    assert int(o[0]["full_graph_nodes"]) == 5 * L + 2
+    c = _run_tp_workers(tmp_path, "collectives", {"FL_TP_FOLD": "0"})
+    for r in range(2):
+        assert int(c[r]["folded"]) == 0
+        assert np.array_equal(c[r]["seq"].view(np.uint32), o[0]["full_seq"].view(np.uint32)), r
+        assert int(c[r]["graph_nodes"]) > 9 * L
+    print("decode graph nodes per layer: folded %d (split attention %d), collective sequence %.1f; us per token (tiny model, two ranks on one GPU): "
+          "folded %.0f / %.0f, collectives %.0f / %.0f" % ((int(o[0]["graph_nodes"]) - 4) // L, (int(o[0]["graph_nodes_split"]) - 4) // L,
+          (int(c[0]["graph_nodes"]) - 4) / L, float(o[0]["us_per_token"]), float(o[1]["us_per_token"]), float(c[0]["us_per_token"]), float(c[1]["us_per_token"])))
+
+
 def test_bench_tensor_parallel_leg_as_two_processes_on_one_gpu():
     """bench.py's world > 1 code -- replica leg, tensor-parallel leg (communicator, sharded model, timing, the JSON line with
     `replicas` beside the headline) -- run the way the driver launches it, with two ranks on this box's one GPU: gloo for the
