@@ -43,6 +43,11 @@ constexpr size_t P2P_CAP = 64 * 1024;          // floats per slot (256 KB): the 
 constexpr int FOLD_FLAG0 = 64, FOLD_TICKET0 = 128, FOLD_EPOCH0 = 144;
 static_assert(FL_COMM_MAX_LOCAL <= 8 && TP_FOLD_KINDS <= 8, "flag page layout");
 constexpr size_t P2P_MAX_COUNT = 16 * 1024;    // messages up to 64 KB go this way (one workgroup moves them)
+// (FL_P2P_MAX_COUNT: up to a whole slot -- rehearsals of larger models on a communicator without RCCL behind it, scripts/dev/run_r5_o.sh)
+static size_t p2p_max_count() {
+    static const size_t v = [] { const char *e = getenv("FL_P2P_MAX_COUNT"); const long n = e ? atol(e) : 0; return n > 0 ? (size_t)n : P2P_MAX_COUNT; }();
+    return v < P2P_CAP ? v : P2P_CAP;
+}
 struct P2PState {
     P2PPeers peers{};
     void *own_buf = nullptr, *own_flag = nullptr;
@@ -103,10 +108,11 @@ static_assert(sizeof(ncclUniqueId) == FL_COMM_ID_BYTES, "ncclUniqueId size");
 extern "C" {
 
 /* The check fl_comm_create runs before it keeps the exchange, for hosts that moved the handles themselves (fl_comm_create_p2p): COLLECTIVE --
- * every rank calls it after fl_comm_p2p_import; patterned slices travel between all ranks through the exchange's tail kernel within 2 s. */
+ * every rank calls it after fl_comm_p2p_import; patterned slices travel between all ranks through the exchange's tail kernel (the first round
+ * waits up to 20 s for a peer, the next two 2 s). */
 int fl_comm_p2p_selftest(fl_comm *c) {
     if (!c || !c->p2p.ready) return set_error(FL_EINVAL, "fl_comm_p2p_selftest: no peer-mapped exchange behind this communicator");
-    return p2p_selftest(c) ? FL_OK : set_error(FL_EHIP, "peer exchange self-test failed on rank %d (a slice did not arrive, or a peer did not within 2 s)", c->rank);
+    return p2p_selftest(c) ? FL_OK : set_error(FL_EHIP, "peer exchange self-test failed on rank %d (a slice did not arrive, or a peer did not in time)", c->rank);
 }
 
 int fl_comm_unique_id(void *out) {
@@ -129,7 +135,7 @@ fl_comm *fl_comm_create(const void *id_bytes, int rank, int world) {
     // peer-mapped exchange buffers for the small messages: handles travel through the communicator itself
     // ON by default since round 5 (FL_P2P=0: RCCL only).  The exchange has run between processes on ONE GPU only -- no multi-GPU node was
     // available to this project -- so a communicator keeps it only if (a) every step of the handle exchange worked on every rank and (b)
-    // the self-test below moved patterned slices between all ranks within its 2 s; anything else leaves the communicator on RCCL alone.
+    // the self-test below moved patterned slices between all ranks within its bounded waits; anything else leaves the communicator on RCCL alone.
     const char *want_p2p_env = getenv("FL_P2P");
     const bool want_p2p = world >= 2 && world <= FL_COMM_MAX_LOCAL && !(want_p2p_env && want_p2p_env[0] == '0');
     // The handshake's staging buffer is allocated BEFORE the communicator exists: once ncclCommInitRank has returned, every rank
@@ -285,7 +291,7 @@ static TpTail fold_tail(const TpFold &f, int kind, unsigned off, unsigned bytes,
     return t;
 }
 
-// Does the exchange work between THESE devices?  Every rank pushes three patterned 1 KB slices through the tail kernel (short timeout: the
+// Does the exchange work between THESE devices?  Every rank pushes three patterned 1 KB slices through the tail kernel (bounded waits: the
 // ranks are in step, the caller has just finished a collective) and checks what arrived from every peer.  Collective: every rank of a
 // communicator whose handles were imported calls it.  A failure leaves the communicator on RCCL alone (fl_comm_create).
 static bool p2p_selftest(fl_comm *c) {
@@ -294,14 +300,17 @@ static bool p2p_selftest(fl_comm *c) {
     constexpr unsigned SL = 1024, W = SL / 4;
     TpTail *td = nullptr;
     if (hipMalloc(&td, sizeof(TpTail)) != hipSuccess) { (void)hipGetLastError(); return false; }
-    const TpTail t = fold_tail(f, TP_FOLD_KINDS - 1, (unsigned)f.rank * SL, SL, 200000000ull /* 2 s */);
-    bool ok = hipMemcpy(td, &t, sizeof t, hipMemcpyHostToDevice) == hipSuccess;
+    // (the first round waits up to 20 s: a peer's first launch from this library may still be loading its code object; then 2 s per round)
+    TpTail t = fold_tail(f, TP_FOLD_KINDS - 1, (unsigned)f.rank * SL, SL, 2000000000ull);
+    bool ok = true;
     unsigned before = 0, after = 0;
     ok = ok && hipMemcpy(&before, f.timeouts, 4, hipMemcpyDeviceToHost) == hipSuccess;
     uint32_t mine[W], all[FL_COMM_MAX_LOCAL * W];
     for (unsigned round = 1; round <= 3 && ok; ++round) {
+        if (round == 2) t.timeout_ticks = 200000000ull;
         for (unsigned i = 0; i < W; ++i) mine[i] = (round << 28) ^ ((unsigned)f.rank << 20) ^ (i * 2654435761u);
-        ok = hipMemcpy(f.region[f.rank] + (size_t)f.rank * SL, mine, SL, hipMemcpyHostToDevice) == hipSuccess &&
+        ok = hipMemcpy(td, &t, sizeof t, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(f.region[f.rank] + (size_t)f.rank * SL, mine, SL, hipMemcpyHostToDevice) == hipSuccess &&
              tp_tail_launch(td, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
              hipMemcpy(all, f.region[f.rank], (size_t)f.world * SL, hipMemcpyDeviceToHost) == hipSuccess;
         for (int r = 0; r < f.world && ok; ++r)
@@ -389,7 +398,7 @@ static int local_allreduce(fl_comm *c, float *buf, size_t count, hipStream_t st)
 int fl_comm_allreduce_sum_f32(fl_comm *c, float *buf_dev, size_t count, void *stream) {
     if (!c || !buf_dev) return set_error(FL_EINVAL, "fl_comm_allreduce: null argument");
     if (c->lg) return local_allreduce(c, buf_dev, count, reinterpret_cast<hipStream_t>(stream));
-    if (c->p2p.ready && count <= P2P_MAX_COUNT) {
+    if (c->p2p.ready && count <= p2p_max_count()) {
         hipError_t e = p2p_exchange(c->p2p.peers, buf_dev, count, nullptr, reinterpret_cast<hipStream_t>(stream));
         return e == hipSuccess ? FL_OK : set_error(FL_EHIP, "peer all-reduce: %s", hipGetErrorString(e));
     }
@@ -432,7 +441,7 @@ static int local_allgather(fl_comm *c, const float *send, size_t count, float *r
 int fl_comm_allgather_f32(fl_comm *c, const float *send_dev, size_t count, float *recv_dev, void *stream) {
     if (!c || !send_dev || !recv_dev) return set_error(FL_EINVAL, "fl_comm_allgather: null argument");
     if (c->lg) return local_allgather(c, send_dev, count, recv_dev, reinterpret_cast<hipStream_t>(stream));
-    if (c->p2p.ready && count <= P2P_MAX_COUNT) {
+    if (c->p2p.ready && count <= p2p_max_count()) {
         hipError_t e = p2p_exchange(c->p2p.peers, const_cast<float *>(send_dev), count, recv_dev, reinterpret_cast<hipStream_t>(stream));
         return e == hipSuccess ? FL_OK : set_error(FL_EHIP, "peer all-gather: %s", hipGetErrorString(e));
     }

@@ -28,6 +28,7 @@
 #include "q4_device.h"
 #include "gemv_prologue.h"
 #include "q4_kernels.h"
+#include "tp_tail.h"
 
 #pragma clang fp contract(off)
 
@@ -181,7 +182,8 @@ __global__ __launch_bounds__(64 * (NWG + 2)) void gemv1_q4_exact_kernel(
     int M, int units, int KB, int woven,                      // (the leading 12-14 dwords are preloaded into SGPRs: build.sh)
     const uint32_t *__restrict__ qs, const float *__restrict__ dW, const float *__restrict__ xf, const void *__restrict__ aux,
     const float *__restrict__ mW, const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs,
-    float *__restrict__ y, const float *__restrict__ resid, float *__restrict__ ynorm, const uint16_t *__restrict__ aux2) {
+    float *__restrict__ y, const float *__restrict__ resid, float *__restrict__ ynorm, const uint16_t *__restrict__ aux2,
+    const TpTail *__restrict__ tt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     constexpr int G2 = PAIR ? 2 : 1, NT = 64 * (NWG + 2);
     constexpr int BPW = 8, KC = BPW * NWG, D = 6;                   // blocks per producer wave and chunk; chunk; chunks in flight
@@ -312,12 +314,15 @@ __global__ __launch_bounds__(64 * (NWG + 2)) void gemv1_q4_exact_kernel(
                 __syncthreads();            // chunk t is complete in LDS; the chain waves are done with chunk t - 1
             }
         }
-        return;
-    }
-
+    } else {
     // chain waves: lane = 8 * (row & 7) + j, chain wave cw holds rows 8 cw .. 8 cw + 7
     const int cw = wg - NWG, crow = cw * 8 + (lane >> 3), cj = lane & 7;
     float acc = 0.f, summs = 0.f, y1 = 0.f;
+    // (with a tail: written through to memory -- the workgroup that sends the rows to the peers runs on another XCD, tp_tail.h)
+    auto put_y = [&](float *p, float v) {
+        if (tt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *p = v;
+    };
     // (all LDS reads of a batch of CB blocks are issued before the first fma: one round trip per batch instead of one per block)
     constexpr int CB = TYPE == FL_TYPE_Q4_1 ? 16 : 32;
     auto chain_chunk = [&](int t) {
@@ -371,11 +376,11 @@ __global__ __launch_bounds__(64 * (NWG + 2)) void gemv1_q4_exact_kernel(
             } else if (cj == 0 && row < M) {
                 const uint16_t hx = __half_as_ushort(__float2half_rn(y1));                // GGML_FP32_TO_FP16
                 const float sl = __half2float(__ushort_as_half(aux2[hx]));               // table_silu_f16
-                y[(grp >> 1) * 16 + crow] = __fmul_rn(sl, v);                             // ggml_mul(silu, tmp)
+                put_y(y + (grp >> 1) * 16 + crow, __fmul_rn(sl, v));                      // ggml_mul(silu, tmp)
             }
         } else if (cj == 0 && row < M) {
             if (resid) v = __fadd_rn(v, resid[row]);
-            y[row] = v;
+            put_y(y + row, v);
         }
     };
 #pragma unroll 1
@@ -384,6 +389,8 @@ __global__ __launch_bounds__(64 * (NWG + 2)) void gemv1_q4_exact_kernel(
         __syncthreads();
     }
     if (T > 0) chain_chunk(T - 1);
+    }
+    if (tt) tp_tail<false>(tt);      // tensor parallel: this launch's rows -> every peer (tp_tail.h); all waves of every workgroup arrive here
 }
 
 // false: the activation does not fit LDS next to the chunk buffers (K > ~100 000) -> the caller takes the per-op sequence
@@ -412,7 +419,8 @@ static bool launch_gemv1_exact(const fl_qtensor &W, const fl_qact *xq, float *y,
     const int n_cu = n_cu_dev[dev];
     const int grid = units < n_cu ? units : n_cu;                   // one resident workgroup per CU, each streaming its share of the rows
     hipLaunchKernelGGL((gemv1_q4_exact_kernel<TYPE, NWG, PRO, PAIR>), dim3(grid), dim3(64 * (NWG + 2)), lds, st, W.M, units, KB, woven,
-                       W.qs, W.d, xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid, ynorm, aux2);
+                       W.qs, W.d, xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid, ynorm, aux2,
+                       tp_take_tail());
     return true;
 }
 

@@ -180,7 +180,7 @@ fl_comm *fl_comm_create_p2p(int rank, int world);
 int fl_comm_p2p_export(fl_comm *c, void *handles_out /* FL_COMM_P2P_HANDLE_BYTES */);
 int fl_comm_p2p_import(fl_comm *c, const void *handles_all /* world * FL_COMM_P2P_HANDLE_BYTES, rank order */);
 int fl_comm_has_p2p(const fl_comm *c);
-/* COLLECTIVE (every rank, after the import): patterned slices through the exchange between all ranks within 2 s -- the check fl_comm_create
+/* COLLECTIVE (every rank, after the import): patterned slices through the exchange between all ranks, bounded waits -- the check fl_comm_create
  * itself runs before it keeps the exchange (a failure there leaves the communicator on RCCL alone). */
 int fl_comm_p2p_selftest(fl_comm *c);
 int fl_comm_p2p_timeouts(const fl_comm *c); /* exchanges that gave up waiting for a peer (~20 s each); 0 on a healthy group */

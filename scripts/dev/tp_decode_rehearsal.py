@@ -30,7 +30,7 @@ def worker(name, rank, world, d, steps):
     cfg = dict(synth.MODELS[name])
     if os.environ.get("FL_LAYERS"):
         cfg["n_layer"] = int(os.environ["FL_LAYERS"])
-    n_ctx = 256
+    n_ctx = int(os.environ.get("FL_NCTX", "256"))
     m = FlModel(cfg, qtype, synth.synth_model_tensors(cfg, qtype), n_ctx=n_ctx, max_batch=8, tp_rank=rank, tp_size=world, device=0)
     m.set_comm(comm)
     toks = np.random.default_rng(0).integers(3, 259, 256).astype(np.int32)

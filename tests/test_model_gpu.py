@@ -360,6 +360,8 @@ def test_bench_tensor_parallel_leg_as_two_processes_on_one_gpu():
     assert d["config"]["parallelism"].startswith("tp2") and d["tp_small_message_path"].startswith("peer-mapped")
     assert d["replicas"]["scaling"] == "weak" and d["replicas"]["prefill_tokens_per_s"] > 0
     assert d["value"] > 0 and d["decode_tokens_per_s"] > 0 and d["config"]["global_batch_tokens"] == 32
+    # the headline leg is the default mode = the row split: its decode runs with the exchanges folded into the producing launches
+    assert d["tp_decode"]["exchanges_folded_into_producers"] is True and d["tp_decode"]["launches_per_layer"] <= 7, d["tp_decode"]
 
 
 def test_rccl_two_ranks_tensor_parallel(tmp_path):
