@@ -318,9 +318,9 @@ __global__ __launch_bounds__(64 * (NWG + 2)) void gemv1_q4_exact_kernel(
     // chain waves: lane = 8 * (row & 7) + j, chain wave cw holds rows 8 cw .. 8 cw + 7
     const int cw = wg - NWG, crow = cw * 8 + (lane >> 3), cj = lane & 7;
     float acc = 0.f, summs = 0.f, y1 = 0.f;
-    // (with a tail: written through to memory -- the workgroup that sends the rows to the peers runs on another XCD, tp_tail.h)
+    // (with a tail: written through to memory, and to every peer's region -- tp_put, tp_tail.h)
     auto put_y = [&](float *p, float v) {
-        if (tt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tt) tp_put(tt, p, v);
         else *p = v;
     };
     // (all LDS reads of a batch of CB blocks are issued before the first fma: one round trip per batch instead of one per block)
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(64 * (NWG + 2)) void gemv1_q4_exact_kernel(
     }
     if (T > 0) chain_chunk(T - 1);
     }
-    if (tt) tp_tail<false>(tt);      // tensor parallel: this launch's rows -> every peer (tp_tail.h); all waves of every workgroup arrive here
+    if (tt) tp_tail<false, false, true>(tt);      // tensor parallel: this launch's rows -> every peer (tp_tail.h); all waves of every workgroup arrive here
 }
 
 // false: the activation does not fit LDS next to the chunk buffers (K > ~100 000) -> the caller takes the per-op sequence

@@ -257,9 +257,9 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
     LLC_STAMP(2);
 
     const uint32_t m8 = 0xF0F0F0F0u;
-    // (with a tail: written through to memory -- the workgroup that sends the rows to the peers runs on another XCD, tp_tail.h)
+    // (with a tail: written through to memory, and to every peer's region -- tp_put, tp_tail.h)
     auto put_y = [&](float *p, float v) __attribute__((always_inline)) {
-        if (tt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tt) tp_put(tt, p, v);
         else *p = v;
     };
     float y1 = 0.f;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
     }
     LLC_STAMP(5);
     LLC_COMMIT(PRO * 100 + PAIR * 10 + NK);
-    if (tt) tp_tail<false>(tt);
+    if (tt) tp_tail<false, false, true>(tt);
 }
 #ifdef LLC_TIMING
 // reset != 0: empty the ring; else copy up to max_rec records of 8 x int64 {t0 entry, t1 loads issued, t2 prologue done, t3 lane sums of the

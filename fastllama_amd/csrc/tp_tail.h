@@ -49,9 +49,20 @@ inline const TpTail *tp_take_tail() { const TpTail *t = tp_pending_tail; tp_pend
 hipError_t tp_tail_launch(const TpTail *tt_dev, hipStream_t st);       // eval_kernels.hip: the tail as a launch of its own (one workgroup)
 
 #ifdef __HIPCC__
+// A producer's store of one value of its slice, with a tail: into this rank's region (written through: the workgroup that publishes runs on another
+// XCD) and straight into every peer's (the same offset), so that the last workgroup has nothing left to copy.  p points into this rank's region.
+__device__ __forceinline__ void tp_put(const TpTail *__restrict__ tt, float *p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int world = tt->world, rank = tt->rank;
+    const size_t off = reinterpret_cast<unsigned char *>(p) - tt->region[rank];
+    for (int r = 0; r < world; ++r)
+        if (r != rank) __hip_atomic_store(reinterpret_cast<float *>(tt->region[r] + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Called by EVERY workgroup of the launch, by all of its threads, after its last global store.  STANDALONE: the launch is the tail itself
 // (one workgroup behind a producer that could not carry it: the kernel boundary made the producer's stores visible).
-template <bool FENCE, bool STANDALONE = false>
+// PUSHED: the workgroups sent their values to the peers themselves (tp_put), the last one only publishes.
+template <bool FENCE, bool STANDALONE = false, bool PUSHED = false>
 __device__ __forceinline__ void tp_tail(const TpTail *__restrict__ tt) {
     __shared__ unsigned tp_last_s;
     const unsigned tid = threadIdx.x, nt = blockDim.x;
@@ -68,7 +79,7 @@ __device__ __forceinline__ void tp_tail(const TpTail *__restrict__ tt) {
     }
     const int world = tt->world, rank = tt->rank;
     const unsigned e = __hip_atomic_load(tt->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-    for (int i = 0; i < tt->n_ranges; ++i) {
+    for (int i = 0; i < (PUSHED ? 0 : tt->n_ranges); ++i) {
         const unsigned words = tt->bytes[i] >> 2;
         const uint32_t *src = reinterpret_cast<const uint32_t *>(tt->region[rank] + tt->off[i]);
         for (unsigned w = tid; w < words; w += nt) {
@@ -85,13 +96,15 @@ __device__ __forceinline__ void tp_tail(const TpTail *__restrict__ tt) {
         const unsigned *f = tt->flag[rank] + tid;
         // bounded: a peer that died must not hang this GPU's queue for ever (the host sees the count and fails the eval: fl_comm_p2p_check)
         const unsigned long long t0 = wall_clock64();
-        while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {      // (epochs only grow)
-            __builtin_amdgcn_s_sleep(2);
+        // (relaxed polls and ONE acquire behind them: an acquire load invalidates the caches every time round the loop)
+        while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {      // (epochs only grow)
+            __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > tt->timeout_ticks) {
                 atomicAdd(tt->timeouts, 1u);
                 break;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     }
     __syncthreads();
     if (tid == 0) {
