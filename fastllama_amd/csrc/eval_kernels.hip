@@ -1439,7 +1439,13 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const int *__res
     }
     DA_STAMP(6);
     DA_COMMIT();
-    if (tt) tp_tail<true>(tt);       // tensor parallel: this rank's heads -> every peer's copy of the Q8_0 planes (tp_tail.h)
+    if (tt) {                        // tensor parallel: this head's Q8_0 blocks -> every peer's copy of the planes, then the exchange's tail (tp_tail.h)
+        __syncthreads();
+        tp_push(tt, oq + h * D, D);
+        tp_push(tt, od + (h * D >> 5), D >> 3);
+        tp_push(tt, os + (h * D >> 5), D >> 3);
+        tp_tail<false, false, true>(tt);
+    }
 }
 #if defined(LLC_TIMING) && !defined(PA_TIMING)
 // stamps: t0 entry, t1 requests issued, t2 rope + K/V stores, t3 scores + max, t4 soft_max, t5 K.Q.V, t6 Q8_0 stored
@@ -1665,7 +1671,14 @@ __global__ __launch_bounds__(DP_T) void decode_pv_kernel(const int *__restrict__
         for (int i = 0; i < 8; ++i) o8[i] = out[tid * 8 + i];
         quantize_store_group(o8, 0, ((h * D + blockIdx.y * 32) >> 3) + tid, E >> 5, 1, oq, od, os);
     }
-    if (tt) tp_tail<true>(tt);
+    if (tt) {
+        const int b = (h * D + blockIdx.y * 32) >> 5;
+        __syncthreads();
+        tp_push(tt, oq + b * 32, 32);
+        tp_push(tt, od + b, 4);
+        tp_push(tt, os + b, 4);
+        tp_tail<false, false, true>(tt);
+    }
 }
 
 hipError_t decode_attention_split(const float *qkv, int E, int D, int H, int n_past, int n_ctx, const float *rope_tab,

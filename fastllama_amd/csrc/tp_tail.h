@@ -59,6 +59,17 @@ __device__ __forceinline__ void tp_put(const TpTail *__restrict__ tt, float *p, 
         if (r != rank) __hip_atomic_store(reinterpret_cast<float *>(tt->region[r] + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// A producer workgroup's own piece of the slice (plain stores, then a barrier) -> every peer's region: all threads of the workgroup
+__device__ __forceinline__ void tp_push(const TpTail *__restrict__ tt, const void *own, unsigned bytes) {
+    const int world = tt->world, rank = tt->rank;
+    const size_t off = reinterpret_cast<const unsigned char *>(own) - tt->region[rank];
+    for (unsigned w = threadIdx.x; w < (bytes >> 2); w += blockDim.x) {
+        const uint32_t v = reinterpret_cast<const uint32_t *>(own)[w];
+        for (int r = 0; r < world; ++r)
+            if (r != rank) __hip_atomic_store(reinterpret_cast<uint32_t *>(tt->region[r] + off) + w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // Called by EVERY workgroup of the launch, by all of its threads, after its last global store.  STANDALONE: the launch is the tail itself
 // (one workgroup behind a producer that could not carry it: the kernel boundary made the producer's stores visible).
 // PUSHED: the workgroups sent their values to the peers themselves (tp_put), the last one only publishes.
