@@ -502,8 +502,9 @@ def main():
                              f"Model::eval (n_past=0, {wk['n_matmuls']} mul_mat_q_f32 + attention/norm/rope ops), synthetic weights, "
                              f"reference-order arithmetic (logits bit-identical to the reference's)"),
                 "n_batch": N, "n_ctx": n_ctx, "global_batch_tokens": N * leg["seqs"],
-                "parallelism": (f"tp{world} (ONE batch: every matmul by output rows; 4 RCCL all-gathers per layer (Q8_0 operands of wo / w2, their "
-                                f"output rows) + 1 of the logits over xGMI; nothing summed across ranks)" if tp else
+                "parallelism": (f"tp{world} (ONE batch: every matmul by output rows; prefill: 4 all-gathers per layer (Q8_0 operands of wo / w2, their "
+                                f"output rows) + 1 of the logits; decode: the same four exchanges as tails of the producing launches when the communicator "
+                                f"has the peer-mapped exchange (tp_decode); nothing summed across ranks)" if tp else
                                 f"dp{world} (one model replica and one batch per GPU, no data-path collective)"),
             },
             "mode": "exact",

@@ -5,9 +5,11 @@
 // collectives they were pack -> all-gather -> unpack (-> add): 11 kernels + 4 collectives per layer.  Here every rank owns a FOLD REGION
 // (comm.cpp; peer-mapped like the small-message exchange buffers) with the SAME layout on every rank -- [x row][x2 row][silu features]
 // [Q8_0 planes of the attention output] -- and the decode kernels of a tensor-parallel model read and write their operands THERE:
-//   * a producer writes its slice (its rows / features / blocks) into its own region, in place;
-//   * the LAST workgroup of the launch to finish (an agent-scope ticket) copies the slice into every peer's region (system-scope stores),
-//     publishes this rank's epoch in every peer's flag word, and waits until every peer's epoch has arrived here (bounded spin);
+//   * a producer writes its slice (its rows / features / blocks) into its own region, in place, AND into every peer's region at the same
+//     offset (system-scope stores: tp_put in the GEMV epilogues, tp_push of a workgroup's own Q8_0 blocks in the attention);
+//   * every workgroup takes a ticket; the LAST one of the launch publishes this rank's epoch in every peer's flag word and waits until every
+//     peer's epoch has arrived here (bounded spin).  (A producer without tp_put / tp_push: the last workgroup copies the slice -- the ranges
+//     of the record -- to the peers first; that is also what the tail does as a launch of its own, tp_tail_kernel.)
 //   * the launch ends => every slice of the vector is in this rank's region, and the next launch -- an ordinary kernel -- reads it.
 // One workgroup per rank waits, so ranks that share a GPU (the two-process rehearsal on the one-GPU test box) cannot starve each other.
 // No pack / unpack / add kernels and no collective launch: the layer is its five decode launches (model.cpp, run_eval_kernels).
@@ -18,10 +20,14 @@
 // only after this rank published it, i.e. after all of this rank's workgroups of that reader have finished.  Its write into the same slot
 // comes three exchanges later.
 //
-// Visibility inside the launch: the producer's stores must have reached memory before its ticket counts (other workgroups run on other XCDs,
-// whose L2s are not coherent with each other) -- either agent-scope atomic stores (write-through; the GEMV, which has hundreds of
-// workgroups: one release fence per workgroup writes back the XCD's whole L2, 58 us per launch, profiles/r04_decode_exact.md) or plain
-// stores and ONE agent-scope release per workgroup (FENCE = true: the attention, a few dozen workgroups).
+// Visibility inside the launch: a peer's flag must not overtake the data.  Every store to a peer is a system-scope atomic store (written
+// through), each workgroup waits for its own (s_waitcnt) before its ticket, the tickets are agent-scope atomics, and the flag stores are
+// system-scope RELEASE stores by the workgroup that saw every ticket.  Stores into the own region that the LAST workgroup has to read back
+// (no tp_put: the ranges) must have reached memory before the ticket too -- other workgroups run on other XCDs, whose L2s are not coherent
+// with each other: agent-scope atomic stores, or plain stores and one agent-scope release per workgroup (FENCE = true; a release writes back
+// the XCD's whole L2 -- per workgroup of a GEMV that was 58 us per launch, profiles/r04_decode_exact.md -- so it is for launches of a few
+// dozen workgroups only; unused since the attention pushes its own blocks).
+// Never run between GPUs: fl_comm_create keeps the exchange only if its collective self-test passes.
 #pragma once
 #include "../../include/fastllama_hip.h"
 #include <hip/hip_runtime.h>
