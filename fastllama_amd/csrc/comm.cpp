@@ -64,6 +64,15 @@ struct fl_comm {
     P2PState p2p;
 };
 
+unsigned long long fl::p2p_timeout_ticks() {
+    static const unsigned long long v = [] {
+        const char *e = getenv("FL_P2P_TIMEOUT_MS");
+        const long ms = e ? atol(e) : 0;
+        return (unsigned long long)(ms > 0 ? ms : 20000) * 100000ull;
+    }();
+    return v;
+}
+
 static int p2p_alloc(fl_comm *c) {
     P2PState &p = c->p2p;
     if (p.own_buf) return FL_OK;
@@ -88,6 +97,7 @@ static int p2p_alloc(fl_comm *c) {
     p.peers.world = c->world;
     p.peers.rank = c->rank;
     p.peers.cap = P2P_CAP;
+    p.peers.timeout_ticks = p2p_timeout_ticks();
     p.peers.buf[c->rank] = static_cast<float *>(p.own_buf);
     p.peers.flag[c->rank] = static_cast<unsigned *>(p.own_flag);
     p.peers.epoch = static_cast<unsigned *>(p.own_flag) + 16;

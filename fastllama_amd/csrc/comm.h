@@ -14,7 +14,10 @@ struct P2PPeers {
     unsigned *epoch;                      // this rank's epoch counter (device memory)
     size_t cap;
     int world, rank;
+    unsigned long long timeout_ticks;     // bounded waits (100 MHz wall clock): p2p_timeout_ticks()
 };
+// how long an exchange waits for a peer before it gives up (counted: fl_comm_p2p_check fails the eval): 20 s, FL_P2P_TIMEOUT_MS overrides (tests)
+unsigned long long p2p_timeout_ticks();
 hipError_t p2p_exchange(const P2PPeers &peers, float *data, size_t count, float *gather_out, hipStream_t st);
 
 // The fold regions of a communicator with the peer-mapped exchange behind it (tp_tail.h): per rank TP_FOLD_BYTES behind the two

@@ -1743,17 +1743,19 @@ __global__ __launch_bounds__(1024) void p2p_exchange_kernel(P2PPeers a, float *d
     if (tid == 0) __hip_atomic_store(a.flag[a.rank] + slot, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (tid < (unsigned)a.world && (int)tid != a.rank) {
         const unsigned *f = a.flag[tid] + slot;
-        // bounded: a peer that died must not hang this GPU's queue for ever.  wall_clock64 ticks at 100 MHz: ~20 s, far beyond
+        // bounded: a peer that died must not hang this GPU's queue for ever.  wall_clock64 ticks at 100 MHz; the bound is ~20 s (p2p_timeout_ticks), far beyond
         // any legitimate skew between ranks; the timeout is recorded next to the epoch (fl_comm_p2p_timeouts) and the sum of
         // whatever is in the slots goes on -- the host sees the count and fails the eval.
         const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
-            __builtin_amdgcn_s_sleep(2);
-            if (wall_clock64() - t0 > 2000000000ull) {
+        // (relaxed polls and one acquire behind them: an acquire load invalidates the caches every time round the loop -- round 5, tp_tail.h)
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > a.timeout_ticks) {
                 atomicAdd(a.epoch + 1, 1u);
                 break;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     }
     __syncthreads();
     if (!gather_out) {

@@ -123,13 +123,17 @@ __device__ unsigned llc_tl_cur;
 // the prologue, not for their bytes (profiles/r05_decode_timeline.md), and three workgroups per CU ran three of them at once behind each other's
 // weight requests.  Same arithmetic per row group; the chain hand-offs of the teams share the workgroup's barriers.
 template <int TYPE, int NK, int PRO, int PAIR, int QPW, int PERSIST, int TEAMS = 1>
-__global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1) void gemv1_q4_exact_llc_kernel(
+#ifndef LLC_PS_OCC
+#define LLC_PS_OCC 1
+#endif
+__global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : (PERSIST && QPW <= 8 && NK == 4) ? LLC_PS_OCC : 1) void gemv1_q4_exact_llc_kernel(
     int M, int units, int KB, int woven,
     const uint32_t *__restrict__ qwd, const float *__restrict__ dW, const float *__restrict__ xf, const void *__restrict__ aux,
     const float *__restrict__ mW, const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs,
     float *__restrict__ y, const float *__restrict__ resid, float *__restrict__ ynorm, const uint16_t *__restrict__ aux2,
     float *pair_ws /* PAIR = 2: [units / 2][16] 64-bit slots (zero between launches) */,
-    const TpTail *__restrict__ tt /* tensor parallel: the exchange of this launch's rows as its tail (tp_tail.h); NULL: none */) {
+    const TpTail *__restrict__ tt /* tensor parallel: the exchange of this launch's rows as its tail (tp_tail.h); NULL: none */,
+    int npass /* PERSIST: K passes of NK x QPW quads per row group (rows longer than one pass holds in registers); else 1 */) {
     constexpr bool Q41 = TYPE == FL_TYPE_Q4_1;
     static_assert(TEAMS == 1 || (PERSIST == 0 && PAIR != 1), "teams: one row group per team");
     constexpr int G2 = PAIR == 1 ? 2 : 1, NT = 64 * NK * TEAMS;
@@ -165,7 +169,23 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
     // round's workgroups are dispatched 7-10 us into the launch, each redoing the prologue: profiles/r05_decode_timeline.md -- and still the faster form.)
     int unit = TEAMS == 1 ? (int)blockIdx.x : min((int)blockIdx.x * TEAMS + team, units - 1);
     const bool live = TEAMS == 1 || (int)blockIdx.x * TEAMS + team < units;      // (a team past the last row group redoes it and stores nothing)
-    const int qlo = (k * NQ) / NK, nq = ((k + 1) * NQ) / NK - qlo;              // (wave-uniform; nq <= QPW by the launcher's choice of NK)
+    // MULTI-PASS rows (PERSIST instantiation, round 5): a row longer than NK x QPW quads is taken in npass passes of that many quads, pass after pass
+    // through the same registers -- the chain state goes from the last wave of a pass to the first wave of the next through LDS, so the summation
+    // order is the row's block order as ever, and a K = 8192 .. 22016 row group runs in the 4 x 8 form (three workgroups per CU) instead of
+    // the 8 x 11 form / round 3's kernel (one per CU).  slice_of: wave k's quads of pass p (wave-uniform; nq <= QPW by the launcher's choice).
+    constexpr int PQ = NK * QPW;
+    auto slice_of = [&](int p_, int &qlo_, int &nq_) __attribute__((always_inline)) {
+        if (PERSIST) {
+            const int lo = (p_ * NQ) / npass, nqp = ((p_ + 1) * NQ) / npass - lo;          // (npass equal parts of the row: <= PQ quads each)
+            qlo_ = lo + (k * nqp) / NK;
+            nq_ = lo + ((k + 1) * nqp) / NK - qlo_;
+        } else {
+            qlo_ = (k * NQ) / NK;
+            nq_ = ((k + 1) * NQ) / NK - qlo_;
+        }
+    };
+    int qlo, nq;
+    slice_of(0, qlo, nq);
     const int r = lane >> 2, g = lane & 3;
     ntv4u w[QPW];
     float dw[QPW], mw[QPW];
@@ -183,7 +203,7 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
     // The scales go out FIRST, then the nibbles, quad by quad: loads return in order, so a quad can be summed as soon as ITS sixteen bytes per
     // lane are there.  (Issued quad by quad -- nibbles, scale, nibbles, scale -- the compiler's scheduler moved all the scale loads behind
     // all the nibble loads, and the first quad's sums waited for the wave's whole slice: round 5, seen in the ISA.)
-    auto load_group = [&](int grp) __attribute__((always_inline)) {
+    auto load_group = [&](int grp, int qlo, int nq) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < QPW; ++i) {
             const int q = qlo + (i < nq ? i : 0);                               // (past the slice: a cache-hot dummy, never used -- unconditional
@@ -219,7 +239,7 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    load_group(unit * G2);
+    load_group(unit * G2, qlo, nq);
     LLC_STAMP(1);
 
     // blocks past K in a partial last quad: zero quants, d_x = s_x = 0 (written before the prologue's closing barrier)
@@ -264,6 +284,7 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
     };
     float y1 = 0.f;
     int par = 0;                                                                // which copy of the chain state this row group uses
+    int pass = 0;                                                               // PERSIST: which K pass of the row group
     auto do_group = [&](auto GI) __attribute__((always_inline)) {
         constexpr int gi = decltype(GI)::value;
         // the residual of this lane's row is requested NOW (PAIR = 0): asked for in the epilogue it was a dependent round trip of ~0.6 us at
@@ -271,7 +292,7 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
         float rsd = 0.f;
         if constexpr (PAIR == 0) {
             const int row_ = unit * 16 + r;
-            if (resid && k == NK - 1) rsd = resid[min(row_, M - 1)];      // (wave-uniform condition, clamped address: a load behind a lane-dependent branch makes the compiler drain every load in flight)
+            if (resid && k == NK - 1 && (!PERSIST || pass == npass - 1)) rsd = resid[min(row_, M - 1)];      // (wave-uniform condition, clamped address: a load behind a lane-dependent branch makes the compiler drain every load in flight)
         }
         // ---- order-free part, all waves at once: per block the two lane sums of this lane's k-group as floats, rn(d_w d_x), m_w
         float f0[QPW][4], f1[QPW][4], dd[QPW][4];
@@ -306,7 +327,7 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
 #pragma unroll 1
         for (int ph = 0; ph < NK; ++ph) {
             if (k == ph) {                                                      // (wave-uniform)
-                if (ph > 0) { a0 = accs[par][lane][0]; a1 = accs[par][lane][1]; if (Q41) summs = accs[par][lane][2]; }
+                if (ph > 0 || (PERSIST && pass > 0)) { a0 = accs[par][lane][0]; a1 = accs[par][lane][1]; if (Q41) summs = accs[par][lane][2]; }
 #pragma unroll
                 for (int i = 0; i < QPW; ++i) {
                     if (i < nq) {
@@ -326,14 +347,14 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
                         }
                     }
                 }
-                if (ph < NK - 1) { accs[par][lane][0] = a0; accs[par][lane][1] = a1; if (Q41) accs[par][lane][2] = summs; }
+                if (ph < NK - 1 || (PERSIST && pass < npass - 1)) { accs[par][lane][0] = a0; accs[par][lane][1] = a1; if (Q41) accs[par][lane][2] = summs; }
             }
             if (ph < NK - 1) __syncthreads();
         }
         if (gi == 0) LLC_STAMP(4);
         // ---- the row group is complete in its last wave: ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)) over the quad of lanes that holds the
         // row (lane g holds accumulators 2g, 2g+1; every lane of the quad ends with the same bits), then the store / the PAIR epilogue
-        if (k == NK - 1) {
+        if (k == NK - 1 && (!PERSIST || pass == npass - 1)) {
             float e = a0, o = a1;
             e = __fadd_rn(e, dpp_f32<DPP_XOR2>(e));      // a0+a4 | a2+a6
             o = __fadd_rn(o, dpp_f32<DPP_XOR2>(o));      // a1+a5 | a3+a7
@@ -377,15 +398,20 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
             // the next row group's bytes start now -- behind this wave's chain and, for the last wave, behind the store (a load issued before the
             // residual's round trip would make the store wait for the whole prefetch: the compiler counts loads, it does not tell them apart).
             // Requested right after the lane sums (when w / dw / mw die) they would keep 40 registers busy next to the 96 of the lane sums.
-            const int next_unit = unit + (int)gridDim.x;
-            if (next_unit < units) load_group(next_unit);
+            // (multi-pass rows: the row group's next pass; the last wave's state reaches the first wave of that pass behind one more barrier)
+            const bool more = pass + 1 < npass;
+            const int next_unit = more ? unit : unit + (int)gridDim.x;
+            int nqlo, nnq;
+            slice_of(more ? pass + 1 : 0, nqlo, nnq);
+            if (next_unit < units) load_group(next_unit, nqlo, nnq);
+            if (more) __syncthreads();
         }
         if (PAIR == 1 && gi == 0) {
             // the w3 group's slice is requested only now.  Requested before the w1 chains it keeps both groups' registers alive: 214
             // VGPRs = two workgroups per CU = 1.3 rounds of the 688 workgroups, 24 us; squeezed under the 170-register cap of three
             // workgroups per CU it spills (22 us, also with the lane sums packed as int16 pairs); this order: 19.5 us
             // (profiles/r04_decode_exact.md).  What it costs: HBM idles while the whole launch sits in its w1 chain phase.
-            load_group(unit * G2 + 1);
+            load_group(unit * G2 + 1, qlo, nq);
             __syncthreads();                            // (the chain state in LDS is free again for the second group)
         }
     };
@@ -400,6 +426,9 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
             // (compiler barrier: the activation's LDS reads do not depend on the row group, and hoisted out of this loop they cost 96 registers)
             asm volatile("" ::: "memory");
             do_group(std::integral_constant<int, 0>{});
+            if (++pass < npass) { slice_of(pass, qlo, nq); continue; }
+            pass = 0;
+            slice_of(0, qlo, nq);
             unit += (int)gridDim.x;
             if (unit >= units) break;
             par ^= 1;
@@ -426,8 +455,8 @@ extern "C" __attribute__((visibility("default"))) int fl_debug_llc_timeline(long
 
 // residency slots of a kernel instantiation on this device: workgroups per CU (occupancy query with the launch's dynamic LDS) x CUs, rounded
 // down to an even number (the two workgroups of a w1|w3 feature pair are neighbours)
-static int llc_slots(const void *fn, int threads, size_t lds) {
-    if (!getenv("FL_LLC_PERSIST") && !getenv("FL_LLC_SLOTS")) return 1 << 30;
+static int llc_slots(const void *fn, int threads, size_t lds, bool always = false) {
+    if (!always && !getenv("FL_LLC_PERSIST") && !getenv("FL_LLC_SLOTS")) return 1 << 30;
     if (const char *e = getenv("FL_LLC_SLOTS")) return std::max(2, atoi(e) & ~1);      // tests: persistent workgroups on small matrices
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
@@ -444,7 +473,14 @@ static bool launch_llc(const fl_qtensor &W, const fl_qact *xq, float *y, hipStre
     constexpr int G2 = PAIR == 1 ? 2 : 1;
     const int KB = W.KB, NQ = (KB + 3) / 4, units = W.M16 / 16 / G2;
     const size_t lds = (size_t)NQ * 128 + (size_t)NQ * 32;                   // LX + d_x + s_x
-    if (lds > 60 * 1024 || units < 1 || NQ > 88) return false;
+    // Multi-pass rows (round 5): rows longer than one pass of the 4 x 8 (Q4_1: 8 x 4) form holds -- K > 4096 -- in that form all the same, pass after pass
+    // (see the kernel); FL_LLC_MP=0: the 4 x 11 / 8 x 11 forms and round 3's kernel as before
+    static const int mp_on = getenv("FL_LLC_MP") ? atoi(getenv("FL_LLC_MP")) : 1;
+    // (where it pays: the shapes that used to fall to round 3's kernel -- LLaMA-65B decode 76.8 -> 91.6 tok/s, 13B 291.6 -> 309.9 (its w2); for LLaMA-7B's
+    //  w2 -- K = 11008 on 256 row groups -- the 8 x 11 form stays ahead, 587 against 556 tok/s, and K = 5120 in the 4 x 11 form, 292 against 282:
+    //  profiles/r05_decode_exact.md.  FL_LLC_MP=2 forces it for every K > 4096: tests)
+    const bool mp = mp_on && PAIR != 1 && NQ > 32 && (mp_on > 1 || NQ > 88 || (NQ > 44 && units > 256));
+    if (lds > 60 * 1024 || units < 1 || (NQ > 88 && !mp)) return false;
     if (qwd_bytes(W) >= (1ull << 31) || (size_t)W.M16 * (size_t)KB * 4 >= (1ull << 31)) return false;      // 32-bit buffer offsets (no LLaMA tensor comes close)
     // (waves along K, quads a wave holds): 4 x 8 covers K <= 4096 with the fewest registers (three waves per SIMD), 4 x 11 K <= 5632,
     // 8 x 11 K <= 11264 -- but an 8-wave workgroup at 186 registers is ONE per CU: good for a matrix of <= 256 row groups (LLaMA-7B's w2:
@@ -452,16 +488,16 @@ static bool launch_llc(const fl_qtensor &W, const fl_qact *xq, float *y, hipStre
     // wq|wk|wv / w1|w3, scripts/dev/dec_ab.sh) -- those, and rows beyond 11264 (13B / 65B w2), stay on round 3's kernel
     // (round 5 tried an 8 x 8 form for K <= 8192 compiled for <= 128 registers -- two workgroups per CU -- : 23-35 scratch spills, LLaMA-65B decode 58.8
     //  against round 3's kernel's 78.6 tok/s in one gpurun call; removed)
-    if (NQ > 44 && units > 256) return false;
+    if (NQ > 44 && units > 256 && !mp) return false;
     const TpTail *tt = tp_take_tail();
     // grid: one workgroup per row group.  FL_LLC_PERSIST=1 (opt-in): when the row groups do not all fit on the chip at once, the PERSIST
     // instantiation with one workgroup per ITS residency slot (see the kernel) -- built, bit-identical, and measured 2 % SLOWER on LLaMA-7B's
     // decode (564.8-567.8 against 577.5 tok/s in one gpurun call, profiles/r05_decode_exact.md): the loop costs 45 registers = two workgroups per CU
     // instead of three, and a row group's bytes are requested one chain phase, not one row group, ahead.
-#define FL_LLC_GO(NK, QPW, PS, TM, GRID)                                                                                                  \
+#define FL_LLC_GO(NK, QPW, PS, TM, GRID, NPASS)                                                                                                  \
     hipLaunchKernelGGL((gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, PS, TM>), dim3(GRID), dim3(64 * NK * TM), lds, st, W.M, units, KB, \
                        woven, W.qwd, W.d, xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid,       \
-                       ynorm, aux2, pair_ws, tt)
+                       ynorm, aux2, pair_ws, tt, NPASS)
     // FL_LLC_TEAMS=1 (opt-in): three row groups per workgroup (TEAMS = 3, the 4 x 8 form: 12 waves = one CU's worth at 136 registers; Q4_1's 8 x 4 form: two)
     // when a launch has more than two row groups per CU -- the prologue once per CU.  Built, bit-identical, and measured SLOWER: 551 against 594 tok/s
     // (Q4_1 402 against 455), profiles/r05_decode_exact.md -- the prologue takes the same 4.6 us whether one or three run on a CU (it waits for the
@@ -477,14 +513,37 @@ static bool launch_llc(const fl_qtensor &W, const fl_qact *xq, float *y, hipStre
             slots1 = llc_slots(reinterpret_cast<const void *>(&gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, 1>), 64 * NK, lds);    \
         }                                                                                                                                 \
         if constexpr (NK == 4 && QPW == 8 && PAIR != 1) {                                                                                 \
-            if (teams_on && units > (teams_min >= 0 ? teams_min : 2 * n_cus)) { FL_LLC_GO(NK, QPW, 0, 3, (units + 2) / 3); break; }       \
+            if (teams_on && units > (teams_min >= 0 ? teams_min : 2 * n_cus)) { FL_LLC_GO(NK, QPW, 0, 3, (units + 2) / 3, 1); break; }       \
         }                                                                                                                                 \
         if constexpr (NK == 8 && QPW == 4 && PAIR != 1) {      /* (Q4_1: 8 x 4 at <= 128 registers: two teams = 16 waves = one CU's worth) */ \
-            if (teams_on && units > (teams_min >= 0 ? teams_min : n_cus)) { FL_LLC_GO(NK, QPW, 0, 2, (units + 1) / 2); break; }           \
+            if (teams_on && units > (teams_min >= 0 ? teams_min : n_cus)) { FL_LLC_GO(NK, QPW, 0, 2, (units + 1) / 2, 1); break; }           \
         }                                                                                                                                 \
-        if (PAIR == 1 || units <= slots0) FL_LLC_GO(NK, QPW, 0, 1, units);                                                                \
-        else FL_LLC_GO(NK, QPW, 1, 1, (units < slots1 ? units : slots1));                                                                 \
+        if (PAIR == 1 || units <= slots0) FL_LLC_GO(NK, QPW, 0, 1, units, 1);                                                             \
+        else FL_LLC_GO(NK, QPW, 1, 1, (units < slots1 ? units : slots1), 1);                                                              \
     } while (0)
+    if constexpr (PAIR != 1) {
+        if (mp) {
+            // passes of at most NK x QPW quads, balanced (the kernel splits NQ into npass equal parts).  Q4_0: 4 x 6 -- 24 quads per pass at 142-146
+            // registers, three workgroups per CU; 4 x 7 (162-168) also three, 4 x 8 needs 184 in the loop form = two.  LLaMA-65B decode 92.7 / 89.6 / 90.0
+            // tok/s, 13B 306.8 / 309.3 / 307.6 (one gpurun call; round 3's kernel: 76.8 / 291.6): all three stream at the ~5 TB/s every GEMV launch of
+            // this path reaches (T = 2.7 us + bytes / 5 TB/s fits the four launches of a 65B layer within 10 %).  FL_LLC_MPQ=8|7|6: A/B.
+            static const int mpq = getenv("FL_LLC_MPQ") ? atoi(getenv("FL_LLC_MPQ")) : 6;
+#define FL_LLC_MP_GO(MNK, MQPW)                                                                                                            \
+            do {                                                                                                                           \
+                static int slots = 0;                                                                                                      \
+                static size_t slots_lds = 0;                                                                                               \
+                if (!slots || slots_lds != lds)                                                                                            \
+                    slots_lds = lds, slots = llc_slots(reinterpret_cast<const void *>(&gemv1_q4_exact_llc_kernel<TYPE, MNK, PRO, PAIR, MQPW, 1>), 64 * MNK, lds, true); \
+                FL_LLC_GO(MNK, MQPW, 1, 1, (units < slots ? units : slots), (NQ + MNK * MQPW - 1) / (MNK * MQPW));                          \
+            } while (0)
+            if constexpr (TYPE == FL_TYPE_Q4_1) FL_LLC_MP_GO(8, 4);
+            else if (mpq == 8) FL_LLC_MP_GO(4, 8);
+            else if (mpq == 6) FL_LLC_MP_GO(4, 6);
+            else FL_LLC_MP_GO(4, 7);
+#undef FL_LLC_MP_GO
+            return true;
+        }
+    }
     if constexpr (TYPE == FL_TYPE_Q4_1) {             // Q4_1 carries m_w as well: 4 x 8 needs 174 registers = two waves per SIMD; 8 x 4 needs <= 126
         static const bool q41_48 = getenv("FL_Q41_48") != nullptr;      // A/B: the 4 x 8 form for Q4_1 as well
         if (NQ <= 32 && !q41_48) { FL_LLC(8, 4); return true; }   // (four): LLaMA-7B Q4_1 decode 412 -> 424 tok/s.  (Q4_0, 139 registers at 4 x 8: no gain)

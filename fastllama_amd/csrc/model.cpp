@@ -489,7 +489,7 @@ static void ensure_fold(fl_model *m) {
         t[k].world = f.world; t[k].rank = f.rank;
         for (int r = 0; r < f.world; ++r) { t[k].region[r] = f.region[r]; t[k].flag[r] = f.flag[r] + k * FL_COMM_MAX_LOCAL; }
         t[k].ticket = f.ticket + k; t[k].epoch = f.epoch + k; t[k].timeouts = f.timeouts;
-        t[k].timeout_ticks = 2000000000ull;                // ~20 s of the 100 MHz wall clock: far beyond any legitimate skew between ranks
+        t[k].timeout_ticks = p2p_timeout_ticks();          // ~20 s of the 100 MHz wall clock: far beyond any legitimate skew between ranks
         t[k].n_ranges = 1;
     }
     const unsigned r = (unsigned)m->rank;

@@ -80,6 +80,28 @@ def main():
     toks = ggjt.text_tokens("The quick brown fox jumps over the lazy dog")
     m = FlModel(cfg, qtype, tensors, n_ctx=128, max_batch=64, tp_rank=rank, tp_size=world, device=dev)
     m.set_comm(comm)
+    if os.environ.get("FL_TP_WORKER_MODE") == "peer_never_arrives":
+        # both ranks decode two tokens; then rank 1 stops taking part: rank 0's next token must come back as an ERROR within the exchange's
+        # bounded waits (FL_P2P_TIMEOUT_MS), not hang (tests/test_model_gpu.py)
+        m.eval([toks[0]], n_past=0)
+        m.eval([toks[1]], n_past=1)
+        folded = L.fl_model_tp_folded(m.h)
+        marker = os.path.join(p2p_dir, "rank0_done")
+        if rank == 0:
+            time.sleep(1.0)
+            t0, err = time.time(), ""
+            try:
+                m.eval([toks[2]], n_past=2)
+            except hip.FastLlamaHipError as e:
+                err = str(e)
+            np.savez(outfile, error=err, seconds=time.time() - t0, folded=folded)
+            open(marker, "w").write("x")
+        else:
+            t0 = time.time()
+            while not os.path.exists(marker) and time.time() - t0 < 120:
+                time.sleep(0.05)
+            np.savez(outfile, folded=folded)
+        os._exit(0)                                              # (the communicator is out of step: no orderly teardown to test here)
     pre = m.eval(toks, all_logits=True)
     dec_graph = m.eval([toks[3]], n_past=len(toks))
     dec_graph2 = m.eval([toks[4]], n_past=len(toks) + 1)            # a replay of the captured graph

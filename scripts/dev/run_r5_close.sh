@@ -18,3 +18,7 @@ cd $R
 python scripts/dev/stats_summary.py gpurun_out/r5_prof_bench > gpurun_out/r5_bench_kernel_stats.txt; head -12 gpurun_out/r5_bench_kernel_stats.txt
 python scripts/dev/stats_summary.py gpurun_out/r5_prof_pre > gpurun_out/r5_prefill_kernel_stats.txt
 python scripts/dev/stats_summary.py gpurun_out/r5_prof_dec > gpurun_out/r5_decode_kernel_stats.txt; head -10 gpurun_out/r5_decode_kernel_stats.txt
+# the raw traces are too big to travel back (gpurun merges <= 64 MiB): summarise here, keep the summaries
+ROUND=r05 PMC_OUT=gpurun_out python scripts/pmc_summary.py > /dev/null 2>&1; ls -la gpurun_out/r05_pmc_traffic.* 2>&1 | tail -2
+rm -rf gpurun_out/r5_prof_bench gpurun_out/r5_prof_pre gpurun_out/r5_prof_dec gpurun_out/pmc_pre_* gpurun_out/pmc_dec_*
+du -sh gpurun_out | tail -1

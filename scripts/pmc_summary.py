@@ -9,6 +9,7 @@ reads on gfx950 (MI355X_MICROARCH.md, HBM section): read bytes = FETCH_SIZE * 10
 import collections, csv, glob, json, os
 ROUND = os.environ.get("ROUND", "r04")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.environ.get("PMC_OUT", f"{ROOT}/profiles")          # (on the GPU box: gpurun_out/, the raw counter CSVs are too big to travel back)
 
 
 def agg(leg, c):
@@ -43,7 +44,7 @@ for leg, mm, pat, title in LEGS:
 json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes), scripts/prefill_only.py 2 and "
                      "scripts/decode_only.py 8 0, LLaMA-7B Q4_0 synthetic, MI355X",
            "correction": "read bytes = FETCH_SIZE*1024*2 (gfx950: 64 B tallied per 128-B request of 16 B/lane streaming reads); WRITE_SIZE*1024",
-           "kernels": out}, open(f"{ROOT}/profiles/{ROUND}_pmc_traffic.json", "w"), indent=1)
+           "kernels": out}, open(f"{OUT}/{ROUND}_pmc_traffic.json", "w"), indent=1)
 head = ("# HBM-side traffic of the eval kernels from PMC counters (" + ROUND + ", MI355X, LLaMA-7B Q4_0 synthetic)\n\n" + __doc__.split("\n\n", 1)[1] +
         "\n\nCalibration on our own kernels: the decode GEMV of w1|w3 reads 22016 x 4096 / 32 x 20 B = 56.36 MB of weights; its corrected "
         "FETCH_SIZE is within 2 % of that (table below).\n\nSummary used by bench.py (`roofline.traffic`, `traffic_source`):\n\n" +
@@ -53,5 +54,5 @@ head = ("# HBM-side traffic of the eval kernels from PMC counters (" + ROUND + "
         "copy, the same 16 B per row and block, plus the f32 scales).  The reference-order prefill GEMM reads the f16 fragment copies (64 B per row and "
         "block = 4x the nibbles: 13.2 GB per 7B eval) -- its FETCH bytes against those, not against the Q4 bytes, say how much the 8 column tiles of a "
         "row panel share through L2; at well under 1.5 TB/s it is far from HBM-bound: the matrix + VALU issue of the SIMDs is the limit.\n")
-open(f"{ROOT}/profiles/{ROUND}_pmc_traffic.md", "w").write(head + "\n".join(md) + "\n")
+open(f"{OUT}/{ROUND}_pmc_traffic.md", "w").write(head + "\n".join(md) + "\n")
 print(head)
