@@ -122,7 +122,7 @@ __device__ unsigned llc_tl_cur;
 // SHARE the prologue: the activation is read, normalised and quantized once per CU instead of once per row group -- a launch's lane sums wait for
 // the prologue, not for their bytes (profiles/r05_decode_timeline.md), and three workgroups per CU ran three of them at once behind each other's
 // weight requests.  Same arithmetic per row group; the chain hand-offs of the teams share the workgroup's barriers.
-template <int TYPE, int NK, int PRO, int PAIR, int QPW, int PERSIST, int TEAMS = 1>
+template <int TYPE, int NK, int PRO, int PAIR, int QPW, int PERSIST, int TEAMS = 1, int TAIL = 0>
 #ifndef LLC_PS_OCC
 #define LLC_PS_OCC 1
 #endif
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
     const uint32_t m8 = 0xF0F0F0F0u;
     // (with a tail: written through to memory, and to every peer's region -- tp_put, tp_tail.h)
     auto put_y = [&](float *p, float v) __attribute__((always_inline)) {
-        if (tt) tp_put(tt, p, v);
+        if constexpr (TAIL) tp_put(tt, p, v);       // (its own instantiation: the launches of an unsharded model are the code they were before the tail)
         else *p = v;
     };
     float y1 = 0.f;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
     }
     LLC_STAMP(5);
     LLC_COMMIT(PRO * 100 + PAIR * 10 + NK);
-    if (tt) tp_tail<false, false, true>(tt);
+    if constexpr (TAIL) tp_tail<false, false, true>(tt);
 }
 #ifdef LLC_TIMING
 // reset != 0: empty the ring; else copy up to max_rec records of 8 x int64 {t0 entry, t1 loads issued, t2 prologue done, t3 lane sums of the
@@ -495,9 +495,16 @@ static bool launch_llc(const fl_qtensor &W, const fl_qact *xq, float *y, hipStre
     // decode (564.8-567.8 against 577.5 tok/s in one gpurun call, profiles/r05_decode_exact.md): the loop costs 45 registers = two workgroups per CU
     // instead of three, and a row group's bytes are requested one chain phase, not one row group, ahead.
 #define FL_LLC_GO(NK, QPW, PS, TM, GRID, NPASS)                                                                                                  \
-    hipLaunchKernelGGL((gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, PS, TM>), dim3(GRID), dim3(64 * NK * TM), lds, st, W.M, units, KB, \
-                       woven, W.qwd, W.d, xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid,       \
-                       ynorm, aux2, pair_ws, tt, NPASS)
+    do {                                                                                                                                  \
+        if (tt)                                                                                                                           \
+            hipLaunchKernelGGL((gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, PS, TM, 1>), dim3(GRID), dim3(64 * NK * TM), lds, st, W.M, units, KB, \
+                               woven, W.qwd, W.d, xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid, \
+                               ynorm, aux2, pair_ws, tt, NPASS);                                                                          \
+        else                                                                                                                              \
+            hipLaunchKernelGGL((gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, PS, TM, 0>), dim3(GRID), dim3(64 * NK * TM), lds, st, W.M, units, KB, \
+                               woven, W.qwd, W.d, xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid, \
+                               ynorm, aux2, pair_ws, tt, NPASS);                                                                          \
+    } while (0)
     // FL_LLC_TEAMS=1 (opt-in): three row groups per workgroup (TEAMS = 3, the 4 x 8 form: 12 waves = one CU's worth at 136 registers; Q4_1's 8 x 4 form: two)
     // when a launch has more than two row groups per CU -- the prologue once per CU.  Built, bit-identical, and measured SLOWER: 551 against 594 tok/s
     // (Q4_1 402 against 455), profiles/r05_decode_exact.md -- the prologue takes the same 4.6 us whether one or three run on a CU (it waits for the
