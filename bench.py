@@ -367,7 +367,7 @@ def main():
             decl = lambda i: model.eval_last_logits(tok1, m["long_past"] + i, lg_host)
             for i in range(3):
                 decl(i)
-            m["decode_long_ms"] = timed(decl, lsteps_) / lsteps_ * 1e3
+            m["decode_long_ms"] = min(timed(decl, lsteps_), timed(decl, lsteps_)) / lsteps_ * 1e3
             if not full:
                 return m
             # ---- a later chunk of a long prompt: the same N tokens behind n_ctx - N cached positions (the reference-order attention over
@@ -384,7 +384,7 @@ def main():
                 decm = lambda i: model.eval_last_logits(tok1, 988 + i, lg_host)
                 for i in range(3):
                     decm(i)
-                m["decode_988_ms"] = timed(decm, 24) / 24 * 1e3
+                m["decode_988_ms"] = min(timed(decm, 24), timed(decm, 24)) / 24 * 1e3      # (the better of two passes, as the n_past 128 legs)
             # ---- roofline of the dominant kernels: HIP events around every matmul launch on the eval stream
             gemm, gemv = KERNELS[mode]
             model.profile(1)
