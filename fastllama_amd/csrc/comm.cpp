@@ -42,6 +42,7 @@ constexpr size_t P2P_CAP = 64 * 1024;          // floats per slot (256 KB): the 
 // the flags peers write, [128 + kind] tickets, [144 + kind] epochs (local)
 constexpr int FOLD_FLAG0 = 64, FOLD_TICKET0 = 128, FOLD_EPOCH0 = 144;
 static_assert(FL_COMM_MAX_LOCAL <= 8 && TP_FOLD_KINDS <= 8, "flag page layout");
+static_assert(3 * FL_COMM_MAX_LOCAL * 1024 <= TP_FOLD_BYTES, "the self-test's three areas");
 constexpr size_t P2P_MAX_COUNT = 16 * 1024;    // messages up to 64 KB go this way (one workgroup moves them)
 // (FL_P2P_MAX_COUNT: up to a whole slot -- rehearsals of larger models on a communicator without RCCL behind it, scripts/dev/run_r5_o.sh)
 static size_t p2p_max_count() {
@@ -318,11 +319,14 @@ static bool p2p_selftest(fl_comm *c) {
     uint32_t mine[W], all[FL_COMM_MAX_LOCAL * W];
     for (unsigned round = 1; round <= 3 && ok; ++round) {
         if (round == 2) t.timeout_ticks = 200000000ull;
+        // (every round has its own area of the region: a peer that is a round ahead must not overwrite the slices this rank is still reading back)
+        const size_t area = (size_t)(round - 1) * FL_COMM_MAX_LOCAL * SL;
+        t.off[0] = (unsigned)(area + (size_t)f.rank * SL);
         for (unsigned i = 0; i < W; ++i) mine[i] = (round << 28) ^ ((unsigned)f.rank << 20) ^ (i * 2654435761u);
         ok = hipMemcpy(td, &t, sizeof t, hipMemcpyHostToDevice) == hipSuccess &&
-             hipMemcpy(f.region[f.rank] + (size_t)f.rank * SL, mine, SL, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(f.region[f.rank] + t.off[0], mine, SL, hipMemcpyHostToDevice) == hipSuccess &&
              tp_tail_launch(td, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
-             hipMemcpy(all, f.region[f.rank], (size_t)f.world * SL, hipMemcpyDeviceToHost) == hipSuccess;
+             hipMemcpy(all, f.region[f.rank] + area, (size_t)f.world * SL, hipMemcpyDeviceToHost) == hipSuccess;
         for (int r = 0; r < f.world && ok; ++r)
             for (unsigned i = 0; i < W && ok; ++i) ok = all[(size_t)r * W + i] == ((round << 28) ^ ((unsigned)r << 20) ^ (i * 2654435761u));
     }

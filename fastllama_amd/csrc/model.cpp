@@ -479,9 +479,9 @@ static void ensure_fold(fl_model *m) {
     const size_t E = (size_t)m->E, F = (size_t)m->G * m->Fl, El = (size_t)m->El, Fl = (size_t)m->Fl, KB = E / FL_QK, KBl = El / FL_QK;
     const size_t off_x = 0, off_x2 = E * 4, off_h = 2 * E * 4, off_q = fl_roundup((int)(off_h + F * 4), 16), off_d = off_q + E, off_s = off_d + KB * 4,
                  total = off_s + KB * 4;
-    if (total > TP_FOLD_BYTES || El % FL_QK != 0) {
+    if (total > TP_FOLD_BYTES) {
         warn("tensor-parallel decode: the exchanged vectors (%zu B) do not fit the communicator's fold region (%zu B): the collective sequence runs "
-             "(same results, 11 kernels + 4 collectives per layer instead of 5 launches)", total, TP_FOLD_BYTES);
+             "(same results, 9 kernels + 4 collectives per layer instead of 5 launches)", total, TP_FOLD_BYTES);
         return;
     }
     TpTail t[4] = {};

@@ -2,7 +2,7 @@
 //
 // Row-split tensor parallelism (the reference's own split across threads, lib/ggml.c:8127-8135: rank = thread with its own HBM) moves four
 // small vectors per layer and decode token between the ranks: the Q8_0 attention output, the wo rows, the silu features, the w2 rows.  As
-// collectives they were pack -> all-gather -> unpack (-> add): 11 kernels + 4 collectives per layer.  Here every rank owns a FOLD REGION
+// collectives they were pack -> all-gather -> unpack (-> add): 9 kernels + 4 collectives per layer.  Here every rank owns a FOLD REGION
 // (comm.cpp; peer-mapped like the small-message exchange buffers) with the SAME layout on every rank -- [x row][x2 row][silu features]
 // [Q8_0 planes of the attention output] -- and the decode kernels of a tensor-parallel model read and write their operands THERE:
 //   * a producer writes its slice (its rows / features / blocks) into its own region, in place, AND into every peer's region at the same
