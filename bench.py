@@ -177,7 +177,7 @@ def main():
                     help="world > 1: tp = ONE batch, Megatron split + RCCL (the headline, strong scaling; a replica leg is measured "
                          "and reported beside it), dp = replicas only.  auto = tp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--peer-exchange", action="store_true", help="tensor-parallel leg: decode-size messages through peer-mapped buffers (FL_P2P=1) instead of RCCL; never run over xGMI so far")
+    ap.add_argument("--peer-exchange", action="store_true", help="(kept for old command lines: the peer-mapped exchange for decode-size messages is on by default since round 5; FL_P2P=0 switches it off)")
     ap.add_argument("--tp-timeout", type=int, default=300, help="seconds the tensor-parallel leg may take before the replica leg is reported alone")
     ap.add_argument("--no-fast", action="store_true", help="skip the fast-mode timings reported beside the headline")
     ap.add_argument("--no-cpu-e2e", action="store_true", help="skip cpu_baseline.end_to_end (the reference's own eval of the same 7B file)")
