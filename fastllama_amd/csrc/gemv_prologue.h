@@ -237,10 +237,32 @@ struct GemvPrologue {
                 for (int i = 0; i < 8; ++i) o[i] = v[it][i];
                 quantize_group_lds_x<LXF>(o, kg, lq, ld_, ls_);
             }
-            for (int kg = threadIdx.x + QIT * NT; kg < gpr; kg += NT) {   // very wide rows: the rest, behind the weights
+            // very wide rows: the rest, behind the weights -- four group-iterations' loads at a time (one iteration at a time every one of them was a
+            // dependent round trip behind the wave's weight requests: LLaMA-65B's w2, K = 22016 on 256 threads, took seven: round 5)
+            // (only when more than three iterations are left: LLaMA-13B's w2, K = 13824, has 2.75 and lost 1.5 % to the batch's dummy loads and
+            //  registers -- 307.9 -> 303.1 tok/s -- where 65B gained 1.4 %, 94.2 -> 95.6, alternating runs on one box, profiles/r05_decode_exact.md)
+            constexpr int RB = 4;
+            const bool batched = gpr - QIT * NT > 3 * NT;                  // (uniform)
+            for (int kg = threadIdx.x + QIT * NT; !batched && kg < gpr; kg += NT) {
                 const float4 a0 = *reinterpret_cast<const float4 *>(xf + kg * 8), a1 = *reinterpret_cast<const float4 *>(xf + kg * 8 + 4);
                 const float o[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                 quantize_group_lds_x<LXF>(o, kg, lq, ld_, ls_);
+            }
+            for (int kg0 = threadIdx.x + QIT * NT; batched && kg0 < gpr; kg0 += RB * NT) {
+                float4 a[RB][2];
+#pragma unroll
+                for (int b = 0; b < RB; ++b) {
+                    const int kg = min(kg0 + b * NT, gpr - 1);             // (past the row: a cache-hot dummy, never used -- unconditional loads)
+                    a[b][0] = *reinterpret_cast<const float4 *>(xf + kg * 8);
+                    a[b][1] = *reinterpret_cast<const float4 *>(xf + kg * 8 + 4);
+                }
+#pragma unroll
+                for (int b = 0; b < RB; ++b) {
+                    const int kg = kg0 + b * NT;
+                    if (kg >= gpr) break;                                  // (gpr % 4 == 0 and NT % 4 == 0: quads stay together)
+                    const float o[8] = {a[b][0].x, a[b][0].y, a[b][0].z, a[b][0].w, a[b][1].x, a[b][1].y, a[b][1].z, a[b][1].w};
+                    quantize_group_lds_x<LXF>(o, kg, lq, ld_, ls_);
+                }
             }
             __syncthreads();
         }
