@@ -134,3 +134,26 @@ def test_a_rank_that_stops_publishing_blocks_its_peers_instead_of_letting_them_r
         return "finished"
 
     assert all(crippled(s) == "blocked" for s in range(20))
+
+
+def test_multi_pass_row_partition_covers_every_quad_once_in_order():
+    """The decode GEMV's multi-pass rows (gemv1_q4_exact_llc.hip, slice_of): a row of NQ quads is taken in npass = ceil(NQ / (NK QPW)) passes, pass p
+    owning quads [p NQ / npass, (p + 1) NQ / npass), wave k of the pass its k-th NK-th of those.  The chain order is the row's block order only if these
+    slices tile [0, NQ) in ascending (pass, wave) order, and a wave's slice must fit its QPW register quads -- for EVERY row length, not only the LLaMA
+    ones the GPU tests run (the formula mirrored here; (NK, QPW) = the shipped forms)."""
+    for NK, QPW in ((4, 6), (4, 7), (4, 8), (8, 4)):
+        PQ = NK * QPW
+        for NQ in range(1, 700):
+            npass = (NQ + PQ - 1) // PQ
+            nxt = 0
+            for p in range(npass):
+                lo = (p * NQ) // npass
+                nqp = ((p + 1) * NQ) // npass - lo
+                assert 0 < nqp <= PQ
+                for k in range(NK):
+                    qlo = lo + (k * nqp) // NK
+                    nq = lo + ((k + 1) * nqp) // NK - qlo
+                    assert 0 <= nq <= QPW, (NK, QPW, NQ, p, k, nq)
+                    assert qlo == nxt
+                    nxt += nq
+            assert nxt == NQ
