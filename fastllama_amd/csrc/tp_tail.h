@@ -96,6 +96,9 @@ __device__ __forceinline__ void tp_tail(const TpTail *__restrict__ tt) {
     }
     const int world = tt->world, rank = tt->rank;
     const unsigned e = __hip_atomic_load(tt->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    // an earlier exchange over this communicator already gave up on a peer: the ranks are out of step and every result since is void -- waiting the
+    // full bound again at each of the token's remaining exchanges would only delay the error the host is about to get (fl_comm_p2p_check)
+    bool gave_up = __hip_atomic_load(tt->timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     for (int i = 0; i < (PUSHED ? 0 : tt->n_ranges); ++i) {
         const unsigned words = tt->bytes[i] >> 2;
         const uint32_t *src = reinterpret_cast<const uint32_t *>(tt->region[rank] + tt->off[i]);
@@ -114,13 +117,11 @@ __device__ __forceinline__ void tp_tail(const TpTail *__restrict__ tt) {
         // bounded: a peer that died must not hang this GPU's queue for ever (the host sees the count and fails the eval: fl_comm_p2p_check)
         const unsigned long long t0 = wall_clock64();
         // (relaxed polls and ONE acquire behind them: an acquire load invalidates the caches every time round the loop)
-        while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {      // (epochs only grow)
+        while (!gave_up && (int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {      // (epochs only grow)
             __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > tt->timeout_ticks) {
-                atomicAdd(tt->timeouts, 1u);
-                break;
-            }
+            if (wall_clock64() - t0 > tt->timeout_ticks) gave_up = true;
         }
+        if (gave_up) atomicAdd(tt->timeouts, 1u);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     }
     __syncthreads();
