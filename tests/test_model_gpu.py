@@ -343,12 +343,13 @@ def test_two_process_row_split_decode_with_the_exchanges_folded_into_the_produce
 
 def test_row_split_decode_fails_loudly_when_a_peer_never_arrives(tmp_path):
     """The folded exchange's failure mode: a rank whose peer never publishes its epoch.  Every wait is bounded (FL_P2P_TIMEOUT_MS here 1 s;
-    20 s by default), each one given up is counted, and fl_model_eval returns an error for that token instead of hanging the GPU's queue."""
+    20 s by default), each one given up is counted (after the first, the communicator's later exchanges do not wait again), and fl_model_eval
+    returns an error for that token instead of hanging the GPU's queue."""
     o = _run_tp_workers(tmp_path, "dies", {"FL_TP_WORKER_MODE": "peer_never_arrives", "FL_P2P_TIMEOUT_MS": "1000"})
     assert int(o[0]["folded"]) == 1 and int(o[1]["folded"]) == 1
     assert "gave up waiting for a peer" in str(o[0]["error"]), str(o[0]["error"])
     assert float(o[0]["seconds"]) < 60, float(o[0]["seconds"])
-    print("a decode token whose peer never arrives: error after %.1f s (13 bounded waits of 1 s)" % float(o[0]["seconds"]))
+    print("a decode token whose peer never arrives: error after %.1f s (bound per wait: 1 s; 13 exchanges in the token)" % float(o[0]["seconds"]))
 
 
 def test_bench_tensor_parallel_leg_as_two_processes_on_one_gpu():
