@@ -139,12 +139,28 @@ def cpu_end_to_end(cfg, N, qtype):
         t0 = time.perf_counter()
         ok = ref.ingest(text) and ref.generate(1, temp=0.0)[0]
         t_eval = time.perf_counter() - t0
+        # ---- the reference's DECODE beside the GPU's (lib/bridge.cpp:240-330): greedy tokens one llama_generate step at a time
+        #      -- each step is ONE Model::eval of one token at n_past = N + i plus the argmax -- timed per token after the warm-up step above
+        n_dec = 16
+        t_tok = []
+        for _ in range(n_dec if ok else 0):
+            t1 = time.perf_counter()
+            if not ref.generate(1, temp=0.0)[0]:
+                break
+            t_tok.append(time.perf_counter() - t1)
         ref.close()
     if not ok:
         return None
-    return {"value": N / t_eval, "unit": "tokens/s", "cores": nthr, "kind": "reference", "seconds_eval": t_eval, "seconds_load": t_load,
-            "sample": (f"the reference's own llama_ingest + first llama_generate step = ONE Model::eval of {N} tokens on the same synthetic "
-                       f"7B file, {nthr} threads of {os.cpu_count()} logical CPUs (includes tokenizing {N} bytes and one argmax)")}
+    out = {"value": N / t_eval, "unit": "tokens/s", "cores": nthr, "kind": "reference", "seconds_eval": t_eval, "seconds_load": t_load,
+           "sample": (f"the reference's own llama_ingest + first llama_generate step = ONE Model::eval of {N} tokens on the same synthetic "
+                      f"7B file, {nthr} threads of {os.cpu_count()} logical CPUs (includes tokenizing {N} bytes and one argmax)")}
+    if t_tok:
+        med = float(np.median(t_tok))
+        out["decode"] = {"value": 1.0 / med, "unit": "tokens/s", "cores": nthr, "kind": "reference", "n_past": N + 1, "tokens": len(t_tok),
+                         "ms_per_token": {"median": med * 1e3, "min": min(t_tok) * 1e3, "max": max(t_tok) * 1e3},
+                         "sample": (f"{len(t_tok)} greedy llama_generate steps (temp 0: one Model::eval of one token + argmax each) behind the "
+                                    f"{N}-token prompt on the same synthetic 7B file, {nthr} threads; median per token")}
+    return out
 
 
 def self_launch(n):
@@ -351,13 +367,16 @@ def main():
             # ---- decode: N = 1 at n_past = 128.. (KV holds the prefill)
             for i in range(3):
                 dec(i)
-            # (two passes of dsteps steps, the better one: a pass right behind the prefill legs now and then runs ~40 % slow for its whole
-            #  duration -- seen in both modes, gone in the next pass, profiles/r05_bench_notes.md -- and this is a side number of a 1.7 ms step)
-            m["decode_ms"] = min(timed(dec, dsteps), timed(dec, dsteps)) / dsteps * 1e3
+            # three passes of dsteps steps: the MEDIAN is the number, every pass is reported (round 5 took the better of two because a pass now
+            # and then ran ~40 % slow; profiles/r06_decode_transient.md has what that was)
+            def passes(fn, n, k=3):
+                ts = [timed(fn, n) / n * 1e3 for _ in range(k)]
+                return float(np.median(ts)), ts
+            m["decode_ms"], m["decode_passes_ms"] = passes(dec, dsteps)
             m["decode_tokens_per_s"] = seqs / (m["decode_ms"] * 1e-3)
             # the same steps with the logits left in HBM (no host round trip per token): what the kernels alone sustain
             dec_nc = lambda i: model.eval_nocopy(tok1, min(128, N) + i)
-            m["decode_ms_device_resident"] = min(timed(dec_nc, dsteps), timed(dec_nc, dsteps)) / dsteps * 1e3
+            m["decode_ms_device_resident"], m["decode_passes_ms_device_resident"] = passes(dec_nc, dsteps)
             # launches of a decode token = kernel nodes of the replayed hipGraph (under the row split: are the exchanges tails of the producers?)
             m["decode_graph_nodes"] = int(hip.load().fl_model_graph_nodes(model.h))
             m["tp_decode_folded"] = bool(hip.load().fl_model_tp_folded(model.h))
@@ -367,7 +386,7 @@ def main():
             decl = lambda i: model.eval_last_logits(tok1, m["long_past"] + i, lg_host)
             for i in range(3):
                 decl(i)
-            m["decode_long_ms"] = min(timed(decl, lsteps_), timed(decl, lsteps_)) / lsteps_ * 1e3
+            m["decode_long_ms"], m["decode_long_passes_ms"] = passes(decl, lsteps_)
             if not full:
                 return m
             # ---- a later chunk of a long prompt: the same N tokens behind n_ctx - N cached positions (the reference-order attention over
@@ -384,7 +403,7 @@ def main():
                 decm = lambda i: model.eval_last_logits(tok1, 988 + i, lg_host)
                 for i in range(3):
                     decm(i)
-                m["decode_988_ms"] = min(timed(decm, 24), timed(decm, 24)) / 24 * 1e3      # (the better of two passes, as the n_past 128 legs)
+                m["decode_988_ms"], _ = passes(decm, 24)
             # ---- roofline of the dominant kernels: HIP events around every matmul launch on the eval stream
             gemm, gemv = KERNELS[mode]
             model.profile(1)
@@ -513,10 +532,10 @@ def main():
                           "also under tensor parallelism (tests/test_wide_models_gpu.py).  fast_mode = FL_FAST=1 / fl_model_set_exact(m, 0): exact "
                           "integer block dots, per-block f32 terms added in the kernels' own order (1e-7 per matmul; ~1e-2 on 7B logits after 32 layers)"),
             "prefill_tokens_per_s": head["prefill_tokens_per_s"],
-            "decode_tokens_per_s": head["decode_tokens_per_s"], "decode_ms_per_token": head["decode_ms"],
-            "decode_device_resident": {"tokens_per_s": leg["seqs"] / (head["decode_ms_device_resident"] * 1e-3), "ms_per_token": head["decode_ms_device_resident"],
+            "decode_tokens_per_s": head["decode_tokens_per_s"], "decode_ms_per_token": head["decode_ms"], "decode_passes_ms_per_token": head["decode_passes_ms"],
+            "decode_device_resident": {"tokens_per_s": leg["seqs"] / (head["decode_ms_device_resident"] * 1e-3), "ms_per_token": head["decode_ms_device_resident"], "passes_ms_per_token": head["decode_passes_ms_device_resident"],
                                        "note": "the same steps with the logits left in HBM (no host round trip per token)"},
-            "timed_region": "token ids in (host), the last token's logits back on the host, per eval: prefill and decode alike; decode legs: the better of two passes of --decode-steps steps",
+            "timed_region": "token ids in (host), the last token's logits back on the host, per eval: prefill and decode alike; decode legs: the MEDIAN of three passes of --decode-steps steps, every pass reported",
             "decode_long_context": {"n_past": leg["long_past"], "tokens_per_s": leg["seqs"] / (leg["decode_long_ms"] * 1e-3),
                                     "ms_per_token": leg["decode_long_ms"]},
             "hbm_roofline": {"peak_GBs": PEAK_HBM_GBS,
@@ -554,7 +573,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(cfg, N, qtype)
                 out["cpu_baseline"]["config1"] = cpu_config1(cfg, qtype)
                 if not args.no_cpu_e2e and args.model == "7B":
-                    out["cpu_baseline"]["end_to_end"] = cpu_end_to_end(cfg, N, qtype)
+                    e2e = cpu_end_to_end(cfg, N, qtype)
+                    if e2e and "decode" in e2e:
+                        out["cpu_baseline"]["decode"] = e2e.pop("decode")
+                    out["cpu_baseline"]["end_to_end"] = e2e
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "unavailable",
                                        "sample": f"failed: {e!r}"}

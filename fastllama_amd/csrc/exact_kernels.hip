@@ -430,14 +430,14 @@ static bool launch_gemv1_exact(const fl_qtensor &W, const fl_qact *xq, float *y,
 // (each entry point tries the round-4 lane-local-chain kernel first: it needs the tensor's QWD copy, gemv1_q4_exact_llc.hip)
 static bool llc_off() { static const bool off = getenv("FL_EXACT_R3") != nullptr; return off; }
 hipError_t gemv1_q4_exact(const fl_qtensor &W, const fl_qact &xq, float *y, hipStream_t st, const float *resid) {
-    if (!llc_off() && gemv1_llc(W, xq, y, st, resid)) return hipGetLastError();
+    if (!llc_off() && (gemv1_stream(W, xq, y, st, resid) || gemv1_llc(W, xq, y, st, resid))) return hipGetLastError();
     const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 0, 0>(W, &xq, y, st, resid, nullptr, nullptr, nullptr, 0, nullptr)),
                              (launch_gemv1_exact<FL_TYPE_Q4_1, 0, 0>(W, &xq, y, st, resid, nullptr, nullptr, nullptr, 0, nullptr)));
     return ok ? hipGetLastError() : hipErrorInvalidValue;
 }
 hipError_t gemv_q4_norm_exact(const fl_qtensor &W, const float *x, const float *norm_w, float *ynorm, float *y, hipStream_t st) {
     if (W.K % 32 != 0 || W.K > 8192) return hipErrorInvalidValue;
-    if (!llc_off() && gemv1_llc_norm(W, x, norm_w, ynorm, y, st)) return hipGetLastError();
+    if (!llc_off() && (gemv1_stream_norm(W, x, norm_w, ynorm, y, st) || gemv1_llc_norm(W, x, norm_w, ynorm, y, st))) return hipGetLastError();
     const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 1, 0>(W, nullptr, y, st, nullptr, x, norm_w, ynorm, 0, nullptr)),
                              (launch_gemv1_exact<FL_TYPE_Q4_1, 1, 0>(W, nullptr, y, st, nullptr, x, norm_w, ynorm, 0, nullptr)));
     return ok ? hipGetLastError() : hipErrorInvalidValue;
@@ -453,14 +453,20 @@ hipError_t gemv_q4_silu_exact(const fl_qtensor &W, const float *h13, const uint1
 hipError_t gemv_q4_norm_silu_exact(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act,
                                    hipStream_t st, float *pair_ws, int form) {
     if (W.K % 32 != 0 || W.K > 8192 || W.M % 32 != 0) return hipErrorInvalidValue;
-    if (!llc_off() && gemv1_llc_norm_silu(W, x, norm_w, silu_tab, act, st, pair_ws, form)) return hipGetLastError();
+    if (!llc_off() && ((form == 0 && gemv1_stream_norm_silu(W, x, norm_w, silu_tab, act, st)) || gemv1_llc_norm_silu(W, x, norm_w, silu_tab, act, st, pair_ws, form)))
+        return hipGetLastError();
     const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab)),
                              (launch_gemv1_exact<FL_TYPE_Q4_1, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab)));
     return ok ? hipGetLastError() : hipErrorInvalidValue;
 }
+hipError_t gemv_q4_norm_silu_q8_exact(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, const fl_qact &out,
+                                      hipStream_t st) {
+    if (W.K % 32 != 0 || W.K > 8192 || W.M % 64 != 0 || llc_off()) return hipErrorInvalidValue;
+    return gemv1_stream_norm_silu_q8(W, x, norm_w, silu_tab, out, st) ? hipGetLastError() : hipErrorInvalidValue;
+}
 hipError_t gemv_q4_quant_exact(const fl_qtensor &W, const float *x, float *y, const float *resid, hipStream_t st) {
     if (W.K % 32 != 0) return hipErrorInvalidValue;
-    if (!llc_off() && gemv1_llc_quant(W, x, y, resid, st)) return hipGetLastError();
+    if (!llc_off() && (gemv1_stream_quant(W, x, y, resid, st) || gemv1_llc_quant(W, x, y, resid, st))) return hipGetLastError();
     const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 3, 0>(W, nullptr, y, st, resid, x, nullptr, nullptr, 0, nullptr)),
                              (launch_gemv1_exact<FL_TYPE_Q4_1, 3, 0>(W, nullptr, y, st, resid, x, nullptr, nullptr, 0, nullptr)));
     return ok ? hipGetLastError() : hipErrorInvalidValue;

@@ -1,0 +1,382 @@
+// gemv1_q4_exact_stream.hip -- the reference-order ("exact") Q4 x Q8_0 matmul for N = 1 (decode), round 6 form: ONE WAVE PER ROW GROUP.
+//
+// What must be reproduced (ggml_vec_dot_q4_{0,1}_q8_0, AVX2 branch, /root/reference/lib/ggml.c:2445-2487, :2639-2689): per output row 8 f32
+// accumulators, accumulator j taking  acc_j = fma(d_w * d_x, float(sum of the products of elements 4j..4j+3), acc_j)  block after block,
+// then ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)) [+ the scalar chain summs = fma(m_w, s_x, summs) for Q4_1].
+//
+// Round 4's kernel (gemv1_q4_exact_llc.hip) splits a 16-row group along K over the 4 (8) waves of a workgroup: every wave converts its slice to
+// lane sums (96 registers) while all slices are in flight, then the chains run slice after slice through LDS -- a load phase, a sum phase and a
+// chain phase per workgroup, one activation prologue per ROW GROUP (1376 of them for LLaMA-7B's w1|w3 on 768 residency slots: two rounds of
+// workgroups, profiles/r05_decode_timeline.md).  That is the right shape for a matrix of one row group per CU (wo, w2).  For matrices of MANY row
+// groups (wq|wk|wv, w1|w3, the lm-head; every matmul of LLaMA-65B) this file turns the split round:
+//   * a wave owns a row group for the WHOLE of K.  lane = (row r, k-group g) keeps the chains 2g, 2g+1 of its row in two registers (the QWD
+//     copy, q4_layout.h, exactly as the llc kernel reads it) and walks the block quads in order: wait for a quad, 3 unpack + 2 v_dot4 + 2 cvt
+//     + scale product + 2 fma per block, request the quad U ahead into the registers just freed.  Nothing but the loads in flight is kept
+//     (U x 5 registers): no lane-sum arrays, no chain hand-off, no barrier after the prologue; the arithmetic runs UNDER the stream;
+//   * a workgroup = 4 such waves = 4 consecutive row groups sharing ONE activation prologue (rms_norm / Q8_0 in LDS, gemv_prologue.h): 344
+//     prologues instead of 1376 for w1|w3, all workgroups co-resident (<= 2 per CU), any K (the loop's trip count) -- no multi-pass rows;
+//   * woven w1|w3 (groups 4b .. 4b+3 = w1 | w3 rows of features 32b .. 32b+15, then of 32b+16 .. 32b+31): the workgroup owns a whole
+//     32-feature block, so it forms silu(w1 x) * (w3 x) (ggml_silu + ggml_mul, lib/llama.cpp:428-431) AND the block's Q8_0 form -- the operand
+//     of the w2 matmul (quantize_row_q8_0, lib/ggml.c:1299-1441) -- itself (EPI = 2): w2's prologue is a 13.8 KB copy instead of an f32
+//     round trip + quantization.  EPI = 1 keeps the f32 features (tensor-parallel fold: the exchange moves f32 slices).
+// Q4_0 bookkeeping as everywhere: unpacked values are 16 (nib - 8), the stored scale is d / 16.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <cstdlib>
+#include <algorithm>
+#include "q4_device.h"
+#include "q4_kernels.h"
+#include "gemv_prologue.h"
+#include "tp_tail.h"
+
+#pragma clang fp contract(off)
+
+namespace fl {
+
+typedef unsigned int sv4u __attribute__((ext_vector_type(4)));
+
+template <int SRC>
+__device__ __forceinline__ float sq_bcast(float v) {      // value of lane (quad base + SRC) of every quad
+    return dpp_f32<SRC | (SRC << 2) | (SRC << 4) | (SRC << 6)>(v);
+}
+
+#ifdef LLC_TIMING   // development build only (scripts/dev/stream_timeline.py): per-workgroup wall-clock stamps of every launch since the last reset
+constexpr unsigned ST_TL_CAP = 1u << 16;
+constexpr int ST_TL_W = 12;       // int64 per record: entry, loads issued, prologue done, loop end of waves 0..3, chains reduced + stored, end, id, spare x2
+__device__ long long st_tl[(size_t)ST_TL_CAP * ST_TL_W];
+__device__ unsigned st_tl_cur;
+#define ST_DECL long long tl_[4] = {0, 0, 0, 0}; __shared__ long long tlw_[4]
+#define ST_STAMP(k) do { tl_[k] = wall_clock64(); } while (0)
+#else
+#define ST_DECL do {} while (0)
+#define ST_STAMP(k) do {} while (0)
+#endif
+
+// EPI 0: y[row] = dot (+ resid[row]); 1: woven w1|w3 -> f32 silu(w1 x) * (w3 x); 2: woven w1|w3 -> the Q8_0 blocks (QA1 planes) of those features
+template <int TYPE, int PRO, int EPI, int U, int TAIL>
+__global__ __launch_bounds__(256, 2) void gemv1_q4_exact_stream_kernel(
+    int M, int groups, int KB, const uint32_t *__restrict__ qwd, const float *__restrict__ dW, const float *__restrict__ xf,
+    const void *__restrict__ aux, const float *__restrict__ mW, const int8_t *__restrict__ xq, const float *__restrict__ xd,
+    const float *__restrict__ xs, float *__restrict__ y, const float *__restrict__ resid, float *__restrict__ ynorm,
+    const uint16_t *__restrict__ silu_tab, int8_t *__restrict__ oq, float *__restrict__ od, float *__restrict__ os,
+    const TpTail *__restrict__ tt) {
+    constexpr bool Q41 = TYPE == FL_TYPE_Q4_1;
+    constexpr int NT = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    __shared__ double sh[4];
+    __shared__ float ex[4][16];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int NQ = (KB + 3) >> 2, NR = (NQ + U - 1) / U, NQP = NR * U;          // quads of a row, rounds of U, quads incl. the padding of the last round
+    // LDS: [LX: the Q8_0 activation as the lanes read it, [NQP][4 k-groups][4 blocks][8 B: e0..e3 | e4..e7]] [d [4 NQP]] [s [4 NQP]]
+    unsigned char *lx = gsm;
+    float *ld_ = reinterpret_cast<float *>(gsm + (size_t)NQP * 128);
+    float *ls_ = ld_ + 4 * NQP;
+
+    ST_DECL;
+    ST_STAMP(0);
+    GP_DECL(PRO);
+    GemvPrologue<PRO, NT, true>::issue(pv, pw, psl, psb, xf, aux, KB, 0);
+
+    const int grp = min((int)blockIdx.x * 4 + wave, groups - 1);
+    const bool live = (int)blockIdx.x * 4 + wave < groups;                   // (a wave past the last row group redoes it and stores nothing)
+    const int r = lane >> 2, g = lane & 3;
+    // buffer loads: the wave-uniform part (row group, quad) in the scalar offset, one lane offset register per plane; bytes past a plane read as zero
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(qwd), 0, (int)((uint32_t)groups * (uint32_t)NQ * 1024u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dW), 0, (int)((uint32_t)groups * (uint32_t)KB * 64u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Q41 ? mW : dW), 0, (int)((uint32_t)groups * (uint32_t)KB * 64u), 0x00020000);
+    const int voff_w = lane * 16;
+    const int voff_d = (g * 16 + r) * 4;                                     // lane (row, g) fetches the scale of block 4q + g of its row
+    // (a partial last quad reads past the row's blocks: the next row group's first scales, or zeros behind the plane -- FINITE numbers that
+    //  meet d_x = 0 and zero quants: the block adds +0 to a chain that can never hold -0; the same holds for the padding quads of the last round)
+    sv4u w[U];
+    float dw[U], mw[U];
+    auto req_scale = [&](int i, int q) __attribute__((always_inline)) {
+        const int sd = (grp * KB + 4 * min(q, NQ - 1)) * 64;
+        dw[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, voff_d, sd, 2));
+        if (Q41) mw[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, voff_d, sd, 2));
+    };
+    auto req_nib = [&](int i, int q) __attribute__((always_inline)) {
+        w[i] = __builtin_bit_cast(sv4u, __builtin_amdgcn_raw_buffer_load_b128(rW, voff_w, (grp * NQ + min(q, NQ - 1)) * 1024, 2 /* nt: read once per token */));
+    };
+    // PRO = 0: the Q8_0 activation (QA1 in HBM) is requested before the weight stream (loads return in order)
+    constexpr int XIT = 4;
+    uint2 xa_[PRO == 0 ? XIT : 1];
+    float xd_[PRO == 0 ? 2 : 1], xs_[PRO == 0 ? 2 : 1];
+    if constexpr (PRO == 0) {
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int i = threadIdx.x + it * NT;
+            xa_[it] = reinterpret_cast<const uint2 *>(xq)[i < KB * 4 ? i : 0];
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = threadIdx.x + it * NT;
+            xd_[it] = xd[i < KB ? i : 0];
+            xs_[it] = Q41 ? xs[i < KB ? i : 0] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float rsd = 0.f;
+    if constexpr (EPI == 0) {
+        if (resid) rsd = resid[min(grp * 16 + r, M - 1)];                   // (wave-uniform condition, clamped address)
+    }
+    // the first U quads, each as (scale, nibbles) -- the order the loop re-requests them in, so that the compiler's count of the loads in flight
+    // (s_waitcnt vmcnt) is the same at the loop's entry and at its back edge: with all scales ahead of all nibbles it waited, every round, as if
+    // only half of them were outstanding (seen in the ISA).  The scheduling barriers keep the pairs in program order.
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        req_scale(i, i);
+        req_nib(i, i);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    ST_STAMP(1);
+    // blocks past K (the partial last quad, the padding quads): d_x = s_x = 0, zero quants (written before the prologue's closing barrier)
+    for (int i = KB * 4 + (int)threadIdx.x; i < NQP * 16; i += NT) {
+        const int b = i >> 2, gg = i & 3;
+        *reinterpret_cast<uint2 *>(lx + (((b >> 2) * 4 + gg) * 4 + (b & 3)) * 8) = make_uint2(0, 0);
+        if (gg == 0) { ld_[b] = 0.f; ls_[b] = 0.f; }
+    }
+    if constexpr (PRO != 0) {
+        GemvPrologue<PRO, NT, true>::finish(pv, pw, psl, psb, xf, aux, KB, 0, reinterpret_cast<int8_t *>(lx), ld_, ls_, sh, ynorm, blockIdx.x == 0);
+    } else {                                          // QA1 in HBM (k-group bytes e0,e2,e4,e6 | e1,e3,e5,e7): re-laid on the way
+        auto put = [&](int i, uint2 lh) __attribute__((always_inline)) {
+            const int b = i >> 2, gg = i & 3;
+            *reinterpret_cast<uint2 *>(lx + (((b >> 2) * 4 + gg) * 4 + (b & 3)) * 8) =
+                make_uint2(__builtin_amdgcn_perm(lh.y, lh.x, 0x05010400u), __builtin_amdgcn_perm(lh.y, lh.x, 0x07030602u));
+        };
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int i = threadIdx.x + it * NT;
+            if (i < KB * 4) put(i, xa_[it]);
+        }
+        for (int i = threadIdx.x + XIT * NT; i < KB * 4; i += NT) put(i, reinterpret_cast<const uint2 *>(xq)[i]);      // (rows beyond K = 8192: the rest)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = threadIdx.x + it * NT;
+            if (i < KB) { ld_[i] = xd_[it]; ls_[i] = xs_[it]; }
+        }
+        for (int i = threadIdx.x + 2 * NT; i < KB; i += NT) { ld_[i] = xd[i]; ls_[i] = Q41 ? xs[i] : 0.f; }
+        __syncthreads();
+    }
+
+    ST_STAMP(2);
+    // ---- the stream: quad after quad, the two chains of this lane in block order
+    const uint32_t m8 = 0xF0F0F0F0u;
+    float a0 = 0.f, a1 = 0.f, summs = 0.f;
+    auto consume = [&](int i, int q) __attribute__((always_inline)) {
+        const uint4 x01 = *reinterpret_cast<const uint4 *>(lx + ((size_t)q * 4 + g) * 32);
+        const uint4 x23 = *reinterpret_cast<const uint4 *>(lx + ((size_t)q * 4 + g) * 32 + 16);
+        const float4 dx4 = *reinterpret_cast<const float4 *>(ld_ + 4 * q);
+        const uint32_t wv[4] = {w[i].x, w[i].y, w[i].z, w[i].w};
+        const uint32_t xa[4] = {x01.x, x01.z, x23.x, x23.z}, xb[4] = {x01.y, x01.w, x23.y, x23.w};
+        const float dxv[4] = {dx4.x, dx4.y, dx4.z, dx4.w};
+        const float dwb[4] = {sq_bcast<0>(dw[i]), sq_bcast<1>(dw[i]), sq_bcast<2>(dw[i]), sq_bcast<3>(dw[i])};
+        float sxv[4] = {0.f, 0.f, 0.f, 0.f}, msb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (Q41) {
+            msb[0] = sq_bcast<0>(mw[i]); msb[1] = sq_bcast<1>(mw[i]); msb[2] = sq_bcast<2>(mw[i]); msb[3] = sq_bcast<3>(mw[i]);
+            const float4 sx4 = *reinterpret_cast<const float4 *>(ls_ + 4 * q);
+            sxv[0] = sx4.x; sxv[1] = sx4.y; sxv[2] = sx4.z; sxv[3] = sx4.w;
+        }
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            uint32_t wa, wb;
+            if (TYPE == FL_TYPE_Q4_0) { wa = (wv[blk] << 4) & m8; wb = wv[blk] & m8; }     // 16 (nib - 8): elements 0..3 | 4..7
+            else { wa = wv[blk] & 0x0F0F0F0Fu; wb = (wv[blk] >> 4) & 0x0F0F0F0Fu; }
+            const float dd = __fmul_rn(dwb[blk], dxv[blk]);                 // rn(d_w d_x); a block past K: d_x = 0
+#ifdef ST_PK
+            // the two lane sums as floats without a conversion: v_dot4 accumulates onto the BITS of 1.5 x 2^23, which as a float is 12582912 + sum
+            // (|sum| <= 4 x 240 x 127 < 2^22: exact), and one packed subtract takes the constant off both (exact: the results are the integers);
+            // the two chains advance in one packed fma -- IEEE fma per half, the same bits as two v_fma_f32
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            // (the three-operand form with the constant in an SGPR: the builtin compiles to v_dot4c, which accumulates in place and costs a v_mov of
+            //  the constant per dot)
+            v2f fm;
+            asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(fm.x) : "v"(wa), "v"(xa[blk]), "s"(0x4B400000));
+            asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(fm.y) : "v"(wb), "v"(xb[blk]), "s"(0x4B400000));
+            const v2f f = fm - (v2f){12582912.0f, 12582912.0f};
+            v2f acc = {a0, a1};
+            acc = __builtin_elementwise_fma((v2f){dd, dd}, f, acc);
+            a0 = acc.x; a1 = acc.y;
+#else
+            const float f0 = (float)__builtin_amdgcn_sdot4((int)wa, (int)xa[blk], 0, false);
+            const float f1 = (float)__builtin_amdgcn_sdot4((int)wb, (int)xb[blk], 0, false);
+            a0 = __fmaf_rn(dd, f0, a0);
+            a1 = __fmaf_rn(dd, f1, a1);
+#endif
+            if (Q41) summs = __fmaf_rn(msb[blk], sxv[blk], summs);          // (a block past K: s_x = 0, m_w finite)
+        }
+    };
+#pragma unroll 1
+    for (int rd = 0; rd < NR - 1; ++rd) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int q = rd * U + i;
+            consume(i, q);
+            req_scale(i, q + U);                                            // (the last round's padding quads: a cache-hot dummy, clamped; they meet d_x = 0)
+            req_nib(i, q + U);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < U; ++i) consume(i, (NR - 1) * U + i);
+
+#ifdef LLC_TIMING
+    asm volatile("" :: "v"(a0), "v"(a1));
+    if (lane == 0) tlw_[wave] = wall_clock64();
+#endif
+    // ---- the row: ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)) over the quad of lanes that holds it (lane g: accumulators 2g, 2g+1)
+    float e = a0, o = a1;
+    e = __fadd_rn(e, dpp_f32<DPP_XOR2>(e));      // a0+a4 | a2+a6
+    o = __fadd_rn(o, dpp_f32<DPP_XOR2>(o));      // a1+a5 | a3+a7
+    e = __fadd_rn(e, dpp_f32<DPP_XOR1>(e));      // (a0+a4)+(a2+a6)
+    o = __fadd_rn(o, dpp_f32<DPP_XOR1>(o));      // (a1+a5)+(a3+a7)
+    float v = __fadd_rn(e, o);
+    if (Q41) v = __fadd_rn(v, summs);
+    // (with a tail: written through to memory, and to every peer's region -- tp_put, tp_tail.h)
+    auto put_y = [&](float *p, float val) __attribute__((always_inline)) {
+        if constexpr (TAIL) tp_put(tt, p, val);
+        else *p = val;
+    };
+    if constexpr (EPI == 0) {
+        const int row = grp * 16 + r;
+        if (g == 0 && row < M && live) {
+            if (resid) v = __fadd_rn(v, rsd);
+            put_y(y + row, v);
+        }
+    } else {
+        if (g == 0) ex[wave][r] = v;
+        __syncthreads();
+        if (wave == 0) {                                                     // feature f of the block in lanes f and f + 32 (both halves compute, the lower stores)
+            const int f = lane & 31, p2 = (f >> 4) * 2;
+            const float h1 = ex[p2][f & 15], h3 = ex[p2 + 1][f & 15];
+            const uint16_t hx = __half_as_ushort(__float2half_rn(h1));                // GGML_FP32_TO_FP16
+            const float sl = __half2float(__ushort_as_half(silu_tab[hx]));           // table_silu_f16
+            const float h = __fmul_rn(sl, h3);                                        // ggml_mul(silu, tmp)
+            if constexpr (EPI == 1) {
+                if (lane < 32) put_y(y + (int)blockIdx.x * 32 + f, h);
+            } else {
+                // quantize_row_q8_0 of the block (lib/ggml.c:1299-1441, AVX2: amax, d = amax / 127, id = 127 / amax, round to nearest even)
+                const float amax = wave_max_f32(fabsf(h));
+                const float dq = __fdiv_rn(amax, 127.0f);
+                const float id = amax != 0.0f ? __fdiv_rn(127.0f, amax) : 0.0f;
+                const int qi = (int)rintf(__fmul_rn(h, id));
+                int isum = quad_sum_i32(qi);
+                isum += dpp_i32<DPP_HALF_MIRROR>(isum);
+                isum += dpp_i32<DPP_MIRROR>(isum);
+                isum += __shfl_xor(isum, 16);                                         // (32 features; the upper half of the wave holds the same 32)
+                if (lane < 32) {
+                    const int i8 = f & 7;                                             // QA1: k-group bytes e0,e2,e4,e6 | e1,e3,e5,e7 (q4_layout.h)
+                    oq[(size_t)blockIdx.x * 32 + (f & 24) + ((i8 & 1) * 4 + (i8 >> 1))] = (int8_t)qi;
+                    if (lane == 0) {
+                        od[blockIdx.x] = dq;
+                        os[blockIdx.x] = __fmul_rn(dq, (float)isum);
+                    }
+                }
+            }
+        }
+    }
+#ifdef LLC_TIMING
+    ST_STAMP(3);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned s_ = atomicAdd(&st_tl_cur, 1u);
+        if (s_ < ST_TL_CAP) {
+            long long *rec = st_tl + (size_t)s_ * ST_TL_W;
+            rec[0] = tl_[0]; rec[1] = tl_[1]; rec[2] = tl_[2];
+            for (int k_ = 0; k_ < 4; ++k_) rec[3 + k_] = tlw_[k_];
+            rec[7] = tl_[3]; rec[8] = wall_clock64();
+            rec[9] = ((long long)(PRO * 100 + EPI * 10 + (U == 16)) << 32) | blockIdx.x;
+        }
+    }
+#endif
+    if constexpr (TAIL) tp_tail<false, false, true>(tt);
+}
+#ifdef LLC_TIMING
+// reset != 0: empty the ring; else copy up to max_rec records of ST_TL_W x int64 and return how many there are
+extern "C" __attribute__((visibility("default"))) int fl_debug_stream_timeline(long long *out, int max_rec, int reset) {
+    unsigned n = 0;
+    if (reset) return (int)hipMemcpyToSymbol(HIP_SYMBOL(st_tl_cur), &n, sizeof n);
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(st_tl_cur), sizeof n) != hipSuccess) return -1;
+    if (n > ST_TL_CAP) n = ST_TL_CAP;
+    if ((int)n > max_rec) n = (unsigned)max_rec;
+    if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(st_tl), sizeof(long long) * ST_TL_W * (size_t)n) != hipSuccess) return -1;
+    return (int)n;
+}
+#endif
+
+// false: no QWD copy, or a shape outside this form's reach -> the caller takes the llc kernel
+template <int TYPE, int PRO, int EPI>
+static bool launch_stream(const fl_qtensor &W, const fl_qact *xq, float *y, hipStream_t st, const float *resid, const float *xf, const void *aux,
+                          float *ynorm, const uint16_t *silu_tab, const fl_qact *out, bool take_tail) {
+    if (!W.qwd) return false;
+    const int KB = W.KB, NQ = (KB + 3) / 4, groups = W.M16 / 16;
+    if (groups < 1 || KB < 1) return false;
+    if (EPI != 0 && (groups % 4 != 0 || W.M != W.M16)) return false;          // a workgroup = the w1 | w3 rows of 32 whole features
+    if (PRO == 1 && W.K > 8192) return false;                                 // (the rms_norm prologue keeps the row in registers: 256 threads x 32)
+    if (qwd_bytes(W) >= (1ull << 31) || (size_t)W.M16 * (size_t)KB * 4 >= (1ull << 31)) return false;      // 32-bit buffer offsets
+    // quads in flight per wave: 16 when that divides the row (K = 4096, 8192: 20 KB per wave), else 8
+    const bool u16 = NQ % 16 == 0 || NQ % 16 >= 13;
+    const int U = u16 ? 16 : 8, NQP = (NQ + U - 1) / U * U;
+    const size_t lds = (size_t)NQP * 160;
+    if (lds > 60 * 1024) return false;
+    const TpTail *tt = take_tail ? tp_take_tail() : nullptr;
+    const dim3 grid((groups + 3) / 4), block(256);
+#define FL_ST_GO(UU, TL)                                                                                                              \
+    hipLaunchKernelGGL((gemv1_q4_exact_stream_kernel<TYPE, PRO, EPI, UU, TL>), grid, block, lds, st, W.M, groups, KB, W.qwd, W.d, xf, \
+                       aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid, ynorm, silu_tab,          \
+                       out ? out->q : nullptr, out ? out->d : nullptr, out ? out->s : nullptr, tt)
+    if constexpr (EPI == 2) {                       // (no exchange of Q8_0 blocks: the fold path keeps the f32 features)
+        if (u16) FL_ST_GO(16, 0); else FL_ST_GO(8, 0);
+    } else {
+        if (tt) { if (u16) FL_ST_GO(16, 1); else FL_ST_GO(8, 1); }
+        else { if (u16) FL_ST_GO(16, 0); else FL_ST_GO(8, 0); }
+    }
+#undef FL_ST_GO
+    return true;
+}
+
+// Which matrices take this form: those whose row groups give every SIMD of the chip a wave or more (wq|wk|wv, w1|w3, the lm-head; everything
+// of LLaMA-65B); a matrix of one row group per CU (wo, w2 of 7B / 13B) keeps the K-sliced workgroups of the llc kernel -- one wave per CU would
+// run its whole row's arithmetic alone.  g_stream_min_groups (fl_debug_set(6, n), tests) overrides the bound.
+int g_stream_min_groups = -1;
+static int stream_min_groups() {
+    if (g_stream_min_groups >= 0) return g_stream_min_groups;
+    static const int v = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        return 2 * cus;
+    }();
+    return v;
+}
+static bool stream_wanted(const fl_qtensor &W) { return W.M16 / 16 >= stream_min_groups(); }
+
+#define FL_TYPED(CALL0, CALL1) (W.type == FL_TYPE_Q4_0 ? (CALL0) : (CALL1))
+bool gemv1_stream(const fl_qtensor &W, const fl_qact &xq, float *y, hipStream_t st, const float *resid) {
+    if (!stream_wanted(W)) return false;
+    return FL_TYPED((launch_stream<FL_TYPE_Q4_0, 0, 0>(W, &xq, y, st, resid, nullptr, nullptr, nullptr, nullptr, nullptr, true)),
+                    (launch_stream<FL_TYPE_Q4_1, 0, 0>(W, &xq, y, st, resid, nullptr, nullptr, nullptr, nullptr, nullptr, true)));
+}
+bool gemv1_stream_norm(const fl_qtensor &W, const float *x, const float *norm_w, float *ynorm, float *y, hipStream_t st) {
+    if (!stream_wanted(W)) return false;
+    return FL_TYPED((launch_stream<FL_TYPE_Q4_0, 1, 0>(W, nullptr, y, st, nullptr, x, norm_w, ynorm, nullptr, nullptr, true)),
+                    (launch_stream<FL_TYPE_Q4_1, 1, 0>(W, nullptr, y, st, nullptr, x, norm_w, ynorm, nullptr, nullptr, true)));
+}
+bool gemv1_stream_quant(const fl_qtensor &W, const float *x, float *y, const float *resid, hipStream_t st) {
+    if (!stream_wanted(W)) return false;
+    return FL_TYPED((launch_stream<FL_TYPE_Q4_0, 3, 0>(W, nullptr, y, st, resid, x, nullptr, nullptr, nullptr, nullptr, true)),
+                    (launch_stream<FL_TYPE_Q4_1, 3, 0>(W, nullptr, y, st, resid, x, nullptr, nullptr, nullptr, nullptr, true)));
+}
+bool gemv1_stream_norm_silu(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act, hipStream_t st) {
+    if (!stream_wanted(W)) return false;
+    return FL_TYPED((launch_stream<FL_TYPE_Q4_0, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, silu_tab, nullptr, true)),
+                    (launch_stream<FL_TYPE_Q4_1, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, silu_tab, nullptr, true)));
+}
+bool gemv1_stream_norm_silu_q8(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, const fl_qact &out, hipStream_t st) {
+    if (!stream_wanted(W)) return false;
+    return FL_TYPED((launch_stream<FL_TYPE_Q4_0, 1, 2>(W, nullptr, nullptr, st, nullptr, x, norm_w, nullptr, silu_tab, &out, false)),
+                    (launch_stream<FL_TYPE_Q4_1, 1, 2>(W, nullptr, nullptr, st, nullptr, x, norm_w, nullptr, silu_tab, &out, false)));
+}
+#undef FL_TYPED
+
+}  // namespace fl

@@ -837,7 +837,20 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
         const bool silu_in_gemm = N >= 9 && m->w13_il && (!exact || xh);   // silu * mul -> Q8_0 is the epilogue of the w1|w3 matmul
         static const bool nopair = getenv("FL_EXACT_NOPAIR") != nullptr;   // A/B: profiles/r04_decode_exact.md
         const bool silu_in_gemv = fused && m->w13_il && !(exact && nopair && !tp);   // decode: silu * mul is the epilogue of the w1|w3 GEMV
-        if (silu_in_gemv) {
+        // reference-order decode, unsharded: the w1|w3 workgroups own whole 32-feature blocks and write the Q8_0 operand of w2 themselves
+        // (gemv1_q4_exact_stream.hip) -- w2 then is the plain N = 1 matmul on m->qF, its prologue a copy
+        bool q8_from_w13 = false;
+        if (silu_in_gemv && exact && !tp) {
+            hipEvent_t e1;
+            M_HIP(prof_begin(m, &e1));
+            const hipError_t e = gemv_q4_norm_silu_q8_exact(*ly.w13, mid, ly.ffn_norm, m->silu_tab, m->qF, st);
+            prof_end(m, e1);
+            if (e == hipSuccess) q8_from_w13 = true;
+            else if (e != hipErrorInvalidValue) M_HIP(e);
+            else (void)hipGetLastError();
+        }
+        if (q8_from_w13) {
+        } else if (silu_in_gemv) {
             M_HIP(mm_norm_silu(m, ly.w13, mid, ly.ffn_norm, m->h13));
         } else if (fused) {
             M_HIP(mm_norm(m, ly.w13, mid, ly.ffn_norm, nullptr, m->h13));
@@ -850,7 +863,8 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
             M_HIP(silu_mul_quant(m->h13, 2 * Fl, N, Fl, m->silu_tab, &m->qF, layout, st, m->w13_il, xh && !m->tp_rows));
         }
         if (!tp) {
-            if (silu_in_gemv) M_HIP(mm_quant(m, ly.w2, m->h13, inp, mid));
+            if (q8_from_w13) M_HIP(mm(m, ly.w2, m->qF, 1, inp, E, mid, E));
+            else if (silu_in_gemv) M_HIP(mm_quant(m, ly.w2, m->h13, inp, mid));
             else if (fused) M_HIP(mm_silu(m, ly.w2, m->h13, inp, mid));
             else M_HIP(mm(m, ly.w2, m->qF, N, inp, E, mid, E));                                   // + inpFF :441
         } else if (m->tp_rows) {

@@ -86,6 +86,16 @@ bool gemv1_llc_silu(const fl_qtensor &W, const float *h13, const uint16_t *silu_
 bool gemv1_llc_norm_silu(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act, hipStream_t st,
                          float *pair_ws, int form);
 bool gemv1_llc_quant(const fl_qtensor &W, const float *x, float *y, const float *resid, hipStream_t st);
+// round 6 form for matrices of many row groups: one wave per row group streaming the whole of K, four row groups per workgroup sharing one
+// activation prologue (gemv1_q4_exact_stream.hip); false: no QWD copy / too few row groups / shape outside its reach (-> the llc kernel).
+// gemv1_stream_norm_silu_q8: the woven w1|w3 matmul whose workgroups write the Q8_0 operand of the w2 matmul themselves (out: QA1 planes)
+bool gemv1_stream(const fl_qtensor &W, const fl_qact &xq, float *y, hipStream_t st, const float *resid);
+bool gemv1_stream_norm(const fl_qtensor &W, const float *x, const float *norm_w, float *ynorm, float *y, hipStream_t st);
+bool gemv1_stream_quant(const fl_qtensor &W, const float *x, float *y, const float *resid, hipStream_t st);
+bool gemv1_stream_norm_silu(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act, hipStream_t st);
+bool gemv1_stream_norm_silu_q8(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, const fl_qact &out, hipStream_t st);
+hipError_t gemv_q4_norm_silu_q8_exact(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, const fl_qact &out,
+                                      hipStream_t st);   // hipErrorInvalidValue: shape outside the form's reach (-> f32 features + gemv_q4_quant_exact)
 hipError_t gemm_q4_exact_valu(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st,
                               const float *resid = nullptr, int ldr = 0);   // v_dot4 form (exact_kernels.hip), cross-check
 hipError_t gemm_q4_naive(const fl_qtensor &W, const fl_qact &xq, int N, float *y, int ldy, hipStream_t st);

@@ -34,6 +34,9 @@ static const fl::InternalTable *const IT = fl_internal_table();
 #define gemv_q4_norm_exact (IT->gemv_q4_norm_exact)
 #define gemv_q4_norm_silu (IT->gemv_q4_norm_silu)
 #define gemv_q4_norm_silu_exact (IT->gemv_q4_norm_silu_exact)
+#define gemv_q4 (IT->gemv_q4)
+#define gemv_q4_exact (IT->gemv_q4_exact)
+#define gemv_q4_norm_silu_q8_exact (IT->gemv_q4_norm_silu_q8_exact)
 #define gemv_q4_quant (IT->gemv_q4_quant)
 #define gemv_q4_quant_exact (IT->gemv_q4_quant_exact)
 #define gemv_q4_silu (IT->gemv_q4_silu)
@@ -49,6 +52,7 @@ static const fl::InternalTable *const IT = fl_internal_table();
 #define softmax_rows (IT->softmax_rows)
 #define g_gemm_force_cfg (*IT->g_gemm_force_cfg)
 #define g_gemv_force_waves (*IT->g_gemv_force_waves)
+#define g_stream_min_groups (*IT->g_stream_min_groups)
 #define g_op_mode (*IT->g_op_mode)
 
 #define FL_HIP(call)                                   \
@@ -79,6 +83,7 @@ int fl_debug_set(int what, int value) {
     if (what == 0) g_gemm_force_cfg = value;
     if (what == 1) g_gemv_force_waves = value;   // 0 = automatic, else 4 / 8 / 16 waves per 16-row group
     if (what == 2) g_debug_exact = value;            // the single-token test hooks (fl_debug_gemv_*, fl_debug_decode_attention*) in exact mode
+    if (what == 6) g_stream_min_groups = value;      // reference-order N = 1 matmuls: row groups from which the one-wave-per-row-group form runs (-1 automatic, 1 always, 1 << 30 never)
     if (what == 5) g_debug_pair1 = value;            // fl_debug_gemv_norm_silu in exact mode: 1 / 2 pins a form of the w1|w3 kernel, 0 automatic
     if (what == 4) g_op_mode = value;            // (= fl_set_op_mode: kept for the sweep scripts)
     return FL_OK;
@@ -221,6 +226,27 @@ int fl_debug_gemv_norm_silu(const fl_qtensor *W, const float *x, const float *no
         ws_bytes = need;
     }
     M_HIP(gemv_q4_norm_silu_exact(*W, x, norm_w, silu_tab, act, (hipStream_t)stream, ws, g_debug_pair1));      // (fl_debug_set(5, form): 0 automatic)
+    return FL_OK;
+}
+/* the woven w1|w3 matmul of the reference-order decode whose workgroups write the Q8_0 operand of w2 themselves (gemv1_q4_exact_stream.hip):
+ * out = Q8_0(silu(w1 . q) * (w3 . q)) as one QA1 vector of K = M / 2 */
+int fl_debug_gemv_norm_silu_q8(const fl_qtensor *W, const float *x, const float *norm_w, const uint16_t *silu_tab, fl_qact *out_, void *stream) {
+    fl_qact_impl *out = static_cast<fl_qact_impl *>(out_);
+    if (!W || !x || !norm_w || !silu_tab || !out) return set_error(FL_EINVAL, "null argument");
+    if ((size_t)(W->M / 2) > out->q_bytes) return set_error(FL_EINVAL, "gemv_norm_silu_q8: output workspace too small");
+    if (!W->qwd) { if (int rc = fl_qtensor_build_qwd(const_cast<fl_qtensor *>(W), stream)) return rc; }      // (this form reads the QWD copy)
+    out->N = 1; out->N16 = 16; out->KB = W->M / 64; out->layout = 1;
+    out->h16_valid = 0;
+    M_HIP(gemv_q4_norm_silu_q8_exact(*W, x, norm_w, silu_tab, *out, (hipStream_t)stream));
+    return FL_OK;
+}
+/* y = W . a (+ resid) for ONE ready-made Q8_0 vector (QA1): the wo / w2 matmul of a decode token */
+int fl_debug_gemv_q8(const fl_qtensor *W, const fl_qact *a_, float *y, const float *resid, void *stream) {
+    const fl_qact_impl *a = static_cast<const fl_qact_impl *>(a_);
+    if (!W || !a || !y) return set_error(FL_EINVAL, "null argument");
+    if (a->layout != 1 || a->KB != W->KB) return set_error(FL_EINVAL, "gemv_q8: needs one QA1 vector of the tensor's K");
+    if (int rc = dbg_qwd(W, stream)) return rc;
+    M_HIP((g_debug_exact ? gemv_q4_exact : gemv_q4)(*W, *a, 1, y, W->M, (hipStream_t)stream, resid, 0));
     return FL_OK;
 }
 int fl_debug_gemv_quant(const fl_qtensor *W, const float *x, float *y, const float *resid, void *stream) {

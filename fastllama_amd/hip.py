@@ -133,7 +133,9 @@ _PROTOS = {
     "fl_debug_gemv_norm": (C.c_int, [C.c_void_p] * 6),
     "fl_debug_gemv_silu": (C.c_int, [C.c_void_p] * 6),
     "fl_debug_gemv_norm_silu": (C.c_int, [C.c_void_p] * 6),
+    "fl_debug_gemv_norm_silu_q8": (C.c_int, [C.c_void_p] * 6),
     "fl_debug_gemv_quant": (C.c_int, [C.c_void_p] * 5),
+    "fl_debug_gemv_q8": (C.c_int, [C.c_void_p] * 5),
     "fl_debug_prefill_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "fl_debug_prefill_attention_scratch": (C.c_int, [C.c_void_p, C.c_int, C.c_long]),

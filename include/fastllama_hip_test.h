@@ -22,6 +22,9 @@ int fl_debug_gemv_silu(const fl_qtensor *W, const float *h13_dev, const uint16_t
                        const float *resid_dev, void *stream); /* y = W . Q8_0(silu(h13[:K]) * h13[K:]) + resid, one launch */
 int fl_debug_gemv_norm_silu(const fl_qtensor *W_woven, const float *x_dev, const float *norm_w_dev, const uint16_t *silu_tab_dev,
                             float *act_dev, void *stream);  /* act = silu(w1.q) * (w3.q), q = Q8_0(norm_w * rms_norm(x)) */
+int fl_debug_gemv_norm_silu_q8(const fl_qtensor *W_woven, const float *x_dev, const float *norm_w_dev, const uint16_t *silu_tab_dev,
+                               fl_qact *out, void *stream);  /* reference order only: out = Q8_0(act) as one QA1 vector, written by the matmul's workgroups */
+int fl_debug_gemv_q8(const fl_qtensor *W, const fl_qact *a /* one QA1 vector */, float *y_dev, const float *resid_dev, void *stream);  /* y = W . a (+ resid): the wo / w2 matmul of a decode token */
 int fl_debug_gemv_quant(const fl_qtensor *W, const float *x_dev, float *y_dev, const float *resid_dev, void *stream);
 int fl_debug_prefill_attention(const float *qkv_dev, int ldq, int D, int H, int N, int n_past, int n_ctx, int E,
                                const float *kc, const float *vc, const uint16_t *exp_tab_dev, float scale, float *ao_dev,
@@ -66,7 +69,7 @@ int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a, float *y_dev, int 
                        void *stream);
 int fl_debug_qact_layout(const fl_qact *a); /* 16 = QA16, 1 = QA1 */
 int fl_debug_gemm_mixed_split(int row_groups, int col_groups, int *n_a, int *mg_split, int *n_b);  /* host logic of the two-tile-shape launch */
-int fl_debug_set(int what, int value);      /* what 0: force GEMM tile configuration id (-1 = automatic); 1: GEMV waves per row group (0 = automatic); 2: the single-token hooks run the reference-order kernels; 4: = fl_set_op_mode; 5: the form of the reference-order w1|w3 kernel fl_debug_gemv_norm_silu runs (1 / 2, 0 automatic) */
+int fl_debug_set(int what, int value);      /* what 0: force GEMM tile configuration id (-1 = automatic); 1: GEMV waves per row group (0 = automatic); 2: the single-token hooks run the reference-order kernels; 4: = fl_set_op_mode; 5: the form of the reference-order w1|w3 kernel fl_debug_gemv_norm_silu runs (1 / 2, 0 automatic); 6: row groups from which a reference-order N = 1 matmul takes the one-wave-per-row-group form (-1 automatic, 1 always, 1 << 30 never) */
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -445,6 +445,91 @@ def test_exact_feed_forward_pair_and_quant_prologue(torch, ops, port, exact_hook
     assert np.array_equal(bits(y.cpu().numpy()), bits(port.mul_mat_q(qt, w2, want_act, strict=False)[0]))
 
 
+@pytest.fixture()
+def stream_form(exact_hooks):
+    """fl_debug_set(6, 1): every reference-order N = 1 matmul takes the one-wave-per-row-group form (gemv1_q4_exact_stream.hip),
+    whatever its row count (automatic: from two row groups per CU on)"""
+    exact_hooks.fl_debug_set(6, 1)
+    yield exact_hooks
+    exact_hooks.fl_debug_set(6, -1)
+
+
+@pytest.mark.parametrize("nm,qt", Q4)
+@pytest.mark.parametrize("M,K", [(48, 64), (300, 256), (130, 2560), (12288, 4096), (1024, 8192), (2000, 5120), (72, 6656), (100, 416)])
+def test_stream_form_with_every_prologue(torch, ops, port, stream_form, nm, qt, M, K):
+    """One wave per row group over the whole of K, four row groups sharing a prologue: rms_norm prologue (+ the normalised vector), plain Q8_0
+    prologue + residual, ready-made Q8_0 operand + residual -- the oracle's bits at ragged row counts, partial quads and padded rounds."""
+    from fastllama_amd import hip
+    L = stream_form
+    rng = np.random.default_rng(M * 7 + K + qt)
+    wq = port.quantize_q4(qt, (rng.standard_normal((M, K)) * 0.05).astype(np.float32))
+    W = ops.QTensor(qt, wq, M, K)
+    x = (rng.standard_normal((1, K)) * 1.7).astype(np.float32)
+    res = rng.standard_normal(M).astype(np.float32)
+    xd, rd = dev(torch, x), dev(torch, res)
+    if K <= 8192:
+        nw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+        y = torch.full((M,), 3.0, device="cuda")
+        yn = torch.zeros((1, K), device="cuda")
+        hip.check(L.fl_debug_gemv_norm(W.handle, xd.data_ptr(), dev(torch, nw).data_ptr(), yn.data_ptr(), y.data_ptr(), None))
+        cur = le.rms_norm_mul(x, nw)
+        assert np.array_equal(bits(yn.cpu().numpy()), bits(cur))
+        assert np.array_equal(bits(y.cpu().numpy()), bits(port.mul_mat_q(qt, wq, cur, strict=False)[0]))
+    want = (port.mul_mat_q(qt, wq, x, strict=False)[0] + res).astype(np.float32)
+    y = torch.full((M,), 3.0, device="cuda")
+    hip.check(L.fl_debug_gemv_quant(W.handle, xd.data_ptr(), y.data_ptr(), rd.data_ptr(), None))
+    assert np.array_equal(bits(y.cpu().numpy()), bits(want))
+    a = ops.QAct(1, K).quantize(xd, layout=1)
+    y = torch.full((M,), 3.0, device="cuda")
+    hip.check(L.fl_debug_gemv_q8(W.handle, a.handle, y.data_ptr(), rd.data_ptr(), None))
+    assert np.array_equal(bits(y.cpu().numpy()), bits(want))
+
+
+@pytest.mark.parametrize("nm,qt", Q4)
+@pytest.mark.parametrize("F,K,E", [(64, 64, 48), (704, 256, 256), (11008, 4096, 4096), (13824, 5120, 512), (4608, 8192, 2048), (96, 416, 32)])
+def test_stream_form_writes_the_q8_operand_of_w2(torch, ops, port, stream_form, nm, qt, F, K, E):
+    """Woven w1|w3 as workgroups of 32 whole features: (a) the f32 features silu(w1 x) * (w3 x); (b) their Q8_0 blocks written by the
+    matmul's workgroups -- the reference's quantize_row_q8_0 of the f32 features, byte for byte -- and w2 on that operand (+ residual)."""
+    from fastllama_amd import hip
+    L = stream_form
+    rng = np.random.default_rng(F + K + qt + 5)
+    w1 = port.quantize_q4(qt, (rng.standard_normal((F, K)) * 0.05).astype(np.float32))
+    w3 = port.quantize_q4(qt, (rng.standard_normal((F, K)) * 0.05).astype(np.float32))
+    rb = w1.shape[1]
+    woven = np.empty((2 * F, rb), np.uint8)
+    wv = woven.reshape(F // 16, 2, 16, rb)
+    wv[:, 0] = w1.reshape(F // 16, 16, rb)
+    wv[:, 1] = w3.reshape(F // 16, 16, rb)
+    W = ops.QTensor(qt, woven, 2 * F, K)
+    x = (rng.standard_normal((1, K)) * 1.3).astype(np.float32)
+    nw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    s = np.empty(1 << 16, np.uint16)
+    L.fl_debug_tables(None, s.ctypes.data_as(C.c_void_p))
+    xd, nd, sd = dev(torch, x), dev(torch, nw), dev(torch, s.view(np.int16))
+    cur = le.rms_norm_mul(x, nw)
+    h1, h3 = port.mul_mat_q(qt, w1, cur, strict=False), port.mul_mat_q(qt, w3, cur, strict=False)
+    want_act = (le.silu(h1) * h3).astype(np.float32)
+    act = torch.full((F,), 9.0, device="cuda")
+    L.fl_debug_set(5, 0)
+    hip.check(L.fl_debug_gemv_norm_silu(W.handle, xd.data_ptr(), nd.data_ptr(), sd.data_ptr(), act.data_ptr(), None))
+    assert np.array_equal(bits(act.cpu().numpy()), bits(want_act[0]))
+    a = ops.QAct(1, F)
+    for _ in range(2):
+        hip.check(L.fl_debug_gemv_norm_silu_q8(W.handle, xd.data_ptr(), nd.data_ptr(), sd.data_ptr(), a.handle, None))
+        a.N, a.K = 1, F
+        got = a.export().cpu().numpy()
+        assert np.array_equal(got[0], port.quantize_row_q8_0(want_act[0]).reshape(-1))
+    w2 = port.quantize_q4(qt, (rng.standard_normal((E, F)) * 0.05).astype(np.float32))
+    W2 = ops.QTensor(qt, w2, E, F)
+    res = rng.standard_normal(E).astype(np.float32)
+    y = torch.empty(E, device="cuda")
+    for form in (1 << 30, 1):                                   # w2 in the K-sliced form and in the one-wave-per-row-group form
+        L.fl_debug_set(6, form)
+        hip.check(L.fl_debug_gemv_q8(W2.handle, a.handle, y.data_ptr(), dev(torch, res).data_ptr(), None))
+        want = (port.mul_mat_q(qt, w2, want_act, strict=False)[0] + res).astype(np.float32)
+        assert np.array_equal(bits(y.cpu().numpy()), bits(want)), form
+
+
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("D,H,n_past", [(32, 4, 0), (32, 4, 9), (128, 32, 0), (128, 32, 1), (128, 32, 31), (128, 8, 130), (128, 4, 511),
                                         (64, 5, 37), (128, 3, 290), (96, 2, 515), (128, 4, 62), (128, 4, 60), (128, 4, 35), (128, 4, 38), (128, 3, 283),
