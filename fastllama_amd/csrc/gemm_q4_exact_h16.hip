@@ -52,10 +52,6 @@ struct XH {
 };
 
 enum { EPI_PLAIN = 0, EPI_ROPE = 1, EPI_SILU = 2 };
-#ifndef XH_PIPE
-#define XH_PIPE 0
-#endif
-
 #ifdef XH_TIMING   // development build only: per-workgroup clocks of the launch phases (scripts/dev/xh_timeline.py)
 __device__ long long xh_dbg[8192 * 8];
 #define XH_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) xh_dbg[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
@@ -188,9 +184,7 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
 #pragma unroll 1
     for (int t = 0; t < nsteps; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's pieces of K-step t have landed
-#ifndef XH_NOBAR
         __builtin_amdgcn_s_barrier();                                          // ... everyone's have, and everyone is done with step t - 1
-#endif
         if (t == 0) XH_STAMP(1);
         if (t == 1) XH_STAMP(2);
         if (t == 2) XH_STAMP(3);
@@ -214,7 +208,7 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
         };
         // B128 (Q4_0): a lane's two MFMA steps of a 16-byte slot in ONE ds_read_b128 (two ds_read_b64 put lanes l and l + 8 on the same
         // banks: half of the kernel's LDS cycles were conflicts), one slot ahead; Q4_1 has no registers left for it
-        constexpr bool B128 = !Q41 && !XH_PIPE;
+        constexpr bool B128 = !Q41;
         typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
         auto slot_a = [&](auto P) XH_ATTR __attribute__((always_inline)) -> v4u32 {
             constexpr int p = decltype(P)::value;
@@ -230,31 +224,14 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
         else { fa = frag_a(XIC(0)); fb = frag_b(XIC(0)); fan = frag_a(XIC(1)); fbn = frag_b(XIC(1)); }
         float dw = *reinterpret_cast<const float *>(base + sw_off), dx = *reinterpret_cast<const float *>(base + sx_off);
         v32f P = __builtin_amdgcn_mfma_f32_32x32x1f32(dw, dx, zero32, 0, 0, 0);             // rn(d_w d_x) of blocks 0 (regs 0..15), 1
-        v32f D0, D1;
-        if (XH_PIPE) D0 = __builtin_amdgcn_mfma_f32_32x32x4f16(__builtin_bit_cast(v4h, fa), __builtin_bit_cast(v4h, fb), zero32, 0, 0, 0);
+        v32f D0;       // (ONE lane-sum tile alive: issuing the next MFMA ahead of the fma of the current one -- two tiles -- buys nothing at two waves per SIMD
+                       //  and does not fit the register file; the setprio / no-LDS / no-DMA / no-barrier ablations: profiles/r05_gemm_exact.md)
         auto group = [&](auto G) XH_ATTR __attribute__((always_inline)) {
             constexpr int g = decltype(G)::value, u = g >> 2, s = g & 3;
-            v32f &Dg = (XH_PIPE && (g & 1)) ? D1 : D0;
-            v32f &Dn = (g & 1) ? D0 : D1;
-            if (XH_PIPE) {
-                if (g + 1 < 4 * KS) {
-                    Dn = __builtin_amdgcn_mfma_f32_32x32x4f16(__builtin_bit_cast(v4h, fan), __builtin_bit_cast(v4h, fbn), zero32, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (g + 2 < 4 * KS) {            // operands of the group after next, in the shadow of that MFMA
-                        fan = frag_a(XIC(g + 2 < 4 * KS ? g + 2 : 0));
-                        fbn = frag_b(XIC(g + 2 < 4 * KS ? g + 2 : 0));
-                    }
-                }
-            } else if (B128) {
+            v32f &Dg = D0;
+            if (B128) {
                 const v2u32 ga = (g & 1) ? v2u32{sa.z, sa.w} : v2u32{sa.x, sa.y}, gb = (g & 1) ? v2u32{sb.z, sb.w} : v2u32{sb.x, sb.y};
-#ifdef XH_SETPRIO   // experiment: coexec6 gives 229 -> 223 ns per tile and block at two waves per SIMD with the MFMA issued at raised priority; in the
-                    // kernel it is a loss (33.15 / 33.16 -> 33.41 / 33.28 ms per eval, one gpurun call, profiles/r05_gemm_exact.md)
-                __builtin_amdgcn_s_setprio(1);
-#endif
                 D0 = __builtin_amdgcn_mfma_f32_32x32x4f16(__builtin_bit_cast(v4h, ga), __builtin_bit_cast(v4h, gb), zero32, 0, 0, 0);
-#ifdef XH_SETPRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (g & 1) {                         // the slot is used up: the next one moves in, the one after it is requested
                     sa = san; sb = sbn;
@@ -267,12 +244,7 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
                 D0 = __builtin_amdgcn_mfma_f32_32x32x4f16(__builtin_bit_cast(v4h, fa), __builtin_bit_cast(v4h, fb), zero32, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 fa = fan; fb = fbn;
-#ifdef XH_NOLDS
-                asm volatile("" : "+v"(fan), "+v"(fbn));
-                if (false) {
-#else
                 if (g + 2 < 4 * KS) {
-#endif
                     fan = frag_a(XIC(g + 2 < 4 * KS ? g + 2 : 0));
                     fbn = frag_b(XIC(g + 2 < 4 * KS ? g + 2 : 0));
                 }
@@ -281,10 +253,8 @@ __global__ __launch_bounds__(256, 2) XH_ATTR void gemm_q4_exact_h16_kernel(
                 dw = *reinterpret_cast<const float *>(base + sw_off + 128);
                 dx = *reinterpret_cast<const float *>(base + sx_off + 128);
             }
-#ifndef XH_NODMA
             if (g < 8) fill_frag(XIC(g < 8 ? g : 0), nst, nkb, ftb);     // ... and the DMA of K-step t + 1
             if (g == 8) fill_scale(nst, nkb, fsc_voff);
-#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -574,7 +544,6 @@ static hipError_t launch_xh(const fl_qtensor &W, const fl_qact &xq, int N, float
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
             cus = 256;
         slots = 2 * cus / 8 * 8;                                               // (a multiple of the 8 XCDs: a workgroup's tiles stay on its XCD)
-        if (getenv("FL_XH_NOPERSIST")) slots = 1 << 30;                        // A/B: one workgroup per tile, as before
     }
     const int grid = tiles < slots ? tiles : slots;
     hipLaunchKernelGGL((gemm_q4_exact_h16_kernel<TYPE, EPI>), dim3(grid), dim3(256), C::LDS_BYTES, st, W.h16, W.d, W.m, xq.h16, xq.d, xq.s, N,

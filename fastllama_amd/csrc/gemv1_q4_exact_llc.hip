@@ -118,15 +118,11 @@ __device__ unsigned llc_tl_cur;
 // the w3 group of the same 16 features (one after the other: three workgroups per CU cover each other's round trips).  QPW: most quads a wave can hold (its lane sums stay in registers until its turn in the chain).
 // PERSIST = 1: the row-group loop (a launch with fewer workgroups than row groups).  Its own instantiation: the loop costs ~45 registers
 // (200: two workgroups per CU instead of three), which a launch whose row groups all fit on the chip at once need not pay.
-// TEAMS > 1 (round 5): one workgroup = TEAMS row groups side by side (TEAMS x NK waves, e.g. 3 x 4 = the 12 waves a CU holds at 136 registers) that
-// SHARE the prologue: the activation is read, normalised and quantized once per CU instead of once per row group -- a launch's lane sums wait for
-// the prologue, not for their bytes (profiles/r05_decode_timeline.md), and three workgroups per CU ran three of them at once behind each other's
-// weight requests.  Same arithmetic per row group; the chain hand-offs of the teams share the workgroup's barriers.
-template <int TYPE, int NK, int PRO, int PAIR, int QPW, int PERSIST, int TEAMS = 1, int TAIL = 0>
-#ifndef LLC_PS_OCC
-#define LLC_PS_OCC 1
-#endif
-__global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : (PERSIST && QPW <= 8 && NK == 4) ? LLC_PS_OCC : 1) void gemv1_q4_exact_llc_kernel(
+// (Round 5 also built workgroups of several row groups sharing one prologue -- "teams": 551 against 594 tok/s, twelve waves behind one barrier stretch
+//  the chain phase -- and persistent workgroups for K <= 4096 -- 581 against 593: both removed in round 6, profiles/r05_decode_exact.md has the numbers.
+//  Matrices of many row groups now take gemv1_q4_exact_stream.hip, whose four row groups per workgroup share a prologue without sharing a barrier.)
+template <int TYPE, int NK, int PRO, int PAIR, int QPW, int PERSIST, int TAIL = 0>
+__global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1) void gemv1_q4_exact_llc_kernel(
     int M, int units, int KB, int woven,
     const uint32_t *__restrict__ qwd, const float *__restrict__ dW, const float *__restrict__ xf, const void *__restrict__ aux,
     const float *__restrict__ mW, const int8_t *__restrict__ xq, const float *__restrict__ xd, const float *__restrict__ xs,
@@ -135,18 +131,13 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
     const TpTail *__restrict__ tt /* tensor parallel: the exchange of this launch's rows as its tail (tp_tail.h); NULL: none */,
     int npass /* PERSIST: K passes of NK x QPW quads per row group (rows longer than one pass holds in registers); else 1 */) {
     constexpr bool Q41 = TYPE == FL_TYPE_Q4_1;
-    static_assert(TEAMS == 1 || (PERSIST == 0 && PAIR != 1), "teams: one row group per team");
-    constexpr int G2 = PAIR == 1 ? 2 : 1, NT = 64 * NK * TEAMS;
+    constexpr int G2 = PAIR == 1 ? 2 : 1, NT = 64 * NK;
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     __shared__ double sh[4];
-    __shared__ float accs_[TEAMS][2][64][3];                                    // the chains' state between the K slices: a_2g, a_2g+1, summs
+    __shared__ float accs[2][64][3];                                            // the chains' state between the K slices: a_2g, a_2g+1, summs
                                                                                 // (two copies: consecutive row groups of a persistent workgroup alternate)
     const int lane = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // (the slice index in an SGPR: the `i < nq` tests below are scalar branches.  Teams: slice k of team t is wave t NK + (k - t) mod NK, so that
-    //  the waves working in one chain phase -- slice ph of every team -- sit on DIFFERENT SIMDs (wave w runs on SIMD w mod 4); with k = w mod NK they
-    //  shared one and the chain phase of three teams took three times as long, profiles/r05_decode_exact.md)
-    const int team = wave_ / NK, k = TEAMS == 1 ? wave_ % NK : (wave_ + team) % NK;
-    float (*accs)[64][3] = accs_[team];
+    const int k = wave_;                                                        // (the slice index in an SGPR: the `i < nq` tests below are scalar branches)
     const int NQ = (KB + 3) >> 2;
     // LDS: [LX: the Q8_0 activation as the lanes read it, [NQ][4 k-groups][4 blocks][8 B: e0..e3 | e4..e7]] [d [4 NQ]] [s [4 NQ]]
     // (round 5: the prologues write LX directly -- round 4 built the QA1 layout first and re-laid it in a second pass behind a barrier)
@@ -158,17 +149,14 @@ __global__ __launch_bounds__(64 * NK * TEAMS, (!PERSIST && QPW <= 8 && NK == 4) 
     LLC_STAMP(0);
     GP_DECL(PRO);
     GemvPrologue<PRO, NT, true>::issue(pv, pw, psl, psb, xf, aux, KB, woven);
-#ifdef LLC_LATE_WEIGHTS   // experiment (profiles/r05_decode_exact.md): the weight stream is requested only once the activation has arrived
-    if constexpr (PRO != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
 
     // ---- this wave's slice of the weight stream: every load goes out before anything waits (nontemporal: read once per token)
     // PERSIST = 1 (round 5, opt-in): a launch has at most one workgroup per residency slot; a workgroup takes the row groups blockIdx.x,
     // blockIdx.x + gridDim.x, ... -- the prologue (the activation's Q8_0 form in LDS) is paid once, and the next row group's weights are requested
     // behind this one's chains (do_group, below).  (LLaMA-7B's woven w1|w3 is 1376 row groups on 768 slots: as one workgroup per row group the second
     // round's workgroups are dispatched 7-10 us into the launch, each redoing the prologue: profiles/r05_decode_timeline.md -- and still the faster form.)
-    int unit = TEAMS == 1 ? (int)blockIdx.x : min((int)blockIdx.x * TEAMS + team, units - 1);
-    const bool live = TEAMS == 1 || (int)blockIdx.x * TEAMS + team < units;      // (a team past the last row group redoes it and stores nothing)
+    int unit = (int)blockIdx.x;
+    constexpr bool live = true;
     // MULTI-PASS rows (PERSIST instantiation, round 5): a row longer than NK x QPW quads is taken in npass passes of that many quads, pass after pass
     // through the same registers -- the chain state goes from the last wave of a pass to the first wave of the next through LDS, so the summation
     // order is the row's block order as ever, and a K = 8192 .. 22016 row group runs in the 4 x 8 form (three workgroups per CU) instead of
@@ -454,18 +442,15 @@ extern "C" __attribute__((visibility("default"))) int fl_debug_llc_timeline(long
 #endif
 
 // residency slots of a kernel instantiation on this device: workgroups per CU (occupancy query with the launch's dynamic LDS) x CUs, rounded
-// down to an even number (the two workgroups of a w1|w3 feature pair are neighbours)
-static int llc_slots(const void *fn, int threads, size_t lds, bool always = false) {
-    if (!always && !getenv("FL_LLC_PERSIST") && !getenv("FL_LLC_SLOTS")) return 1 << 30;
-    if (const char *e = getenv("FL_LLC_SLOTS")) return std::max(2, atoi(e) & ~1);      // tests: persistent workgroups on small matrices
+// down to an even number
+static int llc_slots(const void *fn, int threads, size_t lds) {
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
     return (per_cu * cus) & ~1;
 }
 
-// false: no QWD copy, or a shape outside the kernel's reach (rows too long for the slices' registers, activation beyond LDS)
-// -> the caller takes round 3's kernel
+// false: no QWD copy, or a shape outside the kernel's reach (activation beyond LDS) -> the caller takes round 3's kernel
 template <int TYPE, int PRO, int PAIR>
 static bool launch_llc(const fl_qtensor &W, const fl_qact *xq, float *y, hipStream_t st, const float *resid, const float *xf, const void *aux,
                        float *ynorm, int woven, const uint16_t *aux2, float *pair_ws = nullptr) {
@@ -473,92 +458,50 @@ static bool launch_llc(const fl_qtensor &W, const fl_qact *xq, float *y, hipStre
     constexpr int G2 = PAIR == 1 ? 2 : 1;
     const int KB = W.KB, NQ = (KB + 3) / 4, units = W.M16 / 16 / G2;
     const size_t lds = (size_t)NQ * 128 + (size_t)NQ * 32;                   // LX + d_x + s_x
-    // Multi-pass rows (round 5): rows longer than one pass of the 4 x 8 (Q4_1: 8 x 4) form holds -- K > 4096 -- in that form all the same, pass after pass
-    // (see the kernel); FL_LLC_MP=0: the 4 x 11 / 8 x 11 forms and round 3's kernel as before
-    static const int mp_on = getenv("FL_LLC_MP") ? atoi(getenv("FL_LLC_MP")) : 1;
-    // (where it pays: the shapes that used to fall to round 3's kernel -- LLaMA-65B decode 76.8 -> 91.6 tok/s, 13B 291.6 -> 309.9 (its w2); for LLaMA-7B's
-    //  w2 -- K = 11008 on 256 row groups -- the 8 x 11 form stays ahead, 587 against 556 tok/s, and K = 5120 in the 4 x 11 form, 292 against 282:
-    //  profiles/r05_decode_exact.md.  FL_LLC_MP=2 forces it for every K > 4096: tests)
-    const bool mp = mp_on && PAIR != 1 && NQ > 32 && (mp_on > 1 || NQ > 88 || (NQ > 44 && units > 256));
+    // Which form (profiles/r05_decode_exact.md): a wave keeps its whole K slice in registers -- 4 waves x 8 quads covers K <= 4096 with the fewest
+    // registers (three workgroups per CU), 4 x 11 K <= 5632, 8 x 11 K <= 11264 -- but an 8-wave workgroup at 186 registers is ONE per CU: good for a
+    // matrix of <= 256 row groups (LLaMA-7B's w2), bad for many groups of long rows.  Those, and rows beyond 11264 (13B / 65B w2), are MULTI-PASS rows:
+    // the row in npass equal parts of at most 4 x 6 quads (Q4_1: 8 x 4), pass after pass through the same registers (142-146 VGPRs, three workgroups
+    // per CU), one workgroup per residency slot walking the row groups.
+    const bool mp = PAIR != 1 && NQ > 32 && (NQ > 88 || (NQ > 44 && units > 256));
     if (lds > 60 * 1024 || units < 1 || (NQ > 88 && !mp)) return false;
     if (qwd_bytes(W) >= (1ull << 31) || (size_t)W.M16 * (size_t)KB * 4 >= (1ull << 31)) return false;      // 32-bit buffer offsets (no LLaMA tensor comes close)
-    // (waves along K, quads a wave holds): 4 x 8 covers K <= 4096 with the fewest registers (three waves per SIMD), 4 x 11 K <= 5632,
-    // 8 x 11 K <= 11264 -- but an 8-wave workgroup at 186 registers is ONE per CU: good for a matrix of <= 256 row groups (LLaMA-7B's w2:
-    // 12.5 us against round 3's 15.1), bad for many groups of long rows (65B width, K = 8192: 57 / 93 us against 35 / 63 for
-    // wq|wk|wv / w1|w3, scripts/dev/dec_ab.sh) -- those, and rows beyond 11264 (13B / 65B w2), stay on round 3's kernel
-    // (round 5 tried an 8 x 8 form for K <= 8192 compiled for <= 128 registers -- two workgroups per CU -- : 23-35 scratch spills, LLaMA-65B decode 58.8
-    //  against round 3's kernel's 78.6 tok/s in one gpurun call; removed)
     if (NQ > 44 && units > 256 && !mp) return false;
     const TpTail *tt = tp_take_tail();
-    // grid: one workgroup per row group.  FL_LLC_PERSIST=1 (opt-in): when the row groups do not all fit on the chip at once, the PERSIST
-    // instantiation with one workgroup per ITS residency slot (see the kernel) -- built, bit-identical, and measured 2 % SLOWER on LLaMA-7B's
-    // decode (564.8-567.8 against 577.5 tok/s in one gpurun call, profiles/r05_decode_exact.md): the loop costs 45 registers = two workgroups per CU
-    // instead of three, and a row group's bytes are requested one chain phase, not one row group, ahead.
-#define FL_LLC_GO(NK, QPW, PS, TM, GRID, NPASS)                                                                                                  \
+#define FL_LLC_GO(NK, QPW, PS, GRID, NPASS)                                                                                               \
     do {                                                                                                                                  \
         if (tt)                                                                                                                           \
-            hipLaunchKernelGGL((gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, PS, TM, 1>), dim3(GRID), dim3(64 * NK * TM), lds, st, W.M, units, KB, \
+            hipLaunchKernelGGL((gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, PS, 1>), dim3(GRID), dim3(64 * NK), lds, st, W.M, units, KB, \
                                woven, W.qwd, W.d, xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid, \
                                ynorm, aux2, pair_ws, tt, NPASS);                                                                          \
         else                                                                                                                              \
-            hipLaunchKernelGGL((gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, PS, TM, 0>), dim3(GRID), dim3(64 * NK * TM), lds, st, W.M, units, KB, \
+            hipLaunchKernelGGL((gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, PS, 0>), dim3(GRID), dim3(64 * NK), lds, st, W.M, units, KB, \
                                woven, W.qwd, W.d, xf, aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid, \
                                ynorm, aux2, pair_ws, tt, NPASS);                                                                          \
     } while (0)
-    // FL_LLC_TEAMS=1 (opt-in): three row groups per workgroup (TEAMS = 3, the 4 x 8 form: 12 waves = one CU's worth at 136 registers; Q4_1's 8 x 4 form: two)
-    // when a launch has more than two row groups per CU -- the prologue once per CU.  Built, bit-identical, and measured SLOWER: 551 against 594 tok/s
-    // (Q4_1 402 against 455), profiles/r05_decode_exact.md -- the prologue takes the same 4.6 us whether one or three run on a CU (it waits for the
-    // norm weights' and the activation's round trips, not for the VALU), and twelve waves behind one barrier stretch the chain phase from 0.8 to 2.4 us.
-    static const bool teams_on = getenv("FL_LLC_TEAMS") && atoi(getenv("FL_LLC_TEAMS")) != 0 || getenv("FL_LLC_TEAMS_MIN");
-    static const int teams_min = getenv("FL_LLC_TEAMS_MIN") ? atoi(getenv("FL_LLC_TEAMS_MIN")) : -1;      // tests: teams on small matrices
-    static const int n_cus = [] { int d = 0, c = 0; return (hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && c > 0) ? c : 256; }();
-#define FL_LLC(NK, QPW)                                                                                                                   \
-    do {                                                                                                                                  \
-        static int slots0 = 0, slots1 = 0;                                                                                                \
-        if (!slots0) {                                                                                                                    \
-            slots0 = llc_slots(reinterpret_cast<const void *>(&gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, 0>), 64 * NK, lds);    \
-            slots1 = llc_slots(reinterpret_cast<const void *>(&gemv1_q4_exact_llc_kernel<TYPE, NK, PRO, PAIR, QPW, 1>), 64 * NK, lds);    \
-        }                                                                                                                                 \
-        if constexpr (NK == 4 && QPW == 8 && PAIR != 1) {                                                                                 \
-            if (teams_on && units > (teams_min >= 0 ? teams_min : 2 * n_cus)) { FL_LLC_GO(NK, QPW, 0, 3, (units + 2) / 3, 1); break; }       \
-        }                                                                                                                                 \
-        if constexpr (NK == 8 && QPW == 4 && PAIR != 1) {      /* (Q4_1: 8 x 4 at <= 128 registers: two teams = 16 waves = one CU's worth) */ \
-            if (teams_on && units > (teams_min >= 0 ? teams_min : n_cus)) { FL_LLC_GO(NK, QPW, 0, 2, (units + 1) / 2, 1); break; }           \
-        }                                                                                                                                 \
-        if (PAIR == 1 || units <= slots0) FL_LLC_GO(NK, QPW, 0, 1, units, 1);                                                             \
-        else FL_LLC_GO(NK, QPW, 1, 1, (units < slots1 ? units : slots1), 1);                                                              \
-    } while (0)
     if constexpr (PAIR != 1) {
         if (mp) {
-            // passes of at most NK x QPW quads, balanced (the kernel splits NQ into npass equal parts).  Q4_0: 4 x 6 -- 24 quads per pass at 142-146
-            // registers, three workgroups per CU; 4 x 7 (162-168) also three, 4 x 8 needs 184 in the loop form = two.  LLaMA-65B decode 92.7 / 89.6 / 90.0
-            // tok/s, 13B 306.8 / 309.3 / 307.6 (one gpurun call; round 3's kernel: 76.8 / 291.6): all three stream at the ~5 TB/s every GEMV launch of
-            // this path reaches (T = 2.7 us + bytes / 5 TB/s fits the four launches of a 65B layer within 10 %).  FL_LLC_MPQ=8|7|6: A/B.
-            static const int mpq = getenv("FL_LLC_MPQ") ? atoi(getenv("FL_LLC_MPQ")) : 6;
 #define FL_LLC_MP_GO(MNK, MQPW)                                                                                                            \
             do {                                                                                                                           \
                 static int slots = 0;                                                                                                      \
                 static size_t slots_lds = 0;                                                                                               \
                 if (!slots || slots_lds != lds)                                                                                            \
-                    slots_lds = lds, slots = llc_slots(reinterpret_cast<const void *>(&gemv1_q4_exact_llc_kernel<TYPE, MNK, PRO, PAIR, MQPW, 1>), 64 * MNK, lds, true); \
-                FL_LLC_GO(MNK, MQPW, 1, 1, (units < slots ? units : slots), (NQ + MNK * MQPW - 1) / (MNK * MQPW));                          \
+                    slots_lds = lds, slots = llc_slots(reinterpret_cast<const void *>(&gemv1_q4_exact_llc_kernel<TYPE, MNK, PRO, PAIR, MQPW, 1>), 64 * MNK, lds); \
+                FL_LLC_GO(MNK, MQPW, 1, (units < slots ? units : slots), (NQ + MNK * MQPW - 1) / (MNK * MQPW));                             \
             } while (0)
             if constexpr (TYPE == FL_TYPE_Q4_1) FL_LLC_MP_GO(8, 4);
-            else if (mpq == 8) FL_LLC_MP_GO(4, 8);
-            else if (mpq == 6) FL_LLC_MP_GO(4, 6);
-            else FL_LLC_MP_GO(4, 7);
+            else FL_LLC_MP_GO(4, 6);
 #undef FL_LLC_MP_GO
             return true;
         }
     }
+    // one workgroup per row group
     if constexpr (TYPE == FL_TYPE_Q4_1) {             // Q4_1 carries m_w as well: 4 x 8 needs 174 registers = two waves per SIMD; 8 x 4 needs <= 126
-        static const bool q41_48 = getenv("FL_Q41_48") != nullptr;      // A/B: the 4 x 8 form for Q4_1 as well
-        if (NQ <= 32 && !q41_48) { FL_LLC(8, 4); return true; }   // (four): LLaMA-7B Q4_1 decode 412 -> 424 tok/s.  (Q4_0, 139 registers at 4 x 8: no gain)
+        if (NQ <= 32) { FL_LLC_GO(8, 4, 0, units, 1); return true; }
     }
-    if (NQ <= 32) FL_LLC(4, 8);
-    else if (NQ <= 44) FL_LLC(4, 11);
-    else FL_LLC(8, 11);
-#undef FL_LLC
+    if (NQ <= 32) FL_LLC_GO(4, 8, 0, units, 1);
+    else if (NQ <= 44) FL_LLC_GO(4, 11, 0, units, 1);
+    else FL_LLC_GO(8, 11, 0, units, 1);
 #undef FL_LLC_GO
     return true;
 }

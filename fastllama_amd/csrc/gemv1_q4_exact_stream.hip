@@ -124,6 +124,12 @@ __global__ __launch_bounds__(256, 2) void gemv1_q4_exact_stream_kernel(
     // the first U quads, each as (scale, nibbles) -- the order the loop re-requests them in, so that the compiler's count of the loads in flight
     // (s_waitcnt vmcnt) is the same at the loop's entry and at its back edge: with all scales ahead of all nibbles it waited, every round, as if
     // only half of them were outstanding (seen in the ISA).  The scheduling barriers keep the pairs in program order.
+    // (ALL of them before the prologue.  Holding most of them back until the activation has arrived -- the last workgroups' prologues sit behind the
+    //  27 MB of requests the launch starts with: done 9.4 us into a 14.8 us launch of LLaMA-7B's w1|w3 -- brings the prologues forward (5.5 us) and
+    //  costs more than it gains, the stream starting late: 589 / 566 / 585 tok/s with 4 / 8 / 2 quads up front against 617.  Also measured and not kept,
+    //  profiles/r06_decode_exact.md: a short s_sleep between the activation's requests and the weights' (0.2 us: no change, 0.5 us: -2 %); the next quad's
+    //  activation read from LDS one quad ahead (no change at 16 quads in flight, -8 % at 8); the two chains as one v_pk_fma_f32 with the lane sums
+    //  converted by a v_dot4 onto the bits of 1.5 x 2^23 and a packed subtract (-22 % VALU instructions in the loop, bit-identical, no change in tok/s).)
 #pragma unroll
     for (int i = 0; i < U; ++i) {
         req_scale(i, i);
@@ -185,26 +191,10 @@ __global__ __launch_bounds__(256, 2) void gemv1_q4_exact_stream_kernel(
             if (TYPE == FL_TYPE_Q4_0) { wa = (wv[blk] << 4) & m8; wb = wv[blk] & m8; }     // 16 (nib - 8): elements 0..3 | 4..7
             else { wa = wv[blk] & 0x0F0F0F0Fu; wb = (wv[blk] >> 4) & 0x0F0F0F0Fu; }
             const float dd = __fmul_rn(dwb[blk], dxv[blk]);                 // rn(d_w d_x); a block past K: d_x = 0
-#ifdef ST_PK
-            // the two lane sums as floats without a conversion: v_dot4 accumulates onto the BITS of 1.5 x 2^23, which as a float is 12582912 + sum
-            // (|sum| <= 4 x 240 x 127 < 2^22: exact), and one packed subtract takes the constant off both (exact: the results are the integers);
-            // the two chains advance in one packed fma -- IEEE fma per half, the same bits as two v_fma_f32
-            typedef float v2f __attribute__((ext_vector_type(2)));
-            // (the three-operand form with the constant in an SGPR: the builtin compiles to v_dot4c, which accumulates in place and costs a v_mov of
-            //  the constant per dot)
-            v2f fm;
-            asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(fm.x) : "v"(wa), "v"(xa[blk]), "s"(0x4B400000));
-            asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(fm.y) : "v"(wb), "v"(xb[blk]), "s"(0x4B400000));
-            const v2f f = fm - (v2f){12582912.0f, 12582912.0f};
-            v2f acc = {a0, a1};
-            acc = __builtin_elementwise_fma((v2f){dd, dd}, f, acc);
-            a0 = acc.x; a1 = acc.y;
-#else
             const float f0 = (float)__builtin_amdgcn_sdot4((int)wa, (int)xa[blk], 0, false);
             const float f1 = (float)__builtin_amdgcn_sdot4((int)wb, (int)xb[blk], 0, false);
             a0 = __fmaf_rn(dd, f0, a0);
             a1 = __fmaf_rn(dd, f1, a1);
-#endif
             if (Q41) summs = __fmaf_rn(msb[blk], sxv[blk], summs);          // (a block past K: s_x = 0, m_w finite)
         }
     };
@@ -315,8 +305,10 @@ static bool launch_stream(const fl_qtensor &W, const fl_qact *xq, float *y, hipS
     if (EPI != 0 && (groups % 4 != 0 || W.M != W.M16)) return false;          // a workgroup = the w1 | w3 rows of 32 whole features
     if (PRO == 1 && W.K > 8192) return false;                                 // (the rms_norm prologue keeps the row in registers: 256 threads x 32)
     if (qwd_bytes(W) >= (1ull << 31) || (size_t)W.M16 * (size_t)KB * 4 >= (1ull << 31)) return false;      // 32-bit buffer offsets
-    // quads in flight per wave: 16 when that divides the row (K = 4096, 8192: 20 KB per wave), else 8
-    const bool u16 = NQ % 16 == 0 || NQ % 16 >= 13;
+    // quads in flight per wave: 16 (20 KB per wave, ~170 registers: two workgroups per CU) when that divides the row (K = 4096, 8192) AND the launch's
+    // workgroups are all resident at that (LLaMA-65B's w1|w3 is 688 workgroups: as 16 it ran in two rounds, 89 against 95 tok/s); else 8 (four per CU)
+    static const int n_cus = [] { int d = 0, c = 0; return (hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && c > 0) ? c : 256; }();
+    const bool u16 = (NQ % 16 == 0 || NQ % 16 >= 13) && (groups + 3) / 4 <= 2 * n_cus;
     const int U = u16 ? 16 : 8, NQP = (NQ + U - 1) / U * U;
     const size_t lds = (size_t)NQP * 160;
     if (lds > 60 * 1024) return false;
@@ -336,16 +328,16 @@ static bool launch_stream(const fl_qtensor &W, const fl_qact *xq, float *y, hipS
     return true;
 }
 
-// Which matrices take this form: those whose row groups give every SIMD of the chip a wave or more (wq|wk|wv, w1|w3, the lm-head; everything
-// of LLaMA-65B); a matrix of one row group per CU (wo, w2 of 7B / 13B) keeps the K-sliced workgroups of the llc kernel -- one wave per CU would
-// run its whole row's arithmetic alone.  g_stream_min_groups (fl_debug_set(6, n), tests) overrides the bound.
+// Which matrices take this form: those with three row groups per CU or more (wq|wk|wv, w1|w3, the lm-head of every LLaMA size); a matrix of one or
+// two row groups per CU (wo, w2) keeps the K-sliced workgroups of the llc kernel -- a wave per SIMD or fewer would run a whole row's arithmetic
+// alone and keep too few bytes in flight (LLaMA-65B's w2: 512 waves x 10 KB).  g_stream_min_groups (fl_debug_set(6, n), tests) overrides the bound.
 int g_stream_min_groups = -1;
 static int stream_min_groups() {
     if (g_stream_min_groups >= 0) return g_stream_min_groups;
     static const int v = [] {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        return 2 * cus;
+        return 3 * cus;
     }();
     return v;
 }

@@ -1,5 +1,5 @@
-"""Decode A/B inside one process: python scripts/dev/decode_ab.py [steps] [n_past] [model] [qtype] -- tok/s of the reference-order decode with the
-one-wave-per-row-group form of round 6 on (automatic) and off (fl_debug_set(6, 1 << 30): round 5's kernels), alternating, hipGraph replay."""
+"""Decode A/B inside one process: python scripts/dev/decode_ab.py [steps] [n_past] [model] [qtype] [reps] -- tok/s of the reference-order decode, hipGraph
+replay, alternating between: head and round5 (without the one-wave-per-row-group form: round 5's kernels).  AB=head selects the variants."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -28,9 +28,13 @@ def run(tag):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     print(f"[{tag}] {name} qtype={QT} n_past={past}: {dt*1e3:.3f} ms/token  {1/dt:.1f} tok/s", flush=True)
+# variants: name -> (fl_debug_set(6, .) value, fl_model_set_graph mode)
+VARS = {"head": (-1, 1), "round5": (1 << 30, 1)}
+names = os.environ.get("AB", "head,round5").split(",")
 for r in range(reps):
-    for tag, v in (("stream", -1), ("round5", 1 << 30)):
+    for tag in names:
+        v, mode = VARS[tag]
         L.fl_debug_set(6, v)
-        L.fl_model_set_graph(m.h, 3)          # (the fuse bit flips twice: the captured graph is dropped and the next eval captures the selected kernels)
-        L.fl_model_set_graph(m.h, 1)
+        L.fl_model_set_graph(m.h, mode ^ 2)   # (the fuse bit flips twice: the captured graph is dropped and the next eval captures the selected kernels)
+        L.fl_model_set_graph(m.h, mode)
         run(tag)

@@ -48,3 +48,17 @@ print("|---|---|---|---|---|---|---|---|---|---|---|---|")
 for (k, w), ds in sorted(rows.items()):
     med = lambda key: float(np.median([d[key] for d in ds]))
     print(f"| {k} | {w} | {len(ds)} | {med('dur'):.2f} | {med('ramp'):.2f} | {med('issued'):.2f} | {med('pro'):.2f} / {med('pro_max'):.2f} | {med('loop_min'):.2f} / {med('loop_med'):.2f} / {med('loop_max'):.2f} | {med('last_loop_end'):.2f} | {med('wave_spread'):.2f} | {med('epi'):.2f} | {med('life'):.2f} / {med('life_max'):.2f} |")
+# per-workgroup records of ONE launch of each kind (the launch in the middle of the token), for offline study: gpurun_out/stream_wg_<id>.csv
+os.makedirs("gpurun_out", exist_ok=True)
+seen = {}
+for r in runs:
+    k = int(kid[r[0]]); seen.setdefault((k, len(r)), []).append(r)
+for (k, w), rs in seen.items():
+    r = rs[len(rs) // 2]
+    t = rec[r][:, :9].astype(np.float64) * 0.01
+    t0 = t[:, 0].min()
+    wg = rec[r][:, 9] & 0xffffffff
+    with open(f"gpurun_out/stream_wg_{k}_{w}.csv", "w") as f:
+        f.write("wg,entry,issued,prologue_done,loop_end_w0,loop_end_w1,loop_end_w2,loop_end_w3,stored,end\n")
+        for i in np.argsort(wg):
+            f.write(f"{int(wg[i])}," + ",".join(f"{v - t0:.2f}" for v in t[i]) + "\n")
