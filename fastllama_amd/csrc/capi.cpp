@@ -60,7 +60,7 @@ int ensure_device() {
 
 }  // namespace fl
 
-namespace fl { extern int g_gemm_force_cfg; extern int g_gemv_force_waves; extern int g_stream_min_groups; }
+namespace fl { extern int g_gemm_force_cfg; extern int g_gemv_force_waves; extern int g_stream_min_groups; extern int g_stream_force_nw; }
 using namespace fl;
 
 #define FL_HIP(call)                                   \
@@ -83,7 +83,7 @@ bool op_exact() { return g_op_mode < 0 ? fl_default_exact() != 0 : g_op_mode != 
 // fl_qtensor_build_h16 / fl_qtensor_build_qwd, or fl_model_prepare for a model.
 static std::mutex g_lazy_mu;
 int ensure_h16(const fl_qtensor *W, fl_qact_impl *a, void *st) {
-    if (!W->h16) {
+    if (!__atomic_load_n(&W->h16, __ATOMIC_ACQUIRE)) {     // (set = complete: fl_qtensor_build_h16 publishes the pointer behind the synchronisation)
         std::lock_guard<std::mutex> lk(g_lazy_mu);
         const int rc = W->h16 ? FL_OK : fl_qtensor_build_h16(const_cast<fl_qtensor *>(W), st);      // (a derived copy: logically const)
         if (rc != FL_OK) return rc;
@@ -252,16 +252,21 @@ static bool test_fail_derived(int bit) {
 int fl_qtensor_build_h16(fl_qtensor *W, void *stream) {
     if (!W) return set_error(FL_EINVAL, "null tensor");
     if (!W->h16 && test_fail_derived(1)) return set_error(FL_ENOMEM, "hipMalloc(WH16): out of memory (FL_TEST_FAIL_DERIVED)");
-    if (!W->h16) {
-        hipError_t ea = hipMalloc((void **)&W->h16, wh16_bytes(*W));
-        if (ea != hipSuccess) {
-            W->h16 = nullptr;
-            return hip_fail(ea, "hipMalloc(WH16)");
-        }
+    // A first build goes into a LOCAL pointer and is published -- a release store -- only once the copy is complete and the stream synchronised:
+    // another host thread that finds the pointer set (an acquire load, ensure_h16) may launch on it at once.  A rebuild (LoRA merge:
+    // the tensor's owner changes the weights, nobody else is using the tensor) overwrites the published copy in place.
+    uint16_t *dst = W->h16;
+    if (!dst) {
+        hipError_t ea = hipMalloc((void **)&dst, wh16_bytes(*W));
+        if (ea != hipSuccess) return hip_fail(ea, "hipMalloc(WH16)");
     }
-    hipError_t e = qw16_to_h16(*W, W->h16, S(stream));
+    hipError_t e = qw16_to_h16(*W, dst, S(stream));
     if (e == hipSuccess) e = hipStreamSynchronize(S(stream));
-    if (e != hipSuccess) return hip_fail(e, "fl_qtensor_build_h16");
+    if (e != hipSuccess) {
+        if (!W->h16) (void)hipFree(dst);
+        return hip_fail(e, "fl_qtensor_build_h16");
+    }
+    __atomic_store_n(&W->h16, dst, __ATOMIC_RELEASE);
     return FL_OK;
 }
 
@@ -269,16 +274,18 @@ int fl_qtensor_build_h16(fl_qtensor *W, void *stream) {
 int fl_qtensor_build_qwd(fl_qtensor *W, void *stream) {
     if (!W) return set_error(FL_EINVAL, "null tensor");
     if (!W->qwd && test_fail_derived(2)) return set_error(FL_ENOMEM, "hipMalloc(QWD): out of memory (FL_TEST_FAIL_DERIVED)");
-    if (!W->qwd) {
-        hipError_t ea = hipMalloc((void **)&W->qwd, qwd_bytes(*W));
-        if (ea != hipSuccess) {
-            W->qwd = nullptr;
-            return hip_fail(ea, "hipMalloc(QWD)");
-        }
+    uint32_t *dst = W->qwd;                                // (published only when complete: see fl_qtensor_build_h16)
+    if (!dst) {
+        hipError_t ea = hipMalloc((void **)&dst, qwd_bytes(*W));
+        if (ea != hipSuccess) return hip_fail(ea, "hipMalloc(QWD)");
     }
-    hipError_t e = qw16_to_qwd(*W, W->qwd, S(stream));
+    hipError_t e = qw16_to_qwd(*W, dst, S(stream));
     if (e == hipSuccess) e = hipStreamSynchronize(S(stream));
-    if (e != hipSuccess) return hip_fail(e, "fl_qtensor_build_qwd");
+    if (e != hipSuccess) {
+        if (!W->qwd) (void)hipFree(dst);
+        return hip_fail(e, "fl_qtensor_build_qwd");
+    }
+    __atomic_store_n(&W->qwd, dst, __ATOMIC_RELEASE);
     return FL_OK;
 }
 void fl_qtensor_drop_qwd(fl_qtensor *W) {
@@ -568,7 +575,7 @@ int mul_mat_q_which(const fl_qtensor *W, const fl_qact *a_, float *y, int ldy, i
         if (a->layout != 16) return set_error(FL_EINVAL, "gemm needs the QA16 layout");
         FL_HIP(gemm_q4_exact_valu(*W, *a, a->N, y, ldy, S(st)));
     } else if (which == 3) {               // reference-order kernels, whichever the layout says
-        if (a->layout == 1 && a->N == 1 && !W->qwd) {
+        if (a->layout == 1 && a->N == 1 && !__atomic_load_n(&W->qwd, __ATOMIC_ACQUIRE)) {
             std::lock_guard<std::mutex> lk(g_lazy_mu);
             if (!W->qwd && (rc = fl_qtensor_build_qwd(const_cast<fl_qtensor *>(W), st)) != FL_OK) return rc;
         }
@@ -620,6 +627,6 @@ extern "C" const fl::InternalTable *fl_internal_table(void) {
 #define X(name) &fl::name,
         FL_INTERNAL_FUNCS(X)
 #undef X
-        &fl::g_gemm_force_cfg, &fl::g_gemv_force_waves, &fl::g_op_mode, &fl::g_stream_min_groups};
+        &fl::g_gemm_force_cfg, &fl::g_gemv_force_waves, &fl::g_op_mode, &fl::g_stream_min_groups, &fl::g_stream_force_nw};
     return &t;
 }

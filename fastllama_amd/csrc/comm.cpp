@@ -42,7 +42,6 @@ constexpr size_t P2P_CAP = 64 * 1024;          // floats per slot (256 KB): the 
 // the flags peers write, [128 + kind] tickets, [144 + kind] epochs (local)
 constexpr int FOLD_FLAG0 = 64, FOLD_TICKET0 = 128, FOLD_EPOCH0 = 144;
 static_assert(FL_COMM_MAX_LOCAL <= 8 && TP_FOLD_KINDS <= 8, "flag page layout");
-static_assert(3 * FL_COMM_MAX_LOCAL * 1024 <= TP_FOLD_BYTES, "the self-test's three areas");
 constexpr size_t P2P_MAX_COUNT = 16 * 1024;    // messages up to 64 KB go this way (one workgroup moves them)
 // (FL_P2P_MAX_COUNT: up to a whole slot -- rehearsals of larger models on a communicator without RCCL behind it, scripts/dev/run_r5_o.sh)
 static size_t p2p_max_count() {
@@ -79,10 +78,11 @@ static int p2p_alloc(fl_comm *c) {
     if (p.own_buf) return FL_OK;
     if (c->world < 2 || c->world > FL_COMM_MAX_LOCAL) return set_error(FL_EINVAL, "peer exchange needs 2..%d ranks", FL_COMM_MAX_LOCAL);
     // fine-grained device memory (what RCCL uses for its own peer buffers): coherent for peers while a kernel runs; the kernel
-    // uses system-scope accesses on top of it.  Plain hipMalloc if the runtime refuses the flag.
+    // uses system-scope accesses on top of it.  A runtime that refuses the flag gets NO exchange (round 6): coarse-grained memory would
+    // leave the decode launches' plain loads of peer-written slices to the self-test's luck -- the communicator stays on RCCL, and says so.
     auto alloc = [](void **ptr, size_t bytes) {
         hipError_t r = hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocFinegrained);
-        if (r != hipSuccess) { (void)hipGetLastError(); r = hipMalloc(ptr, bytes); }
+        if (r != hipSuccess) { (void)hipGetLastError(); warn("peer exchange: hipDeviceMallocFinegrained refused (%s): no peer-mapped exchange, collectives go through RCCL", hipGetErrorString(r)); }
         return r;
     };
     hipError_t e = alloc(&p.own_buf, 2 * P2P_CAP * sizeof(float) + TP_FOLD_BYTES);
@@ -119,11 +119,14 @@ static_assert(sizeof(ncclUniqueId) == FL_COMM_ID_BYTES, "ncclUniqueId size");
 extern "C" {
 
 /* The check fl_comm_create runs before it keeps the exchange, for hosts that moved the handles themselves (fl_comm_create_p2p): COLLECTIVE --
- * every rank calls it after fl_comm_p2p_import; patterned slices travel between all ranks through the exchange's tail kernel (the first round
- * waits up to 20 s for a peer, the next two 2 s). */
+ * every rank calls it after fl_comm_p2p_import.  Three epochs of the decode pattern over the same slots (p2p_selftest below); the first epoch waits up
+ * to 20 s for a peer, the next two 2 s.  On failure the exchange is FREED: the communicator can no longer fold a model's exchanges. */
 int fl_comm_p2p_selftest(fl_comm *c) {
     if (!c || !c->p2p.ready) return set_error(FL_EINVAL, "fl_comm_p2p_selftest: no peer-mapped exchange behind this communicator");
-    return p2p_selftest(c) ? FL_OK : set_error(FL_EHIP, "peer exchange self-test failed on rank %d (a slice did not arrive, or a peer did not in time)", c->rank);
+    if (p2p_selftest(c)) return FL_OK;
+    const int rank = c->rank;
+    p2p_free(c);                 // a communicator known to be bad must not fold a model's exchanges: its waits would be skipped from now on (tp_tail.h)
+    return set_error(FL_EHIP, "peer exchange self-test failed on rank %d (a slice did not arrive intact, or a peer did not in time): the exchange is gone", rank);
 }
 
 int fl_comm_unique_id(void *out) {
@@ -302,37 +305,38 @@ static TpTail fold_tail(const TpFold &f, int kind, unsigned off, unsigned bytes,
     return t;
 }
 
-// Does the exchange work between THESE devices?  Every rank pushes three patterned 1 KB slices through the tail kernel (bounded waits: the
-// ranks are in step, the caller has just finished a collective) and checks what arrived from every peer.  Collective: every rank of a
-// communicator whose handles were imported calls it.  A failure leaves the communicator on RCCL alone (fl_comm_create).
+// Does the exchange work between THESE devices, the way the decode path uses it?  Three epochs over the SAME slots, each a multi-workgroup producer
+// launch with fused tails (tp_put from many workgroups, the ticket, the publish / wait) followed by a consumer launch that reads every rank's slice with
+// plain loads -- after the producer launch of the next epoch has first pulled the old lines into its caches (tp_selftest_epoch, eval_kernels.hip).
+// Collective: every rank of a communicator whose handles were imported calls it.  A failure leaves the communicator on RCCL alone (fl_comm_create) or
+// without the exchange (fl_comm_p2p_selftest).  What it cannot show on the one-GPU test box: that system-scope stores cross xGMI the way they cross
+// between processes on one device -- it is the check that runs on the real node before any model folds its exchanges.
 static bool p2p_selftest(fl_comm *c) {
     TpFold f;
     if (!comm_fold(c, &f)) return false;
-    constexpr unsigned SL = 1024, W = SL / 4;
-    TpTail *td = nullptr;
-    if (hipMalloc(&td, sizeof(TpTail)) != hipSuccess) { (void)hipGetLastError(); return false; }
-    // (the first round waits up to 20 s: a peer's first launch from this library may still be loading its code object; then 2 s per round)
-    TpTail t = fold_tail(f, TP_FOLD_KINDS - 1, (unsigned)f.rank * SL, SL, 2000000000ull);
+    constexpr unsigned SLW = 1024;                                   // words per rank's slice (4 KB: several cache lines per workgroup)
+    static_assert((size_t)FL_COMM_MAX_LOCAL * SLW * 4 <= TP_FOLD_BYTES, "the self-test's area");
+    struct Dev { TpTail t[2]; unsigned errors, sink[8]; } *dv = nullptr;
+    if (hipMalloc((void **)&dv, sizeof(Dev)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    // (the first epoch waits up to 20 s: a peer's first launch from this library may still be loading its code object; then 2 s per wait)
+    Dev h{};
+    h.t[0] = fold_tail(f, TP_FOLD_KINDS - 1, (unsigned)f.rank * SLW * 4, SLW * 4, 2000000000ull);      // the exchange
+    h.t[1] = fold_tail(f, TP_FOLD_KINDS - 2, 0, 0, 2000000000ull);                                       // the barrier behind the consumer
+    h.t[1].n_ranges = 0;
     bool ok = true;
     unsigned before = 0, after = 0;
     ok = ok && hipMemcpy(&before, f.timeouts, 4, hipMemcpyDeviceToHost) == hipSuccess;
-    uint32_t mine[W], all[FL_COMM_MAX_LOCAL * W];
-    for (unsigned round = 1; round <= 3 && ok; ++round) {
-        if (round == 2) t.timeout_ticks = 200000000ull;
-        // (every round has its own area of the region: a peer that is a round ahead must not overwrite the slices this rank is still reading back)
-        const size_t area = (size_t)(round - 1) * FL_COMM_MAX_LOCAL * SL;
-        t.off[0] = (unsigned)(area + (size_t)f.rank * SL);
-        for (unsigned i = 0; i < W; ++i) mine[i] = (round << 28) ^ ((unsigned)f.rank << 20) ^ (i * 2654435761u);
-        ok = hipMemcpy(td, &t, sizeof t, hipMemcpyHostToDevice) == hipSuccess &&
-             hipMemcpy(f.region[f.rank] + t.off[0], mine, SL, hipMemcpyHostToDevice) == hipSuccess &&
-             tp_tail_launch(td, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
-             hipMemcpy(all, f.region[f.rank] + area, (size_t)f.world * SL, hipMemcpyDeviceToHost) == hipSuccess;
-        for (int r = 0; r < f.world && ok; ++r)
-            for (unsigned i = 0; i < W && ok; ++i) ok = all[(size_t)r * W + i] == ((round << 28) ^ ((unsigned)r << 20) ^ (i * 2654435761u));
+    // (the area is NOT cleared first: a peer that is ahead may already be writing its first slice into it; whatever the slots hold, only this epoch's
+    //  pattern passes)
+    for (unsigned epoch = 1; epoch <= 3 && ok; ++epoch) {
+        if (epoch == 2) h.t[0].timeout_ticks = h.t[1].timeout_ticks = 200000000ull;
+        ok = hipMemcpy(dv, &h, sizeof h, hipMemcpyHostToDevice) == hipSuccess &&
+             tp_selftest_epoch(&dv->t[0], &dv->t[1], 0, SLW, epoch, &dv->errors, dv->sink, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+             hipMemcpy(&h.errors, &dv->errors, 4, hipMemcpyDeviceToHost) == hipSuccess && h.errors == 0;
     }
     if (hipMemcpy(&after, f.timeouts, 4, hipMemcpyDeviceToHost) != hipSuccess || after != before) ok = false;
     if (after != before) c->p2p.timeouts_seen = after;          // (the self-test's give-ups are not an eval's)
-    (void)hipFree(td);
+    (void)hipFree(dv);
     (void)hipGetLastError();
     return ok;
 }

@@ -1220,9 +1220,11 @@ __device__ __forceinline__ float att_reduce8(float4 a) {
 // products added in order, the last n % 4 as FMAs.  The 8 lanes of a row each hold four of them (p4, v4: elements 4 l8 .. 4 l8 + 3
 // behind the 32-wide body; what lies past n is ignored); s: the body's sum, the same bits in all 8 lanes.  The running value walks up
 // the lanes (DPP row_shr:1), lane j adding its four rounded products -- or, the lane holding the last n % 4, its FMAs -- in order;
-// the result is lane 7's.  (Round 3 had lane 0 walk the elements itself, each one a dependent global load: 3.7 us of the reference-
+// the result is the lane's that holds the last elements -- lane min(n >> 2, 7), att_leftovers_last -- and the walk stops there (round 6: it used to
+// go on to lane 7 whatever n).  (Round 3 had lane 0 walk the elements itself, each one a dependent global load: 3.7 us of the reference-
 // order decode attention's 11.4 at n = 1 .. 31, profiles/r04_decode_exact.md.)
 constexpr int DPP_ROW_SHR1 = 0x111;
+__device__ __forceinline__ int att_leftovers_last(int n) { return min(n >> 2, 7); }
 __device__ __forceinline__ float att_leftovers_lanes(float s, const float4 p4, const float4 v4, int n, int l8) {
 #pragma clang fp contract(off)     // plain operators under this pragma: hipcc contracts a * b + c even across __fmul_rn / __fadd_rn
     const int nfull = n >> 2, nt = n & 3;
@@ -1242,6 +1244,7 @@ __device__ __forceinline__ float att_leftovers_lanes(float s, const float4 p4, c
         }
         const float up = dpp_f32<DPP_ROW_SHR1>(t);         // lane j + 1 takes over from lane j
         s = l8 == j + 1 ? up : l8 == j ? t : s;
+        if (j >= nfull) break;                             // (uniform: n is the same for every lane) lane j held the last elements
     }
     return s;
 }
@@ -1277,6 +1280,9 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const int *__res
 
     // ---- requests first.  Loads return in order: the few bytes rope needs (this token's q, k, v and the rope table row)
     //      go out before the K / V history, or rope would wait for all of it ----
+    // (round 6 tried the K rows and V pieces of the first 256 positions requested WHATEVER the position is -- nothing waits for the position's round
+    //  trip, what lies beyond it is masked -- with the rope row last: 591-597 against 611-620 tok/s, the over-fetch and the rope row queued behind
+    //  the history cost more than the position's round trip, profiles/r06_decode_exact.md)
     const float *q = qkv + h * D, *k = qkv + E + h * D, *v = qkv + 2 * E + h * D;
     float2 cs = {0.f, 0.f}, xq = cs, xk = cs;
     float vv = 0.f;
@@ -1422,7 +1428,7 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const int *__res
             if (d < D) {
                 const float4 p4 = *reinterpret_cast<const float4 *>(sc + (p0 < P ? p0 : np));     // (a lane past P: ignored)
                 a = att_leftovers_lanes(a, p4, with_fresh(d, p0, v4), P - np, l8);
-                if (l8 == 7) out[d] = a;
+                if (l8 == att_leftovers_last(P - np)) out[d] = a;
             }
         } else if (d < D && l8 == 0) {
             out[d] = a;
@@ -1660,7 +1666,7 @@ __global__ __launch_bounds__(DP_T) void decode_pv_kernel(const int *__restrict__
     if (ORD && (P & 31)) {
         const float4 p4 = *reinterpret_cast<const float4 *>(sc + np + l8 * 4);
         a = att_leftovers_lanes(a, p4, vleft, P - np, l8);
-        if (l8 == 7) out[tid >> 3] = a;
+        if (l8 == att_leftovers_last(P - np)) out[tid >> 3] = a;
     } else if (l8 == 0) {
         out[tid >> 3] = a;
     }
@@ -1783,6 +1789,45 @@ thread_local const TpTail *tp_pending_tail = nullptr;
 __global__ __launch_bounds__(256) void tp_tail_kernel(const TpTail *__restrict__ tt) { tp_tail<false, true>(tt); }
 hipError_t tp_tail_launch(const TpTail *tt_dev, hipStream_t st) {
     hipLaunchKernelGGL(tp_tail_kernel, dim3(1), dim3(256), 0, st, tt_dev);
+    return hipGetLastError();
+}
+
+// The exchange's self-test AS THE DECODE PATH USES IT (comm.cpp p2p_selftest; ADVICE r5 / VERDICT r5 item 7).  One epoch = two launches:
+//   produce: several workgroups; each first READS every rank's slice of the test area with plain loads -- the lines of the previous epoch are now in
+//            this CU's L1 and this XCD's L2, as a decode launch's operands of the previous token are -- then writes its share of this rank's slice with
+//            tp_put (own region written through + every peer's region, many workgroups at once), then the fused tail: ticket, publish, wait;
+//   consume: the NEXT launch reads every rank's slice with PLAIN loads, as the next decode launch reads its operand, and counts words that are not
+//            this epoch's pattern; its own tail (another exchange kind, no data) keeps any rank from producing epoch e + 1 into slots a peer is still reading.
+// The same slots every epoch.  pattern(e, r, i) = e * 0x9E3779B9 ^ r << 20 ^ i * 2654435761.
+__device__ __forceinline__ unsigned tp_selftest_pattern(unsigned e, unsigned r, unsigned i) { return (e * 0x9E3779B9u) ^ (r << 20) ^ (i * 2654435761u); }
+__global__ __launch_bounds__(256) void tp_selftest_produce_kernel(const TpTail *__restrict__ tt, unsigned area_off, unsigned slice_words, unsigned epoch,
+                                                                  unsigned *__restrict__ sink) {
+    const int world = tt->world, rank = tt->rank;
+    const unsigned *area = reinterpret_cast<const unsigned *>(tt->region[rank] + area_off);
+    unsigned acc = 0;
+    for (unsigned i = threadIdx.x; i < slice_words * (unsigned)world; i += 256) acc ^= area[i];        // plain loads: cache what the previous epoch left
+    if (acc == 0x13572468u) sink[blockIdx.x] = acc;                                                    // (keeps the loads alive)
+    __syncthreads();
+    float *mine = reinterpret_cast<float *>(tt->region[rank] + area_off) + (size_t)rank * slice_words;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < slice_words; i += gridDim.x * 256)
+        tp_put(tt, mine + i, __uint_as_float(tp_selftest_pattern(epoch, (unsigned)rank, i)));
+    tp_tail<false, false, true>(tt);
+}
+__global__ __launch_bounds__(256) void tp_selftest_consume_kernel(const TpTail *__restrict__ barrier_tt, unsigned area_off, unsigned slice_words, unsigned epoch,
+                                                                  unsigned *__restrict__ errors) {
+    const int world = barrier_tt->world, rank = barrier_tt->rank;
+    const unsigned *area = reinterpret_cast<const unsigned *>(barrier_tt->region[rank] + area_off);
+    unsigned bad = 0;
+    for (int r = 0; r < world; ++r)
+        for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < slice_words; i += gridDim.x * 256)
+            bad += area[(size_t)r * slice_words + i] != tp_selftest_pattern(epoch, (unsigned)r, i);     // plain loads, the launch after the exchange
+    if (bad) atomicAdd(errors, bad);
+    tp_tail<false, false, true>(barrier_tt);
+}
+hipError_t tp_selftest_epoch(const TpTail *exchange_dev, const TpTail *barrier_dev, unsigned area_off, unsigned slice_words, unsigned epoch,
+                             unsigned *errors_dev, unsigned *sink_dev, hipStream_t st) {
+    hipLaunchKernelGGL(tp_selftest_produce_kernel, dim3(8), dim3(256), 0, st, exchange_dev, area_off, slice_words, epoch, sink_dev);
+    hipLaunchKernelGGL(tp_selftest_consume_kernel, dim3(8), dim3(256), 0, st, barrier_dev, area_off, slice_words, epoch, errors_dev);
     return hipGetLastError();
 }
 

@@ -24,7 +24,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
+#include <mutex>
 #include "eval_kernels.h"
+#include "runtime.h"
 #include "q4_device.h"
 #include "gemv_prologue.h"
 #include "q4_kernels.h"
@@ -428,16 +431,15 @@ static bool launch_gemv1_exact(const fl_qtensor &W, const fl_qact *xq, float *y,
 // the exact forms of gemv_q4 (N = 1) / gemv_q4_norm / gemv_q4_silu / gemv_q4_norm_silu / gemv_q4_quant (q4_kernels.h);
 // hipErrorInvalidValue: shape outside this kernel's reach -> the caller takes the per-op sequence
 // (each entry point tries the round-4 lane-local-chain kernel first: it needs the tensor's QWD copy, gemv1_q4_exact_llc.hip)
-static bool llc_off() { static const bool off = getenv("FL_EXACT_R3") != nullptr; return off; }
 hipError_t gemv1_q4_exact(const fl_qtensor &W, const fl_qact &xq, float *y, hipStream_t st, const float *resid) {
-    if (!llc_off() && (gemv1_stream(W, xq, y, st, resid) || gemv1_llc(W, xq, y, st, resid))) return hipGetLastError();
+    if ((gemv1_stream(W, xq, y, st, resid) || gemv1_llc(W, xq, y, st, resid))) return hipGetLastError();
     const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 0, 0>(W, &xq, y, st, resid, nullptr, nullptr, nullptr, 0, nullptr)),
                              (launch_gemv1_exact<FL_TYPE_Q4_1, 0, 0>(W, &xq, y, st, resid, nullptr, nullptr, nullptr, 0, nullptr)));
     return ok ? hipGetLastError() : hipErrorInvalidValue;
 }
 hipError_t gemv_q4_norm_exact(const fl_qtensor &W, const float *x, const float *norm_w, float *ynorm, float *y, hipStream_t st) {
     if (W.K % 32 != 0 || W.K > 8192) return hipErrorInvalidValue;
-    if (!llc_off() && (gemv1_stream_norm(W, x, norm_w, ynorm, y, st) || gemv1_llc_norm(W, x, norm_w, ynorm, y, st))) return hipGetLastError();
+    if ((gemv1_stream_norm(W, x, norm_w, ynorm, y, st) || gemv1_llc_norm(W, x, norm_w, ynorm, y, st))) return hipGetLastError();
     const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 1, 0>(W, nullptr, y, st, nullptr, x, norm_w, ynorm, 0, nullptr)),
                              (launch_gemv1_exact<FL_TYPE_Q4_1, 1, 0>(W, nullptr, y, st, nullptr, x, norm_w, ynorm, 0, nullptr)));
     return ok ? hipGetLastError() : hipErrorInvalidValue;
@@ -445,7 +447,7 @@ hipError_t gemv_q4_norm_exact(const fl_qtensor &W, const float *x, const float *
 hipError_t gemv_q4_silu_exact(const fl_qtensor &W, const float *h13, const uint16_t *silu_tab, float *y, const float *resid,
                               hipStream_t st, bool woven) {
     if (W.K % 32 != 0) return hipErrorInvalidValue;
-    if (!llc_off() && gemv1_llc_silu(W, h13, silu_tab, y, resid, st, woven)) return hipGetLastError();
+    if (gemv1_llc_silu(W, h13, silu_tab, y, resid, st, woven)) return hipGetLastError();
     const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 2, 0>(W, nullptr, y, st, resid, h13, silu_tab, nullptr, woven ? 1 : 0, nullptr)),
                              (launch_gemv1_exact<FL_TYPE_Q4_1, 2, 0>(W, nullptr, y, st, resid, h13, silu_tab, nullptr, woven ? 1 : 0, nullptr)));
     return ok ? hipGetLastError() : hipErrorInvalidValue;
@@ -453,7 +455,7 @@ hipError_t gemv_q4_silu_exact(const fl_qtensor &W, const float *h13, const uint1
 hipError_t gemv_q4_norm_silu_exact(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, float *act,
                                    hipStream_t st, float *pair_ws, int form) {
     if (W.K % 32 != 0 || W.K > 8192 || W.M % 32 != 0) return hipErrorInvalidValue;
-    if (!llc_off() && ((form == 0 && gemv1_stream_norm_silu(W, x, norm_w, silu_tab, act, st)) || gemv1_llc_norm_silu(W, x, norm_w, silu_tab, act, st, pair_ws, form)))
+    if (((form == 0 && gemv1_stream_norm_silu(W, x, norm_w, silu_tab, act, st)) || gemv1_llc_norm_silu(W, x, norm_w, silu_tab, act, st, pair_ws, form)))
         return hipGetLastError();
     const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab)),
                              (launch_gemv1_exact<FL_TYPE_Q4_1, 1, 1>(W, nullptr, act, st, nullptr, x, norm_w, nullptr, 0, silu_tab)));
@@ -461,12 +463,12 @@ hipError_t gemv_q4_norm_silu_exact(const fl_qtensor &W, const float *x, const fl
 }
 hipError_t gemv_q4_norm_silu_q8_exact(const fl_qtensor &W, const float *x, const float *norm_w, const uint16_t *silu_tab, const fl_qact &out,
                                       hipStream_t st) {
-    if (W.K % 32 != 0 || W.K > 8192 || W.M % 64 != 0 || llc_off()) return hipErrorInvalidValue;
+    if (W.K % 32 != 0 || W.K > 8192 || W.M % 64 != 0) return hipErrorInvalidValue;
     return gemv1_stream_norm_silu_q8(W, x, norm_w, silu_tab, out, st) ? hipGetLastError() : hipErrorInvalidValue;
 }
 hipError_t gemv_q4_quant_exact(const fl_qtensor &W, const float *x, float *y, const float *resid, hipStream_t st) {
     if (W.K % 32 != 0) return hipErrorInvalidValue;
-    if (!llc_off() && (gemv1_stream_quant(W, x, y, resid, st) || gemv1_llc_quant(W, x, y, resid, st))) return hipGetLastError();
+    if ((gemv1_stream_quant(W, x, y, resid, st) || gemv1_llc_quant(W, x, y, resid, st))) return hipGetLastError();
     const bool ok = FL_TYPED((launch_gemv1_exact<FL_TYPE_Q4_0, 3, 0>(W, nullptr, y, st, resid, x, nullptr, nullptr, 0, nullptr)),
                              (launch_gemv1_exact<FL_TYPE_Q4_1, 3, 0>(W, nullptr, y, st, resid, x, nullptr, nullptr, 0, nullptr)));
     return ok ? hipGetLastError() : hipErrorInvalidValue;
@@ -1173,24 +1175,38 @@ hipError_t attn_scores_exact(const float *qkv, int ldq, int D, int H, int N, int
 // outside its reach -- the caller runs attn_scores_exact + softmax_rows
 hipError_t attn_scores_softmax_exact(const float *qkv, int ldq, int D, int H, int N, int n_past, const float *kc, int ldk, float scale,
                                      float *att, int ld_att, int64_t head_stride, const uint16_t *exp_tab, hipStream_t st) {
-    static const bool off = getenv("FL_XA_NOFUSE") != nullptr;                 // A/B (profiles/r05_attn_exact.md)
     const int P = n_past + N;
-    if (off || !exp_tab || D % 32 != 0 || D > 128 || N < 1 || (ldq & 3) || (ldk & 3) || P > 1024) return hipErrorInvalidValue;
+    if (!exp_tab || D % 32 != 0 || D > 128 || N < 1 || (ldq & 3) || (ldk & 3) || P > 1024) return hipErrorInvalidValue;
     const int PLD = ((P + 31) & ~31) + 1;
     const size_t lds = (size_t)32 * PLD * 4;
-    static bool attr_set[64] = {false};      // (per device)
+    // 131 KB of dynamic LDS must be asked for once per device: 0 = not tried, 1 = granted, -1 = refused (remembered and said ONCE: the caller's
+    // two-launch path gives the same bits, and a refusal retried on every layer of every eval would be a silent cliff -- ADVICE r5)
+    static std::atomic<int> attr_state[64];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        const size_t mx = (size_t)32 * 1025 * 4;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_scores_exact_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_scores_exact_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_scores_exact_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_scores_exact_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
-        if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidValue;
+    int stt = attr_state[dev].load(std::memory_order_acquire);
+    if (stt == 0) {
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lk(mu);
+        stt = attr_state[dev].load(std::memory_order_relaxed);
+        if (stt == 0) {
+            const size_t mx = (size_t)32 * 1025 * 4;
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_scores_exact_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_scores_exact_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_scores_exact_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_scores_exact_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
+            stt = e == hipSuccess ? 1 : -1;
+            if (stt < 0) {
+                (void)hipGetLastError();
+                warn("device %d refuses %zu bytes of dynamic LDS (%s): the reference-order prefill attention runs K.Q and soft_max as two launches (same results)",
+                     dev, mx, hipGetErrorString(e));
+            }
+            attr_state[dev].store(stt, std::memory_order_release);
+        }
     }
+    if (stt < 0) return hipErrorInvalidValue;
     const dim3 grid(H, (N + 31) / 32);
 #define FL_XS(NST) hipLaunchKernelGGL((attn_scores_exact_kernel<NST, true>), grid, dim3(512), lds, st, qkv, ldq, N, n_past, kc, ldk, scale, att, ld_att, head_stride, exp_tab, PLD)
     if (D == 32) FL_XS(1);

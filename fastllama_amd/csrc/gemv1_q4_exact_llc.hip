@@ -70,6 +70,37 @@ __global__ __launch_bounds__(256) void qw16_to_qwd_kernel(const uint32_t *__rest
     qwd[u] = o;
 }
 
+// QWD -> QW16 qs: the inverse (a permutation of nibbles: lossless) -- a tensor whose QW16 nibble plane was dropped gets it back from its QWD copy
+template <int TYPE>
+__global__ __launch_bounds__(256) void qwd_to_qw16_kernel(const uint32_t *__restrict__ qwd, uint32_t *__restrict__ qs, int64_t n /* groups * KB * 64 */, int KB, int NQ) {
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one output dword: (group, block, row, position p)
+    if (u >= n) return;
+    const int p = (int)(u & 3), row = (int)((u >> 2) & 15);
+    const int64_t gb = u >> 6;
+    const int grp = (int)(gb / KB), b = (int)(gb % KB);
+    const int g = p ^ (((row >> 3) & 1) << 1);                      // the k-group stored at position p of this row
+    const uint32_t v = qwd[((((int64_t)grp * NQ + (b >> 2)) * 16 + row) * 4 + g) * 4 + (b & 3)];
+    uint32_t o = 0;                                                  // QWD byte t = element t | element t + 4 << 4; QW16 nibble k = element k
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t by = (v >> (8 * t)) & 0xFF;
+        o |= (by & 0xF) << (4 * t);
+        o |= (by >> 4) << (4 * (t + 4));
+    }
+    qs[u] = o;
+}
+hipError_t qwd_to_qw16(const fl_qtensor &W, uint32_t *qs, hipStream_t st) {
+    if (!W.qwd) return hipErrorInvalidValue;
+    const int NQ = (W.KB + 3) / 4;
+    const int64_t n = (int64_t)(W.M16 / 16) * W.KB * 64;
+    if (n == 0) return hipSuccess;
+    const int64_t nb = (n + 255) / 256;
+    if (nb >= (1ll << 31)) return hipErrorInvalidValue;
+    if (W.type == FL_TYPE_Q4_0) hipLaunchKernelGGL(qwd_to_qw16_kernel<FL_TYPE_Q4_0>, dim3((unsigned)nb), dim3(256), 0, st, W.qwd, qs, n, W.KB, NQ);
+    else hipLaunchKernelGGL(qwd_to_qw16_kernel<FL_TYPE_Q4_1>, dim3((unsigned)nb), dim3(256), 0, st, W.qwd, qs, n, W.KB, NQ);
+    return hipGetLastError();
+}
+
 size_t qwd_bytes(const fl_qtensor &W) { return (size_t)(W.M16 / 16) * (size_t)((W.KB + 3) / 4) * 1024; }
 
 hipError_t qw16_to_qwd(const fl_qtensor &W, uint32_t *qwd, hipStream_t st) {
@@ -136,6 +167,7 @@ __global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1)
     __shared__ double sh[4];
     __shared__ float accs[2][64][3];                                            // the chains' state between the K slices: a_2g, a_2g+1, summs
                                                                                 // (two copies: consecutive row groups of a persistent workgroup alternate)
+    __shared__ int chain_seq[2];                                                // chain turns taken, per copy (only grows): the hand-off from slice to slice
     const int lane = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int k = wave_;                                                        // (the slice index in an SGPR: the `i < nq` tests below are scalar branches)
     const int NQ = (KB + 3) >> 2;
@@ -145,6 +177,7 @@ __global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1)
     float *ld_ = reinterpret_cast<float *>(gsm + (size_t)NQ * 128);             // (d and s padded to whole quads: 16-byte reads; the padding is
     float *ls_ = ld_ + 4 * NQ;                                                  //  zero, so a block past K has dd = 0 and adds nothing)
 
+    if (threadIdx.x < 2) chain_seq[threadIdx.x] = 0;                            // (ahead of the prologue's closing barrier)
     LLC_T_DECL;
     LLC_STAMP(0);
     GP_DECL(PRO);
@@ -273,6 +306,7 @@ __global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1)
     float y1 = 0.f;
     int par = 0;                                                                // which copy of the chain state this row group uses
     int pass = 0;                                                               // PERSIST: which K pass of the row group
+    int turn0[2] = {0, 0};                                                      // chain_seq[copy] when the current row (group) of that copy started
     auto do_group = [&](auto GI) __attribute__((always_inline)) {
         constexpr int gi = decltype(GI)::value;
         // the residual of this lane's row is requested NOW (PAIR = 0): asked for in the epilogue it was a dependent round trip of ~0.6 us at
@@ -310,12 +344,19 @@ __global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1)
             }
         }
         if (gi == 0) LLC_STAMP(3);
-        // ---- the chains, slice after slice: wave k continues from the state wave k - 1 left in LDS
+        // ---- the chains, slice after slice: wave k continues from the state wave k - 1 left in LDS.  The hand-off is wave to wave (round 6): a
+        // wave waits for ITS predecessor's turn number in chain_seq, not at a workgroup barrier -- behind barriers the second slice's chain could
+        // not start before the LAST slice's bytes had arrived and been summed, and the NK chain phases of a row stood one after the other behind the
+        // whole stream (2.7 us of LLaMA-7B's 10 us w2 launch, profiles/r05_decode_timeline.md); now a slice's chain runs as soon as its own lane
+        // sums and its predecessor's state are there.  LDS serves a wave's accesses in order: state first, turn number behind it.
         float a0 = 0.f, a1 = 0.f, summs = 0.f;
-#pragma unroll 1
-        for (int ph = 0; ph < NK; ++ph) {
-            if (k == ph) {                                                      // (wave-uniform)
-                if (ph > 0 || (PERSIST && pass > 0)) { a0 = accs[par][lane][0]; a1 = accs[par][lane][1]; if (Q41) summs = accs[par][lane][2]; }
+        {
+            const int turn = turn0[par] + pass * NK + k;                        // this slice's turn in the row's chain (multi-pass rows: pass after pass)
+            {
+                if (pass * NK + k > 0) {                                        // (wave-uniform; a row's first slice starts from zero)
+                    while (__hip_atomic_load(&chain_seq[par], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < turn) __builtin_amdgcn_s_sleep(1);
+                    a0 = accs[par][lane][0]; a1 = accs[par][lane][1]; if (Q41) summs = accs[par][lane][2];
+                }
 #pragma unroll
                 for (int i = 0; i < QPW; ++i) {
                     if (i < nq) {
@@ -335,9 +376,10 @@ __global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1)
                         }
                     }
                 }
-                if (ph < NK - 1 || (PERSIST && pass < npass - 1)) { accs[par][lane][0] = a0; accs[par][lane][1] = a1; if (Q41) accs[par][lane][2] = summs; }
+                if (k < NK - 1 || (PERSIST && pass < npass - 1)) { accs[par][lane][0] = a0; accs[par][lane][1] = a1; if (Q41) accs[par][lane][2] = summs; }
+                __hip_atomic_store(&chain_seq[par], turn + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if (ph < NK - 1) __syncthreads();
+            if (!PERSIST || pass == npass - 1) turn0[par] += npass * NK;        // (the copy's next row starts behind this one's last turn)
         }
         if (gi == 0) LLC_STAMP(4);
         // ---- the row group is complete in its last wave: ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)) over the quad of lanes that holds the
@@ -386,13 +428,12 @@ __global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1)
             // the next row group's bytes start now -- behind this wave's chain and, for the last wave, behind the store (a load issued before the
             // residual's round trip would make the store wait for the whole prefetch: the compiler counts loads, it does not tell them apart).
             // Requested right after the lane sums (when w / dw / mw die) they would keep 40 registers busy next to the 96 of the lane sums.
-            // (multi-pass rows: the row group's next pass; the last wave's state reaches the first wave of that pass behind one more barrier)
+            // (multi-pass rows: the row group's next pass; the last wave's state reaches the first wave of that pass through chain_seq)
             const bool more = pass + 1 < npass;
             const int next_unit = more ? unit : unit + (int)gridDim.x;
             int nqlo, nnq;
             slice_of(more ? pass + 1 : 0, nqlo, nnq);
             if (next_unit < units) load_group(next_unit, nqlo, nnq);
-            if (more) __syncthreads();
         }
         if (PAIR == 1 && gi == 0) {
             // the w3 group's slice is requested only now.  Requested before the w1 chains it keeps both groups' registers alive: 214

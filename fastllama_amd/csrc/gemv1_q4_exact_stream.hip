@@ -54,9 +54,12 @@ __device__ unsigned st_tl_cur;
 #endif
 
 // EPI 0: y[row] = dot (+ resid[row]); 1: woven w1|w3 -> f32 silu(w1 x) * (w3 x); 2: woven w1|w3 -> the Q8_0 blocks (QA1 planes) of those features
-template <int TYPE, int PRO, int EPI, int U, int TAIL>
-__global__ __launch_bounds__(256, 2) void gemv1_q4_exact_stream_kernel(
-    int M, int groups, int KB, const uint32_t *__restrict__ qwd, const float *__restrict__ dW, const float *__restrict__ xf,
+// nw <= MAXW: the waves of a workgroup that stream a row group each (workgroup b: row groups b nw .. b nw + nw - 1); the workgroup has 64 MAXW threads,
+// the others only help with the prologue.  Four by default; launches that would not be resident at four take one workgroup per CU with equal shares
+// (launch_stream below).
+template <int TYPE, int PRO, int EPI, int U, int MAXW, int TAIL>
+__global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void gemv1_q4_exact_stream_kernel(
+    int M, int groups, int nw, int KB, const uint32_t *__restrict__ qwd, const float *__restrict__ dW, const float *__restrict__ xf,
     const void *__restrict__ aux, const float *__restrict__ mW, const int8_t *__restrict__ xq, const float *__restrict__ xd,
     const float *__restrict__ xs, float *__restrict__ y, const float *__restrict__ resid, float *__restrict__ ynorm,
     const uint16_t *__restrict__ silu_tab, int8_t *__restrict__ oq, float *__restrict__ od, float *__restrict__ os,
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void gemv1_q4_exact_stream_kernel(
     constexpr int NT = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     __shared__ double sh[4];
-    __shared__ float ex[4][16];
+    __shared__ float ex[MAXW][16];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NQ = (KB + 3) >> 2, NR = (NQ + U - 1) / U, NQP = NR * U;          // quads of a row, rounds of U, quads incl. the padding of the last round
     // LDS: [LX: the Q8_0 activation as the lanes read it, [NQP][4 k-groups][4 blocks][8 B: e0..e3 | e4..e7]] [d [4 NQP]] [s [4 NQP]]
@@ -78,8 +81,9 @@ __global__ __launch_bounds__(256, 2) void gemv1_q4_exact_stream_kernel(
     GP_DECL(PRO);
     GemvPrologue<PRO, NT, true>::issue(pv, pw, psl, psb, xf, aux, KB, 0);
 
-    const int grp = min((int)blockIdx.x * 4 + wave, groups - 1);
-    const bool live = (int)blockIdx.x * 4 + wave < groups;                   // (a wave past the last row group redoes it and stores nothing)
+    const bool active = wave < nw && (int)blockIdx.x * nw + wave < groups;   // (wave-uniform) this wave streams a row group; the others help with the prologue
+    const int grp = min((int)blockIdx.x * nw + wave, groups - 1);
+    const bool live = active;
     const int r = lane >> 2, g = lane & 3;
     // buffer loads: the wave-uniform part (row group, quad) in the scalar offset, one lane offset register per plane; bytes past a plane read as zero
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(qwd), 0, (int)((uint32_t)groups * (uint32_t)NQ * 1024u), 0x00020000);
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void gemv1_q4_exact_stream_kernel(
     }
     float rsd = 0.f;
     if constexpr (EPI == 0) {
-        if (resid) rsd = resid[min(grp * 16 + r, M - 1)];                   // (wave-uniform condition, clamped address)
+        if (resid && active) rsd = resid[min(grp * 16 + r, M - 1)];         // (wave-uniform condition, clamped address)
     }
     // the first U quads, each as (scale, nibbles) -- the order the loop re-requests them in, so that the compiler's count of the loads in flight
     // (s_waitcnt vmcnt) is the same at the loop's entry and at its back edge: with all scales ahead of all nibbles it waited, every round, as if
@@ -130,11 +134,13 @@ __global__ __launch_bounds__(256, 2) void gemv1_q4_exact_stream_kernel(
     //  profiles/r06_decode_exact.md: a short s_sleep between the activation's requests and the weights' (0.2 us: no change, 0.5 us: -2 %); the next quad's
     //  activation read from LDS one quad ahead (no change at 16 quads in flight, -8 % at 8); the two chains as one v_pk_fma_f32 with the lane sums
     //  converted by a v_dot4 onto the bits of 1.5 x 2^23 and a packed subtract (-22 % VALU instructions in the loop, bit-identical, no change in tok/s).)
+    if (active) {
 #pragma unroll
-    for (int i = 0; i < U; ++i) {
-        req_scale(i, i);
-        req_nib(i, i);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < U; ++i) {
+            req_scale(i, i);
+            req_nib(i, i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     ST_STAMP(1);
@@ -198,22 +204,24 @@ __global__ __launch_bounds__(256, 2) void gemv1_q4_exact_stream_kernel(
             if (Q41) summs = __fmaf_rn(msb[blk], sxv[blk], summs);          // (a block past K: s_x = 0, m_w finite)
         }
     };
+    if (active) {
 #pragma unroll 1
-    for (int rd = 0; rd < NR - 1; ++rd) {
+        for (int rd = 0; rd < NR - 1; ++rd) {
 #pragma unroll
-        for (int i = 0; i < U; ++i) {
-            const int q = rd * U + i;
-            consume(i, q);
-            req_scale(i, q + U);                                            // (the last round's padding quads: a cache-hot dummy, clamped; they meet d_x = 0)
-            req_nib(i, q + U);
+            for (int i = 0; i < U; ++i) {
+                const int q = rd * U + i;
+                consume(i, q);
+                req_scale(i, q + U);                                        // (the last round's padding quads: a cache-hot dummy, clamped; they meet d_x = 0)
+                req_nib(i, q + U);
+            }
         }
-    }
 #pragma unroll
-    for (int i = 0; i < U; ++i) consume(i, (NR - 1) * U + i);
+        for (int i = 0; i < U; ++i) consume(i, (NR - 1) * U + i);
+    }
 
 #ifdef LLC_TIMING
     asm volatile("" :: "v"(a0), "v"(a1));
-    if (lane == 0) tlw_[wave] = wall_clock64();
+    if (lane == 0 && wave < 4) tlw_[wave] = wall_clock64();
 #endif
     // ---- the row: ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)) over the quad of lanes that holds it (lane g: accumulators 2g, 2g+1)
     float e = a0, o = a1;
@@ -237,14 +245,16 @@ __global__ __launch_bounds__(256, 2) void gemv1_q4_exact_stream_kernel(
     } else {
         if (g == 0) ex[wave][r] = v;
         __syncthreads();
-        if (wave == 0) {                                                     // feature f of the block in lanes f and f + 32 (both halves compute, the lower stores)
-            const int f = lane & 31, p2 = (f >> 4) * 2;
+        // the workgroup's nw / 4 blocks of 32 features: the first wave of a block's four finishes it
+        const int blk = (int)blockIdx.x * (nw >> 2) + (wave >> 2);
+        if ((wave & 3) == 0 && active) {                                     // feature f of the block in lanes f and f + 32 (both halves compute, the lower stores)
+            const int f = lane & 31, p2 = wave + (f >> 4) * 2;
             const float h1 = ex[p2][f & 15], h3 = ex[p2 + 1][f & 15];
             const uint16_t hx = __half_as_ushort(__float2half_rn(h1));                // GGML_FP32_TO_FP16
             const float sl = __half2float(__ushort_as_half(silu_tab[hx]));           // table_silu_f16
             const float h = __fmul_rn(sl, h3);                                        // ggml_mul(silu, tmp)
             if constexpr (EPI == 1) {
-                if (lane < 32) put_y(y + (int)blockIdx.x * 32 + f, h);
+                if (lane < 32) put_y(y + blk * 32 + f, h);
             } else {
                 // quantize_row_q8_0 of the block (lib/ggml.c:1299-1441, AVX2: amax, d = amax / 127, id = 127 / amax, round to nearest even)
                 const float amax = wave_max_f32(fabsf(h));
@@ -257,10 +267,10 @@ __global__ __launch_bounds__(256, 2) void gemv1_q4_exact_stream_kernel(
                 isum += __shfl_xor(isum, 16);                                         // (32 features; the upper half of the wave holds the same 32)
                 if (lane < 32) {
                     const int i8 = f & 7;                                             // QA1: k-group bytes e0,e2,e4,e6 | e1,e3,e5,e7 (q4_layout.h)
-                    oq[(size_t)blockIdx.x * 32 + (f & 24) + ((i8 & 1) * 4 + (i8 >> 1))] = (int8_t)qi;
+                    oq[(size_t)blk * 32 + (f & 24) + ((i8 & 1) * 4 + (i8 >> 1))] = (int8_t)qi;
                     if (lane == 0) {
-                        od[blockIdx.x] = dq;
-                        os[blockIdx.x] = __fmul_rn(dq, (float)isum);
+                        od[blk] = dq;
+                        os[blk] = __fmul_rn(dq, (float)isum);
                     }
                 }
             }
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void gemv1_q4_exact_stream_kernel(
             rec[0] = tl_[0]; rec[1] = tl_[1]; rec[2] = tl_[2];
             for (int k_ = 0; k_ < 4; ++k_) rec[3 + k_] = tlw_[k_];
             rec[7] = tl_[3]; rec[8] = wall_clock64();
-            rec[9] = ((long long)(PRO * 100 + EPI * 10 + (U == 16)) << 32) | blockIdx.x;
+            rec[9] = ((long long)(PRO * 100 + EPI * 10 + (U == 16)) << 32) | blockIdx.x;      // (stamps of the first four waves only)
         }
     }
 #endif
@@ -295,6 +305,9 @@ extern "C" __attribute__((visibility("default"))) int fl_debug_stream_timeline(l
 }
 #endif
 
+// fl_debug_set(7, n) (tests): streaming waves per workgroup of the rms_norm forms, 0 = automatic
+int g_stream_force_nw = 0;
+
 // false: no QWD copy, or a shape outside this form's reach -> the caller takes the llc kernel
 template <int TYPE, int PRO, int EPI>
 static bool launch_stream(const fl_qtensor &W, const fl_qact *xq, float *y, hipStream_t st, const float *resid, const float *xf, const void *aux,
@@ -302,28 +315,49 @@ static bool launch_stream(const fl_qtensor &W, const fl_qact *xq, float *y, hipS
     if (!W.qwd) return false;
     const int KB = W.KB, NQ = (KB + 3) / 4, groups = W.M16 / 16;
     if (groups < 1 || KB < 1) return false;
-    if (EPI != 0 && (groups % 4 != 0 || W.M != W.M16)) return false;          // a workgroup = the w1 | w3 rows of 32 whole features
+    if (EPI != 0 && (groups % 4 != 0 || W.M != W.M16)) return false;          // a block = the w1 | w3 rows of 32 whole features = four row groups
     if (PRO == 1 && W.K > 8192) return false;                                 // (the rms_norm prologue keeps the row in registers: 256 threads x 32)
     if (qwd_bytes(W) >= (1ull << 31) || (size_t)W.M16 * (size_t)KB * 4 >= (1ull << 31)) return false;      // 32-bit buffer offsets
-    // quads in flight per wave: 16 (20 KB per wave, ~170 registers: two workgroups per CU) when that divides the row (K = 4096, 8192) AND the launch's
-    // workgroups are all resident at that (LLaMA-65B's w1|w3 is 688 workgroups: as 16 it ran in two rounds, 89 against 95 tok/s); else 8 (four per CU)
     static const int n_cus = [] { int d = 0, c = 0; return (hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && c > 0) ? c : 256; }();
-    const bool u16 = (NQ % 16 == 0 || NQ % 16 >= 13) && (groups + 3) / 4 <= 2 * n_cus;
+    // Row groups per workgroup: four, as long as that is at most two workgroups per CU (all resident at 16 quads in flight).  Measured against ONE
+    // workgroup per CU with the same number of row groups in each (profiles/r06_decode_exact.md): LLaMA-7B's wq|wk|wv as 256 x 3 instead of 192 x 4
+    // 10.1 against 9.2 us, w1|w3 as 172 x 8 instead of 344 x 4 15.4 against 15.5, 13B 374 against 390 tok/s -- four it is.  Beyond two workgroups per
+    // CU (LLaMA-65B's w1|w3: 688 of four) the launch IS one workgroup per CU with equal shares (230 x 12: 98 -> 103 tok/s).
+    // (The Q8_0 / plain-operand prologues are written for 256 threads: always four -- no LLaMA matrix takes them.)
+    int nw = 4;
+    if (PRO == 1) {
+        const int units = EPI == 0 ? groups : groups / 4, per = EPI == 0 ? 1 : 4;
+        if ((groups + 3) / 4 > 2 * n_cus) nw = std::max(4, per * ((units + n_cus - 1) / n_cus));
+        if (g_stream_force_nw > 0) nw = EPI == 0 ? g_stream_force_nw : (g_stream_force_nw + 3) / 4 * 4;
+        nw = std::min(nw, 12);
+    }
+    const int maxw = nw <= 4 ? 4 : nw <= 8 ? 8 : 12;
+    // quads in flight per wave: 16 (20 KB per wave, ~170 registers) when that divides the row (K = 4096, 8192) and the workgroup has at most 8 waves
+    // (two per SIMD); else 8
+    const bool u16 = (NQ % 16 == 0 || NQ % 16 >= 13) && maxw <= 8;
     const int U = u16 ? 16 : 8, NQP = (NQ + U - 1) / U * U;
     const size_t lds = (size_t)NQP * 160;
     if (lds > 60 * 1024) return false;
     const TpTail *tt = take_tail ? tp_take_tail() : nullptr;
-    const dim3 grid((groups + 3) / 4), block(256);
-#define FL_ST_GO(UU, TL)                                                                                                              \
-    hipLaunchKernelGGL((gemv1_q4_exact_stream_kernel<TYPE, PRO, EPI, UU, TL>), grid, block, lds, st, W.M, groups, KB, W.qwd, W.d, xf, \
-                       aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid, ynorm, silu_tab,          \
+    const dim3 grid((groups + nw - 1) / nw), block(64 * maxw);
+#define FL_ST_GO(UU, MW, TL)                                                                                                              \
+    hipLaunchKernelGGL((gemv1_q4_exact_stream_kernel<TYPE, PRO, EPI, UU, MW, TL>), grid, block, lds, st, W.M, groups, nw, KB, W.qwd, W.d, xf, \
+                       aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid, ynorm, silu_tab,              \
                        out ? out->q : nullptr, out ? out->d : nullptr, out ? out->s : nullptr, tt)
-    if constexpr (EPI == 2) {                       // (no exchange of Q8_0 blocks: the fold path keeps the f32 features)
-        if (u16) FL_ST_GO(16, 0); else FL_ST_GO(8, 0);
+#define FL_ST_TL(UU, MW)                                                                                                                  \
+    do {                                                                                                                                  \
+        if constexpr (EPI == 2) FL_ST_GO(UU, MW, 0);          /* (no exchange of Q8_0 blocks: the fold path keeps the f32 features) */      \
+        else if (tt) FL_ST_GO(UU, MW, 1);                                                                                                 \
+        else FL_ST_GO(UU, MW, 0);                                                                                                         \
+    } while (0)
+    if constexpr (PRO == 1) {
+        if (maxw == 4) { if (u16) FL_ST_TL(16, 4); else FL_ST_TL(8, 4); }
+        else if (maxw == 8) { if (u16) FL_ST_TL(16, 8); else FL_ST_TL(8, 8); }
+        else FL_ST_TL(8, 12);
     } else {
-        if (tt) { if (u16) FL_ST_GO(16, 1); else FL_ST_GO(8, 1); }
-        else { if (u16) FL_ST_GO(16, 0); else FL_ST_GO(8, 0); }
+        if (u16) FL_ST_TL(16, 4); else FL_ST_TL(8, 4);
     }
+#undef FL_ST_TL
 #undef FL_ST_GO
     return true;
 }

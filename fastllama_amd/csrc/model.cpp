@@ -108,6 +108,9 @@ struct fl_model : Act {
     fl_comm *comm = nullptr;
     bool finalized = false;
     size_t dev_bytes = 0;
+    bool lean = false;           // fl_model_prepare(.., 4): only the named copies, and no QW16 nibble plane beside BOTH derived copies
+    bool lean_h16 = false, lean_qwd = false;      // lean mode: which copies fl_model_prepare named
+    bool qs_dropped = false;     // the matmul tensors' QW16 nibble planes are gone (restore_qs brings them back from QWD)
     // decode hipGraph
     bool graph_enabled = true;
     bool fuse_decode = true;     // N == 1: norm-in-GEMV + one attention kernel per layer
@@ -468,10 +471,10 @@ int fl_model_set_comm(fl_model *m, fl_comm *c) {
 }
 
 // Row-split tensor-parallel decode over the communicator's fold regions (tp_tail.h): lays the four exchanged vectors out in the region
-// and builds the exchange records.  Before any graph capture (it allocates).  Every rank takes the same decision: the peer-mapped exchange is
-// agreed on by all ranks when the communicator is made, the sizes are the model's.  FL_TP_FOLD=0: the collective sequence (A/B, tests).
-static void ensure_fold(fl_model *m) {
-    if (m->fold_state != 0) return;
+// and builds the exchange records.  Before any graph capture (it allocates).  fold_local decides for THIS rank (the environment, the region's
+// size, an allocation); ensure_fold then has the ranks agree -- a sum over the communicator -- and folds only if every rank can: a rank on the
+// collective sequence next to peers spinning in fused tails would hang both.  FL_TP_FOLD=0: the collective sequence (A/B, tests).
+static void fold_local(fl_model *m) {
     m->fold_state = -1;
     if (const char *e = getenv("FL_TP_FOLD")) if (e[0] == '0') return;
     TpFold f;
@@ -513,6 +516,26 @@ static void ensure_fold(fl_model *m) {
     m->fq = fl_qact{reinterpret_cast<int8_t *>(own + off_q), reinterpret_cast<float *>(own + off_d), reinterpret_cast<float *>(own + off_s), 1, 16, (int)KB, nullptr};
     m->fql = fl_qact{m->fq.q + r * El, m->fq.d + r * KBl, m->fq.s + r * KBl, 1, 16, (int)KBl, nullptr};
     m->fold_state = 1;
+}
+static void ensure_fold(fl_model *m) {
+    if (m->fold_state != 0) return;
+    fold_local(m);
+    if (!m->comm || m->G < 2) return;
+    // COLLECTIVE: every rank of the communicator gets here before its first single-token eval, whatever it decided; the word travels in a work
+    // buffer that exists on every rank (nothing that could fail locally sits in front of the collective)
+    float mine = m->fold_state > 0 ? 1.f : 0.f, all = 0.f;
+    const bool moved = hipMemcpy(m->part, &mine, sizeof mine, hipMemcpyHostToDevice) == hipSuccess;
+    if (!moved) (void)hipMemset(m->part, 0, sizeof mine);
+    const bool summed = fl_comm_allreduce_sum_f32(m->comm, m->part, 1, m->stream) == FL_OK && hipStreamSynchronize(m->stream) == hipSuccess &&
+                        hipMemcpy(&all, m->part, sizeof all, hipMemcpyDeviceToHost) == hipSuccess;
+    if (summed && all == (float)m->G) return;              // every rank folds (or, with fold_state < 0 here, this rank would have made the sum smaller)
+    if (m->fold_state > 0) {
+        warn("tensor-parallel decode: %s: every rank runs the collective sequence (same results)",
+             summed ? "another rank cannot fold the exchanges into the decode launches" : "the ranks could not agree on folding the exchanges");
+        if (m->fold_dev) { (void)hipFree(m->fold_dev); m->fold_dev = nullptr; }
+        m->fold_state = -1;
+    }
+    (void)hipGetLastError();
 }
 
 namespace {
@@ -596,8 +619,7 @@ static hipError_t mm_norm_silu(fl_model *m, const fl_qtensor *W, const float *x,
     hipEvent_t e1;
     hipError_t r = prof_begin(m, &e1);
     if (r != hipSuccess) return r;
-    static const int form = getenv("FL_EXACT_PAIR") ? atoi(getenv("FL_EXACT_PAIR")) : 0;     // A/B: 1 / 2 pins a form (profiles/r04_decode_exact.md)
-    if (m->exact) r = gemv_q4_norm_silu_exact(*W, x, norm_w, m->silu_tab, act, m->stream, m->pair_ws, form);
+    if (m->exact) r = gemv_q4_norm_silu_exact(*W, x, norm_w, m->silu_tab, act, m->stream, m->pair_ws, 0);
     else r = gemv_q4_norm_silu(*W, x, norm_w, m->silu_tab, act, m->stream);
     prof_end(m, e1);
     return r;
@@ -625,8 +647,47 @@ static hipError_t mm_silu(fl_model *m, const fl_qtensor *W, const float *h13, fl
 
 // The WH16 copies of every matmul weight (4 x the nibble bytes: 13 GB at 7B of the 288 GB), built on the first reference-order
 // eval with N >= 9.  No memory for them: the round-3 kernel, which reads the nibbles, keeps the mode working.
+static std::vector<fl_qtensor *> matmul_tensors(fl_model *m) {
+    std::vector<fl_qtensor *> ts;
+    for (Layer &ly : m->layers) for (fl_qtensor *t : {ly.wqkv, ly.wo, ly.w13, ly.w2}) ts.push_back(t);
+    ts.push_back(m->output);
+    return ts;
+}
+// Lean memory mode.  With BOTH derived copies resident nothing in the reference-order path reads a matmul tensor's QW16 nibble
+// plane: N >= 2 takes WH16 (the H16 GEMM is exact at any N; run_eval_kernels lowers its threshold from 9 to 2 while the plane is gone), N = 1 takes
+// QWD, the scales stay (both kernels read them from the QW16 planes).  lean_drop frees the planes (3.3 GB at 7B); restore_qs rebuilds them from QWD -- a
+// permutation of nibbles, lossless -- before anything that does read them: the fast mode, a LoRA merge, a tensor download, a rebuild of a copy.
+static int restore_qs(fl_model *m) {
+    if (!m->qs_dropped) return FL_OK;
+    for (fl_qtensor *t : matmul_tensors(m)) {
+        if (t->qs) continue;
+        const size_t bytes = (size_t)t->M16 * t->KB * 16;
+        uint32_t *qs = nullptr;
+        M_HIP(hipMalloc((void **)&qs, bytes));
+        const hipError_t e = qwd_to_qw16(*t, qs, m->stream);
+        if (e != hipSuccess) { (void)hipFree(qs); return hip_fail(e, "qwd_to_qw16"); }
+        t->qs = qs;
+        m->dev_bytes += bytes;
+    }
+    M_HIP(hipStreamSynchronize(m->stream));
+    m->qs_dropped = false;
+    return FL_OK;
+}
+static void lean_drop(fl_model *m) {
+    if (!m->lean || m->qs_dropped || m->h16_state <= 0 || m->qwd_state <= 0 || !m->lora_backups.empty() || !m->exact) return;
+    (void)hipStreamSynchronize(m->stream);
+    for (fl_qtensor *t : matmul_tensors(m)) {
+        if (!t->qs || !t->h16 || !t->qwd || !t->owns) continue;
+        (void)hipFree(t->qs);
+        t->qs = nullptr;
+        m->dev_bytes -= (size_t)t->M16 * t->KB * 16;
+        m->qs_dropped = true;
+    }
+}
+
 static void ensure_h16(fl_model *m) {
     if (m->h16_state != 0) return;
+    if (m->lean && !m->lean_h16) { m->h16_state = -1; return; }      // (lean mode: a copy that was not asked for is never built -- same bits from the nibble-operand kernel)
     std::vector<fl_qtensor *> ts;
     for (Layer &ly : m->layers) for (fl_qtensor *t : {ly.wqkv, ly.wo, ly.w13, ly.w2}) ts.push_back(t);
     ts.push_back(m->output);
@@ -652,6 +713,7 @@ static void ensure_h16(fl_model *m) {
 // -- outside any graph capture.  No memory for them: round 3's producer / chain-wave kernel, which reads QW16, keeps the mode working.
 static void ensure_qwd(fl_model *m) {
     if (m->qwd_state != 0) return;
+    if (m->lean && !m->lean_qwd) { m->qwd_state = -1; return; }
     std::vector<fl_qtensor *> ts;
     for (Layer &ly : m->layers) for (fl_qtensor *t : {ly.wqkv, ly.wo, ly.w13, ly.w2}) ts.push_back(t);
     ts.push_back(m->output);
@@ -727,10 +789,15 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
     // reference-order prefill: the H16 form of the GEMM (gemm_q4_exact_h16.hip) with rope / K-V stores and silu * mul -> Q8_0 as its
     // epilogues; every Q8_0 operand gets its XH16 copy
     // (the fused launchers' own preconditions are part of the decision: a shape they refuse takes the unfused reference-order sequence)
-    const bool xh = exact && N >= 9 && !dyn && m->h16_state > 0 && m->qE.h16 && m->qEl.h16 && m->qF.h16 && !getenv("FL_EXACT_R3") &&
+    // (lean mode with the QW16 nibble planes dropped: every N >= 2 takes the H16 form -- exact at any N -- since nothing else can read the weights)
+    const bool xh = exact && N >= (m->qs_dropped ? 2 : 9) && !dyn && m->h16_state > 0 && m->qE.h16 && m->qEl.h16 && m->qF.h16 &&
                     D % 4 == 0 && El % 4 == 0 && l0 < m->L && gemm_q4_exact_h16_supports(*m->layers[l0].wqkv, m->qE, N) &&
                     gemm_q4_exact_h16_supports(*m->layers[l0].w13, m->qE, N) && m->layers[l0].w13->M % 64 == 0;
     m->xh = xh;
+    if (m->qs_dropped && (!exact || (N >= 2 && !xh))) {      // a path that reads the QW16 nibble planes after all: bring them back (they stay)
+        const int rc = restore_qs(m);
+        if (rc != FL_OK) return rc;
+    }
     // Row-split tensor-parallel decode over the fold region (tp_tail.h): the rows between the launches live in this rank's region, every
     // producer writes its slice there, and the exchange is the tail of the producing launch -- the layer is its five decode launches.
     const bool fold = tp && m->tp_rows && exact && fused && m->w13_il && m->fold_state > 0 && !kv_wait && !kv_rec && !body_only;
@@ -835,8 +902,7 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
         }
         // feed-forward                                                                             :412-436
         const bool silu_in_gemm = N >= 9 && m->w13_il && (!exact || xh);   // silu * mul -> Q8_0 is the epilogue of the w1|w3 matmul
-        static const bool nopair = getenv("FL_EXACT_NOPAIR") != nullptr;   // A/B: profiles/r04_decode_exact.md
-        const bool silu_in_gemv = fused && m->w13_il && !(exact && nopair && !tp);   // decode: silu * mul is the epilogue of the w1|w3 GEMV
+        const bool silu_in_gemv = fused && m->w13_il;   // decode: silu * mul is the epilogue of the w1|w3 GEMV
         // reference-order decode, unsharded: the w1|w3 workgroups own whole 32-feature blocks and write the Q8_0 operand of w2 themselves
         // (gemv1_q4_exact_stream.hip) -- w2 then is the plain N = 1 matmul on m->qF, its prologue a copy
         bool q8_from_w13 = false;
@@ -1162,6 +1228,7 @@ int fl_model_set_graph(fl_model *m, int mode) {
  * the reference's x86 build; 0: the fast kernels (exact block dots, own f32 order).  The decode graphs are re-captured. */
 int fl_model_set_exact(fl_model *m, int on) {
     if (!m) return set_error(FL_EINVAL, "null model");
+    if (!on && m->qs_dropped) { const int rc = restore_qs(m); if (rc != FL_OK) return rc; }      // (the fast kernels read the QW16 nibble planes)
     if ((on != 0) != m->exact) {
         if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
         if (m->graph_exec_long) (void)hipGraphExecDestroy(m->graph_exec_long);
@@ -1175,9 +1242,39 @@ int fl_model_get_exact(const fl_model *m) { return m && m->exact ? 1 : 0; }
 int fl_model_prepare(fl_model *m, int flags) {
     if (!m) return set_error(FL_EINVAL, "null model");
     if (!m->finalized) return set_error(FL_EINVAL, "fl_model_prepare: model not finalized");
+    if (flags & 4) {                       // lean: exactly the named copies, from now on
+        m->lean = true;
+        m->lean_h16 = (flags & 1) != 0;
+        m->lean_qwd = (flags & 2) != 0;
+        if (m->h16_state < 0 && m->lean_h16) m->h16_state = 0;      // (a copy an earlier lean call left out may be named now)
+        if (m->qwd_state < 0 && m->lean_qwd) m->qwd_state = 0;
+    }
+    if ((flags & 3) && m->qs_dropped) { const int rc = restore_qs(m); if (rc != FL_OK) return rc; }      // (the copies are built from the nibble planes)
     if (flags & 1) ensure_h16(m);
     if (flags & 2) ensure_qwd(m);
     M_HIP(hipStreamSynchronize(m->stream));
+    lean_drop(m);
+    return FL_OK;
+}
+/* resident bytes by kind: [0] QW16 nibble planes, [1] scale planes (d, m), [2] WH16 copies, [3] QWD copies, [4] everything else (K / V cache, work
+ * buffers, tables, token embeddings' share included in 0 / 1) */
+int fl_model_memory(const fl_model *m_, size_t *bytes5) {
+    fl_model *m = const_cast<fl_model *>(m_);
+    if (!m || !bytes5) return set_error(FL_EINVAL, "null argument");
+    size_t b[5] = {0, 0, 0, 0, 0};
+    std::vector<fl_qtensor *> ts = matmul_tensors(m);
+    if (m->tok_emb) ts.push_back(m->tok_emb);
+    for (fl_qtensor *t : ts) {
+        if (!t) continue;
+        const size_t nblk = (size_t)t->M16 * t->KB;
+        if (t->qs) b[0] += nblk * 16;
+        b[1] += nblk * (t->m ? 8 : 4);
+        if (t->h16) b[2] += wh16_bytes(*t);
+        if (t->qwd) b[3] += qwd_bytes(*t);
+    }
+    const size_t known = b[0] + b[1] + b[2] + b[3];
+    b[4] = m->dev_bytes > known ? m->dev_bytes - known : 0;
+    for (int i = 0; i < 5; ++i) bytes5[i] = b[i];
     return FL_OK;
 }
 /* launches of one decode token: the nodes of the decode hipGraph captured last (0: none captured yet) */
@@ -1367,6 +1464,7 @@ extern "C" int fl_model_lora_apply(fl_model *m, const char *base_name, const flo
     int rc = locate_tensor(m, base_name, &tr);
     if (rc != FL_OK) return rc;
     fl_qtensor *t = tr.t;
+    if ((rc = restore_qs(m)) != FL_OK) return rc;          // (lean mode: the merge works on the QW16 planes; they stay until the next fl_model_prepare(.., 4))
     M_HIP(hipStreamSynchronize(m->stream));
     const size_t nblk = (size_t)t->M16 * t->KB;
     if (keep_backup) {
@@ -1418,6 +1516,7 @@ extern "C" int fl_model_lora_apply(fl_model *m, const char *base_name, const flo
 /* put back every tensor saved by fl_model_lora_apply(keep_backup = 1) and drop the copies */
 extern "C" int fl_model_lora_restore(fl_model *m) {
     if (!m) return set_error(FL_EINVAL, "null model");
+    if (const int rc = restore_qs(m)) return rc;
     M_HIP(hipStreamSynchronize(m->stream));
     // (device-to-device copies on the EVAL stream: a plain hipMemcpy runs on the null stream, which a non-blocking stream does not wait for)
     for (auto &bk : m->lora_backups) {
@@ -1450,6 +1549,7 @@ extern "C" int fl_model_tensor_download(fl_model *m, const char *base_name, void
     int rc = locate_tensor(m, base_name, &tr);
     if (rc != FL_OK) return rc;
     const fl_qtensor *t = tr.t;
+    if ((rc = restore_qs(m)) != FL_OK) return rc;
     const int bs = t->type == FL_TYPE_Q4_0 ? 20 : 24;
     void *aos = nullptr;
     M_HIP(hipMalloc(&aos, (size_t)t->M * t->KB * bs));

@@ -80,6 +80,7 @@ hipError_t gemm_q4_exact_h16_silu(const fl_qtensor &W, const fl_qact &xq, int N,
 // launchers return false when the tensor has no QWD copy or the shape is outside the kernel's reach (-> round 3's kernel)
 size_t qwd_bytes(const fl_qtensor &W);
 hipError_t qw16_to_qwd(const fl_qtensor &W, uint32_t *qwd, hipStream_t st);
+hipError_t qwd_to_qw16(const fl_qtensor &W, uint32_t *qs, hipStream_t st);   // the inverse: W.qwd -> a QW16 nibble plane (lean memory mode, model.cpp)
 bool gemv1_llc(const fl_qtensor &W, const fl_qact &xq, float *y, hipStream_t st, const float *resid);
 bool gemv1_llc_norm(const fl_qtensor &W, const float *x, const float *norm_w, float *ynorm, float *y, hipStream_t st);
 bool gemv1_llc_silu(const fl_qtensor &W, const float *h13, const uint16_t *silu_tab, float *y, const float *resid, hipStream_t st, bool woven);

@@ -53,6 +53,7 @@ static const fl::InternalTable *const IT = fl_internal_table();
 #define g_gemm_force_cfg (*IT->g_gemm_force_cfg)
 #define g_gemv_force_waves (*IT->g_gemv_force_waves)
 #define g_stream_min_groups (*IT->g_stream_min_groups)
+#define g_stream_force_nw (*IT->g_stream_force_nw)
 #define g_op_mode (*IT->g_op_mode)
 
 #define FL_HIP(call)                                   \
@@ -83,6 +84,7 @@ int fl_debug_set(int what, int value) {
     if (what == 0) g_gemm_force_cfg = value;
     if (what == 1) g_gemv_force_waves = value;   // 0 = automatic, else 4 / 8 / 16 waves per 16-row group
     if (what == 2) g_debug_exact = value;            // the single-token test hooks (fl_debug_gemv_*, fl_debug_decode_attention*) in exact mode
+    if (what == 7) g_stream_force_nw = value;        // ... and its row groups per workgroup (0 automatic; rounded up to whole 32-feature blocks for the woven forms)
     if (what == 6) g_stream_min_groups = value;      // reference-order N = 1 matmuls: row groups from which the one-wave-per-row-group form runs (-1 automatic, 1 always, 1 << 30 never)
     if (what == 5) g_debug_pair1 = value;            // fl_debug_gemv_norm_silu in exact mode: 1 / 2 pins a form of the w1|w3 kernel, 0 automatic
     if (what == 4) g_op_mode = value;            // (= fl_set_op_mode: kept for the sweep scripts)
@@ -178,7 +180,7 @@ int fl_debug_rmsnorm_quant(const float *x, int ldx, const float *w, int N, int E
 }
 // (the reference-order single-token hooks run the kernel of record: it reads the tensor's QWD copy)
 static int dbg_qwd(const fl_qtensor *W, void *stream) {
-    if (!g_debug_exact || !W || W->qwd || getenv("FL_EXACT_R3")) return FL_OK;
+    if (!g_debug_exact || !W || W->qwd) return FL_OK;
     return fl_qtensor_build_qwd(const_cast<fl_qtensor *>(W), stream);
 }
 int fl_debug_gemv_norm(const fl_qtensor *W, const float *x, const float *norm_w, float *ynorm, float *y, void *stream) {

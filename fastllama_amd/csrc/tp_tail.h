@@ -53,6 +53,9 @@ struct TpTail {
 extern thread_local const TpTail *tp_pending_tail;
 inline const TpTail *tp_take_tail() { const TpTail *t = tp_pending_tail; tp_pending_tail = nullptr; return t; }
 hipError_t tp_tail_launch(const TpTail *tt_dev, hipStream_t st);       // eval_kernels.hip: the tail as a launch of its own (one workgroup)
+// one epoch of the communicator's self-test (eval_kernels.hip): a multi-workgroup producer with fused tails, then a consumer launch reading with plain loads
+hipError_t tp_selftest_epoch(const TpTail *exchange_dev, const TpTail *barrier_dev, unsigned area_off, unsigned slice_words, unsigned epoch,
+                             unsigned *errors_dev, unsigned *sink_dev, hipStream_t st);
 
 #ifdef __HIPCC__
 // A producer's store of one value of its slice, with a tail: into this rank's region (written through: the workgroup that publishes runs on another

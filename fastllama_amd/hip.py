@@ -157,6 +157,7 @@ _PROTOS = {
     "fl_default_exact": (C.c_int, []),
     "fl_model_prepare": (C.c_int, [C.c_void_p, C.c_int]),
     "fl_model_prepared": (C.c_int, [C.c_void_p]),
+    "fl_model_memory": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fl_model_graph_nodes": (C.c_int, [C.c_void_p]),
     "fl_model_tp_folded": (C.c_int, [C.c_void_p]),
     "fl_set_op_mode": (C.c_int, [C.c_int]),

@@ -46,8 +46,7 @@ def main():
     rank, world, idfile, outfile = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch
-    import oracle
-    from fastllama_amd import hip
+    from fastllama_amd import hip, ops
     from harness import ggjt
     from harness.flmodel import FlModel
     p2p_dir = sys.argv[5] if len(sys.argv) > 5 else None         # peer-exchange communicator, every rank on device 0 (see below)
@@ -76,7 +75,12 @@ def main():
             raise SystemExit("fl_comm_create: " + L.fl_last_error().decode())
         comm = C.c_void_p(comm)
     cfg, qtype = ggjt.SMALL, ggjt.Q4_0
-    tensors = ggjt.synth_tensors(cfg, qtype, oracle.Port().quantize_q4, seed=4321)
+    # the weights are quantized by the LIBRARY's quantize_row_q_reference -- bit for bit the rule of the reference's ggml_quantize_q4_x
+    # (tests/test_kernels_gpu.py) and of the checker the parent test quantizes its copy with: a rank needs no checker library to start
+    def quantize(qt, w):
+        t = torch.from_numpy(np.ascontiguousarray(w)).cuda(dev)
+        return ops.quantize_row_q(qt, t.view(-1), reference=True).view(w.shape[0], -1).cpu().numpy()
+    tensors = ggjt.synth_tensors(cfg, qtype, quantize, seed=4321)
     toks = ggjt.text_tokens("The quick brown fox jumps over the lazy dog")
     m = FlModel(cfg, qtype, tensors, n_ctx=128, max_batch=64, tp_rank=rank, tp_size=world, device=dev)
     m.set_comm(comm)

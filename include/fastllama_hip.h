@@ -238,9 +238,15 @@ int fl_default_exact(void); /* the mode new models start in: environment FL_EXAC
  * 130 GB at 65B) and QWD for single-token evals (1 x).  By default they are built inside the first eval that needs them; fl_model_prepare
  * builds them NOW (flags bit 0: WH16, bit 1: QWD), so that no timed or latency-sensitive eval pays for it.  Returns FL_OK also when a copy does
  * not fit: the warning handler is told how many bytes were missing and the kernel family that reads the primary layout runs instead (same bits,
- * ~1.3-1.45 x the time).  fl_model_prepared: which copies are resident (same bits; a negative state = tried and dropped reads as 0). */
+ * ~1.3-1.45 x the time).  fl_model_prepared: which copies are resident (same bits; a negative state = tried and dropped reads as 0).
+ * flags bit 2 (value 4) -- LEAN memory mode: from now on the model holds exactly the copies named in this call (a decode-only session, flags 2 | 4,
+ * never builds the 13 GB of WH16: its prefill runs the nibble-operand kernel, same bits), and when BOTH copies are resident the QW16 nibble planes of
+ * the matmul tensors -- which nothing in the reference-order path reads then -- are freed (3.3 GB at 7B).  They come back from the QWD copy, bit for bit,
+ * before anything that reads them: fl_model_set_exact(m, 0), a LoRA merge, fl_model_tensor_download, a later fl_model_prepare.
+ * fl_model_memory: resident bytes by kind: [0] QW16 nibble planes, [1] scale planes, [2] WH16, [3] QWD, [4] everything else (K / V, work buffers). */
 int fl_model_prepare(fl_model *m, int flags);
 int fl_model_prepared(const fl_model *m);
+int fl_model_memory(const fl_model *m, size_t *bytes5);
 /* Kernel nodes of the decode hipGraph captured last = launches per decode token (0: none captured yet). */
 int fl_model_graph_nodes(const fl_model *m);
 /* 1: the decode exchanges of this row-split tensor-parallel model are the tails of the launches that produce the data (peer-mapped

@@ -448,10 +448,11 @@ def test_exact_feed_forward_pair_and_quant_prologue(torch, ops, port, exact_hook
 @pytest.fixture()
 def stream_form(exact_hooks):
     """fl_debug_set(6, 1): every reference-order N = 1 matmul takes the one-wave-per-row-group form (gemv1_q4_exact_stream.hip),
-    whatever its row count (automatic: from two row groups per CU on)"""
+    whatever its row count (automatic: from three row groups per CU on)"""
     exact_hooks.fl_debug_set(6, 1)
     yield exact_hooks
     exact_hooks.fl_debug_set(6, -1)
+    exact_hooks.fl_debug_set(7, 0)
 
 
 @pytest.mark.parametrize("nm,qt", Q4)
@@ -469,12 +470,17 @@ def test_stream_form_with_every_prologue(torch, ops, port, stream_form, nm, qt, 
     xd, rd = dev(torch, x), dev(torch, res)
     if K <= 8192:
         nw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
-        y = torch.full((M,), 3.0, device="cuda")
-        yn = torch.zeros((1, K), device="cuda")
-        hip.check(L.fl_debug_gemv_norm(W.handle, xd.data_ptr(), dev(torch, nw).data_ptr(), yn.data_ptr(), y.data_ptr(), None))
         cur = le.rms_norm_mul(x, nw)
-        assert np.array_equal(bits(yn.cpu().numpy()), bits(cur))
-        assert np.array_equal(bits(y.cpu().numpy()), bits(port.mul_mat_q(qt, wq, cur, strict=False)[0]))
+        want_n = port.mul_mat_q(qt, wq, cur, strict=False)[0]
+        # row groups per workgroup: automatic (one workgroup per CU), 1, 3 (a 4-wave workgroup with an idle wave), 7 (8 waves), 12
+        for per_wg in (0, 1, 3, 7, 12):
+            L.fl_debug_set(7, per_wg)
+            y = torch.full((M,), 3.0, device="cuda")
+            yn = torch.zeros((1, K), device="cuda")
+            hip.check(L.fl_debug_gemv_norm(W.handle, xd.data_ptr(), dev(torch, nw).data_ptr(), yn.data_ptr(), y.data_ptr(), None))
+            assert np.array_equal(bits(yn.cpu().numpy()), bits(cur)), per_wg
+            assert np.array_equal(bits(y.cpu().numpy()), bits(want_n)), per_wg
+        L.fl_debug_set(7, 0)
     want = (port.mul_mat_q(qt, wq, x, strict=False)[0] + res).astype(np.float32)
     y = torch.full((M,), 3.0, device="cuda")
     hip.check(L.fl_debug_gemv_quant(W.handle, xd.data_ptr(), y.data_ptr(), rd.data_ptr(), None))
@@ -509,16 +515,19 @@ def test_stream_form_writes_the_q8_operand_of_w2(torch, ops, port, stream_form, 
     cur = le.rms_norm_mul(x, nw)
     h1, h3 = port.mul_mat_q(qt, w1, cur, strict=False), port.mul_mat_q(qt, w3, cur, strict=False)
     want_act = (le.silu(h1) * h3).astype(np.float32)
-    act = torch.full((F,), 9.0, device="cuda")
     L.fl_debug_set(5, 0)
-    hip.check(L.fl_debug_gemv_norm_silu(W.handle, xd.data_ptr(), nd.data_ptr(), sd.data_ptr(), act.data_ptr(), None))
-    assert np.array_equal(bits(act.cpu().numpy()), bits(want_act[0]))
     a = ops.QAct(1, F)
-    for _ in range(2):
-        hip.check(L.fl_debug_gemv_norm_silu_q8(W.handle, xd.data_ptr(), nd.data_ptr(), sd.data_ptr(), a.handle, None))
-        a.N, a.K = 1, F
-        got = a.export().cpu().numpy()
-        assert np.array_equal(got[0], port.quantize_row_q8_0(want_act[0]).reshape(-1))
+    for per_wg in (0, 4, 8, 12):                                # blocks of 32 features per workgroup: automatic (one workgroup per CU), 1, 2, 3
+        L.fl_debug_set(7, per_wg)
+        act = torch.full((F,), 9.0, device="cuda")
+        hip.check(L.fl_debug_gemv_norm_silu(W.handle, xd.data_ptr(), nd.data_ptr(), sd.data_ptr(), act.data_ptr(), None))
+        assert np.array_equal(bits(act.cpu().numpy()), bits(want_act[0])), per_wg
+        for _ in range(2):
+            hip.check(L.fl_debug_gemv_norm_silu_q8(W.handle, xd.data_ptr(), nd.data_ptr(), sd.data_ptr(), a.handle, None))
+            a.N, a.K = 1, F
+            got = a.export().cpu().numpy()
+            assert np.array_equal(got[0], port.quantize_row_q8_0(want_act[0]).reshape(-1)), per_wg
+    L.fl_debug_set(7, 0)
     w2 = port.quantize_q4(qt, (rng.standard_normal((E, F)) * 0.05).astype(np.float32))
     W2 = ops.QTensor(qt, w2, E, F)
     res = rng.standard_normal(E).astype(np.float32)
