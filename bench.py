@@ -274,7 +274,7 @@ def main():
         try:
             if args.model != "7B" or qtype != 2 or N != 512 or tp:
                 return None, None
-            for rnd in ("r05", "r04", "r03", "r02"):              # the latest committed pass that has the kernel
+            for rnd in ("r06", "r05", "r04", "r03", "r02"):       # the latest committed pass that has the kernel
                 path = os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json")
                 if os.path.exists(path):
                     with open(path) as f:
@@ -286,7 +286,7 @@ def main():
             return None, None
 
     KERNELS = {   # (prefill GEMM, decode GEMV) of a mode: names as rocprofv3 prints them
-        "exact": ("gemm_q4_exact_h16_kernel", "gemv1_q4_exact_llc_kernel"),
+        "exact": ("gemm_q4_exact_h16_kernel", "gemv1_q4_exact_stream_kernel"),
         "fast": ("gemm_q4_mfma32_kernel", "gemv_q4_kernel"),
     }
 

@@ -8,6 +8,11 @@ namespace fl {
 
 // rms_norm(x) * w -> optional f32 copy y_f32 (may be null) -> optional Q8_0 workspace `out` (may be null)
 // with_h16 (layout 16): also the XH16 copy of the quants (q4_layout.h), the operand form of the reference-order prefill GEMM
+// row-split tensor parallelism, prefill (model.cpp): x = all-gathered rows + residual, written, then rms_norm * w -> Q8_0 -- one launch; and the
+// all-gathered packed QA16 planes of every rank's K blocks -> the consumer's d / s planes + XH16 copy (+ q plane) -- one launch
+hipError_t rmsnorm_quant_gathered(const float *gathered, int G, int El, const float *resid, int ldr, float *x, int ldx, const float *w, int N, int E,
+                                  float *y_f32, int ldy, const fl_qact *out, int layout, hipStream_t st, bool with_h16);
+hipError_t gathered_qa16_to_operand(const void *stage, size_t msg_bytes, int G, int KBl, int N, const fl_qact &full, bool with_q, bool with_h16, hipStream_t st);
 hipError_t rmsnorm_quant(const float *x, int ldx, const float *w, int N, int E, float *y_f32, int ldy,
                          const fl_qact *out, int layout, hipStream_t st, bool with_h16 = false);
 // silu_table(h13[:, :F]) * h13[:, F:2F] -> Q8_0

@@ -42,11 +42,15 @@ __device__ __forceinline__ double block_sum_f64(double v, double *sh) {
 // ------------------------------------------------------------------------------------------------
 constexpr int RN_MAXIT = 4;  // 256 threads * 8 elements * 4 = E <= 8192
 
-__global__ __launch_bounds__(256) void rmsnorm_quant_kernel(const float *__restrict__ x, int ldx,
+// gath (row-split tensor parallelism, prefill): the row is not in x yet -- it is the all-gathered output rows of the wo / w2 matmul, tmp[rank][n][El],
+// plus the residual (the ggml_add of lib/llama.cpp:407, :441: one plain f32 add per element, as gather_rows_add_kernel did in a launch of its own);
+// the sum is written to x (the next residual) on the way.
+struct RmsGather { const float *tmp; const float *resid; int ldr, El, rows; };      // rows = N of the all-gather (the stride between ranks is rows * El)
+__global__ __launch_bounds__(256) void rmsnorm_quant_kernel(float *__restrict__ x, int ldx,
                                                             const float *__restrict__ w, int N, int E,
                                                             float *__restrict__ y_f32, int ldy, int layout,
                                                             int8_t *__restrict__ q, float *__restrict__ d,
-                                                            float *__restrict__ s, uint16_t *__restrict__ h16) {
+                                                            float *__restrict__ s, uint16_t *__restrict__ h16, const RmsGather gath) {
     __shared__ double sh[4];
     const int n = blockIdx.x;
     const int gpr = E >> 3, KB = E >> 5;
@@ -66,7 +70,17 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_kernel(const float *__restr
 #pragma unroll
     for (int it = 0; it < RN_MAXIT; ++it) {
         const int kg = threadIdx.x + it * 256;
-        if (kg < gpr && n < N) {
+        if (kg < gpr && n < N && gath.tmp) {
+            const int e = kg * 8, r = e / gath.El, j = e - r * gath.El;      // (El % 8 == 0: the eight elements are one rank's)
+            const float *tp = gath.tmp + ((int64_t)r * gath.rows + n) * gath.El + j, *rp = gath.resid + (int64_t)n * gath.ldr + e;
+            const float4 a = *reinterpret_cast<const float4 *>(tp), c = *reinterpret_cast<const float4 *>(tp + 4);
+            const float4 ra = *reinterpret_cast<const float4 *>(rp), rc = *reinterpret_cast<const float4 *>(rp + 4);
+            v[it][0] = __fadd_rn(a.x, ra.x); v[it][1] = __fadd_rn(a.y, ra.y); v[it][2] = __fadd_rn(a.z, ra.z); v[it][3] = __fadd_rn(a.w, ra.w);
+            v[it][4] = __fadd_rn(c.x, rc.x); v[it][5] = __fadd_rn(c.y, rc.y); v[it][6] = __fadd_rn(c.z, rc.z); v[it][7] = __fadd_rn(c.w, rc.w);
+            float4 *xp = reinterpret_cast<float4 *>(x + (int64_t)n * ldx + e);
+            xp[0] = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
+            xp[1] = make_float4(v[it][4], v[it][5], v[it][6], v[it][7]);
+        } else if (kg < gpr && n < N) {
             const float4 a = *reinterpret_cast<const float4 *>(x + (int64_t)n * ldx + kg * 8);
             const float4 c = *reinterpret_cast<const float4 *>(x + (int64_t)n * ldx + kg * 8 + 4);
             v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
@@ -101,9 +115,19 @@ hipError_t rmsnorm_quant(const float *x, int ldx, const float *w, int N, int E, 
                          const fl_qact *out, int layout, hipStream_t st, bool with_h16) {
     if (E % 32 != 0 || E > 256 * 8 * RN_MAXIT) return hipErrorInvalidValue;
     const int rows = (out && layout == 16) ? fl_roundup(N, 16) : N;
+    hipLaunchKernelGGL(rmsnorm_quant_kernel, dim3(rows), dim3(256), 0, st, const_cast<float *>(x), ldx, w, N, E, y_f32, ldy, layout,
+                       out ? out->q : nullptr, out ? out->d : nullptr, out ? out->s : nullptr,
+                       out && with_h16 && layout == 16 ? out->h16 : nullptr, RmsGather{nullptr, nullptr, 0, 0, 0});
+    return hipGetLastError();
+}
+// x[n][:] = gathered[rank][n][El] + resid[n][:] (written), then rms_norm * w -> Q8_0 as above: one launch instead of gather_rows_add + rmsnorm_quant
+hipError_t rmsnorm_quant_gathered(const float *gathered, int G, int El, const float *resid, int ldr, float *x, int ldx, const float *w, int N, int E,
+                                  float *y_f32, int ldy, const fl_qact *out, int layout, hipStream_t st, bool with_h16) {
+    if (E % 32 != 0 || E > 256 * 8 * RN_MAXIT || G * El != E || El % 8 != 0 || (ldr & 3) || (ldx & 3)) return hipErrorInvalidValue;
+    const int rows = (out && layout == 16) ? fl_roundup(N, 16) : N;
     hipLaunchKernelGGL(rmsnorm_quant_kernel, dim3(rows), dim3(256), 0, st, x, ldx, w, N, E, y_f32, ldy, layout,
                        out ? out->q : nullptr, out ? out->d : nullptr, out ? out->s : nullptr,
-                       out && with_h16 && layout == 16 ? out->h16 : nullptr);
+                       out && with_h16 && layout == 16 ? out->h16 : nullptr, RmsGather{gathered, resid, ldr, El, N});
     return hipGetLastError();
 }
 
@@ -1948,6 +1972,58 @@ hipError_t unpack3(const void *stage, size_t msg_bytes, int G, int rows, void *o
     hipLaunchKernelGGL(unpack3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const uint32_t *>(stage),
                        (int64_t)(msg_bytes >> 2), G, rows, reinterpret_cast<uint32_t *>(o0), (int)(chunk0 >> 2), reinterpret_cast<uint32_t *>(o1),
                        (int)(chunk1 >> 2), reinterpret_cast<uint32_t *>(o2), (int)(chunk2 >> 2));
+    return hipGetLastError();
+}
+
+// The all-gathered Q8_0 operand of a row-split wo / w2 matmul (prefill): message r = rank r's QA16 planes of ITS KBl blocks, packed [q | d | s] for the
+// N16 columns of this eval -> the consumer's operand of KB = G KBl blocks: the d / s planes (QA16), the XH16 copy the reference-order GEMM reads
+// (q4_layout.h), and -- qout != null -- the q plane for consumers that read QA16.  One launch for what unpack3 + qa16_to_h16 did in two.
+// One thread per (column group incl. the second half of the last 32-column tile, global block, column).
+__global__ __launch_bounds__(256) void gathered_qa16_to_operand_kernel(const unsigned char *__restrict__ stage, int64_t msg, int G, int KBl, int NGT,
+                                                                       int64_t n_threads, uint4 *__restrict__ qout, float *__restrict__ dout,
+                                                                       float *__restrict__ sout, uint16_t *__restrict__ xh) {
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_threads) return;
+    const int KB = G * KBl, c16 = (int)(u & 15);
+    const int64_t gb = u >> 4;
+    const int grp = (int)(gb / KB), B = (int)(gb % KB), r = B / KBl, b = B - r * KBl;
+    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
+    if (grp < NGT) {
+        const unsigned char *m = stage + (int64_t)r * msg;
+        const int64_t cb = ((int64_t)grp * KBl + b) * 16 + c16, nq = (int64_t)NGT * 16 * KBl * 32, nd = (int64_t)NGT * 16 * KBl * 4;
+        const uint4 *qp = reinterpret_cast<const uint4 *>(m + cb * 32);
+        r0 = qp[0]; r1 = qp[1];
+        const int64_t ob = ((int64_t)grp * KB + B) * 16 + c16;
+        dout[ob] = *reinterpret_cast<const float *>(m + nq + cb * 4);
+        sout[ob] = *reinterpret_cast<const float *>(m + nq + nd + cb * 4);
+        if (qout) { qout[2 * ob] = r0; qout[2 * ob + 1] = r1; }
+    }
+    if (!xh) return;
+    const uint32_t dw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    const int tile = grp >> 1, i = (grp & 1) * 16 + c16;
+    unsigned char *blk = reinterpret_cast<unsigned char *>(xh) + ((int64_t)tile * KB + B) * 2048;
+    auto h16_of = [](int v) -> uint32_t { return (uint32_t)__half_as_ushort(__int2half_rn(v)); };
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {                       // (the 8-byte position p of QA16 holds k-group p ^ (((col >> 3) & 1) << 1), bytes e0,e2,e4,e6,e1,e3,e5,e7)
+        const int g = p ^ (((c16 >> 3) & 1) << 1);
+        int el[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            el[2 * t] = (int)(int8_t)((dw[2 * p] >> (8 * t)) & 0xFF);
+            el[2 * t + 1] = (int)(int8_t)((dw[2 * p + 1] >> (8 * t)) & 0xFF);
+        }
+        unsigned char *dst = blk + (g >> 1) * 1024 + (g & 1) * 8;
+        *reinterpret_cast<uint2 *>(dst + i * 16) = make_uint2(h16_of(el[0]) | (h16_of(el[1]) << 16), h16_of(el[2]) | (h16_of(el[3]) << 16));
+        *reinterpret_cast<uint2 *>(dst + (i + 32) * 16) = make_uint2(h16_of(el[4]) | (h16_of(el[5]) << 16), h16_of(el[6]) | (h16_of(el[7]) << 16));
+    }
+}
+hipError_t gathered_qa16_to_operand(const void *stage, size_t msg_bytes, int G, int KBl, int N, const fl_qact &full, bool with_q, bool with_h16, hipStream_t st) {
+    const int NGT = fl_roundup(N, 16) / 16, NG2 = (N + 31) / 32 * 2;
+    if ((msg_bytes & 15) || (with_h16 && !full.h16) || msg_bytes != (size_t)NGT * 16 * KBl * 40) return hipErrorInvalidValue;
+    const int64_t n = (int64_t)(with_h16 ? NG2 : NGT) * G * KBl * 16;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gathered_qa16_to_operand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<const unsigned char *>(stage),
+                       (int64_t)msg_bytes, G, KBl, NGT, n, with_q ? reinterpret_cast<uint4 *>(full.q) : nullptr, full.d, full.s, with_h16 ? full.h16 : nullptr);
     return hipGetLastError();
 }
 

@@ -53,6 +53,18 @@ __device__ unsigned st_tl_cur;
 #define ST_STAMP(k) do {} while (0)
 #endif
 
+// K / V history prefetch (the wq|wk|wv launch of a decode layer): the attention that follows reads, per head, the first min(pos, 256) rows of the K cache and
+// D rows of the V cache -- from HBM, 1.5-2 us behind its requests, while its 32 workgroups have nothing else to do.  Workgroup b of THIS launch runs
+// on XCD b % 8 and head h's attention workgroup on XCD h % 8: b touches one dword of every 128-byte line of the heads of its XCD class, right behind its
+// own weight requests; the lines wait in that XCD's L2 (which outlives the launch boundary for data nobody writes).  A hint: placement is what the
+// dispatcher does, not a contract -- a miss costs what it cost before.
+struct StreamPrefetch {
+    const float *kc, *vc;          // this layer's K cache [n_ctx][E] and transposed V cache [E][n_ctx]
+    const int *pos;                // device: the position (rows 0 .. pos - 1 are the history)
+    int E, D, H, n_ctx;
+};
+thread_local StreamPrefetch stream_pending_prefetch = {nullptr, nullptr, nullptr, 0, 0, 0, 0};
+
 // EPI 0: y[row] = dot (+ resid[row]); 1: woven w1|w3 -> f32 silu(w1 x) * (w3 x); 2: woven w1|w3 -> the Q8_0 blocks (QA1 planes) of those features
 // nw <= MAXW: the waves of a workgroup that stream a row group each (workgroup b: row groups b nw .. b nw + nw - 1); the workgroup has 64 MAXW threads,
 // the others only help with the prologue.  Four by default; launches that would not be resident at four take one workgroup per CU with equal shares
@@ -63,7 +75,7 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void gemv1_q4_exact_s
     const void *__restrict__ aux, const float *__restrict__ mW, const int8_t *__restrict__ xq, const float *__restrict__ xd,
     const float *__restrict__ xs, float *__restrict__ y, const float *__restrict__ resid, float *__restrict__ ynorm,
     const uint16_t *__restrict__ silu_tab, int8_t *__restrict__ oq, float *__restrict__ od, float *__restrict__ os,
-    const TpTail *__restrict__ tt) {
+    const TpTail *__restrict__ tt, const StreamPrefetch pf) {
     constexpr bool Q41 = TYPE == FL_TYPE_Q4_1;
     constexpr int NT = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
@@ -143,6 +155,30 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void gemv1_q4_exact_s
         }
     }
 
+    // ---- the K / V history of the attention that follows: one dword per 128-byte line, for the heads of this workgroup's XCD class
+    // (two loads per thread at most, requested and left alone: nothing waits for them before the kernel's end -- a loop would wait for each, and
+    //  with it for every weight request issued before it)
+    float pf0 = 0.f, pf1 = 0.f;
+    if constexpr (EPI == 0 && PRO == 1) {
+        if (pf.kc) {
+            const int pos = min(*pf.pos, 256), cls = (int)blockIdx.x & 7, ncls_wg = ((int)gridDim.x + 7 - cls) >> 3;
+            const int hpc = (pf.H + 7 - cls) >> 3;                            // heads h = cls, cls + 8, ...
+            const int klines = pf.D >> 5, vlines = (pos + 31) >> 5;          // 128-byte lines per K row of a head / per V row's history
+            const int per_head = pos * klines + pf.D * vlines, total = hpc * per_head;
+            auto line = [&](int i) __attribute__((always_inline)) -> const float * {
+                i = min(i, total - 1);
+                const int hh = i / per_head, j = i - hh * per_head, h = cls + 8 * hh;
+                if (j < pos * klines) return pf.kc + (size_t)(j / klines) * pf.E + h * pf.D + (j % klines) * 32;
+                const int jj = j - pos * klines;
+                return pf.vc + (size_t)(h * pf.D + jj / vlines) * pf.n_ctx + (jj % vlines) * 32;
+            };
+            if (total > 0) {
+                const int i0 = ((int)blockIdx.x >> 3) * (64 * MAXW) + (int)threadIdx.x, stride = ncls_wg * 64 * MAXW;
+                pf0 = *line(i0);
+                pf1 = *line(i0 + stride);
+            }
+        }
+    }
     ST_STAMP(1);
     // blocks past K (the partial last quad, the padding quads): d_x = s_x = 0, zero quants (written before the prologue's closing barrier)
     for (int i = KB * 4 + (int)threadIdx.x; i < NQP * 16; i += NT) {
@@ -290,6 +326,7 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void gemv1_q4_exact_s
         }
     }
 #endif
+    asm volatile("" :: "v"(pf0), "v"(pf1));                   // (the prefetch loads are waited for here at the latest; nothing uses them)
     if constexpr (TAIL) tp_tail<false, false, true>(tt);
 }
 #ifdef LLC_TIMING
@@ -339,11 +376,13 @@ static bool launch_stream(const fl_qtensor &W, const fl_qact *xq, float *y, hipS
     const size_t lds = (size_t)NQP * 160;
     if (lds > 60 * 1024) return false;
     const TpTail *tt = take_tail ? tp_take_tail() : nullptr;
+    StreamPrefetch pf = {nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    if (PRO == 1 && EPI == 0) { pf = stream_pending_prefetch; stream_pending_prefetch.kc = nullptr; }      // (offered by the model for exactly this launch)
     const dim3 grid((groups + nw - 1) / nw), block(64 * maxw);
 #define FL_ST_GO(UU, MW, TL)                                                                                                              \
     hipLaunchKernelGGL((gemv1_q4_exact_stream_kernel<TYPE, PRO, EPI, UU, MW, TL>), grid, block, lds, st, W.M, groups, nw, KB, W.qwd, W.d, xf, \
                        aux, W.m, xq ? xq->q : nullptr, xq ? xq->d : nullptr, xq ? xq->s : nullptr, y, resid, ynorm, silu_tab,              \
-                       out ? out->q : nullptr, out ? out->d : nullptr, out ? out->s : nullptr, tt)
+                       out ? out->q : nullptr, out ? out->d : nullptr, out ? out->s : nullptr, tt, pf)
 #define FL_ST_TL(UU, MW)                                                                                                                  \
     do {                                                                                                                                  \
         if constexpr (EPI == 2) FL_ST_GO(UU, MW, 0);          /* (no exchange of Q8_0 blocks: the fold path keeps the f32 features) */      \
@@ -377,6 +416,9 @@ static int stream_min_groups() {
 }
 static bool stream_wanted(const fl_qtensor &W) { return W.M16 / 16 >= stream_min_groups(); }
 
+void gemv1_stream_offer_kv_prefetch(const float *kc, const float *vc, const int *pos_dev, int E, int D, int H, int n_ctx) {
+    stream_pending_prefetch = StreamPrefetch{kc, vc, pos_dev, E, D, H, n_ctx};
+}
 #define FL_TYPED(CALL0, CALL1) (W.type == FL_TYPE_Q4_0 ? (CALL0) : (CALL1))
 bool gemv1_stream(const fl_qtensor &W, const fl_qact &xq, float *y, hipStream_t st, const float *resid) {
     if (!stream_wanted(W)) return false;

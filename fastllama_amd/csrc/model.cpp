@@ -114,6 +114,7 @@ struct fl_model : Act {
     // decode hipGraph
     bool graph_enabled = true;
     bool fuse_decode = true;     // N == 1: norm-in-GEMV + one attention kernel per layer
+    bool kv_prefetch = true;     // reference-order decode: the wq|wk|wv launch touches the K / V history the attention reads (fl_model_set_graph bit 9 switches it off: A/B)
     bool fuse_prefill_attn = true;   // N >= 9: KQ + soft_max + KQV in one launch
     int force_deep_attn = 0;         // debugging: always the key-tiled form of that launch
     bool ingest_one_stream = false;  // debugging: fl_model_ingest takes its chunks one after the other
@@ -605,11 +606,11 @@ static hipError_t mm_qkv_rope(fl_model *m, const fl_qtensor *W, const fl_qact &a
 }
 
 // prefill: Q8_0(silu(w1 x) * (w3 x)) straight from the w1|w3 matmul (rows woven by 16) into the w2 matmul's operand
-static hipError_t mm_silu_gemm(fl_model *m, const fl_qtensor *W, const fl_qact &a, int N) {
+static hipError_t mm_silu_gemm(fl_model *m, const fl_qtensor *W, const fl_qact &a, int N, const fl_qact &out) {
     hipEvent_t e1;
     hipError_t r = prof_begin(m, &e1);
     if (r != hipSuccess) return r;
-    r = (m->exact ? gemm_q4_exact_h16_silu : gemm_q4_mfma_silu)(*W, a, N, m->silu_tab, m->qF, m->stream);
+    r = (m->exact ? gemm_q4_exact_h16_silu : gemm_q4_mfma_silu)(*W, a, N, m->silu_tab, out, m->stream);
     prof_end(m, e1);
     return r;
 }
@@ -804,6 +805,41 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
     float *inp = fold ? m->fx : m->x, *mid = fold ? m->fx2 : m->x2;
     if (!body_only) M_HIP(get_rows_qw16(*m->tok_emb, m->tok_dev, N, inp, E, st));       // inpL = get_rows  llama.cpp:304
     if (l1 < 0) l1 = m->L;
+    // Row-split tensor parallelism, prefill (round 6): per exchange ONE collective and at most one kernel, instead of pack3 ->
+    // all-gather -> unpack3 -> qa16_to_h16 and all-gather -> gather_rows_add:
+    //   * the producers of the Q8_0 operands (the attention's P.V epilogue, the silu epilogue of w1|w3) write their planes straight into the send
+    //     buffer, packed [q | d | s] for THIS eval's columns (tp_send_view): no pack launch;
+    //   * one launch turns the G gathered messages into what the consumer GEMM reads -- d / s planes and the XH16 copy (gathered_qa16_to_operand);
+    //   * the all-gathered output rows of wo / w2 are NOT added to the residual in a launch of their own: the rms_norm that follows reads them from
+    //     the gather buffer, adds, writes the sum back as the next residual and normalises (rmsnorm_quant_gathered) -- `pend` carries the debt.
+    // 20 -> 14 graph nodes per layer (10 kernels + 4 collectives); same arithmetic, element for element (tests/test_wide_models_gpu.py).
+    const bool tpg = tp && m->tp_rows && exact && layout == 16 && !fused && m->comm && El % 32 == 0 && Fl % 32 == 0;
+    struct { bool on; const float *resid; float *out; } pend = {false, nullptr, nullptr};
+    auto tp_send_view = [&](int Kl) -> fl_qact {
+        const size_t N16 = (size_t)fl_roundup(N, 16), nq = N16 * (size_t)Kl, nd = N16 * (size_t)(Kl / FL_QK) * 4;
+        return fl_qact{reinterpret_cast<int8_t *>(m->ag_send), reinterpret_cast<float *>(m->ag_send + nq), reinterpret_cast<float *>(m->ag_send + nq + nd),
+                       N, (int)N16, Kl / FL_QK, nullptr};
+    };
+    const fl_qact sEl = tpg ? tp_send_view(El) : m->qEl, sF = tpg ? tp_send_view(Fl) : m->qF;
+    // the operand of a row-split wo / w2 matmul from every rank's blocks of it (in the send buffer), then this rank's rows, then their all-gather
+    auto tp_matmul_rows = [&](const fl_qtensor *W, int Kl, const fl_qact &full, const float *resid, float *out) -> int {
+        const size_t msg = (size_t)fl_roundup(N, 16) * (size_t)(Kl / FL_QK) * 40;
+        int rc = fl_comm_allgather_f32(m->comm, reinterpret_cast<const float *>(m->ag_send), msg / 4, reinterpret_cast<float *>(m->ag_tmp), st);
+        if (rc != FL_OK) return rc;
+        M_HIP(gathered_qa16_to_operand(m->ag_tmp, msg, m->G, Kl / FL_QK, N, full, !xh, xh, st));
+        M_HIP(mm(m, W, full, N, m->part, El, nullptr, 0));
+        if ((rc = fl_comm_allgather_f32(m->comm, m->part, (size_t)N * El, reinterpret_cast<float *>(m->ag_tmp), st)) != FL_OK) return rc;
+        pend = {true, resid, out};
+        return FL_OK;
+    };
+    // rms_norm * w -> Q8_0 of `x`, which may still be owed the gathered rows + residual
+    auto norm_q8 = [&](float *x, const float *w, float *y_f32) -> hipError_t {
+        if (pend.on) {
+            pend.on = false;
+            return rmsnorm_quant_gathered(reinterpret_cast<const float *>(m->ag_tmp), m->G, El, pend.resid, E, x, E, w, N, E, y_f32, E, &m->qE, layout, st, xh);
+        }
+        return rmsnorm_quant(x, E, w, N, E, y_f32, E, &m->qE, layout, st, xh);
+    };
     for (int l = l0; l < l1; ++l) {
         const Layer &ly = m->layers[l];
         float *kc = m->kc + (size_t)l * n_ctx * El, *vc = m->vc + (size_t)l * n_ctx * El;
@@ -822,7 +858,9 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
         }
         if (fused) {
             // decode: norm folded into the matmul, attention in one launch per layer (rope .. KQV .. Q8_0)
+            if (exact && dyn && !tp && !split_attn && m->kv_prefetch) gemv1_stream_offer_kv_prefetch(kc, vc, dyn, El, D, Hl, n_ctx);
             M_HIP(mm_norm(m, ly.wqkv, inp, ly.attn_norm, nullptr, m->qkv));
+            gemv1_stream_offer_kv_prefetch(nullptr, nullptr, nullptr, 0, 0, 0, 0);      // (a launcher that did not take it must not leave it for the lm-head)
             const float kq_scale = 1.0f / sqrtf((float)E / (float)m->H);
             if (kv_wait) M_HIP(hipStreamWaitEvent(st, kv_wait[l], 0));        // (a one-token chunk of a pipelined ingest)
             if (split_attn)
@@ -834,7 +872,7 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
             if (kv_rec) M_HIP(hipEventRecord(kv_rec[l], st));
         } else {
             // norm + attention_norm*cur -> Q8_0                                                        llama.cpp:311-319
-            M_HIP(rmsnorm_quant(inp, E, ly.attn_norm, N, E, nullptr, 0, &m->qE, layout, st, xh));     // (xh: + the XH16 copy)
+            M_HIP(norm_q8(inp, ly.attn_norm, nullptr));                                               // (xh: + the XH16 copy)
             if ((N >= 9 && !dyn && fuse_pa) || xh) {
                 M_HIP(mm_qkv_rope(m, ly.wqkv, m->qE, N, kc, vc, n_past));                              // wq, wk, wv + rope + KV store
             } else {
@@ -871,7 +909,7 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
                 if (!softmaxed) M_HIP(softmax_rows(m->att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, Hl, m->exp_tab, st, dyn));
                 // KQV, merged back to [N, n_embd]                                                      :389-398
                 bool quantized = xa && layout == 16 && El % 32 == 0;        // the MFMA form writes the Q8_0 operand of wo itself
-                xe = xa ? attn_pv_exact(m->att, n_ctx, (int64_t)N * n_ctx, D, Hl, N, n_past, vc, n_ctx, m->ao, El, st, quantized ? &m->qEl : nullptr,
+                xe = xa ? attn_pv_exact(m->att, n_ctx, (int64_t)N * n_ctx, D, Hl, N, n_past, vc, n_ctx, m->ao, El, st, quantized ? &sEl : nullptr,
                                         xh && !m->tp_rows)
                         : hipErrorInvalidValue;
                 if (xe == hipErrorInvalidValue) {
@@ -882,13 +920,16 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
                 }
                 M_HIP(xe);
                 if (quantized) {}
-                else if (layout == 16) M_HIP(quantize_q8_qa16(m->ao, El, N, El, m->qEl, st, xh && !m->tp_rows));
+                else if (layout == 16) M_HIP(quantize_q8_qa16(m->ao, El, N, El, sEl, st, xh && !m->tp_rows));
                 else M_HIP(quantize_q8_qa1(m->ao, El, N, El, m->qEl, st));
             }   // (the one-launch kernel wrote the Q8_0 operand of the wo matmul itself)
         }
         // wo projection + residual                                                                 :401-407
         if (!tp) {
             M_HIP(mm(m, ly.wo, m->qEl, N, mid, E, inp, E));
+        } else if (tpg) {
+            const int rc = tp_matmul_rows(ly.wo, El, m->qE, inp, mid);                              // mid = rows + inp: owed to the ffn norm
+            if (rc != FL_OK) return rc;
         } else if (m->tp_rows) {
             int rc = tp_gather_qact(m, m->qEl, m->qE, N, El, layout, xh);                           // the operand, K = n_embd
             if (rc != FL_OK) return rc;
@@ -921,18 +962,21 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
         } else if (fused) {
             M_HIP(mm_norm(m, ly.w13, mid, ly.ffn_norm, nullptr, m->h13));
         } else {
-            M_HIP(rmsnorm_quant(mid, E, ly.ffn_norm, N, E, nullptr, 0, &m->qE, layout, st, xh));
-            if (silu_in_gemm) M_HIP(mm_silu_gemm(m, ly.w13, m->qE, N));
+            M_HIP(norm_q8(mid, ly.ffn_norm, nullptr));
+            if (silu_in_gemm) M_HIP(mm_silu_gemm(m, ly.w13, m->qE, N, sF));
             else M_HIP(mm(m, ly.w13, m->qE, N, m->h13, 2 * Fl, nullptr, 0));
         }
         if (!fused && !silu_in_gemm) {
-            M_HIP(silu_mul_quant(m->h13, 2 * Fl, N, Fl, m->silu_tab, &m->qF, layout, st, m->w13_il, xh && !m->tp_rows));
+            M_HIP(silu_mul_quant(m->h13, 2 * Fl, N, Fl, m->silu_tab, &sF, layout, st, m->w13_il, xh && !m->tp_rows));
         }
         if (!tp) {
             if (q8_from_w13) M_HIP(mm(m, ly.w2, m->qF, 1, inp, E, mid, E));
             else if (silu_in_gemv) M_HIP(mm_quant(m, ly.w2, m->h13, inp, mid));
             else if (fused) M_HIP(mm_silu(m, ly.w2, m->h13, inp, mid));
             else M_HIP(mm(m, ly.w2, m->qF, N, inp, E, mid, E));                                   // + inpFF :441
+        } else if (tpg) {
+            const int rc = tp_matmul_rows(ly.w2, Fl, m->qFf, mid, inp);                             // inp = rows + mid: owed to the next layer's norm
+            if (rc != FL_OK) return rc;
         } else if (m->tp_rows) {
             int rc;
             if (silu_in_gemv) {                   // decode: the f32 silu * mul features of every rank, quantized by the GEMV's prologue
@@ -955,6 +999,10 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
             M_HIP(add_rows(m->part, E, mid, E, inp, E, N, E, st));
         }
     }
+    if (pend.on && (body_only || skip_head)) {           // no norm follows in this call: the add is a launch of its own after all
+        pend.on = false;
+        M_HIP(gather_rows_add(reinterpret_cast<const float *>(m->ag_tmp), m->G, N, El, pend.resid, E, pend.out, E, st));
+    }
     if (body_only || skip_head) return FL_OK;
     // final norm (kept in f32 for the embeddings) + lm head                                        :452-465
     float *lg = m->Vl > 0 ? m->logits_part : logits_dst ? logits_dst : m->logits;       // (the overrides: a half of a split eval writes
@@ -963,7 +1011,7 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
     if (fused) {
         M_HIP(mm_norm(m, m->output, inp, m->norm_w, xn, lg));
     } else {
-        M_HIP(rmsnorm_quant(inp, E, m->norm_w, N, E, xn, E, &m->qE, layout, st, xh));
+        M_HIP(norm_q8(inp, m->norm_w, xn));
         M_HIP(mm(m, m->output, m->qE, N, lg, ldlg, nullptr, 0));
     }
     if (m->Vl > 0) {                                          // rows V/G of the lm-head per rank -> gather the logits slices
@@ -1215,12 +1263,14 @@ int fl_model_set_graph(fl_model *m, int mode) {
     m->ingest_one_stream = (mode & 128) != 0;
     m->split_eval = (mode & 256) != 0;
     m->split_past = (mode & 8) ? INT_MAX : (mode & 16) ? 0 : 256;
-    if (fuse != m->fuse_decode) {
+    const bool kvp = (mode & 512) == 0;
+    if (fuse != m->fuse_decode || kvp != m->kv_prefetch) {
         if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
         if (m->graph_exec_long) (void)hipGraphExecDestroy(m->graph_exec_long);
         m->graph_exec = m->graph_exec_long = nullptr;
     }
     m->fuse_decode = fuse;
+    m->kv_prefetch = kvp;
     return FL_OK;
 }
 

@@ -90,6 +90,8 @@ bool gemv1_llc_quant(const fl_qtensor &W, const float *x, float *y, const float 
 // round 6 form for matrices of many row groups: one wave per row group streaming the whole of K, four row groups per workgroup sharing one
 // activation prologue (gemv1_q4_exact_stream.hip); false: no QWD copy / too few row groups / shape outside its reach (-> the llc kernel).
 // gemv1_stream_norm_silu_q8: the woven w1|w3 matmul whose workgroups write the Q8_0 operand of the w2 matmul themselves (out: QA1 planes)
+// the next gemv1_stream_norm launch of this thread also touches the K / V history its decode layer's attention will read (an L2 hint; nullptr: none)
+void gemv1_stream_offer_kv_prefetch(const float *kc, const float *vc, const int *pos_dev, int E, int D, int H, int n_ctx);
 bool gemv1_stream(const fl_qtensor &W, const fl_qact &xq, float *y, hipStream_t st, const float *resid);
 bool gemv1_stream_norm(const fl_qtensor &W, const float *x, const float *norm_w, float *ynorm, float *y, hipStream_t st);
 bool gemv1_stream_quant(const fl_qtensor &W, const float *x, float *y, const float *resid, hipStream_t st);

@@ -22,6 +22,8 @@ MODELS = {
     "65B": dict(n_embd=8192, n_head=64, n_layer=80, n_ff=22016, n_vocab=32000),
     # tiny shape for smoke tests (same structure, every K a multiple of 64)
     "tiny": dict(n_embd=256, n_head=4, n_layer=2, n_ff=704, n_vocab=512),
+    # ... and one that splits eight ways by rows (8 heads, n_ff / 8 a multiple of 32): the 8-rank rehearsal of bench.py's tensor-parallel leg
+    "tiny8": dict(n_embd=512, n_head=8, n_layer=2, n_ff=1024, n_vocab=512),
 }
 
 

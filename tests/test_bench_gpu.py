@@ -81,6 +81,19 @@ def test_bench_self_launched_tensor_parallel_leg():
     assert d["n_gpus"] == 2 and d["tp_ok"] is True and d["scaling"] == "strong" and d["n_ranks_rccl"] == 0 and "tp_error" not in d
 
 
+def test_bench_tensor_parallel_leg_as_eight_processes_on_one_gpu():
+    """`python bench.py --gpus 8` the way the driver will run it on an 8-GPU node, rehearsed as EIGHT processes on the one GPU there is (peer
+    exchange instead of RCCL, a model that splits eight ways by rows): rank bookkeeping, the handle exchange, the self-test, the row split and
+    the folded decode all run with world = 8, so that the first real node does not trip on a rank-count bug."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--model", "tiny8", "--n-batch", "32", "--steps",
+                        "2", "--warmup", "1", "--decode-steps", "4", "--no-fast", "--tp-timeout", "600"], capture_output=True, text=True, timeout=1500,
+                       cwd=ROOT, env=_clean_env(FL_BENCH_DEVICE="0", FL_BENCH_BACKEND="gloo", FL_BENCH_P2P_ONLY="1"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 8 and d["tp_ok"] is True and d["scaling"] == "strong" and d["n_ranks_rccl"] == 0 and "tp_error" not in d
+    assert d["tp_decode"]["exchanges_folded_into_producers"] is True
+
+
 def test_bench_reports_both_modes_and_config3():
     """N = 1: the headline is the default (reference-order) mode, the fast mode's timings sit beside it; tp_ok / n_ranks_rccl are null."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "tiny", "--n-batch", "64", "--steps", "2",
