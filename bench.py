@@ -465,6 +465,9 @@ def main():
             r["long_past"] = r["exact"]["long_past"]
             r["decode_long_ms"] = r["exact"]["decode_long_ms"]
             r["model_device_bytes"] = hip.load().fl_model_device_bytes(model.h)
+            mem = (ctypes.c_size_t * 5)()
+            if hip.load().fl_model_memory(model.h, mem) == 0:
+                r["model_memory_bytes"] = dict(zip(("qw16_nibble_planes", "scale_planes", "wh16_copies", "qwd_copies", "kv_cache_and_work_buffers"), (int(v) for v in mem)))
             # ---- a prompt longer than n_batch: the session's ingest loop evaluates it n_batch tokens at a time; fl_model_ingest keeps
             #      two of those evals in flight (same results).  Reported beside the headline, which stays the single n_batch eval.
             if not tp and n_ctx >= 2 * N:
@@ -548,7 +551,7 @@ def main():
             "decode_n_past_988": ({"tokens_per_s": leg["seqs"] / (head["decode_988_ms"] * 1e-3), "ms_per_token": head["decode_988_ms"]} if "decode_988_ms" in head else None),
             "prefill_long_prompt": leg.get("long_prompt"),
             "roofline": head["roofline"], "roofline_decode": head["roofline_decode"],
-            "model_device_bytes": leg["model_device_bytes"],
+            "model_device_bytes": leg["model_device_bytes"], "model_memory_bytes": leg.get("model_memory_bytes"),
             # is the headline the tensor-parallel eval over RCCL, and how many ranks does the RCCL communicator itself count?
             "tp_ok": bool(tp) if world > 1 else None, "n_ranks_rccl": leg.get("n_ranks_rccl", 0) if world > 1 else None,
         }

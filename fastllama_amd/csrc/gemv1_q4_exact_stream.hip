@@ -164,6 +164,7 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void gemv1_q4_exact_s
             const int pos = min(*pf.pos, 256), cls = (int)blockIdx.x & 7, ncls_wg = ((int)gridDim.x + 7 - cls) >> 3;
             const int hpc = (pf.H + 7 - cls) >> 3;                            // heads h = cls, cls + 8, ...
             const int klines = pf.D >> 5, vlines = (pos + 31) >> 5;          // 128-byte lines per K row of a head / per V row's history
+            // (K rows only: 618 / 394 tok/s at 7B / 13B against 619 / 397 with both and 617 / 385 without the hint, profiles/r06_decode_exact.md)
             const int per_head = pos * klines + pf.D * vlines, total = hpc * per_head;
             auto line = [&](int i) __attribute__((always_inline)) -> const float * {
                 i = min(i, total - 1);

@@ -17,14 +17,15 @@ past = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 qtype = int(os.environ.get("FL_QTYPE", "2"))
 L = hip.load()
 lib = C.CDLL(hip.LIB_PATH)
-for f in ("fl_debug_llc_timeline", "fl_debug_da_timeline"):
+for f in ("fl_debug_llc_timeline", "fl_debug_da_timeline", "fl_debug_stream_timeline"):
     getattr(lib, f).argtypes = [C.c_void_p, C.c_int, C.c_int]
 cfg = dict(synth.MODELS[name])
 m = FlModel(cfg, qtype, synth.synth_model_tensors(cfg, qtype), n_ctx=1024, max_batch=512)
 toks = np.random.default_rng(0).integers(3, 259, 512).astype(np.int32)
 m.eval_nocopy(toks[:max(past, 1)], 0)
 t1 = toks[:1].copy()
-KNAME = {104: "wq|wk|wv + rms_norm prologue", 900: "attention (one launch)", 4: "wo (+ residual)", 8: "wo (+ residual), 8 slices",
+KNAME = {1101: "wq|wk|wv + rms_norm prologue (round 6: one wave per row group)", 1121: "w1|w3 woven + rms_norm -> the Q8_0 operand of w2 (round 6: one wave per row group)",
+         104: "wq|wk|wv + rms_norm prologue", 900: "attention (one launch)", 4: "wo (+ residual)", 8: "w2 on the Q8_0 operand w1|w3 wrote (+ residual), 8 slices",
          124: "w1|w3 woven + rms_norm, pair exchange", 114: "w1|w3 woven + rms_norm, one workgroup per pair", 308: "w2 + Q8_0 prologue (+ residual)",
          304: "w2 + Q8_0 prologue (+ residual), 4 slices"}
 
@@ -43,10 +44,18 @@ def one_token(graph):
     for i in range(4):
         m.eval_nocopy(t1, past + i)
     torch.cuda.synchronize()
-    lib.fl_debug_llc_timeline(None, 0, 1); lib.fl_debug_da_timeline(None, 0, 1)
+    lib.fl_debug_llc_timeline(None, 0, 1); lib.fl_debug_da_timeline(None, 0, 1); lib.fl_debug_stream_timeline(None, 0, 1)
     m.eval_nocopy(t1, past + 4)
     torch.cuda.synchronize()
-    rec = np.concatenate([fetch(lib.fl_debug_llc_timeline, 1 << 17, 12), fetch(lib.fl_debug_da_timeline, 1 << 14, 8)])
+    # the one-wave-per-row-group kernel's ring (gemv1_q4_exact_stream.hip: entry, loads issued, prologue done, loop end of waves 0..3, stored, end, id) in the
+    # llc record's terms: last byte summed = the last wave's loop end, "chains" = loop end -> stored, first quad summed = prologue done; ids + 1000
+    sraw = fetch(lib.fl_debug_stream_timeline, 1 << 16, 12)
+    srec = np.zeros((len(sraw), 12), np.int64)
+    if len(sraw):
+        srec[:, 0:3] = sraw[:, 0:3]
+        srec[:, 3] = sraw[:, 3:7].max(axis=1); srec[:, 4] = sraw[:, 7]; srec[:, 5] = sraw[:, 8]; srec[:, 6] = sraw[:, 2]
+        srec[:, 7] = (((sraw[:, 9] >> 32) + 1000) << 32) | (sraw[:, 9] & 0xffffffff)
+    rec = np.concatenate([fetch(lib.fl_debug_llc_timeline, 1 << 17, 12), fetch(lib.fl_debug_da_timeline, 1 << 14, 8), srec])
     rec = rec[np.argsort(rec[:, 0], kind="stable")]
     kid = rec[:, 7] >> 32
     # launches run one after the other on the stream: a launch = a maximal run of one kernel id on the time axis (the lm-head, also 104, follows a 308)
@@ -81,7 +90,7 @@ for graph, what in ((1, "hipGraph replay"), (0, "plain stream launches")):
     print(f"\n## {name} Q4_{qtype - 2}, n_past {past + 4}, reference-order decode, {what}: {len(runs)} launches, {tok_us:.1f} us from the first wave of the token to its last store\n")
     print("| launch (median over layers 2..) | workgroups | duration: first wave -> last end | dispatch ramp (first -> last workgroup start) | entry -> loads issued | entry -> prologue done | entry -> first quad summed | entry -> last byte summed (median / last workgroup, from launch start) | chains | last byte -> launch end | workgroup lifetime median / max | gap to the next launch's first wave |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|")
-    seq = [104, 900, 4, 8, 124, 114, 308, 304]
+    seq = [1101, 104, 900, 4, 1121, 124, 114, 8, 308, 304]
     for k in seq:
         rs = [r for r in runs[5:-1] if r["kid"] == k and "gap" in r]
         if not rs:
@@ -95,7 +104,7 @@ for graph, what in ((1, "hipGraph replay"), (0, "plain stream launches")):
                 pm = np.median(np.array([r["pro"] for r in rs]), axis=0)
                 print(f"|   ... its rms_norm prologue, from entry: x arrived and squared {pm[0]:.2f}, first barrier passed {pm[1]:.2f}, scale known + norm weights arrived {pm[2]:.2f} | | | | | | | | | | | |")
             print(f"| {KNAME.get(k, k)} | {rs[0]['wgs']} | {med('dur'):.2f} | {med('ramp'):.2f} | {med('issue'):.2f} | {med('prologue'):.2f} | {med('first_data'):.2f} | {med('last_data_med'):.2f} / {med('last_data'):.2f} | {med('chains'):.2f} | {med('tail'):.2f} | {med('life_med'):.2f} / {med('life_max'):.2f} | {med('gap'):.2f} |")
-    lay = [r for r in runs if r["kid"] == 104]
+    lay = [r for r in runs if r["kid"] in (104, 1101)]
     if len(lay) > 3:
         per_layer = np.diff([r["first"] for r in lay[:-1]])
         print(f"\nlayer period (first wave of wq|wk|wv to the next layer's): median {np.median(per_layer):.2f} us, min {per_layer.min():.2f}, max {per_layer.max():.2f}; "

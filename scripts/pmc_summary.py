@@ -26,7 +26,7 @@ def agg(leg, c):
 out, md = {}, []
 # legs: default (reference-order) mode: pmc_pre_* / pmc_dec_*; fast mode (FL_FAST=1): pmc_fpre_* / pmc_fdec_* when present
 LEGS = [("pre", "gemm_q4_exact_h16_kernel", "gemm_q4_exact_h16_", "prefill (n_batch 512), reference-order mode"),
-        ("dec", "gemv1_q4_exact_llc_kernel", "gemv1_q4_exact_", "decode, reference-order mode"),
+        ("dec", "gemv1_q4_exact_stream_kernel", "gemv1_q4_exact_", "decode, reference-order mode (every N = 1 matmul launch: the stream and the llc kernel)"),
         ("fpre", "gemm_q4_mfma32_kernel", "gemm_q4_mfma32_", "prefill (n_batch 512), fast mode"),     # (pat: incl. the mixed-tile launch)
         ("fdec", "gemv_q4_kernel", "gemv_q4_kernel", "decode, fast mode")]
 LEGS = [l for l in LEGS if glob.glob(f"{ROOT}/gpurun_out/pmc_{l[0]}_FETCH_SIZE/**/*counter_collection.csv", recursive=True)]

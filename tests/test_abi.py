@@ -272,7 +272,9 @@ def test_bench_gpus_n_starts_its_own_ranks():
                        capture_output=True, text=True, timeout=600, env=env)
     out = r.stderr + r.stdout
     assert r.returncode != 0
-    assert out.count("no CPU path") >= 2, out[-2000:]            # one refusal per rank
+    # one refusal per rank -- or, when the launcher takes the second rank down the moment the first has failed, one refusal and the launcher's own
+    # report of a second local rank
+    assert out.count("no CPU path") >= 2 or (out.count("no CPU path") == 1 and "local_rank: 1" in out), out[-2000:]
     assert not any(line.startswith("{") for line in r.stdout.splitlines())
 
 
