@@ -37,12 +37,14 @@ hipError_t dot_f32_abt_exact(const float *A, int lda, int64_t sAz, const float *
 hipError_t attn_scores_exact(const float *qkv, int ldq, int D, int H, int N, int n_past, const float *kc, int ldk, float scale,
                              float *att, int ld_att, int64_t head_stride, hipStream_t st);
 hipError_t attn_scores_softmax_exact(const float *qkv, int ldq, int D, int H, int N, int n_past, const float *kc, int ldk, float scale,
-                                     float *att, int ld_att, int64_t head_stride, const uint16_t *exp_tab, hipStream_t st);   // + soft_max in the same launch (<= 1024 keys)
+                                     float *att, int ld_att, int64_t head_stride, const uint16_t *exp_tab, hipStream_t st,
+                                     bool compact = false);   // + soft_max in the same launch (<= 1024 keys)
 // out != NULL: the result leaves as the Q8_0 operand of the wo matmul (QA16, K = ldo; with_h16: + its XH16 copy) instead of f32 rows in ao
 hipError_t attn_pv_exact(const float *att, int ld_att, int64_t head_stride, int D, int H, int N, int n_past, const float *vc, int n_ctx,
-                         float *ao, int ldo, hipStream_t st, const fl_qact *out = nullptr, bool with_h16 = false);
+                         float *ao, int ldo, hipStream_t st, const fl_qact *out = nullptr, bool with_h16 = false, bool compact = false);
+// compact: the probabilities leave as fp16 table values + one f32 factor per row (softmax_rows_reg_kernel); attn_pv_exact(compact) reads that
 hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab,
-                        hipStream_t st, const int *dyn_past = nullptr);
+                        hipStream_t st, const int *dyn_past = nullptr, bool compact = false);
 // prefill: KQ*scale + mask + soft_max + KQV per (head, 32 query rows), score rows in LDS; q = roped Q rows of qkv,
 // kc / vc already hold the new positions.  When the rows do not fit LDS (deep contexts) the key-tiled form runs instead:
 // same launch count, the scores take one trip through `scratch` ([H] x s_head floats, rows of ld_s >= n_past + N floats,

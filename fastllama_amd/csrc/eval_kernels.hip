@@ -1113,7 +1113,11 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float *__restrict__ S
 // The same row held in registers (P <= 64 * IT): every load of the row and every table gather is issued before the first
 // is waited for.  The loop form above pays a dependent memory round trip per 64 columns, three times over -- at 2048
 // keys that is most of the three-kernel attention path.  Same arithmetic; the f64 sum of fp16 terms is exact in any order.
-template <int IT>
+// COMPACT (round 6): a probability is rn(t * inv) with t an fp16 table value and inv one f32 per row -- the row is written as its P fp16 values t
+// (zeros past the last visible key) in the first half of its own storage plus inv in the row's last float (S[ld - 1]); the V.P kernel
+// (attn_pv_exact, compact = true) forms the same products while it stages the piece.  Half the bytes written here and half the bytes of every
+// re-read there (V.P reads each row once per feature block).  The row is complete in registers before the first store: in place is safe.
+template <int IT, bool COMPACT>
 __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(float *__restrict__ S, int ld, int64_t sz, int N, int P,
                                                                int n_past, const uint16_t *__restrict__ exp_tab,
                                                                int rows_total) {
@@ -1144,19 +1148,32 @@ __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(float *__restrict
     for (int u = 0; u < IT; ++u) sum += (double)x[u];
     sum = wave_sum_f64(sum);
     const float inv = (float)(1.0 / sum);
+    if constexpr (COMPACT) {
+        __half *ph = reinterpret_cast<__half *>(p);
 #pragma unroll
-    for (int u = 0; u < IT; ++u) {
-        const int i = lane + 64 * u;
-        if (i < P) p[i] = i < L ? __fmul_rn(x[u], inv) : 0.f;
+        for (int u = 0; u < IT; ++u) {
+            const int i = lane + 64 * u;
+            if (i < P) ph[i] = __float2half_rn(i < L ? x[u] : 0.f);      // (exact: x[u] is an fp16 table value or zero)
+        }
+        if (lane == 0) p[ld - 1] = inv;
+    } else {
+#pragma unroll
+        for (int u = 0; u < IT; ++u) {
+            const int i = lane + 64 * u;
+            if (i < P) p[i] = i < L ? __fmul_rn(x[u], inv) : 0.f;
+        }
     }
 }
 
+// compact: see softmax_rows_reg_kernel; hipErrorInvalidValue where that form does not reach (rows of more than 2048 keys, a device-side n_past)
 hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab,
-                        hipStream_t st, const int *dyn_past) {
+                        hipStream_t st, const int *dyn_past, bool compact) {
     const int rows = N * batch;
     const dim3 grid((rows + 3) / 4), block(256);
+    if (compact && (dyn_past || P > 64 * 32 || P < 4 || ld < P)) return hipErrorInvalidValue;
     if (!dyn_past && P <= 64 * 32) {
-#define FL_SM(IT) hipLaunchKernelGGL(softmax_rows_reg_kernel<IT>, grid, block, 0, st, S, ld, sz, N, P, n_past, exp_tab, rows)
+#define FL_SM(IT) do { if (compact) hipLaunchKernelGGL((softmax_rows_reg_kernel<IT, true>), grid, block, 0, st, S, ld, sz, N, P, n_past, exp_tab, rows); \
+                       else hipLaunchKernelGGL((softmax_rows_reg_kernel<IT, false>), grid, block, 0, st, S, ld, sz, N, P, n_past, exp_tab, rows); } while (0)
         if (P <= 64 * 4) FL_SM(4);
         else if (P <= 64 * 8) FL_SM(8);
         else if (P <= 64 * 16) FL_SM(16);

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include <atomic>
 #include <mutex>
+#include <type_traits>
 #include "eval_kernels.h"
 #include "runtime.h"
 #include "q4_device.h"
@@ -712,7 +713,7 @@ template <int NST, bool SM>
 __global__ __launch_bounds__(512) void attn_scores_exact_kernel(const float *__restrict__ qkv, int ldq, int N, int n_past,
                                                                 const float *__restrict__ kc, int ldk, float scale,
                                                                 float *__restrict__ att, int ld_att, int64_t head_stride,
-                                                                const uint16_t *__restrict__ exp_tab, int PLD) {
+                                                                const uint16_t *__restrict__ exp_tab, int PLD, int compact) {
     extern __shared__ float sm_rows[];                        // SM: [32][PLD] scaled scores
     constexpr int D = 32 * NST, MS = (NST + 1) / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -748,6 +749,7 @@ __global__ __launch_bounds__(512) void attn_scores_exact_kernel(const float *__r
     float kv[MS][32];
     const int last_key = n_past + min(q0 + 31, N - 1);       // keys this query block can see: [0, last_key]
     const int ntiles = last_key / 32 + 1;
+    // (the NEXT tile's rows in a second register set, requested before this tile's MFMAs: 64 more registers than two waves per SIMD have -- 90 spilled)
     for (int kt = wave; kt < ntiles; kt += 8) {
         const int k0 = kt * 32;
         load_row(kc + (int64_t)min(k0 + i, last_key) * ldk + hd * D, kv);
@@ -838,18 +840,28 @@ __global__ __launch_bounds__(512) void attn_scores_exact_kernel(const float *__r
             sum = wave_sum_f64(sum);
             const float inv = (float)(1.0 / sum);
             float *prow = att + hd * head_stride + (int64_t)q * ld_att;
+            if (compact) {                                    // fp16 table values + the row's factor (softmax_rows_reg_kernel, eval_kernels.hip)
+                __half *ph = reinterpret_cast<__half *>(prow);
 #pragma unroll
-            for (int u = 0; u < IT; ++u) {
-                const int c = lane + 64 * u;
-                if (c < P) prow[c] = c < L ? __fmul_rn(x[u], inv) : 0.f;
+                for (int u = 0; u < IT; ++u) {
+                    const int c = lane + 64 * u;
+                    if (c < P) ph[c] = __float2half_rn(c < L ? x[u] : 0.f);
+                }
+                if (lane == 0) prow[ld_att - 1] = inv;
+            } else {
+#pragma unroll
+                for (int u = 0; u < IT; ++u) {
+                    const int c = lane + 64 * u;
+                    if (c < P) prow[c] = c < L ? __fmul_rn(x[u], inv) : 0.f;
+                }
             }
         }
     }
 }
 
 #ifdef XA_TIMING   // development build only: per-workgroup clocks of the V.P launch (scripts/dev/xa_timeline.py)
-__device__ long long xa_dbg[1024 * 16];
-#define XA_STAMP(k) do { if (threadIdx.x == 0) xa_dbg[((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) % 1024 * 16 + (k)] = wall_clock64(); } while (0)
+__device__ long long xa_dbg[2 * 1024 * 16];      // [0]: the 100 MHz wall clock, [1]: the shader clock's counter (their ratio = the clock the launch ran at)
+#define XA_STAMP(k) do { if (threadIdx.x == 0) { const int xi_ = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) % 1024 * 16 + (k); xa_dbg[xi_] = wall_clock64(); xa_dbg[1024 * 16 + xi_] = clock64(); } } while (0)
 #else
 #define XA_STAMP(k) do {} while (0)
 #endif
@@ -862,7 +874,10 @@ __device__ __forceinline__ void lds_barrier() {
 }
 // ONE: the whole context is one piece for every query block (n_past + N <= 512): its own kernel, because the two forms want different
 // registers (a V block in flight + four chain tiles here; eight chain tiles carried across pieces there)
-template <bool ONE>
+// HP (round 6, several pieces only): the probabilities arrive COMPACT -- fp16 table values t in the first half of each row and the row's factor inv
+// in its last float (softmax_rows_reg_kernel, eval_kernels.hip) -- and p = rn(t * inv), the product soft_max itself would have stored, is formed while
+// the piece goes to LDS.  Every probability row is read once per feature block: half the bytes each time (profiles/r06_attn_exact.md).
+template <bool ONE, bool HP = false>
 __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restrict__ att, int ld_att, int64_t head_stride, int D, int N,
                                                             int n_past, const float *__restrict__ vc, int n_ctx, float *__restrict__ ao,
                                                             int ldo, int8_t *__restrict__ oq, float *__restrict__ od,
@@ -917,14 +932,19 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
     // (k0: first key of the piece -- 0 when the context is one piece)
     // Buffer loads (round 5): the wave-uniform part of the address (the piece's first key) travels in the scalar offset, the lane's part is
     // one 32-bit register per load, and bytes past the tile's rows read as zero (descriptor bounds; keys past the row's end are the next
-    // row's -- every such value is dropped or zeroed by wide_store).  As flat loads the sixteen 64-bit addresses of a tile lived in
+    // row's -- every such value is past the piece's columns or belongs to a step past the body, which the chains skip).  As flat loads the sixteen 64-bit addresses of a tile lived in
     // registers (or, with a second tile in flight, in scratch memory).
     auto tile_rsrc = [&](const float *base, int rows, int row_stride) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)((unsigned)rows * (unsigned)row_stride * 4u), 0x00020000);
     };
-    auto wide_load = [&](float4 (&v)[16], __amdgpu_buffer_rsrc_t rs, int row_stride, int rows_valid, int k0 = 0) {
+    // (part: all sixteen loads, or -- tag 0 .. 3 -- a quarter of them: a tile requested under a piece's chains goes out a quarter per 128-key trip,
+    // between the MFMAs.  All at once, the 96-128 KB of a piece queue at the CU's one address unit for ~1500 cycles, and a wave issues in order:
+    // it stood there before its first MFMA.)
+    constexpr std::integral_constant<int, -1> whole{};
+    auto wide_load = [&](float4 (&v)[16], __amdgpu_buffer_rsrc_t rs, int row_stride, int rows_valid, int k0, auto part) __attribute__((always_inline)) {
+        constexpr int T = decltype(part)::value;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = T < 0 ? 0 : 4 * T; u < (T < 0 ? 16 : 4 * T + 4); ++u) {
             const int row = 8 * (u & 3) + s_rr, col = 32 * (4 * wave + (u >> 2)) + 4 * s_kk;
             const int voff = (min(row, rows_valid - 1) * row_stride + col) * 4;
             typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
@@ -932,33 +952,95 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
             v[u] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
         }
     };
-    auto wide_store = [&](float *dst, const float4 (&v)[16], int rows_valid, int kt, int k0 = 0) {
+    // (No masks, round 6: every key of a body piece is < P, where soft_max wrote +0 past a query's last visible key and the cache holds real V rows --
+    // p = +0 times a finite v adds a zero to a chain that never holds -0; rows past the batch are copies of its last row and are never stored.  The
+    // per-value compares and selects were a third of the 5000 cycles a piece spent between its two barriers.)
+    // valid: the piece's body keys (a multiple of 32); columns [valid, its round-up to whole 128-key trips of the chains) are ZEROS, so that the chains
+    // run without a compare or select of their own (a ragged last piece only: a whole piece takes the branch without the selects)
+    auto wide_store = [&](float *dst, const float4 (&v)[16], int valid) {
+        const int kt = (valid + 127) & ~127;
+        if (kt == valid) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int row = 8 * (u & 3) + s_rr, col = 32 * (4 * wave + (u >> 2)) + 4 * s_kk;
-            if (col < kt) {                                  // (wave-uniform: kt is a multiple of 64, a wave-store covers 32 keys)
-                float *d = dst + row * XA_LD + col;
-                const bool rv = row < rows_valid;
-                d[0] = rv && k0 + col < kend ? v[u].x : 0.f;
-                d[1] = rv && k0 + col + 1 < kend ? v[u].y : 0.f;
-                d[2] = rv && k0 + col + 2 < kend ? v[u].z : 0.f;
-                d[3] = rv && k0 + col + 3 < kend ? v[u].w : 0.f;
+            for (int u = 0; u < 16; ++u) {
+                const int row = 8 * (u & 3) + s_rr, col = 32 * (4 * wave + (u >> 2)) + 4 * s_kk;
+                if (col < kt) {                              // (wave-uniform: a wave-store covers 32 keys)
+                    float *d = dst + row * XA_LD + col;
+                    d[0] = v[u].x;
+                    d[1] = v[u].y;
+                    d[2] = v[u].z;
+                    d[3] = v[u].w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int row = 8 * (u & 3) + s_rr, col = 32 * (4 * wave + (u >> 2)) + 4 * s_kk;
+                if (col < kt) {
+                    float *d = dst + row * XA_LD + col;
+                    const bool in = col < valid;             // (the lane's four keys are inside or outside together)
+                    d[0] = in ? v[u].x : 0.f;
+                    d[1] = in ? v[u].y : 0.f;
+                    d[2] = in ? v[u].z : 0.f;
+                    d[3] = in ? v[u].w : 0.f;
+                }
             }
         }
     };
-    auto chunk_len = [&](int c) { return min(XA_KT, ((nbody - c * XA_KT) + 63) & ~63); };   // zero padded to whole MFMA pairs
+    auto chunk_len = [&](int c) { return min(XA_KT, nbody - c * XA_KT); };                  // body keys of piece c
     const int rows_q = min(32, N - q0);
+    // compact probabilities: thread -> 8 x 16 bytes (8 keys each): lane (rr, kk) of wave w takes, for u = 0 .. 7, row 8 (u & 3) + rr, keys
+    // 64 (2 w + (u >> 2)) + 8 kk .. + 7 -- a wave-load is 8 rows x one 128-byte line again, a wave-store of one component 2 lanes per bank
+    float inv4[4];
+    if constexpr (HP) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) inv4[r] = prow[(int64_t)(q0 + min(8 * r + s_rr, rows_q - 1)) * ld_att + ld_att - 1];
+    }
+    typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
+    auto wide_load_h = [&](v4u_ (&v)[8], __amdgpu_buffer_rsrc_t rs, int k0, auto part) __attribute__((always_inline)) {
+        constexpr int T = decltype(part)::value;
+#pragma unroll
+        for (int u = T < 0 ? 0 : 2 * T; u < (T < 0 ? 8 : 2 * T + 2); ++u) {
+            const int row = 8 * (u & 3) + s_rr, col = 64 * (2 * wave + (u >> 2)) + 8 * s_kk;
+            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, min(row, rows_q - 1) * ld_att * 4 + col * 2, k0 * 2, 0);
+        }
+    };
+    auto wide_store_h = [&](float *dst, const v4u_ (&v)[8], int valid) {
+        const int kt = (valid + 127) & ~127;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = 8 * (u & 3) + s_rr, col = 64 * (2 * wave + (u >> 2)) + 8 * s_kk;
+            if (col < kt) {                                  // (wave-uniform: a wave-store covers 64 keys)
+                float *d = dst + row * XA_LD + col;
+                const bool in = col < valid;                 // (zeros behind the body, as wide_store; the lane's eight keys together.  A select, not a
+                const unsigned w4[4] = {in ? v[u].x : 0u, in ? v[u].y : 0u, in ? v[u].z : 0u, in ? v[u].w : 0u};      // factor: those halves are anything)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = __half2float(__ushort_as_half((unsigned short)(w4[j >> 1] >> (16 * (j & 1)))));
+                    d[j] = __fmul_rn(t, inv4[u & 3]);
+                }
+            }
+        }
+    };
     constexpr bool one_piece = ONE;                          // short contexts: P staged once, V blocks requested one ahead
     const __amdgpu_buffer_rsrc_t rsP = tile_rsrc(prow + (int64_t)q0 * ld_att, rows_q, ld_att);
     float4 vnext[16];
-    float4 pnext[ONE ? 1 : 16];                              // (multi-piece form: the next piece's probabilities in flight)
+    float4 pnext[ONE || HP ? 1 : 16];                        // (multi-piece form: the next piece's probabilities in flight)
+    v4u_ hnext[HP ? 8 : 1];                                  // (... in their compact form)
+    auto load_p = [&](int k0, auto part) __attribute__((always_inline)) {
+        if constexpr (HP) wide_load_h(hnext, rsP, k0, part);
+        else if constexpr (!ONE) wide_load(pnext, rsP, ld_att, rows_q, k0, part);
+    };
+    auto store_p = [&](int kt) __attribute__((always_inline)) {
+        if constexpr (HP) wide_store_h(Ps, hnext, kt);
+        else if constexpr (!ONE) wide_store(Ps, pnext, kt);
+    };
     XA_STAMP(0);
     if constexpr (one_piece) {
         float4 pfirst[16];
-        wide_load(pfirst, rsP, ld_att, rows_q);
-        wide_load(vnext, tile_rsrc(vc + (int64_t)(hd * D) * n_ctx, 32, n_ctx), n_ctx, 32);
-        wide_store(Ps, pfirst, rows_q, chunk_len(0));
-        wide_store(Vs, vnext, 32, chunk_len(0));
+        wide_load(pfirst, rsP, ld_att, rows_q, 0, whole);
+        wide_load(vnext, tile_rsrc(vc + (int64_t)(hd * D) * n_ctx, 32, n_ctx), n_ctx, 32, 0, whole);
+        wide_store(Ps, pfirst, chunk_len(0));
+        wide_store(Vs, vnext, chunk_len(0));
     }
     XA_STAMP(1);
     float *Ts = xs_ + 64 * XA_LD;                            // the waves' t tiles meet here: [4 waves][16 e][64 lanes]
@@ -967,29 +1049,54 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
     const bool left_visible = nleft > 0 && kend > np;
     for (int d0 = 0; d0 < D; d0 += 32) {
         // wave w: partial sums l = w and l = w + 4, all four jj: chains over ALL 32-key steps of the body, two steps per MFMA.
-        // chain(acc, l, k0, cend): the four jj chains of partial sum l over the staged keys [k0, cend)
-        auto chain = [&](v16f (&acc)[4], int l, int k0, int cend) __attribute__((always_inline)) {
-            for (int cs = k0; cs < cend; cs += 128) {         // two MFMAs (four 32-key steps) per chain and trip: 16 operand reads, then 8 MFMAs
-                float a[2][4], b[2][4];
+        // chain(acc, NL, l, valid): the four jj chains of the NL partial sums l, l + 4 over the staged piece (valid body keys + zeros to a whole trip).
+        // A trip = 128 keys = 8 NL MFMAs; its 16 NL operand reads are issued one trip AHEAD, before the previous trip's MFMAs (round 6): a wave is alone
+        // on its SIMD, nothing else covers the LDS round trip -- read-then-multiply per pair of MFMAs ran them at 150 cycles apiece instead of 64
+        // (profiles/r06_attn_exact.md).
+        // between(tag t), t = 0 .. 3: what the caller wants issued among the MFMAs of trip t (a quarter of the next tiles' loads); called for every t.
+        auto chain = [&](auto &acc, auto nl_tag, int l, int valid, auto &&between) __attribute__((always_inline)) {
+            constexpr int NL = decltype(nl_tag)::value;
+            const int kt = (valid + 127) & ~127;              // (whole trips: the tiles hold zeros behind the body)
+            auto fetch = [&](float (&a)[NL][2][4], float (&b)[NL][2][4], int cs) __attribute__((always_inline)) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int c0 = cs + 64 * u + 32 * h;      // (a step past the body: zeros -- fma(0, 0, c) = c)
-                    const bool ok = c0 < cend;
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const int e = (ok ? c0 - k0 : 0) + 8 * jj + l;
-                        const float av = Ps[i * XA_LD + e], bv = Vs[i * XA_LD + e];
-                        a[u][jj] = ok ? av : 0.f;
-                        b[u][jj] = ok ? bv : 0.f;
-                    }
-                }
+                    for (int n = 0; n < NL; ++n)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int e = cs + 64 * u + 32 * h + 8 * jj + l + 4 * n;
+                            a[n][u][jj] = Ps[i * XA_LD + e];
+                            b[n][u][jj] = Vs[i * XA_LD + e];
+                        }
+            };
+            auto mac = [&](const float (&a)[NL][2][4], const float (&b)[NL][2][4]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj)
-                        acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][jj], b[u][jj], acc[jj], 0, 0, 0);
-            }
+#pragma unroll
+                        for (int n = 0; n < NL; ++n)
+                            acc[n][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n][u][jj], b[n][u][jj], acc[n][jj], 0, 0, 0);
+            };
+            float a0[NL][2][4], b0[NL][2][4], a1[NL][2][4], b1[NL][2][4];
+            if (kt > 0) fetch(a0, b0, 0);
+            static_assert(XA_KT == 512, "four 128-key trips per piece");
+            auto two_trips = [&](auto t0) __attribute__((always_inline)) {
+                constexpr int T0 = decltype(t0)::value, cs = 128 * T0;
+                const bool first = cs < kt, second = cs + 128 < kt;      // (wave-uniform)
+                if (second) fetch(a1, b1, cs + 128);
+                between(std::integral_constant<int, T0>{});
+                if (first) mac(a0, b0);
+                if (cs + 256 < kt) fetch(a0, b0, cs + 256);
+                between(std::integral_constant<int, T0 + 1>{});
+                if (second) mac(a1, b1);
+            };
+            two_trips(std::integral_constant<int, 0>{});
+            two_trips(std::integral_constant<int, 2>{});
         };
+        auto nothing = [](auto) {};
+        constexpr std::integral_constant<int, 1> one_sum{};
+        constexpr std::integral_constant<int, 2> two_sums{};
         v16f tw;
         if constexpr (one_piece) {
             // one partial sum at a time: its four chain tiles (64 registers) are folded to v_l = (s0+s1)+(s2+s3) before the other starts
@@ -997,15 +1104,18 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
             // two register files per feature block (profiles/r04_attn_exact.md)
             lds_barrier();                                    // P, V staged / the previous block is done with Ps, Vs and Ts
             const int kt = chunk_len(0);
-            if (d0 + 32 < D) wide_load(vnext, tile_rsrc(vc + (int64_t)(hd * D + d0 + 32) * n_ctx, 32, n_ctx), n_ctx, 32);
+            const bool more = d0 + 32 < D;
+            const __amdgpu_buffer_rsrc_t rsV = tile_rsrc(vc + (int64_t)(hd * D + d0 + 32) * n_ctx, more ? 32 : 0, n_ctx);
+            auto next_v = [&](auto part) __attribute__((always_inline)) { if (more) wide_load(vnext, rsV, n_ctx, 32, 0, part); };
             v16f v0;
 #pragma unroll
             for (int li = 0; li < 2; ++li) {
-                v16f t4[4] = {{}, {}, {}, {}};
-                chain(t4, wave + 4 * li, 0, nbody);
+                v16f t4[1][4] = {{{}, {}, {}, {}}};
+                if (li == 0) chain(t4, one_sum, wave + 4 * li, nbody, next_v);
+                else chain(t4, one_sum, wave + 4 * li, nbody, nothing);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float v = __fadd_rn(__fadd_rn(t4[0][e], t4[1][e]), __fadd_rn(t4[2][e], t4[3][e]));   // (s0+s1)+(s2+s3)
+                    const float v = __fadd_rn(__fadd_rn(t4[0][0][e], t4[0][1][e]), __fadd_rn(t4[0][2][e], t4[0][3][e]));   // (s0+s1)+(s2+s3)
                     if (li == 0) v0[e] = v;
                     else tw[e] = __fadd_rn(v0[e], v);                                                            // t_w = v_w + v_{w+4} (lo128 + hi128)
                 }
@@ -1018,43 +1128,28 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
             // next to the 128 accumulator registers: a wave alone on its SIMD (one workgroup per CU) has the unified 512-register file.
             v16f tl[2][4] = {{{}, {}, {}, {}}, {{}, {}, {}, {}}};
             if (d0 == 0) {                                    // (later feature blocks: requested during the previous block's last chains)
-                wide_load(pnext, rsP, ld_att, rows_q, 0);
-                wide_load(vnext, tile_rsrc(vc + (int64_t)(hd * D) * n_ctx, 32, n_ctx), n_ctx, 32, 0);
+                load_p(0, whole);
+                wide_load(vnext, tile_rsrc(vc + (int64_t)(hd * D) * n_ctx, 32, n_ctx), n_ctx, 32, 0, whole);
             }
-#ifdef XA_NOPIPE   // A/B build (profiles/r05_attn_exact.md): round 4's order -- a piece is requested behind the barrier that ended the previous one
-            for (int c = 0; c < nchunk; ++c) {
-                const int k0 = c * XA_KT, kt = chunk_len(c);
-                lds_barrier();
-                if (c > 0 || d0 > 0) {
-                    wide_load(pnext, rsP, ld_att, rows_q, k0);
-                    wide_load(vnext, tile_rsrc(vc + (int64_t)(hd * D + d0) * n_ctx, 32, n_ctx), n_ctx, 32, k0);
-                }
-                wide_store(Ps, pnext, rows_q, kt, k0);
-                wide_store(Vs, vnext, 32, kt, k0);
-                lds_barrier();
-                const int cend = min(nbody, k0 + XA_KT);
-                chain(tl[0], wave, k0, cend);
-                chain(tl[1], wave + 4, k0, cend);
-            }
-#else
             for (int c = 0; c < nchunk; ++c) {
                 const int k0 = c * XA_KT, kt = chunk_len(c);
                 lds_barrier();                                // the previous piece is done with Ps, Vs and Ts
-                wide_store(Ps, pnext, rows_q, kt, k0);
-                wide_store(Vs, vnext, 32, kt, k0);
+                if (d0 == 0 && c < 4) XA_STAMP(8 + 2 * c);
+                store_p(kt);
+                wide_store(Vs, vnext, kt);
                 lds_barrier();
-                if (c + 1 < nchunk) {
-                    wide_load(pnext, rsP, ld_att, rows_q, k0 + XA_KT);
-                    wide_load(vnext, tile_rsrc(vc + (int64_t)(hd * D + d0) * n_ctx, 32, n_ctx), n_ctx, 32, k0 + XA_KT);
-                } else if (d0 + 32 < D) {
-                    wide_load(pnext, rsP, ld_att, rows_q, 0);
-                    wide_load(vnext, tile_rsrc(vc + (int64_t)(hd * D + d0 + 32) * n_ctx, 32, n_ctx), n_ctx, 32, 0);
-                }
-                const int cend = min(nbody, k0 + XA_KT);
-                chain(tl[0], wave, k0, cend);
-                chain(tl[1], wave + 4, k0, cend);
+                if (d0 == 0 && c < 4) XA_STAMP(9 + 2 * c);
+                // the next piece -- of this feature block, or the first one of the next block -- requested among this piece's MFMAs
+                const bool same = c + 1 < nchunk, any = same || d0 + 32 < D;
+                const int nk0 = same ? k0 + XA_KT : 0;
+                const __amdgpu_buffer_rsrc_t rsV = tile_rsrc(vc + (int64_t)(hd * D + d0 + (same ? 0 : 32)) * n_ctx, any ? 32 : 0, n_ctx);
+                chain(tl, two_sums, wave, kt, [&](auto part) __attribute__((always_inline)) {
+                    if (any) {
+                        load_p(nk0, part);
+                        wide_load(vnext, rsV, n_ctx, 32, nk0, part);
+                    }
+                });
             }
-#endif
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float v0 = __fadd_rn(__fadd_rn(tl[0][0][e], tl[0][1][e]), __fadd_rn(tl[0][2][e], tl[0][3][e]));   // (s0+s1)+(s2+s3)
@@ -1065,7 +1160,15 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
         if (d0 == 0) XA_STAMP(2); else if (d0 == 32) XA_STAMP(6);
         lds_barrier();                                        // every wave is done with Ps / Vs
         if (left_visible) {                                  // the leftover keys [np, P) to columns 0.. of both tiles
-            stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, rows_q, np, 32);
+            if constexpr (HP) {
+                for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
+                    const int r = idx >> 5, k = idx & 31, rc = min(r, rows_q - 1);
+                    const float *row = prow + (int64_t)(q0 + rc) * ld_att;
+                    const float t = __half2float(reinterpret_cast<const __half *>(row)[min(np + k, P - 1)]);
+                    Ps[r * XA_LD + k] = r < rows_q && np + k < kend ? __fmul_rn(t, row[ld_att - 1]) : 0.f;
+                }
+            } else
+                stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, rows_q, np, 32);
             stage(Vs, vc + (int64_t)(hd * D + d0) * n_ctx, n_ctx, 32, np, 32);
         }
         {
@@ -1147,7 +1250,7 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
             lds_barrier();                                    // wave 0 / the quantizing threads are done with Ps, Vs and Os
             if (left_visible)                                // the single staged P piece was overwritten by the leftovers: stage it again
                 stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, rows_q, 0, chunk_len(0));
-            wide_store(Vs, vnext, 32, chunk_len(0));
+            wide_store(Vs, vnext, chunk_len(0));
         }
         if (d0 == 0) XA_STAMP(5);
     }
@@ -1155,6 +1258,7 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
 }
 #ifdef XA_TIMING
 extern "C" __attribute__((visibility("default"))) int fl_debug_xa_timing(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(xa_dbg), sizeof(long long) * 1024 * 16); }
+extern "C" __attribute__((visibility("default"))) int fl_debug_xa_cycles(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(xa_dbg), sizeof(long long) * 1024 * 16, sizeof(long long) * 1024 * 16); }
 #endif
 
 // hipErrorInvalidValue: shape outside these kernels' reach (head_dim not a multiple of 32 or > 128, unaligned rows): the caller
@@ -1163,7 +1267,7 @@ hipError_t attn_scores_exact(const float *qkv, int ldq, int D, int H, int N, int
                              float *att, int ld_att, int64_t head_stride, hipStream_t st) {
     if (D % 32 != 0 || D > 128 || N < 1 || (ldq & 3) || (ldk & 3)) return hipErrorInvalidValue;
     const dim3 grid(H, (N + 31) / 32);
-#define FL_XS(NST) hipLaunchKernelGGL((attn_scores_exact_kernel<NST, false>), grid, dim3(512), 0, st, qkv, ldq, N, n_past, kc, ldk, scale, att, ld_att, head_stride, nullptr, 0)
+#define FL_XS(NST) hipLaunchKernelGGL((attn_scores_exact_kernel<NST, false>), grid, dim3(512), 0, st, qkv, ldq, N, n_past, kc, ldk, scale, att, ld_att, head_stride, nullptr, 0, 0)
     if (D == 32) FL_XS(1);
     else if (D == 64) FL_XS(2);
     else if (D == 96) FL_XS(3);
@@ -1174,9 +1278,9 @@ hipError_t attn_scores_exact(const float *qkv, int ldq, int D, int H, int N, int
 // K.Q, scale, mask AND soft_max in one launch (contexts of up to 1024 keys: the 32 score rows of a workgroup wait in LDS); hipErrorInvalidValue:
 // outside its reach -- the caller runs attn_scores_exact + softmax_rows
 hipError_t attn_scores_softmax_exact(const float *qkv, int ldq, int D, int H, int N, int n_past, const float *kc, int ldk, float scale,
-                                     float *att, int ld_att, int64_t head_stride, const uint16_t *exp_tab, hipStream_t st) {
+                                     float *att, int ld_att, int64_t head_stride, const uint16_t *exp_tab, hipStream_t st, bool compact) {
     const int P = n_past + N;
-    if (!exp_tab || D % 32 != 0 || D > 128 || N < 1 || (ldq & 3) || (ldk & 3) || P > 1024) return hipErrorInvalidValue;
+    if (!exp_tab || D % 32 != 0 || D > 128 || N < 1 || (ldq & 3) || (ldk & 3) || P > 1024 || (compact && (P < 4 || ld_att < P))) return hipErrorInvalidValue;
     const int PLD = ((P + 31) & ~31) + 1;
     const size_t lds = (size_t)32 * PLD * 4;
     // 131 KB of dynamic LDS must be asked for once per device: 0 = not tried, 1 = granted, -1 = refused (remembered and said ONCE: the caller's
@@ -1208,7 +1312,7 @@ hipError_t attn_scores_softmax_exact(const float *qkv, int ldq, int D, int H, in
     }
     if (stt < 0) return hipErrorInvalidValue;
     const dim3 grid(H, (N + 31) / 32);
-#define FL_XS(NST) hipLaunchKernelGGL((attn_scores_exact_kernel<NST, true>), grid, dim3(512), lds, st, qkv, ldq, N, n_past, kc, ldk, scale, att, ld_att, head_stride, exp_tab, PLD)
+#define FL_XS(NST) hipLaunchKernelGGL((attn_scores_exact_kernel<NST, true>), grid, dim3(512), lds, st, qkv, ldq, N, n_past, kc, ldk, scale, att, ld_att, head_stride, exp_tab, PLD, compact ? 1 : 0)
     if (D == 32) FL_XS(1);
     else if (D == 64) FL_XS(2);
     else if (D == 96) FL_XS(3);
@@ -1217,8 +1321,9 @@ hipError_t attn_scores_softmax_exact(const float *qkv, int ldq, int D, int H, in
     return hipGetLastError();
 }
 hipError_t attn_pv_exact(const float *att, int ld_att, int64_t head_stride, int D, int H, int N, int n_past, const float *vc, int n_ctx,
-                         float *ao, int ldo, hipStream_t st, const fl_qact *out, bool with_h16) {
+                         float *ao, int ldo, hipStream_t st, const fl_qact *out, bool with_h16, bool compact) {
     if (D % 32 != 0 || D > 128 || N < 1 || (n_ctx & 3) || (out && (ldo & 31))) return hipErrorInvalidValue;
+    if (compact && (n_past + N <= XA_KT || (ld_att & 3))) return hipErrorInvalidValue;      // (one piece: the f32 form; softmax_rows / attn_scores_softmax_exact take the same flag)
     const size_t lds = (size_t)2 * 32 * XA_LD * 4 + 4 * 64 * 16 * 4 + 32 * 33 * 4;
     static bool attr_set[64] = {false};      // (per device)
     int dev = 0;
@@ -1228,6 +1333,8 @@ hipError_t attn_pv_exact(const float *att, int ld_att, int64_t head_stride, int 
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_pv_exact_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_pv_exact_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_pv_exact_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
@@ -1237,6 +1344,9 @@ hipError_t attn_pv_exact(const float *att, int ld_att, int64_t head_stride, int 
     if (n_past + N <= XA_KT)
         hipLaunchKernelGGL(attn_pv_exact_kernel<true>, dim3(H, (N + 31) / 32), dim3(256), lds, st, att, ld_att, head_stride, D, N, n_past, vc, n_ctx, ao, ldo,
                            oq, od, os, oh);
+    else if (compact)
+        hipLaunchKernelGGL((attn_pv_exact_kernel<false, true>), dim3(H, (N + 31) / 32), dim3(256), lds, st, att, ld_att, head_stride, D, N, n_past, vc, n_ctx, ao,
+                           ldo, oq, od, os, oh);
     else
         hipLaunchKernelGGL(attn_pv_exact_kernel<false>, dim3(H, (N + 31) / 32), dim3(256), lds, st, att, ld_att, head_stride, D, N, n_past, vc, n_ctx, ao, ldo,
                            oq, od, os, oh);

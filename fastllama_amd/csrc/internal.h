@@ -42,6 +42,7 @@ void build_rope_table(float *rt, int n_ctx, int D);
 #define FL_INTERNAL_FUNCS(X) \
     X(attn_pv_exact) \
     X(attn_scores_exact) \
+    X(attn_scores_softmax_exact) \
     X(build_f16_tables) \
     X(build_rope_table) \
     X(check_mm) \

@@ -892,8 +892,10 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
                 // KQ, scale, mask, soft_max                                                            :364-379
                 const bool xa = exact && !dyn && N >= 2 && D % 32 == 0 && D <= 128;   // the MFMA forms of the exact products
                 // (contexts of up to 1024 keys: K.Q and soft_max in one launch, the score rows waiting in LDS)
+                // (contexts of 513 .. 2048 keys: the probabilities travel compact -- fp16 table values + one factor per row -- between the launches)
+                const bool compact = xa && P > 512 && P <= 2048 && (n_ctx & 3) == 0;
                 bool softmaxed = false;
-                hipError_t xe = xa ? attn_scores_softmax_exact(m->qkv, 3 * El, D, Hl, N, n_past, kc, El, kq_scale, m->att, n_ctx, (int64_t)N * n_ctx, m->exp_tab, st)
+                hipError_t xe = xa ? attn_scores_softmax_exact(m->qkv, 3 * El, D, Hl, N, n_past, kc, El, kq_scale, m->att, n_ctx, (int64_t)N * n_ctx, m->exp_tab, st, compact)
                                    : hipErrorInvalidValue;
                 if (xe == hipSuccess) softmaxed = true;
                 else if (xa) {
@@ -906,11 +908,11 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
                                                                     kq_scale, 1, n_past, st, dyn, n_ctx);
                 }
                 M_HIP(xe);
-                if (!softmaxed) M_HIP(softmax_rows(m->att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, Hl, m->exp_tab, st, dyn));
+                if (!softmaxed) M_HIP(softmax_rows(m->att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, Hl, m->exp_tab, st, dyn, compact));
                 // KQV, merged back to [N, n_embd]                                                      :389-398
                 bool quantized = xa && layout == 16 && El % 32 == 0;        // the MFMA form writes the Q8_0 operand of wo itself
                 xe = xa ? attn_pv_exact(m->att, n_ctx, (int64_t)N * n_ctx, D, Hl, N, n_past, vc, n_ctx, m->ao, El, st, quantized ? &sEl : nullptr,
-                                        xh && !m->tp_rows)
+                                        xh && !m->tp_rows, compact)
                         : hipErrorInvalidValue;
                 if (xe == hipErrorInvalidValue) {
                     (void)hipGetLastError();

@@ -14,6 +14,7 @@ using namespace fl;
 static const fl::InternalTable *const IT = fl_internal_table();
 #define attn_pv_exact (IT->attn_pv_exact)
 #define attn_scores_exact (IT->attn_scores_exact)
+#define attn_scores_softmax_exact (IT->attn_scores_softmax_exact)
 #define build_f16_tables (IT->build_f16_tables)
 #define build_rope_table (IT->build_rope_table)
 #define check_mm (IT->check_mm)
@@ -150,12 +151,12 @@ int fl_debug_gemm_silu(const fl_qtensor *W, const fl_qact *a_, const uint16_t *s
 }
 /* test hook: the P.V product of the reference-order prefill attention with its Q8_0 epilogue: att = soft_max'ed probabilities [H][N][n_ctx]
  * (as fl_debug_attn_exact leaves them) -> out = Q8_0 of the merged [N, E] rows (QA16 + the XH16 copy) */
-int fl_debug_attn_pv_exact_q8(const float *att, int n_ctx, int D, int H, int N, int n_past, const float *vc, int E, fl_qact *out_, void *st) {
+int fl_debug_attn_pv_exact_q8(const float *att, int n_ctx, int D, int H, int N, int n_past, const float *vc, int E, fl_qact *out_, int compact, void *st) {
     fl_qact_impl *out = static_cast<fl_qact_impl *>(out_);
     if (!att || !vc || !out) return set_error(FL_EINVAL, "null argument");
     if (E != out->K || N > out->cap_N16 || E != H * D) return set_error(FL_EINVAL, "attn_pv_exact_q8: bad output workspace");
     out->N = N; out->N16 = fl_roundup(N, 16); out->KB = E / 32; out->layout = 16;
-    FL_HIP(attn_pv_exact(att, n_ctx, (int64_t)N * n_ctx, D, H, N, n_past, vc, n_ctx, nullptr, E, S(st), out, true));
+    FL_HIP(attn_pv_exact(att, n_ctx, (int64_t)N * n_ctx, D, H, N, n_past, vc, n_ctx, nullptr, E, S(st), out, true, compact != 0));
     out->h16_valid = 1;
     return FL_OK;
 }
@@ -293,22 +294,28 @@ int fl_debug_gemm_f32_abt_exact(const float *A, int lda, long sAz, const float *
     M_HIP(dot_f32_abt_exact(A, lda, sAz, B, ldb, sBz, Cc, ldc, sCz, M, Nn, K, batch, alpha, causal_mode, n_past, (hipStream_t)stream, nullptr, 0));
     return FL_OK;
 }
-/* test hook: exact-mode prefill attention on caller-provided buffers: scores (MFMA form when which = 1, one half-wave per dot when 0)
- * -> soft_max -> P.V; att: [H][N][n_ctx] scratch, ao: [N][E] f32 result */
+/* test hook: exact-mode prefill attention on caller-provided buffers: scores (MFMA form when which >= 1, one half-wave per dot when 0)
+ * -> soft_max -> P.V; att: [H][N][n_ctx] scratch, ao: [N][E] f32 result.  which = 2: the probabilities compact between the launches (contexts of
+ * 513 .. 2048 keys); which = 3: that with K.Q and soft_max as one launch (up to 1024 keys) */
 int fl_debug_attn_exact(const float *qkv, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc, const float *vc,
                         const uint16_t *exp_tab_dev, float scale, float *att, float *ao, int which, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const int P = n_past + N;
-    if (which) M_HIP(attn_scores_exact(qkv, ldq, D, H, N, n_past, kc, E, scale, att, n_ctx, (int64_t)N * n_ctx, st));
-    else M_HIP(dot_f32_abt_exact(qkv, ldq, D, kc, E, D, att, n_ctx, (int64_t)N * n_ctx, N, P, D, H, scale, 1, n_past, st, nullptr, 0));
-    M_HIP(softmax_rows(att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, H, exp_tab_dev, st, nullptr));
-    if (which) M_HIP(attn_pv_exact(att, n_ctx, (int64_t)N * n_ctx, D, H, N, n_past, vc, n_ctx, ao, E, st, nullptr, false));
+    const bool compact = which >= 2;
+    if (which == 3) {
+        M_HIP(attn_scores_softmax_exact(qkv, ldq, D, H, N, n_past, kc, E, scale, att, n_ctx, (int64_t)N * n_ctx, exp_tab_dev, st, true));
+    } else {
+        if (which) M_HIP(attn_scores_exact(qkv, ldq, D, H, N, n_past, kc, E, scale, att, n_ctx, (int64_t)N * n_ctx, st));
+        else M_HIP(dot_f32_abt_exact(qkv, ldq, D, kc, E, D, att, n_ctx, (int64_t)N * n_ctx, N, P, D, H, scale, 1, n_past, st, nullptr, 0));
+        M_HIP(softmax_rows(att, n_ctx, (int64_t)N * n_ctx, N, P, n_past, H, exp_tab_dev, st, nullptr, compact));
+    }
+    if (which) M_HIP(attn_pv_exact(att, n_ctx, (int64_t)N * n_ctx, D, H, N, n_past, vc, n_ctx, ao, E, st, nullptr, false, compact));
     else M_HIP(dot_f32_abt_exact(att, n_ctx, (int64_t)N * n_ctx, vc, n_ctx, (int64_t)D * n_ctx, ao, E, D, N, D, P, H, 1.0f, 2, n_past, st, nullptr, 0));
     return FL_OK;
 }
 int fl_debug_softmax_rows(float *S, int ld, long sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab_dev,
                           void *stream) {
-    M_HIP(softmax_rows(S, ld, sz, N, P, n_past, batch, exp_tab_dev, (hipStream_t)stream, nullptr));
+    M_HIP(softmax_rows(S, ld, sz, N, P, n_past, batch, exp_tab_dev, (hipStream_t)stream, nullptr, false));
     return FL_OK;
 }
 

@@ -53,11 +53,12 @@ int fl_debug_gemm_f32_abt_exact(const float *A, int lda, long sAz, const float *
                                 /* the same product in ggml_vec_dot_f32's order (exact mode's attention matmuls) */
 int fl_debug_attn_exact(const float *qkv_dev, int ldq, int D, int H, int N, int n_past, int n_ctx, int E, const float *kc_dev,
                         const float *vc_dev, const uint16_t *exp_tab_dev, float scale, float *att_dev /* [H][N][n_ctx] scratch */,
-                        float *ao_dev /* [N][E] */, int which /* 1: MFMA forms (n_past + N <= 512), 0: one half-wave per dot */, void *stream);
+                        float *ao_dev /* [N][E] */, int which /* 1: MFMA forms, 0: one half-wave per dot, 2: MFMA forms with the probabilities compact between soft_max and P.V (513 .. 2048 keys), 3: that with K.Q and soft_max as one launch (<= 1024 keys) */, void *stream);
 int fl_debug_softmax_rows(float *S_dev, int ld, long sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab_dev,
                           void *stream);
 int fl_debug_attn_pv_exact_q8(const float *att_dev /* probabilities, as fl_debug_attn_exact leaves them */, int n_ctx, int D, int H, int N,
-                              int n_past, const float *vc_dev, int E, fl_qact *out /* Q8_0 of the [N][E] result */, void *stream);
+                              int n_past, const float *vc_dev, int E, fl_qact *out /* Q8_0 of the [N][E] result */,
+                              int compact /* att_dev as fl_debug_attn_exact(which >= 2) leaves it */, void *stream);
 
 /* test hooks: force one kernel family regardless of N (N must suit the layout of `a`) */
 /* the fused forms of the prefill GEMM: + residual; wq|wk|wv with rope + KV-cache stores; woven w1|w3 with silu*mul -> Q8_0 */

@@ -590,11 +590,16 @@ def test_exact_decode_attention(torch, ops, port, exact_hooks, D, H, n_past, spl
                                           (128, 2, 9, 500), (128, 2, 200, 312), (32, 3, 2, 5),
                                           # contexts beyond one 512-key piece of the V.P kernel: the 8 chains of a wave are carried across pieces
                                           (128, 2, 70, 600), (64, 3, 33, 1000), (128, 1, 512, 512), (128, 2, 100, 1947), (32, 2, 40, 1003),
-                                          (128, 1, 64, 448), (96, 2, 31, 993)])
+                                          (128, 1, 64, 448), (96, 2, 31, 993),
+                                          # ... with the probabilities compact between soft_max and V.P: whole and ragged last pieces, P = n_ctx (the row's
+                                          # factor sits in the float a score held), ragged query blocks, every leftover form again
+                                          (128, 2, 512, 1536), (128, 1, 40, 984), (64, 2, 100, 413), (128, 1, 33, 480), (32, 2, 70, 1951), (128, 2, 9, 504),
+                                          (96, 1, 48, 977), (128, 1, 5, 2043)])
 def test_exact_prefill_attention_mfma_forms(torch, ops, port, D, H, N, n_past):
     """K.Q and V.P of a batch on the f32-input MFMA (its k = 0, 1 chain is the reference's fma chain): the same bits as the
     one-half-wave-per-dot kernel and as the oracle -- every leftover form (P % 32), causal tiles, ragged last query block, and
-    contexts of several 512-key pieces."""
+    contexts of several 512-key pieces; beyond 512 keys also the form the model runs (round 6): probabilities as fp16 table values + one
+    factor per row between the launches, K.Q and soft_max as one launch up to 1024 keys."""
     from fastllama_amd import hip
     L = hip.load()
     E, P = H * D, n_past + N
@@ -602,7 +607,7 @@ def test_exact_prefill_attention_mfma_forms(torch, ops, port, D, H, N, n_past):
     rng = np.random.default_rng(D + H + N + n_past)
     qkv = rng.standard_normal((N, 3 * E)).astype(np.float32)
     kc = np.zeros((n_ctx, E), np.float32)
-    vc = np.full((E, n_ctx), 7.0, np.float32)                 # stale values beyond the context must not leak in
+    vc = np.full((E, n_ctx), np.nan, np.float32)              # whatever lies beyond the context must not leak in (nor be multiplied by a zero)
     kc[:P] = rng.standard_normal((P, E))
     vc[:, :P] = rng.standard_normal((E, P))
     e = np.empty(1 << 16, np.uint16)
@@ -610,14 +615,17 @@ def test_exact_prefill_attention_mfma_forms(torch, ops, port, D, H, N, n_past):
     ed, qd, kd, vd = dev(torch, e.view(np.int16)), dev(torch, qkv), dev(torch, kc), dev(torch, vc)
     scale = np.float32(1.0) / np.sqrt(np.float32(D))
     outs = []
-    for which in (0, 1):
+    compact_forms = ((2,) if 512 < P <= 2048 else ()) + ((3,) if 512 < P <= 1024 else ())
+    for which in compact_forms + (0, 1):
         att = torch.full((H, N, n_ctx), float("nan"), device="cuda")
         ao = torch.full((N, E), 3.0, device="cuda")
         hip.check(L.fl_debug_attn_exact(qd.data_ptr(), 3 * E, D, H, N, n_past, n_ctx, E, kd.data_ptr(), vd.data_ptr(), ed.data_ptr(),
                                         float(scale), att.data_ptr(), ao.data_ptr(), which, None))
         torch.cuda.synchronize()
         outs.append(ao.cpu().numpy())
-    assert np.array_equal(bits(outs[0]), bits(outs[1])), int((bits(outs[0]) != bits(outs[1])).sum())
+    for o in outs[:-1]:
+        assert np.array_equal(bits(o), bits(outs[-1])), int((bits(o) != bits(outs[-1])).sum())
+    outs = outs[-2:]
     want = np.empty((N, E), np.float32)
     for h in range(H):
         sl = slice(h * D, (h + 1) * D)
@@ -627,11 +635,20 @@ def test_exact_prefill_attention_mfma_forms(torch, ops, port, D, H, N, n_past):
     assert np.array_equal(bits(outs[1]), bits(want))
     # the form the model runs for N >= 9: P.V writes the Q8_0 operand of the wo matmul itself (att still holds the probabilities) ...
     a = ops.QAct(N, E)
-    hip.check(L.fl_debug_attn_pv_exact_q8(att.data_ptr(), n_ctx, D, H, N, n_past, vd.data_ptr(), E, a.handle, None))
+    hip.check(L.fl_debug_attn_pv_exact_q8(att.data_ptr(), n_ctx, D, H, N, n_past, vd.data_ptr(), E, a.handle, 0, None))
     a.N, a.K = N, E
     got_q = a.export().cpu().numpy()
     for n in range(N):
         assert np.array_equal(got_q[n], port.quantize_row_q8_0(want[n])), n
+    if compact_forms:                                         # ... from compact probabilities
+        att = torch.full((H, N, n_ctx), float("nan"), device="cuda")
+        ao = torch.full((N, E), 3.0, device="cuda")
+        hip.check(L.fl_debug_attn_exact(qd.data_ptr(), 3 * E, D, H, N, n_past, n_ctx, E, kd.data_ptr(), vd.data_ptr(), ed.data_ptr(),
+                                        float(scale), att.data_ptr(), ao.data_ptr(), 2, None))
+        a = ops.QAct(N, E)
+        hip.check(L.fl_debug_attn_pv_exact_q8(att.data_ptr(), n_ctx, D, H, N, n_past, vd.data_ptr(), E, a.handle, 1, None))
+        a.N, a.K = N, E
+        assert np.array_equal(a.export().cpu().numpy(), got_q)
     # ... and its f16 fragment copy, which the reference-order GEMM reads (q4_layout.h XH16): a matmul on it equals the oracle's
     if N >= 9:
         wq = port.quantize_q4(oracle.Q4_0, (rng.standard_normal((80, E)) * 0.05).astype(np.float32))
