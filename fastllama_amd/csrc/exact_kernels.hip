@@ -699,8 +699,10 @@ namespace fl {
 //           levels; leftover keys (P % 32) in order.  Any context length (round 3; contexts beyond 512 keys used to fall back
 //           to dot_f32_abt_exact, one half-wave per dot).
 // ------------------------------------------------------------------------------------------------
-constexpr int XA_KT = 512;      // keys the pv kernel holds in LDS
+constexpr int XA_KT = 512;      // keys the pv kernel holds in LDS (a context of one piece)
 constexpr int XA_LD = XA_KT + 1;
+constexpr int XD_KT = 256;      // ... per piece and buffer behind a deeper context: two buffers, one under the MFMAs while the other is filled
+constexpr int XD_LD = XD_KT + 1;
 
 // lane (i, h) of an MFMA supplies, for the 32-element step st = 2 m + h, element 8 jj + l of row i.  The key row of a tile is kept in
 // registers (the 32 elements of each of the lane's MS = ceil(NST / 2) steps, zeros for a step past the row; straight from HBM/L2
@@ -883,8 +885,9 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
                                                             int ldo, int8_t *__restrict__ oq, float *__restrict__ od,
                                                             float *__restrict__ os, uint16_t *__restrict__ oh) {
     extern __shared__ __attribute__((aligned(16))) float xs_[];
-    float *Ps = xs_;                                         // [32 queries][XA_LD]   probabilities, zero past each query's last key
-    float *Vs = xs_ + 32 * XA_LD;                            // [32 features][XA_LD]
+    constexpr int LD = ONE ? XA_LD : XD_LD;
+    float *Ps = xs_;                                         // [32 queries][LD]   probabilities, zero past each query's last key
+    float *Vs = xs_ + 32 * LD;                               // [32 features][LD]     (several pieces: buffer 0; buffer 1 = the next 64 rows)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // heaviest query blocks first (block i sees (i + 1) 32-key steps): with one or two workgroups resident per CU the launch runs in
     // rounds, and the CU that finishes a light block of the first round takes the heaviest one left -- every CU ends up with about
@@ -894,7 +897,7 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
     const int P = n_past + N;                                // the dot runs over all P keys (soft_max wrote zeros past the diagonal)
     const int kend = min(P, n_past + min(q0 + 31, N - 1) + 1);     // ... but past this block's last visible key every term is +0
     const int np = P & ~31, nbody = min(np, (kend + 31) & ~31);     // whole 32-key steps that can hold a non-zero probability
-    const int nchunk = (nbody + XA_KT - 1) / XA_KT;          // 512-key pieces of the body: the 32 chains of an output run through all of them
+    const int npc = (nbody + XD_KT - 1) / XD_KT;             // 256-key pieces of the body: the 32 chains of an output run through all of them
     const float *prow = att + hd * head_stride;
     // staging of keys [k0, k0 + kt): float4 pieces, sixteen loads in flight per thread (a one-load-at-a-time loop is a chain of L2
     // round trips); keys >= kend and rows >= rows_valid become +0
@@ -912,7 +915,7 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
                 const int idx = base + u * 256;
                 if (idx < total4) {
                     const int r = idx / q4n, k = (idx % q4n) * 4;
-                    float *d = dst + r * XA_LD + k;
+                    float *d = dst + r * LD + k;
                     const bool rv = r < rows_valid;
                     d[0] = rv && k0 + k < kend ? v[u].x : 0.f;
                     d[1] = rv && k0 + k + 1 < kend ? v[u].y : 0.f;
@@ -988,52 +991,87 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
     };
     auto chunk_len = [&](int c) { return min(XA_KT, nbody - c * XA_KT); };                  // body keys of piece c
     const int rows_q = min(32, N - q0);
-    // compact probabilities: thread -> 8 x 16 bytes (8 keys each): lane (rr, kk) of wave w takes, for u = 0 .. 7, row 8 (u & 3) + rr, keys
-    // 64 (2 w + (u >> 2)) + 8 kk .. + 7 -- a wave-load is 8 rows x one 128-byte line again, a wave-store of one component 2 lanes per bank
-    float inv4[4];
+    // ---- several pieces (ONE = false; round 6) ----
+    // Two LDS buffers of 256 keys (P tile + V tile each): the MFMA chains of piece g run from buffer g & 1 while piece g + 1 goes from registers into the
+    // other buffer and piece g + 2 is requested -- both AMONG the MFMAs (sched_group_barrier), so the staging costs issue slots, not time.  (Round 5: one
+    // 512-key buffer; per piece 2.6 us of stores between two barriers, then 4.1 us of chains that waited out an LDS round trip per pair of MFMAs and had
+    // queued the next piece's 24 loads per thread before the first one -- 1.85 us of MFMA work; profiles/r06_attn_exact.md.)  A piece is (feature block,
+    // 256 keys); the sequence runs through the feature blocks, so the first piece of the next block is under way during the last of this one.
+    // thread -> f32 tile: 8 float4, lane (rr, kk) of wave w, u = 0 .. 7: row 8 (u & 3) + rr, keys 32 (2 w + (u >> 2)) + 4 kk .. + 3;
+    //        -> compact P tile: 4 x 16 bytes, u = 0 .. 3: row 8 u + rr, keys 64 w + 8 kk .. + 7 (a wave-load: 8 rows x one 128-byte line either way)
+    typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
+    struct PieceRegs {
+        v4u_ hp[HP ? 4 : 1];
+        float4 fp[HP || ONE ? 1 : 8];
+        float4 v[ONE ? 1 : 8];
+    };
+    float inv4[4];                                           // compact P: the factors of rows 8 r + rr
     if constexpr (HP) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) inv4[r] = prow[(int64_t)(q0 + min(8 * r + s_rr, rows_q - 1)) * ld_att + ld_att - 1];
     }
-    typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
-    auto wide_load_h = [&](v4u_ (&v)[8], __amdgpu_buffer_rsrc_t rs, int k0, auto part) __attribute__((always_inline)) {
-        constexpr int T = decltype(part)::value;
+    auto piece_len = [&](int c) { return min(XD_KT, nbody - c * XD_KT); };                  // body keys of piece c (a multiple of 32)
+    // (part: the whole piece (-1) or one of its twelve wave-loads, numbered as store_piece's parts)
+    auto load_piece = [&](PieceRegs &R, __amdgpu_buffer_rsrc_t rsp, __amdgpu_buffer_rsrc_t rsv, int k0, auto part) __attribute__((always_inline)) {
+        constexpr int PT = decltype(part)::value;
+        if constexpr (HP) {
 #pragma unroll
-        for (int u = T < 0 ? 0 : 2 * T; u < (T < 0 ? 8 : 2 * T + 2); ++u) {
-            const int row = 8 * (u & 3) + s_rr, col = 64 * (2 * wave + (u >> 2)) + 8 * s_kk;
-            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, min(row, rows_q - 1) * ld_att * 4 + col * 2, k0 * 2, 0);
+            for (int u = 0; u < 4; ++u)
+                if (PT < 0 || PT == u)
+                    R.hp[u] = __builtin_amdgcn_raw_buffer_load_b128(rsp, min(8 * u + s_rr, rows_q - 1) * ld_att * 4 + (64 * wave + 8 * s_kk) * 2, k0 * 2, 0);
         }
-    };
-    auto wide_store_h = [&](float *dst, const v4u_ (&v)[8], int valid) {
-        const int kt = (valid + 127) & ~127;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int row = 8 * (u & 3) + s_rr, col = 64 * (2 * wave + (u >> 2)) + 8 * s_kk;
-            if (col < kt) {                                  // (wave-uniform: a wave-store covers 64 keys)
-                float *d = dst + row * XA_LD + col;
-                const bool in = col < valid;                 // (zeros behind the body, as wide_store; the lane's eight keys together.  A select, not a
-                const unsigned w4[4] = {in ? v[u].x : 0u, in ? v[u].y : 0u, in ? v[u].z : 0u, in ? v[u].w : 0u};      // factor: those halves are anything)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float t = __half2float(__ushort_as_half((unsigned short)(w4[j >> 1] >> (16 * (j & 1)))));
-                    d[j] = __fmul_rn(t, inv4[u & 3]);
-                }
+            if (!(PT < 0 || PT == (HP ? 4 + u : u))) continue;
+            const int row = 8 * (u & 3) + s_rr, col = 32 * (2 * wave + (u >> 2)) + 4 * s_kk;
+            if constexpr (!HP && !ONE) {
+                const v4u_ r = __builtin_amdgcn_raw_buffer_load_b128(rsp, (min(row, rows_q - 1) * ld_att + col) * 4, k0 * 4, 0);
+                R.fp[u] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+            }
+            if constexpr (!ONE) {
+                const v4u_ r = __builtin_amdgcn_raw_buffer_load_b128(rsv, (row * n_ctx + col) * 4, k0 * 4, 0);
+                R.v[u] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
             }
         }
+    };
+    // valid body keys; columns [valid, whole 128-key trips) become zeros (FULL: valid = 256, no compare at all); columns past the trips are not written
+    // (pd / vd: the LANE's first element of the buffer's P / V tile -- st_base below -- as an offset into the LDS array that the compiler cannot fold
+    // with the other buffers': the four tiles span 128 KB, a ds instruction's immediate reaches 64 KB, and folded into one base every address of
+    // every buffer became a register of its own, computed ahead of the loop and spilled: 1.1 KB of scratch)
+    // valid body keys; the columns behind them become zeros: every piece runs its two 128-key trips.  part: all of the piece (-1) or one of its
+    // twelve wave-stores, in the order the loads were issued (compact P: four P then eight V; f32 P: eight P + V pairs)
+    auto store_piece = [&](const PieceRegs &R, int pd_, int vd_, int valid, auto part) __attribute__((always_inline)) {
+        constexpr int PT = decltype(part)::value;
+        float *const pd = xs_ + pd_, *const vd = xs_ + vd_;
+        if constexpr (HP) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (PT < 0 || PT == u) {
+                    float *d = pd + 8 * u * LD;
+                    const bool in = 64 * wave + 8 * s_kk < valid;     // (the lane's eight keys together; a select, not a factor: those halves are anything)
+                    const unsigned w4[4] = {in ? R.hp[u].x : 0u, in ? R.hp[u].y : 0u, in ? R.hp[u].z : 0u, in ? R.hp[u].w : 0u};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        d[j] = __fmul_rn(__half2float(__ushort_as_half((unsigned short)(w4[j >> 1] >> (16 * (j & 1))))), inv4[u]);
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (PT < 0 || PT == (HP ? 4 + u : u)) {
+                const bool in = 32 * (2 * wave + (u >> 2)) + 4 * s_kk < valid;
+                if constexpr (!HP && !ONE) {
+                    float *d = pd + 8 * (u & 3) * LD + 32 * (u >> 2);
+                    d[0] = in ? R.fp[u].x : 0.f; d[1] = in ? R.fp[u].y : 0.f; d[2] = in ? R.fp[u].z : 0.f; d[3] = in ? R.fp[u].w : 0.f;
+                }
+                if constexpr (!ONE) {
+                    float *d = vd + 8 * (u & 3) * LD + 32 * (u >> 2);
+                    d[0] = in ? R.v[u].x : 0.f; d[1] = in ? R.v[u].y : 0.f; d[2] = in ? R.v[u].z : 0.f; d[3] = in ? R.v[u].w : 0.f;
+                }
+            }
     };
     constexpr bool one_piece = ONE;                          // short contexts: P staged once, V blocks requested one ahead
     const __amdgpu_buffer_rsrc_t rsP = tile_rsrc(prow + (int64_t)q0 * ld_att, rows_q, ld_att);
     float4 vnext[16];
-    float4 pnext[ONE || HP ? 1 : 16];                        // (multi-piece form: the next piece's probabilities in flight)
-    v4u_ hnext[HP ? 8 : 1];                                  // (... in their compact form)
-    auto load_p = [&](int k0, auto part) __attribute__((always_inline)) {
-        if constexpr (HP) wide_load_h(hnext, rsP, k0, part);
-        else if constexpr (!ONE) wide_load(pnext, rsP, ld_att, rows_q, k0, part);
-    };
-    auto store_p = [&](int kt) __attribute__((always_inline)) {
-        if constexpr (HP) wide_store_h(Ps, hnext, kt);
-        else if constexpr (!ONE) wide_store(Ps, pnext, kt);
-    };
     XA_STAMP(0);
     if constexpr (one_piece) {
         float4 pfirst[16];
@@ -1043,129 +1081,29 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
         wide_store(Vs, vnext, chunk_len(0));
     }
     XA_STAMP(1);
-    float *Ts = xs_ + 64 * XA_LD;                            // the waves' t tiles meet here: [4 waves][16 e][64 lanes]
+    float *Ts = xs_ + (ONE ? 64 * XA_LD : 128 * XD_LD);      // the waves' t tiles meet here: [4 waves][16 e][64 lanes]
     float *Os = Ts + 4 * 64 * 16;                            // oq: the finished [32 queries][33] tile of a feature block, on its way to Q8_0
     const int nleft = P - np;                                // < 32 keys behind the body, taken in order
     const bool left_visible = nleft > 0 && kend > np;
-    for (int d0 = 0; d0 < D; d0 += 32) {
-        // wave w: partial sums l = w and l = w + 4, all four jj: chains over ALL 32-key steps of the body, two steps per MFMA.
-        // chain(acc, NL, l, valid): the four jj chains of the NL partial sums l, l + 4 over the staged piece (valid body keys + zeros to a whole trip).
-        // A trip = 128 keys = 8 NL MFMAs; its 16 NL operand reads are issued one trip AHEAD, before the previous trip's MFMAs (round 6): a wave is alone
-        // on its SIMD, nothing else covers the LDS round trip -- read-then-multiply per pair of MFMAs ran them at 150 cycles apiece instead of 64
-        // (profiles/r06_attn_exact.md).
-        // between(tag t), t = 0 .. 3: what the caller wants issued among the MFMAs of trip t (a quarter of the next tiles' loads); called for every t.
-        auto chain = [&](auto &acc, auto nl_tag, int l, int valid, auto &&between) __attribute__((always_inline)) {
-            constexpr int NL = decltype(nl_tag)::value;
-            const int kt = (valid + 127) & ~127;              // (whole trips: the tiles hold zeros behind the body)
-            auto fetch = [&](float (&a)[NL][2][4], float (&b)[NL][2][4], int cs) __attribute__((always_inline)) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int n = 0; n < NL; ++n)
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            const int e = cs + 64 * u + 32 * h + 8 * jj + l + 4 * n;
-                            a[n][u][jj] = Ps[i * XA_LD + e];
-                            b[n][u][jj] = Vs[i * XA_LD + e];
-                        }
-            };
-            auto mac = [&](const float (&a)[NL][2][4], const float (&b)[NL][2][4]) __attribute__((always_inline)) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                        for (int n = 0; n < NL; ++n)
-                            acc[n][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n][u][jj], b[n][u][jj], acc[n][jj], 0, 0, 0);
-            };
-            float a0[NL][2][4], b0[NL][2][4], a1[NL][2][4], b1[NL][2][4];
-            if (kt > 0) fetch(a0, b0, 0);
-            static_assert(XA_KT == 512, "four 128-key trips per piece");
-            auto two_trips = [&](auto t0) __attribute__((always_inline)) {
-                constexpr int T0 = decltype(t0)::value, cs = 128 * T0;
-                const bool first = cs < kt, second = cs + 128 < kt;      // (wave-uniform)
-                if (second) fetch(a1, b1, cs + 128);
-                between(std::integral_constant<int, T0>{});
-                if (first) mac(a0, b0);
-                if (cs + 256 < kt) fetch(a0, b0, cs + 256);
-                between(std::integral_constant<int, T0 + 1>{});
-                if (second) mac(a1, b1);
-            };
-            two_trips(std::integral_constant<int, 0>{});
-            two_trips(std::integral_constant<int, 2>{});
-        };
-        auto nothing = [](auto) {};
-        constexpr std::integral_constant<int, 1> one_sum{};
-        constexpr std::integral_constant<int, 2> two_sums{};
-        v16f tw;
-        if constexpr (one_piece) {
-            // one partial sum at a time: its four chain tiles (64 registers) are folded to v_l = (s0+s1)+(s2+s3) before the other starts
-            // -- with both alive (128) next to the 64 registers of the V block in flight the kernel shuffled ~600 values between the
-            // two register files per feature block (profiles/r04_attn_exact.md)
-            lds_barrier();                                    // P, V staged / the previous block is done with Ps, Vs and Ts
-            const int kt = chunk_len(0);
-            const bool more = d0 + 32 < D;
-            const __amdgpu_buffer_rsrc_t rsV = tile_rsrc(vc + (int64_t)(hd * D + d0 + 32) * n_ctx, more ? 32 : 0, n_ctx);
-            auto next_v = [&](auto part) __attribute__((always_inline)) { if (more) wide_load(vnext, rsV, n_ctx, 32, 0, part); };
-            v16f v0;
-#pragma unroll
-            for (int li = 0; li < 2; ++li) {
-                v16f t4[1][4] = {{{}, {}, {}, {}}};
-                if (li == 0) chain(t4, one_sum, wave + 4 * li, nbody, next_v);
-                else chain(t4, one_sum, wave + 4 * li, nbody, nothing);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float v = __fadd_rn(__fadd_rn(t4[0][0][e], t4[0][1][e]), __fadd_rn(t4[0][2][e], t4[0][3][e]));   // (s0+s1)+(s2+s3)
-                    if (li == 0) v0[e] = v;
-                    else tw[e] = __fadd_rn(v0[e], v);                                                            // t_w = v_w + v_{w+4} (lo128 + hi128)
-                }
-                if (li == 0) asm volatile("" : "+v"(v0));     // (folded before the second partial sum's MFMAs are issued)
-            }
-        } else {
-            // Software pipeline over the 512-key pieces (round 5): the NEXT piece's P and V tiles are requested right after this piece's tiles
-            // have been stored to LDS and travel under this piece's MFMA chains (~4000 cycles); round 4 requested a piece behind the barrier that
-            // ended the previous one and waited out the round trip every time (90 us per layer at 1024-2048 keys).  The 32 float4 in flight sit
-            // next to the 128 accumulator registers: a wave alone on its SIMD (one workgroup per CU) has the unified 512-register file.
-            v16f tl[2][4] = {{{}, {}, {}, {}}, {{}, {}, {}, {}}};
-            if (d0 == 0) {                                    // (later feature blocks: requested during the previous block's last chains)
-                load_p(0, whole);
-                wide_load(vnext, tile_rsrc(vc + (int64_t)(hd * D) * n_ctx, 32, n_ctx), n_ctx, 32, 0, whole);
-            }
-            for (int c = 0; c < nchunk; ++c) {
-                const int k0 = c * XA_KT, kt = chunk_len(c);
-                lds_barrier();                                // the previous piece is done with Ps, Vs and Ts
-                if (d0 == 0 && c < 4) XA_STAMP(8 + 2 * c);
-                store_p(kt);
-                wide_store(Vs, vnext, kt);
-                lds_barrier();
-                if (d0 == 0 && c < 4) XA_STAMP(9 + 2 * c);
-                // the next piece -- of this feature block, or the first one of the next block -- requested among this piece's MFMAs
-                const bool same = c + 1 < nchunk, any = same || d0 + 32 < D;
-                const int nk0 = same ? k0 + XA_KT : 0;
-                const __amdgpu_buffer_rsrc_t rsV = tile_rsrc(vc + (int64_t)(hd * D + d0 + (same ? 0 : 32)) * n_ctx, any ? 32 : 0, n_ctx);
-                chain(tl, two_sums, wave, kt, [&](auto part) __attribute__((always_inline)) {
-                    if (any) {
-                        load_p(nk0, part);
-                        wide_load(vnext, rsV, n_ctx, 32, nk0, part);
-                    }
-                });
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float v0 = __fadd_rn(__fadd_rn(tl[0][0][e], tl[0][1][e]), __fadd_rn(tl[0][2][e], tl[0][3][e]));   // (s0+s1)+(s2+s3)
-                const float v1 = __fadd_rn(__fadd_rn(tl[1][0][e], tl[1][1][e]), __fadd_rn(tl[1][2][e], tl[1][3][e]));
-                tw[e] = __fadd_rn(v0, v1);                                                                              // t_w = v_w + v_{w+4} (lo128 + hi128)
-            }
-        }
+    // several pieces: what lives across pieces AND feature blocks -- the registers of the piece under way, the first trip's operands of the next
+    // piece (read right behind the barrier that completed its buffer), the 8 chain tiles of the feature block
+    PieceRegs R;
+    // what follows a feature block's chains: the waves' t tiles meet, the last two tree levels, the leftover keys, the stores (f32 rows or Q8_0 blocks)
+    auto finish_block = [&](int d0, const v16f &tw) __attribute__((always_inline)) {
+        // (the thread's indices taken afresh: derived from the kernel's own, every address below is loop-invariant, and the compiler computes all of
+        // them ahead of the piece loop -- where the chains need the registers -- and spills them)
+        int tid_ = threadIdx.x;
+        if constexpr (!ONE) asm volatile("" : "+v"(tid_));
+        const int tid = tid_, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
         if (d0 == 0) XA_STAMP(2); else if (d0 == 32) XA_STAMP(6);
         lds_barrier();                                        // every wave is done with Ps / Vs
         if (left_visible) {                                  // the leftover keys [np, P) to columns 0.. of both tiles
             if constexpr (HP) {
-                for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
+                for (int idx = tid; idx < 32 * 32; idx += 256) {
                     const int r = idx >> 5, k = idx & 31, rc = min(r, rows_q - 1);
                     const float *row = prow + (int64_t)(q0 + rc) * ld_att;
                     const float t = __half2float(reinterpret_cast<const __half *>(row)[min(np + k, P - 1)]);
-                    Ps[r * XA_LD + k] = r < rows_q && np + k < kend ? __fmul_rn(t, row[ld_att - 1]) : 0.f;
+                    Ps[r * LD + k] = r < rows_q && np + k < kend ? __fmul_rn(t, row[ld_att - 1]) : 0.f;
                 }
             } else
                 stage(Ps, prow + (int64_t)q0 * ld_att, ld_att, rows_q, np, 32);
@@ -1183,7 +1121,7 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
             // (Wave 0 alone, row by row, each behind the branches of the leftover code: 2.2 us per feature block, profiles/r04_attn_exact.md.)
             const float *t0 = Ts + lane, *t1 = Ts + 1024 + lane, *t2 = Ts + 2048 + lane, *t3 = Ts + 3072 + lane;
             // C layout: col = lane & 31 = feature, row = (e & 3) + 8 (e >> 2) + 4 h = query
-            const float *vr = Vs + i * XA_LD;
+            const float *vr = Vs + i * LD;
             float sv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1194,7 +1132,7 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int ql = j + 8 * wave + 4 * h;             // (e & 3) + 8 (e >> 2) + 4 h with e = 4 wave + j
-                    const float *pr = Ps + ql * XA_LD;
+                    const float *pr = Ps + ql * LD;
                     float s = sv[j];
                     // the n % 32 leftovers as the reference's build compiled them (chunks of 8, one of 4: rounded products added in
                     // order; the last n % 4: FMAs); keys past this block's last visible one carry p = +0 and change nothing
@@ -1231,8 +1169,8 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
             // block = 32 consecutive features of one query = one row of this tile): QA16 (+ its XH16 copy), 4 adjacent lanes per block,
             // the arithmetic of quantize_q8_kernel; queries past N are the layout's padding: zero blocks
             lds_barrier();   
-            if (threadIdx.x < 128) {
-                const int ql = threadIdx.x >> 2, part = threadIdx.x & 3, q = q0 + ql, KBo = ldo >> 5, kg = ((hd * D + d0) >> 3) + part;
+            if (tid < 128) {
+                const int ql = tid >> 2, part = tid & 3, q = q0 + ql, KBo = ldo >> 5, kg = ((hd * D + d0) >> 3) + part;
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) v[u] = q < N ? Os[ql * 33 + part * 8 + u] : 0.f;
@@ -1246,6 +1184,84 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
             }
         }
         if (d0 == 0) XA_STAMP(4);
+    };
+    // wave w: partial sums l = w and l = w + 4, all four jj: chains over ALL 32-key steps of the body, two steps per MFMA.
+    // chain(acc, NL, l, valid): the four jj chains of the NL partial sums l, l + 4 over the staged piece (valid body keys + zeros to a whole trip).
+    // A trip = 128 keys = 8 NL MFMAs; its 16 NL operand reads are issued one trip AHEAD, before the previous trip's MFMAs (round 6): a wave is alone
+    // on its SIMD, nothing else covers the LDS round trip -- read-then-multiply per pair of MFMAs ran them at 150 cycles apiece instead of 64
+    // (profiles/r06_attn_exact.md).
+    // between(tag t), t = 0 .. 3: what the caller wants issued among the MFMAs of trip t (a quarter of the next tiles' loads); called for every t.
+    auto chain = [&](auto &acc, auto nl_tag, int l, int valid, auto &&between) __attribute__((always_inline)) {
+        constexpr int NL = decltype(nl_tag)::value;
+        const int kt = (valid + 127) & ~127;              // (whole trips: the tiles hold zeros behind the body)
+        auto fetch = [&](float (&a)[NL][2][4], float (&b)[NL][2][4], int cs) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int n = 0; n < NL; ++n)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int e = cs + 64 * u + 32 * h + 8 * jj + l + 4 * n;
+                        a[n][u][jj] = Ps[i * XA_LD + e];
+                        b[n][u][jj] = Vs[i * XA_LD + e];
+                    }
+        };
+        auto mac = [&](const float (&a)[NL][2][4], const float (&b)[NL][2][4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int n = 0; n < NL; ++n)
+                        acc[n][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n][u][jj], b[n][u][jj], acc[n][jj], 0, 0, 0);
+        };
+        float a0[NL][2][4], b0[NL][2][4], a1[NL][2][4], b1[NL][2][4];
+        if (kt > 0) fetch(a0, b0, 0);
+        static_assert(XA_KT == 512, "four 128-key trips per piece");
+        auto two_trips = [&](auto t0) __attribute__((always_inline)) {
+            constexpr int T0 = decltype(t0)::value, cs = 128 * T0;
+            const bool first = cs < kt, second = cs + 128 < kt;      // (wave-uniform)
+            if (second) fetch(a1, b1, cs + 128);
+            between(std::integral_constant<int, T0>{});
+            if (first) mac(a0, b0);
+            if (cs + 256 < kt) fetch(a0, b0, cs + 256);
+            between(std::integral_constant<int, T0 + 1>{});
+            if (second) mac(a1, b1);
+        };
+        two_trips(std::integral_constant<int, 0>{});
+        two_trips(std::integral_constant<int, 2>{});
+    };
+    auto nothing = [](auto) {};
+    constexpr std::integral_constant<int, 1> one_sum{};
+    constexpr std::integral_constant<int, 2> two_sums{};
+    if constexpr (one_piece) {
+    for (int d0 = 0; d0 < D; d0 += 32) {
+        v16f tw;
+        {
+            // one partial sum at a time: its four chain tiles (64 registers) are folded to v_l = (s0+s1)+(s2+s3) before the other starts
+            // -- with both alive (128) next to the 64 registers of the V block in flight the kernel shuffled ~600 values between the
+            // two register files per feature block (profiles/r04_attn_exact.md)
+            lds_barrier();                                    // P, V staged / the previous block is done with Ps, Vs and Ts
+            const int kt = chunk_len(0);
+            const bool more = d0 + 32 < D;
+            const __amdgpu_buffer_rsrc_t rsV = tile_rsrc(vc + (int64_t)(hd * D + d0 + 32) * n_ctx, more ? 32 : 0, n_ctx);
+            auto next_v = [&](auto part) __attribute__((always_inline)) { if (more) wide_load(vnext, rsV, n_ctx, 32, 0, part); };
+            v16f v0;
+#pragma unroll
+            for (int li = 0; li < 2; ++li) {
+                v16f t4[1][4] = {{{}, {}, {}, {}}};
+                if (li == 0) chain(t4, one_sum, wave + 4 * li, nbody, next_v);
+                else chain(t4, one_sum, wave + 4 * li, nbody, nothing);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = __fadd_rn(__fadd_rn(t4[0][0][e], t4[0][1][e]), __fadd_rn(t4[0][2][e], t4[0][3][e]));   // (s0+s1)+(s2+s3)
+                    if (li == 0) v0[e] = v;
+                    else tw[e] = __fadd_rn(v0[e], v);                                                            // t_w = v_w + v_{w+4} (lo128 + hi128)
+                }
+                if (li == 0) asm volatile("" : "+v"(v0));     // (folded before the second partial sum's MFMAs are issued)
+            }
+        }
+        finish_block(d0, tw);
         if (one_piece && d0 + 32 < D) {
             lds_barrier();                                    // wave 0 / the quantizing threads are done with Ps, Vs and Os
             if (left_visible)                                // the single staged P piece was overwritten by the leftovers: stage it again
@@ -1253,6 +1269,119 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
             wide_store(Vs, vnext, chunk_len(0));
         }
         if (d0 == 0) XA_STAMP(5);
+    }
+    } else {
+        // the lane's first element of buffer 0's tiles, for the chains' reads (row i, key 32 h + wave) and for the stores (store_piece); buffer 1: + 64 LD
+        auto own = [](int v) { asm volatile("" : "+v"(v)); return v; };
+        const int rd_lane = i * LD + 32 * h + wave, st_lane = s_rr * LD + 64 * wave + (HP ? 8 : 4) * s_kk, stv_lane = 32 * LD + s_rr * LD + 64 * wave + 4 * s_kk;
+        // wave w: partial sums l = w and w + 4; a trip = 128 keys = 16 MFMAs, its 32 operand reads issued one trip ahead
+        auto fetchd = [&](float (&a)[2][2][4], float (&b)[2][2][4], int pb, int cs) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int e = cs + 64 * u + 8 * jj + 4 * n;
+                        a[n][u][jj] = xs_[pb + e];
+                        b[n][u][jj] = xs_[pb + 32 * LD + e];
+                    }
+        };
+        auto macd = [&](v16f (&tl)[2][4], const float (&a)[2][2][4], const float (&b)[2][2][4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        tl[n][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n][u][jj], b[n][u][jj], tl[n][jj], 0, 0, 0);
+        };
+        auto rsv = [&](int dd) { return tile_rsrc(vc + (int64_t)(hd * D + dd) * n_ctx, 32, n_ctx); };
+        constexpr std::integral_constant<int, -1> whole_piece{};
+        // The sequence of pieces: (feature block d0, 256 keys c), c fastest; the buffers alternate.  Under the 32 MFMAs of a piece: its second trip's operand
+        // reads (trip 0), then the NEXT piece of the sequence from the registers into the other buffer (the stores among the last ten MFMAs of trip 1); the
+        // registers free again, the piece after that one is requested -- it has a piece's time (~0.9 us) until its own stores.  One straight-line body:
+        // with the MFMAs in several branches (ragged pieces, a last piece without a successor) the compiler gave each branch its own accumulator registers
+        // and copied all 128 at every join.  So a ragged piece runs both trips (its buffer holds zeros behind the body) and the last piece of all stores zeros.
+        // (A second register set -- the piece stored during piece g requested while piece g - 2 ran, two pieces' time for its loads instead of the 0.6 us
+        // between a request and its first store here -- measured SLOWER, 159 against 143 us per launch: 48 more registers than the 256 the operands can
+        // live in, so the sets travelled through the accumulator file, and the compiler's count of outstanding loads turned conservative across the
+        // loop's two bodies: half the pieces waited for the newest request anyway.)
+        auto seq_next = [&](int &c, int &d0) { if (++c == npc) { c = 0; d0 += 32; } };
+        int c = 0, d0 = 0, cur = 0;                           // the piece about to run, its buffer
+        int cl = 0, dl = 0;                                   // the piece requested last
+        load_piece(R, rsP, rsv(0), 0, whole_piece);
+        store_piece(R, own(st_lane), own(stv_lane), piece_len(0), whole_piece);
+        // (a request past the end of the sequence goes out all the same, for the last block's rows: one straight-line body)
+        seq_next(cl, dl);
+        load_piece(R, rsP, rsv(min(dl, D - 32)), cl * XD_KT, whole_piece);
+        lds_barrier();
+        v16f tl[2][4] = {{{}, {}, {}, {}}, {{}, {}, {}, {}}};
+        float a0[2][2][4], b0[2][2][4];
+        fetchd(a0, b0, own(rd_lane), 0);
+        XA_STAMP(1);
+        auto piece = [&](PieceRegs &RS) __attribute__((always_inline)) {      // RS: holds the next piece; takes the one after it
+            int c1 = c, d1 = d0;
+            seq_next(c1, d1);
+            const bool has1 = d1 < D;
+            const int rd = own(rd_lane + cur * 64 * LD), rdn = own(rd_lane + (cur ^ 1) * 64 * LD);
+            const int stp = own(st_lane + (cur ^ 1) * 64 * LD), stv = own(stv_lane + (cur ^ 1) * 64 * LD);
+            float a1[2][2][4], b1[2][2][4];
+            fetchd(a1, b1, rd, 128);
+            macd(tl, a0, b0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // two LDS reads
+            }
+            __builtin_amdgcn_sched_barrier(0);                // (the stores stay behind trip 0)
+            // trip 1: from its fifth MFMA on, one of the next piece's twelve wave-stores in front of each (the order pinned: left alone, the scheduler
+            // puts every store -- and its wait for the load -- in front of the first MFMA)
+            // ... and right behind each store, the same part of the piece after that one is requested into the registers just freed: every load has
+            // one whole piece's time (requested all together behind the last store, the first had 0.35 us less)
+            const int v1 = has1 ? piece_len(c1) : 0;
+            seq_next(cl, dl);
+            const __amdgpu_buffer_rsrc_t rsvn = rsv(min(dl, D - 32));
+            auto trip1 = [&](auto... K) __attribute__((always_inline)) {
+                auto one = [&](auto k) __attribute__((always_inline)) {
+                    constexpr int KK = decltype(k)::value, u = KK >> 3, jj = (KK >> 1) & 3, n = KK & 1;
+                    if constexpr (KK >= 4) {
+                        store_piece(RS, stp, stv, v1, std::integral_constant<int, KK - 4>{});
+                        load_piece(RS, rsP, rsvn, cl * XD_KT, std::integral_constant<int, KK - 4>{});
+                    }
+                    tl[n][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[n][u][jj], b1[n][u][jj], tl[n][jj], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                (one(K), ...);
+            };
+            trip1(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{},
+                  std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{}, std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{},
+                  std::integral_constant<int, 8>{}, std::integral_constant<int, 9>{}, std::integral_constant<int, 10>{}, std::integral_constant<int, 11>{},
+                  std::integral_constant<int, 12>{}, std::integral_constant<int, 13>{}, std::integral_constant<int, 14>{}, std::integral_constant<int, 15>{});
+            lds_barrier();                                    // buffer cur is free, buffer cur ^ 1 complete
+            fetchd(a0, b0, rdn, 0);
+            if (c1 == 0) {                                    // that was the feature block's last piece
+                Ps = xs_ + cur * 64 * LD;                     // (the leftovers go through the buffer just left; the other one holds the next block's first piece)
+                Vs = Ps + 32 * LD;
+                v16f tw;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v0 = __fadd_rn(__fadd_rn(tl[0][0][e], tl[0][1][e]), __fadd_rn(tl[0][2][e], tl[0][3][e]));   // (s0+s1)+(s2+s3)
+                    const float v1_ = __fadd_rn(__fadd_rn(tl[1][0][e], tl[1][1][e]), __fadd_rn(tl[1][2][e], tl[1][3][e]));
+                    tw[e] = __fadd_rn(v0, v1_);                                                                             // t_w = v_w + v_{w+4} (lo128 + hi128)
+                }
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) tl[n][jj] = v16f{};
+                finish_block(d0, tw);
+                if (has1) lds_barrier();                      // (the next piece's stores go into the buffer the leftovers were read from)
+            }
+            c = c1;
+            d0 = d1;
+            cur ^= 1;
+        };
+        while (d0 < D) piece(R);
     }
     XA_STAMP(7);
 }
@@ -1324,7 +1453,7 @@ hipError_t attn_pv_exact(const float *att, int ld_att, int64_t head_stride, int 
                          float *ao, int ldo, hipStream_t st, const fl_qact *out, bool with_h16, bool compact) {
     if (D % 32 != 0 || D > 128 || N < 1 || (n_ctx & 3) || (out && (ldo & 31))) return hipErrorInvalidValue;
     if (compact && (n_past + N <= XA_KT || (ld_att & 3))) return hipErrorInvalidValue;      // (one piece: the f32 form; softmax_rows / attn_scores_softmax_exact take the same flag)
-    const size_t lds = (size_t)2 * 32 * XA_LD * 4 + 4 * 64 * 16 * 4 + 32 * 33 * 4;
+    const size_t lds = (size_t)(2 * 32 * XA_LD > 4 * 32 * XD_LD ? 2 * 32 * XA_LD : 4 * 32 * XD_LD) * 4 + 4 * 64 * 16 * 4 + 32 * 33 * 4;
     static bool attr_set[64] = {false};      // (per device)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
