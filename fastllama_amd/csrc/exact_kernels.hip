@@ -771,29 +771,20 @@ __global__ __launch_bounds__(512) void attn_scores_exact_kernel(const float *__r
                     c = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, kv[m][8 * jj + l], c, 0, 0, 0);
                 }
                 if (jj == 0) p01 = c;
-                else if (jj == 1) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) p01[e] = __fadd_rn(p01[e], c[e]);      // s0 + s1
-                } else if (jj == 2) vs = c;
-                else {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) vs[e] = __fadd_rn(p01[e], __fadd_rn(vs[e], c[e]));   // (s0 + s1) + (s2 + s3)
-                }
+                // (whole-tile adds: two floats per v_pk_add_f32 -- the same IEEE add, half the instructions; nothing here that could contract to an fma)
+                else if (jj == 1) p01 = p01 + c;             // s0 + s1
+                else if (jj == 2) vs = c;
+                else vs = p01 + (vs + c);                    // (s0 + s1) + (s2 + s3)
                 if (NST > 2 && jj < 3) asm volatile("" : "+v"(z), "+v"(p01));   // (one chain at a time: 128 operand registers leave room for few tiles)
             }
             if ((lo & 1) == 0) t = vs;                       // v_l, waits for v_{l+4}
             else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) t[e] = __fadd_rn(t[e], vs[e]);            // t_l
+                t = t + vs;                                  // t_l
                 if (lo == 1 || lo == 5) u = t;               // t0 / t2
                 else {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) u[e] = __fadd_rn(u[e], t[e]);         // t0 + t1 / t2 + t3
+                    u = u + t;                               // t0 + t1 / t2 + t3
                     if (lo == 3) total = u;
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) total[e] = __fadd_rn(total[e], u[e]);
-                    }
+                    else total = total + u;
                 }
             }
             // every MFMA of the next group starts from z, which passes through this statement together with the group's result:
