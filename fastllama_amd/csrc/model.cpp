@@ -893,7 +893,7 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
                 const bool xa = exact && !dyn && N >= 2 && D % 32 == 0 && D <= 128;   // the MFMA forms of the exact products
                 // (contexts of up to 1024 keys: K.Q and soft_max in one launch, the score rows waiting in LDS)
                 // (contexts of 513 .. 2048 keys: the probabilities travel compact -- fp16 table values + one factor per row -- between the launches)
-                const bool compact = xa && P > 512 && P <= 2048 && (n_ctx & 3) == 0;
+                const bool compact = xa && P > 512 && P <= 2048 && (n_ctx & 3) == 0 && (El & 31) == 0;   // (... and nothing attn_pv_exact could refuse)
                 bool softmaxed = false;
                 hipError_t xe = xa ? attn_scores_softmax_exact(m->qkv, 3 * El, D, Hl, N, n_past, kc, El, kq_scale, m->att, n_ctx, (int64_t)N * n_ctx, m->exp_tab, st, compact)
                                    : hipErrorInvalidValue;
