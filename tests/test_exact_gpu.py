@@ -594,7 +594,9 @@ def test_exact_decode_attention(torch, ops, port, exact_hooks, D, H, n_past, spl
                                           # ... with the probabilities compact between soft_max and V.P: whole and ragged last pieces, P = n_ctx (the row's
                                           # factor sits in the float a score held), ragged query blocks, every leftover form again
                                           (128, 2, 512, 1536), (128, 1, 40, 984), (64, 2, 100, 413), (128, 1, 33, 480), (32, 2, 70, 1951), (128, 2, 9, 504),
-                                          (96, 1, 48, 977), (128, 1, 5, 2043)])
+                                          (96, 1, 48, 977), (128, 1, 5, 2043),
+                                          # beyond 2048 keys: f32 probabilities again (the loop form of soft_max), nine and ten pieces of 256 keys
+                                          (64, 1, 40, 2260), (128, 1, 33, 2535)])
 def test_exact_prefill_attention_mfma_forms(torch, ops, port, D, H, N, n_past):
     """K.Q and V.P of a batch on the f32-input MFMA (its k = 0, 1 chain is the reference's fma chain): the same bits as the
     one-half-wave-per-dot kernel and as the oracle -- every leftover form (P % 32), causal tiles, ragged last query block, and
