@@ -43,6 +43,9 @@ hipError_t attn_scores_softmax_exact(const float *qkv, int ldq, int D, int H, in
 hipError_t attn_pv_exact(const float *att, int ld_att, int64_t head_stride, int D, int H, int N, int n_past, const float *vc, int n_ctx,
                          float *ao, int ldo, hipStream_t st, const fl_qact *out = nullptr, bool with_h16 = false, bool compact = false);
 // compact: the probabilities leave as fp16 table values + one f32 factor per row (softmax_rows_reg_kernel); attn_pv_exact(compact) reads that
+// dst[0] = n_past, dst[1] = token: what a replayed decode graph reads its position and its token from -- set by a launch, whose arguments are copied
+// when it is enqueued (two 4-byte copies from one pinned staging pair raced with the host's next token when the caller does not wait between evals)
+hipError_t set_decode_inputs(int *dst, int n_past, int token, hipStream_t st);
 hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab,
                         hipStream_t st, const int *dyn_past = nullptr, bool compact = false);
 // prefill: KQ*scale + mask + soft_max + KQV per (head, 32 query rows), score rows in LDS; q = roped Q rows of qkv,

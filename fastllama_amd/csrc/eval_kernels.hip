@@ -1165,6 +1165,15 @@ __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(float *__restrict
     }
 }
 
+__global__ void set_decode_inputs_kernel(int *__restrict__ dst, int n_past, int token) {
+    dst[0] = n_past;
+    dst[1] = token;
+}
+hipError_t set_decode_inputs(int *dst, int n_past, int token, hipStream_t st) {
+    hipLaunchKernelGGL(set_decode_inputs_kernel, dim3(1), dim3(1), 0, st, dst, n_past, token);
+    return hipGetLastError();
+}
+
 // compact: see softmax_rows_reg_kernel; hipErrorInvalidValue where that form does not reach (rows of more than 2048 keys, a device-side n_past)
 hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, int batch, const uint16_t *exp_tab,
                         hipStream_t st, const int *dyn_past, bool compact) {

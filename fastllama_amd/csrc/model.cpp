@@ -132,7 +132,6 @@ struct fl_model : Act {
     hipGraphExec_t graph_exec_long = nullptr;    // [1] n_past >= split_past: attention split over (head, slice) workgroups
     int split_past = 256;                        // first position that takes the two-launch decode attention
     int *npast_dev = nullptr;
-    int32_t *pinned = nullptr;   // [token, n_past] staging in pinned host memory
     // live per-kernel timing of the quantized matmuls (bench.py roofline leg)
     bool profile = false;
     std::vector<hipEvent_t> ev;   // pairs
@@ -437,7 +436,6 @@ int fl_model_finalize(fl_model *m) {
         M_HIP(hipMemcpy(m->rope_tab, rt.data(), rt.size() * 4, hipMemcpyHostToDevice));
     }
     if ((rc = dev_alloc(m, (void **)&m->npast_dev, 16)) != FL_OK) return rc;
-    M_HIP(hipHostMalloc((void **)&m->pinned, 16, hipHostMallocDefault));
     m->ldl = fl_roundup(V, 4);   // e.g. the 32001-token vocabularies of Alpaca / Vicuna style checkpoints
     if ((rc = act_alloc(m, *m)) != FL_OK) return rc;
     if (m->tp_rows) {
@@ -803,7 +801,7 @@ static int run_eval_kernels(fl_model *m, int N, int n_past, const int *dyn, bool
     // producer writes its slice there, and the exchange is the tail of the producing launch -- the layer is its five decode launches.
     const bool fold = tp && m->tp_rows && exact && fused && m->w13_il && m->fold_state > 0 && !kv_wait && !kv_rec && !body_only;
     float *inp = fold ? m->fx : m->x, *mid = fold ? m->fx2 : m->x2;
-    if (!body_only) M_HIP(get_rows_qw16(*m->tok_emb, m->tok_dev, N, inp, E, st));       // inpL = get_rows  llama.cpp:304
+    if (!body_only) M_HIP(get_rows_qw16(*m->tok_emb, dyn ? dyn + 1 : m->tok_dev, N, inp, E, st));       // inpL = get_rows  llama.cpp:304 (a decode graph: its token lies behind its position)
     if (l1 < 0) l1 = m->L;
     // Row-split tensor parallelism, prefill (round 6): per exchange ONE collective and at most one kernel, instead of pack3 ->
     // all-gather -> unpack3 -> qa16_to_h16 and all-gather -> gather_rows_add:
@@ -1109,10 +1107,8 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
     const bool split_attn = N == 1 && n_past >= m->split_past;
     if (use_graph) {
         hipGraphExec_t &exec = split_attn ? m->graph_exec_long : m->graph_exec;
-        m->pinned[0] = tokens[0];
-        m->pinned[1] = n_past;
-        M_HIP(hipMemcpyAsync(m->tok_dev, &m->pinned[0], 4, hipMemcpyHostToDevice, st));
-        M_HIP(hipMemcpyAsync(m->npast_dev, &m->pinned[1], 4, hipMemcpyHostToDevice, st));
+        // the position and the token of this replay: npast_dev[0], npast_dev[1] (one launch, its arguments copied at enqueue)
+        M_HIP(set_decode_inputs(m->npast_dev, n_past, tokens[0], st));
         if (!exec) {
             hipGraph_t g = nullptr;
             M_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -1132,6 +1128,7 @@ int fl_model_eval(fl_model *m, const int32_t *tokens, int N, int n_past, float *
         if (exec) {
             M_HIP(hipGraphLaunch(exec, st));
         } else {
+            M_HIP(hipMemcpyAsync(m->tok_dev, m->npast_dev + 1, 4, hipMemcpyDeviceToDevice, st));      // (plain launches read the token where a prefill's are)
             const int rc = run_eval_kernels(m, 1, n_past, nullptr, split_attn);
             if (rc != FL_OK) return rc;
         }
@@ -1647,7 +1644,6 @@ void fl_model_free(fl_model *m) {
     for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
     if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
     if (m->graph_exec_long) (void)hipGraphExecDestroy(m->graph_exec_long);
-    if (m->pinned) (void)hipHostFree(m->pinned);
     fr(m->npast_dev);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
