@@ -318,10 +318,21 @@ __global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1)
         }
         // ---- order-free part, all waves at once: per block the two lane sums of this lane's k-group as floats, rn(d_w d_x), m_w
         float f0[QPW][4], f1[QPW][4], dd[QPW][4];
+        // Q4_1, eight-wave forms with 8+ quads per wave (one workgroup per CU whatever the registers, up to 256): m_w broadcast and s_x read HERE.
+        // Left in the chain -- 11 LDS reads behind the turn's acquire, 44 DPP moves -- they made every slice's turn of LLaMA-7B's w2 longer: the
+        // launch took 15.0 us where the bytes (1.2 x Q4_0's) ask for 11 (round 6).  The 4-quad forms with a prologue keep them in the chain: 104-106
+        // registers as they are, and 128 is what gives them two workgroups per CU.
+        constexpr bool PRE_M = Q41 && (QPW >= 8 || PRO == 0);                     // (PRO = 0, 4 quads: 68 -> ~100 registers, still two workgroups per CU)
+        float msb_[PRE_M ? QPW : 1][4], sxv_[PRE_M ? QPW : 1][4];
 #pragma unroll
         for (int i = 0; i < QPW; ++i) {
             if (i < nq) {                                                       // (wave-uniform)
                 const int q = qlo + i;
+                if constexpr (PRE_M) {
+                    msb_[i][0] = quad_bcast<0>(mw[i]); msb_[i][1] = quad_bcast<1>(mw[i]); msb_[i][2] = quad_bcast<2>(mw[i]); msb_[i][3] = quad_bcast<3>(mw[i]);
+                    const float4 sx4 = *reinterpret_cast<const float4 *>(ls_ + 4 * q);
+                    sxv_[i][0] = sx4.x; sxv_[i][1] = sx4.y; sxv_[i][2] = sx4.z; sxv_[i][3] = sx4.w;
+                }
                 const uint4 x01 = *reinterpret_cast<const uint4 *>(lx + ((size_t)q * 4 + g) * 32);
                 const uint4 x23 = *reinterpret_cast<const uint4 *>(lx + ((size_t)q * 4 + g) * 32 + 16);
                 const float4 dx4 = *reinterpret_cast<const float4 *>(ld_ + 4 * q);
@@ -361,7 +372,10 @@ __global__ __launch_bounds__(64 * NK, (!PERSIST && QPW <= 8 && NK == 4) ? 3 : 1)
                 for (int i = 0; i < QPW; ++i) {
                     if (i < nq) {
                         float sxv[4] = {0.f, 0.f, 0.f, 0.f}, msb[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (Q41) {
+                        if constexpr (PRE_M) {
+#pragma unroll
+                            for (int blk = 0; blk < 4; ++blk) { msb[blk] = msb_[i][blk]; sxv[blk] = sxv_[i][blk]; }
+                        } else if (Q41) {
                             // (m_w of a block sits in one lane of the row's quad, as d_w does; broadcast here, in the chain -- kept as four registers
                             //  per quad since the order-free part it cost Q4_1 its third workgroup per CU: round 5)
                             msb[0] = quad_bcast<0>(mw[i]); msb[1] = quad_bcast<1>(mw[i]); msb[2] = quad_bcast<2>(mw[i]); msb[3] = quad_bcast<3>(mw[i]);
