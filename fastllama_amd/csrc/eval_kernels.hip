@@ -1300,6 +1300,7 @@ __device__ __forceinline__ float att_leftovers_lanes(float s, const float4 p4, c
 }
 
 constexpr int DA_T = 512, DA_KPRE = 4, DA_VPRE = 8;
+constexpr int DA_PARTS = 2;     // workgroups per 128-feature head (four: 1.564 against 1.570 ms per token, within the noise; 64 features are one whole V pass)
 
 template <int ORD>
 // (argument order: the position pointer and what the first requests need lead -- those 14 dwords are preloaded into SGPRs,
@@ -1325,7 +1326,12 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const int *__res
     const int l8 = tid & 7, r64 = tid >> 3;
     const int J = D >> 5;                                  // float4 pieces per lane and K row (<= 4)
     const float *kbase = kc + h * D + l8 * 4;
-    const int nvr = (D + 63) >> 6;                         // row passes of the V phase (<= 2)
+    // Round 6: a head of 128 features is TWO workgroups (blockIdx.y: features [64 y, 64 y + 64)).  Both compute the head's scores and soft_max -- the K rows
+    // of the second reader hit the L2 of the XCD both run on (workgroup (h, y) -> XCD h % 8) -- and each streams the V rows of its own half, the half of a
+    // head's bytes a single CU could not pull any faster (~20 GB/s: profiles/r06_decode_exact.md).  The fresh k row is stored by half 0, the fresh v
+    // values and the Q8_0 blocks by the half that owns the features.
+    const int parts = (int)gridDim.y, part = (int)blockIdx.y, Dp = D / parts, d0p = part * Dp;
+    const int nvr = (Dp + 63) >> 6;                        // row passes of the V phase (<= 2)
     const int nchunk = (P + 31) >> 5;                      // 32-position pieces
 
     // ---- requests first.  Loads return in order: the few bytes rope needs (this token's q, k, v and the rope table row)
@@ -1355,10 +1361,10 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const int *__res
     float4 vreg[2][DA_VPRE];
 #pragma unroll
     for (int rp = 0; rp < 2; ++rp) {
-        const int d = rp * 64 + r64;
+        const int dl = rp * 64 + r64, d = d0p + dl;
 #pragma unroll
         for (int c = 0; c < DA_VPRE; ++c)
-            if (rp < nvr && d < D && c < nchunk && c * 32 + l8 * 4 < P)
+            if (rp < nvr && dl < Dp && c < nchunk && c * 32 + l8 * 4 < P)
                 vreg[rp][c] = *reinterpret_cast<const float4 *>(vc + (int64_t)(h * D + d) * n_ctx + c * 32 + l8 * 4);
     }
 
@@ -1370,11 +1376,11 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const int *__res
         const float k0 = __fmaf_rn(xk.x, cs.x, -__fmul_rn(xk.y, cs.y)), k1 = __fmaf_rn(xk.x, cs.y, __fmul_rn(xk.y, cs.x));
         ks[2 * tid] = k0;
         ks[2 * tid + 1] = k1;
-        *reinterpret_cast<float2 *>(kc + (int64_t)pos * E + h * D + 2 * tid) = make_float2(k0, k1);
+        if (part == 0) *reinterpret_cast<float2 *>(kc + (int64_t)pos * E + h * D + 2 * tid) = make_float2(k0, k1);
     } else if (tid >= 64 && tid < 64 + D) {
         const int d = tid - 64;
         vs[d] = vv;
-        vc[(int64_t)(h * D + d) * n_ctx + pos] = vv;
+        if (d >= d0p && d < d0p + Dp) vc[(int64_t)(h * D + d) * n_ctx + pos] = vv;
     }
     if (tid < 4) sc[P + tid] = 0.f;                        // tail of the last float4 of probabilities
     __syncthreads();
@@ -1454,9 +1460,10 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const int *__res
 #pragma unroll
     for (int rp = 0; rp < 2; ++rp) {
         if (rp >= nvr) break;
-        const int d = rp * 64 + r64;
+        const int dl = rp * 64 + r64, d = d0p + dl;
+        const bool mine = dl < Dp;
         float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (d < D) {
+        if (mine) {
 #pragma unroll
             for (int c = 0; c < DA_VPRE; ++c)
                 if (c < nlane && c * 32 + l8 * 4 < P) pv(a4, d, c, vreg[rp][c]);
@@ -1472,34 +1479,34 @@ __global__ __launch_bounds__(DA_T) void decode_attention_kernel(const int *__res
 #pragma unroll
                 for (int c = 0; c < DA_VPRE; ++c)
                     if (c == nlane) v4 = vreg[rp][c];
-            } else if (d < D && p0 < P) {
+            } else if (mine && p0 < P) {
                 v4 = *reinterpret_cast<const float4 *>(vc + (int64_t)(h * D + d) * n_ctx + p0);
             }
-            if (d < D) {
+            if (mine) {
                 const float4 p4 = *reinterpret_cast<const float4 *>(sc + (p0 < P ? p0 : np));     // (a lane past P: ignored)
                 a = att_leftovers_lanes(a, p4, with_fresh(d, p0, v4), P - np, l8);
                 if (l8 == att_leftovers_last(P - np)) out[d] = a;
             }
-        } else if (d < D && l8 == 0) {
+        } else if (mine && l8 == 0) {
             out[d] = a;
         }
     }
     __syncthreads();
     DA_STAMP(5);
     // ---- Q8_0 of the head's outputs: D/8 groups, 4 adjacent lanes per block ----
-    if (tid < D / 8) {
+    if (tid < Dp / 8) {
         float o8[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o8[i] = out[tid * 8 + i];
-        quantize_store_group(o8, 0, (h * D >> 3) + tid, E >> 5, 1, oq, od, os);
+        for (int i = 0; i < 8; ++i) o8[i] = out[d0p + tid * 8 + i];
+        quantize_store_group(o8, 0, ((h * D + d0p) >> 3) + tid, E >> 5, 1, oq, od, os);
     }
     DA_STAMP(6);
     DA_COMMIT();
     if (tt) {                        // tensor parallel: this head's Q8_0 blocks -> every peer's copy of the planes, then the exchange's tail (tp_tail.h)
         __syncthreads();
-        tp_push(tt, oq + h * D, D);
-        tp_push(tt, od + (h * D >> 5), D >> 3);
-        tp_push(tt, os + (h * D >> 5), D >> 3);
+        tp_push(tt, oq + h * D + d0p, Dp);
+        tp_push(tt, od + ((h * D + d0p) >> 5), Dp >> 3);
+        tp_push(tt, os + ((h * D + d0p) >> 5), Dp >> 3);
         tp_tail<false, false, true>(tt);
     }
 }
@@ -1526,10 +1533,10 @@ hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, i
     const size_t lds = (size_t)(4 * D + n_ctx + 4) * 4 + 8 * 8 + 8 * 4;
     const TpTail *tt = tp_take_tail();
     if (exact)
-        hipLaunchKernelGGL(decode_attention_kernel<1>, dim3(H), dim3(DA_T), lds, st, dyn_past, qkv, reinterpret_cast<const float2 *>(rope_tab),
+        hipLaunchKernelGGL(decode_attention_kernel<1>, dim3(H, D == 128 ? DA_PARTS : 1), dim3(DA_T), lds, st, dyn_past, qkv, reinterpret_cast<const float2 *>(rope_tab),
                            kc, vc, E, D, n_past, n_ctx, exp_tab, scale, out->q, out->d, out->s, tt);
     else
-        hipLaunchKernelGGL(decode_attention_kernel<0>, dim3(H), dim3(DA_T), lds, st, dyn_past, qkv, reinterpret_cast<const float2 *>(rope_tab),
+        hipLaunchKernelGGL(decode_attention_kernel<0>, dim3(H, D == 128 ? DA_PARTS : 1), dim3(DA_T), lds, st, dyn_past, qkv, reinterpret_cast<const float2 *>(rope_tab),
                            kc, vc, E, D, n_past, n_ctx, exp_tab, scale, out->q, out->d, out->s, tt);
     return hipGetLastError();
 }
