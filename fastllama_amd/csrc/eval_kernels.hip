@@ -1553,7 +1553,9 @@ hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, i
 // max is exact and the f64 sum of fp16 table values is exact in any order: the result is bit-identical to the
 // one-launch kernel (tests/test_eval_ops_gpu.py::test_decode_attention_split_equals_fused).
 // ------------------------------------------------------------------------------------------------
-constexpr int DS_T = 512, DS_POS = 128, DP_T = 256, DP_BATCH = 16;
+// (round 6: slices of 64 positions -- 128: 547 -> 571 tok/s at 512 positions, 513 -> 530 at 1000; 32 positions of 256 threads: the same as 64)
+constexpr int DS_T = 512, DS_POS = 64, DS_PP = DS_T / 8, DP_T = 256, DP_BATCH = 16;      // (DS_PP: positions per pass, eight lanes each)
+static_assert(DS_POS % DS_PP == 0 && DS_T >= 256, "whole passes; the rope / v threads");
 
 template <int ORD>
 __global__ __launch_bounds__(DS_T) void decode_scores_kernel(const int *__restrict__ dyn_past, const float *__restrict__ qkv, int E, int D,
@@ -1578,10 +1580,10 @@ __global__ __launch_bounds__(DS_T) void decode_scores_kernel(const int *__restri
         vv = v[tid - 64];
     }
     const float *kbase = kc + h * D + l8 * 4;
-    float4 kreg[DS_POS / 64][4];
+    float4 kreg[DS_POS / DS_PP][4];
 #pragma unroll
-    for (int u = 0; u < DS_POS / 64; ++u) {
-        const int p = p0 + u * 64 + r64;
+    for (int u = 0; u < DS_POS / DS_PP; ++u) {
+        const int p = p0 + u * DS_PP + r64;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (j < J && p < pos) kreg[u][j] = *reinterpret_cast<const float4 *>(kbase + (int64_t)p * E + j * 32);
@@ -1604,8 +1606,8 @@ __global__ __launch_bounds__(DS_T) void decode_scores_kernel(const int *__restri
     for (int j = 0; j < 4; ++j)
         if (j < J) q4[j] = *reinterpret_cast<const float4 *>(qs + l8 * 4 + j * 32);
 #pragma unroll
-    for (int u = 0; u < DS_POS / 64; ++u) {
-        const int p = p0 + u * 64 + r64;
+    for (int u = 0; u < DS_POS / DS_PP; ++u) {
+        const int p = p0 + u * DS_PP + r64;
         if (p >= P) continue;
         float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
