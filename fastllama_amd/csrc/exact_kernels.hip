@@ -1381,6 +1381,261 @@ extern "C" __attribute__((visibility("default"))) int fl_debug_xa_timing(long lo
 extern "C" __attribute__((visibility("default"))) int fl_debug_xa_cycles(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(xa_dbg), sizeof(long long) * 1024 * 16, sizeof(long long) * 1024 * 16); }
 #endif
 
+// ------------------------------------------------------------------------------------------------
+// V.P behind a deep context with EIGHT waves (round 6, second form): wave w owns partial sum l = w (its four jj chains: 64 accumulator registers), two
+// waves share a SIMD -- so one wave's stores of the next piece (LDS-write bound: 64 KB per 256-key piece, ~1100 cycles that a wave alone on its SIMD
+// could not put under its own MFMAs, profiles/r06_attn_exact.md) run beside the other wave's MFMAs.  The sequence of pieces, the two 256-key buffers,
+// the compact probabilities, the zero-filled ragged pieces and the leftover keys are attn_pv_exact_kernel<false, .>'s; the tree behind the chains is
+// the same one, the eight v_l tiles meeting in LDS in two steps (t_w = v_w + v_{w+4}, then (t0 + t1) + (t2 + t3)).
+// ------------------------------------------------------------------------------------------------
+template <bool HP>
+__global__ __launch_bounds__(512) void attn_pv_exact8_kernel(const float *__restrict__ att, int ld_att, int64_t head_stride, int D, int N,
+                                                             int n_past, const float *__restrict__ vc, int n_ctx, float *__restrict__ ao,
+                                                             int ldo, int8_t *__restrict__ oq, float *__restrict__ od,
+                                                             float *__restrict__ os, uint16_t *__restrict__ oh) {
+    extern __shared__ __attribute__((aligned(16))) float xs_[];
+    constexpr int LD = XD_LD;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qb = (int)gridDim.y - 1 - (int)blockIdx.y, hd = blockIdx.x, q0 = qb * 32;        // (heaviest query blocks first)
+    const int i = lane & 31, h = lane >> 5;
+    const int P = n_past + N;
+    const int kend = min(P, n_past + min(q0 + 31, N - 1) + 1);
+    const int np = P & ~31, nbody = min(np, (kend + 31) & ~31);
+    const int npc = (nbody + XD_KT - 1) / XD_KT;
+    const float *prow = att + hd * head_stride;
+    const int rows_q = min(32, N - q0);
+    const int s_rr = lane >> 3, s_kk = lane & 7;
+    float *Ts = xs_ + 128 * LD;                              // [4 tiles][16 e][64 lanes]
+    float *Os = Ts + 4 * 64 * 16;                            // [32 queries][33]
+    auto own = [](int v) { asm volatile("" : "+v"(v)); return v; };
+    typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
+    // thread -> f32 tile: 4 float4, u = 0 .. 3: row 8 u + rr, keys 32 w + 4 kk .. + 3; -> compact P tile: 2 x 16 bytes, u = 0, 1: row 16 (w >> 2) + 8 u + rr,
+    // keys 64 (w & 3) + 8 kk .. + 7 (a wave-load: 8 rows x one 128-byte line either way)
+    struct Regs { v4u_ hp[HP ? 2 : 1]; float4 fp[HP ? 1 : 4]; float4 v[4]; } R;
+    const int prow0 = 16 * (wave >> 2) + s_rr;               // compact: this lane's first P row
+    float inv2[2];
+    if constexpr (HP) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) inv2[u] = prow[(int64_t)(q0 + min(prow0 + 8 * u, rows_q - 1)) * ld_att + ld_att - 1];
+    }
+    auto rsrc = [&](const float *base, int rows, int row_stride) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)((unsigned)rows * (unsigned)row_stride * 4u), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rsP = rsrc(prow + (int64_t)q0 * ld_att, rows_q, ld_att);
+    auto rsv = [&](int dd) { return rsrc(vc + (int64_t)(hd * D + dd) * n_ctx, 32, n_ctx); };
+    auto piece_len = [&](int c) { return min(XD_KT, nbody - c * XD_KT); };
+    // parts 0 .. 5 of a piece (compact P: two P then four V; f32 P: four P + V pairs, parts 4 and 5 empty), -1: all
+    auto load_piece = [&](__amdgpu_buffer_rsrc_t rsvv, int k0, auto part) __attribute__((always_inline)) {
+        constexpr int PT = decltype(part)::value;
+        if constexpr (HP) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (PT < 0 || PT == u)
+                    R.hp[u] = __builtin_amdgcn_raw_buffer_load_b128(rsP, min(prow0 + 8 * u, rows_q - 1) * ld_att * 4 + (64 * (wave & 3) + 8 * s_kk) * 2, k0 * 2, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!(PT < 0 || PT == (HP ? 2 + u : u))) continue;
+            const int row = 8 * u + s_rr, col = 32 * wave + 4 * s_kk;
+            if constexpr (!HP) {
+                const v4u_ r = __builtin_amdgcn_raw_buffer_load_b128(rsP, (min(row, rows_q - 1) * ld_att + col) * 4, k0 * 4, 0);
+                R.fp[u] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+            }
+            const v4u_ r = __builtin_amdgcn_raw_buffer_load_b128(rsvv, (row * n_ctx + col) * 4, k0 * 4, 0);
+            R.v[u] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+        }
+    };
+    // pb: the buffer's first float (0 or 64 LD); valid body keys, zeros behind them up to the piece's 256
+    const int st_lane = s_rr * LD + 32 * wave + 4 * s_kk, sth_lane = prow0 * LD + 64 * (wave & 3) + 8 * s_kk;
+    auto store_piece = [&](int pb, int valid, auto part) __attribute__((always_inline)) {
+        constexpr int PT = decltype(part)::value;
+        if constexpr (HP) {
+            float *const pd = xs_ + own(pb + sth_lane);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (PT < 0 || PT == u) {
+                    float *d = pd + 8 * u * LD;
+                    const bool in = 64 * (wave & 3) + 8 * s_kk < valid;
+                    const unsigned w4[4] = {in ? R.hp[u].x : 0u, in ? R.hp[u].y : 0u, in ? R.hp[u].z : 0u, in ? R.hp[u].w : 0u};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        d[j] = __fmul_rn(__half2float(__ushort_as_half((unsigned short)(w4[j >> 1] >> (16 * (j & 1))))), inv2[u]);
+                }
+        }
+        float *const fd = xs_ + own(pb + st_lane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (PT < 0 || PT == (HP ? 2 + u : u)) {
+                const bool in = 32 * wave + 4 * s_kk < valid;
+                if constexpr (!HP) {
+                    float *d = fd + 8 * u * LD;
+                    d[0] = in ? R.fp[u].x : 0.f; d[1] = in ? R.fp[u].y : 0.f; d[2] = in ? R.fp[u].z : 0.f; d[3] = in ? R.fp[u].w : 0.f;
+                }
+                float *d = fd + 32 * LD + 8 * u * LD;
+                d[0] = in ? R.v[u].x : 0.f; d[1] = in ? R.v[u].y : 0.f; d[2] = in ? R.v[u].z : 0.f; d[3] = in ? R.v[u].w : 0.f;
+            }
+    };
+    // the chains: lane (i, h) of wave l reads row i, keys cs + 64 u + 32 h + 8 jj + l of the P tile and of the V tile (32 LD behind it)
+    const int rd_lane = i * LD + 32 * h + wave;
+    auto fetch = [&](float (&a)[2][4], float (&b)[2][4], int pb, int cs) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                a[u][jj] = xs_[pb + cs + 64 * u + 8 * jj];
+                b[u][jj] = xs_[pb + 32 * LD + cs + 64 * u + 8 * jj];
+            }
+    };
+    constexpr std::integral_constant<int, -1> whole_piece{};
+    auto seq_next = [&](int &c, int &d0) { if (++c == npc) { c = 0; d0 += 32; } };
+    int c = 0, d0 = 0, cur = 0;                               // the piece about to run, its buffer
+    int cl = 0, dl = 0;                                       // the piece requested last
+    load_piece(rsv(0), 0, whole_piece);
+    store_piece(0, piece_len(0), whole_piece);
+    seq_next(cl, dl);
+    load_piece(rsv(min(dl, D - 32)), cl * XD_KT, whole_piece);
+    lds_barrier();
+    v16f acc[4] = {{}, {}, {}, {}};
+    float a0[2][4], b0[2][4];
+    fetch(a0, b0, own(rd_lane), 0);
+    const int nleft = P - np;
+    const bool left_visible = nleft > 0 && kend > np;
+    while (d0 < D) {
+        int c1 = c, d1 = d0;
+        seq_next(c1, d1);
+        const bool has1 = d1 < D;
+        const int rd = own(rd_lane + cur * 64 * LD), rdn = own(rd_lane + (cur ^ 1) * 64 * LD);
+        const int stb = (cur ^ 1) * 64 * LD;
+        float a1[2][4], b1[2][4];
+        fetch(a1, b1, rd, 128);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][jj], b0[u][jj], acc[jj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                    // (the stores stay behind trip 0)
+        const int v1 = has1 ? piece_len(c1) : 0;
+        seq_next(cl, dl);
+        const __amdgpu_buffer_rsrc_t rsvn = rsv(min(dl, D - 32));
+        auto trip1 = [&](auto... K) __attribute__((always_inline)) {
+            auto one = [&](auto k) __attribute__((always_inline)) {
+                constexpr int KK = decltype(k)::value, u = KK >> 2, jj = KK & 3;
+                if constexpr (KK >= 2) {
+                    store_piece(stb, v1, std::integral_constant<int, KK - 2>{});
+                    load_piece(rsvn, cl * XD_KT, std::integral_constant<int, KK - 2>{});
+                }
+                acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][jj], b1[u][jj], acc[jj], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            (one(K), ...);
+        };
+        trip1(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{},
+              std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{}, std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{});
+        lds_barrier();                                        // buffer cur is free, buffer cur ^ 1 complete
+        fetch(a0, b0, rdn, 0);
+        if (c1 == 0) {                                        // that was the feature block's last piece
+            float *Ps = xs_ + cur * 64 * LD, *Vs = Ps + 32 * LD;      // (the leftovers go through the buffer just left)
+            int tid_ = threadIdx.x;
+            asm volatile("" : "+v"(tid_));                    // (the thread's indices taken afresh: nothing below is hoisted above the piece loop)
+            const int tid = tid_, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
+            v16f vt;                                          // v_l = (s0 + s1) + (s2 + s3)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) vt[e] = __fadd_rn(__fadd_rn(acc[0][e], acc[1][e]), __fadd_rn(acc[2][e], acc[3][e]));
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[jj] = v16f{};
+            if (left_visible) {                              // the leftover keys [np, P) to columns 0.. of both tiles
+                for (int idx = tid; idx < 32 * 32; idx += 512) {
+                    const int r = idx >> 5, k = idx & 31, rc = min(r, rows_q - 1);
+                    const float *row = prow + (int64_t)(q0 + rc) * ld_att;
+                    float pv;
+                    if constexpr (HP) pv = __fmul_rn(__half2float(reinterpret_cast<const __half *>(row)[min(np + k, P - 1)]), row[ld_att - 1]);
+                    else pv = row[min(np + k, P - 1)];
+                    Ps[r * LD + k] = r < rows_q && np + k < kend ? pv : 0.f;
+                    const float vv = vc[(int64_t)(hd * D + d0 + r) * n_ctx + min(np + k, P - 1)];
+                    Vs[r * LD + k] = np + k < kend ? vv : 0.f;
+                }
+            }
+            // t_w = v_w + v_{w+4} (lo128 + hi128): waves 4 .. 7 hand their tiles over, waves 0 .. 3 add and publish t_w
+            if (wave >= 4) {
+                float *dst = Ts + (wave - 4) * 1024 + lane;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dst[e * 64] = vt[e];
+            }
+            lds_barrier();
+            if (wave < 4) {
+                float *dst = Ts + wave * 1024 + lane;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) vt[e] = __fadd_rn(vt[e], dst[e * 64]);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dst[e * 64] = vt[e];     // (each lane rewrites the slots it just read: no barrier between)
+            }
+            lds_barrier();
+            {
+                // every wave finishes two of the sixteen query rows a lane holds (e = 2 wave, 2 wave + 1): (t0 + t1) + (t2 + t3), then the leftover keys
+                const float *t0 = Ts + lane, *t1 = Ts + 1024 + lane, *t2 = Ts + 2048 + lane, *t3 = Ts + 3072 + lane;
+                const float *vr = Vs + i * LD;
+                float sv[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int e = 2 * wave + j;
+                    sv[j] = __fadd_rn(__fadd_rn(t0[e * 64], t1[e * 64]), __fadd_rn(t2[e * 64], t3[e * 64]));
+                }
+                if (nleft > 0) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int e = 2 * wave + j, ql = (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const float *pr = Ps + ql * LD;
+                        float s = sv[j];
+                        int k = 0;
+                        for (; k + 8 <= nleft; k += 8)
+                            for (int u = 0; u < 8; ++u)
+                                if (np + k + u < kend) {
+                                    const float prd = pr[k + u] * vr[k + u];
+                                    s = s + prd;
+                                }
+                        if (nleft - k >= 4) {
+                            for (int u = 0; u < 4; ++u)
+                                if (np + k + u < kend) {
+                                    const float prd = pr[k + u] * vr[k + u];
+                                    s = s + prd;
+                                }
+                            k += 4;
+                        }
+                        for (; k < nleft; ++k)
+                            if (np + k < kend) s = __fmaf_rn(pr[k], vr[k], s);
+                        sv[j] = s;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int e = 2 * wave + j, ql = (e & 3) + 8 * (e >> 2) + 4 * h, q = q0 + ql;
+                    if (oq) Os[ql * 33 + i] = sv[j];
+                    else if (q < N) ao[(int64_t)q * ldo + hd * D + d0 + i] = sv[j];
+                }
+            }
+            if (oq) {
+                lds_barrier();
+                if (tid < 128) {
+                    const int ql = tid >> 2, part = tid & 3, q = q0 + ql, KBo = ldo >> 5, kg = ((hd * D + d0) >> 3) + part;
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = q < N ? Os[ql * 33 + part * 8 + u] : 0.f;
+                    if (q < ((N + 15) & ~15)) {
+                        quantize_store_group(v, q, kg, KBo, 16, oq, od, os, oh);
+                    } else if (oh) {                         // (columns [N16, N32) exist in the XH16 copy only)
+                        unsigned char *dst = reinterpret_cast<unsigned char *>(oh) + ((((int64_t)(q >> 5) * KBo + (kg >> 2)) * 2 + (part >> 1)) * 64 + (q & 31)) * 16 + (part & 1) * 8;
+                        *reinterpret_cast<uint2 *>(dst) = make_uint2(0, 0);
+                        *reinterpret_cast<uint2 *>(dst + 512) = make_uint2(0, 0);
+                    }
+                }
+            }
+            if (has1) lds_barrier();                          // (the next piece's stores go into the buffer the leftovers were read from)
+        }
+        c = c1;
+        d0 = d1;
+        cur ^= 1;
+    }
+}
+
 // hipErrorInvalidValue: shape outside these kernels' reach (head_dim not a multiple of 32 or > 128, unaligned rows): the caller
 // (run_eval_kernels, model.cpp) then takes dot_f32_abt_exact
 hipError_t attn_scores_exact(const float *qkv, int ldq, int D, int H, int N, int n_past, const float *kc, int ldk, float scale,
@@ -1440,6 +1695,7 @@ hipError_t attn_scores_softmax_exact(const float *qkv, int ldq, int D, int H, in
 #undef FL_XS
     return hipGetLastError();
 }
+int g_pv_waves = 8;      // waves per workgroup of the V.P kernel behind a deep context (8: attn_pv_exact8_kernel; 4: the round's first form; fl_debug_set(8, .))
 hipError_t attn_pv_exact(const float *att, int ld_att, int64_t head_stride, int D, int H, int N, int n_past, const float *vc, int n_ctx,
                          float *ao, int ldo, hipStream_t st, const fl_qact *out, bool with_h16, bool compact) {
     if (D % 32 != 0 || D > 128 || N < 1 || (n_ctx & 3) || (out && (ldo & 31))) return hipErrorInvalidValue;
@@ -1455,15 +1711,25 @@ hipError_t attn_pv_exact(const float *att, int ld_att, int64_t head_stride, int 
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_pv_exact_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_pv_exact_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_pv_exact8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_pv_exact8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     int8_t *oq = out ? out->q : nullptr;
     float *od = out ? out->d : nullptr, *os = out ? out->s : nullptr;
     uint16_t *oh = out && with_h16 ? out->h16 : nullptr;
-    if (n_past + N <= XA_KT)
+    if (n_past + N <= XA_KT)                                  // (the eight-wave form on short contexts: 33.05 / 32.83 against 33.05 ms per eval -- the same)
         hipLaunchKernelGGL(attn_pv_exact_kernel<true>, dim3(H, (N + 31) / 32), dim3(256), lds, st, att, ld_att, head_stride, D, N, n_past, vc, n_ctx, ao, ldo,
                            oq, od, os, oh);
+    else if (g_pv_waves >= 8 && compact)
+        hipLaunchKernelGGL((attn_pv_exact8_kernel<true>), dim3(H, (N + 31) / 32), dim3(512), lds, st, att, ld_att, head_stride, D, N, n_past, vc, n_ctx, ao,
+                           ldo, oq, od, os, oh);
+    else if (g_pv_waves >= 8)
+        hipLaunchKernelGGL((attn_pv_exact8_kernel<false>), dim3(H, (N + 31) / 32), dim3(512), lds, st, att, ld_att, head_stride, D, N, n_past, vc, n_ctx, ao,
+                           ldo, oq, od, os, oh);
     else if (compact)
         hipLaunchKernelGGL((attn_pv_exact_kernel<false, true>), dim3(H, (N + 31) / 32), dim3(256), lds, st, att, ld_att, head_stride, D, N, n_past, vc, n_ctx, ao,
                            ldo, oq, od, os, oh);

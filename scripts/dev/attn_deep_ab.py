@@ -6,6 +6,7 @@ import numpy as np, torch
 from fastllama_amd import hip
 L = hip.load(); hip.require_device(0)
 which = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+if len(sys.argv) > 2: L.fl_debug_set(8, int(sys.argv[2]))          # waves per workgroup of the deep V.P kernel (8 / 4)
 D, H, N, n_past, n_ctx = 128, 32, 512, 1536, 2048
 E = D * H
 rng = np.random.default_rng(1)
@@ -25,4 +26,4 @@ for _ in range(5):
     for _ in range(40): run()
     b.record(); torch.cuda.synchronize()
     ts.append(a.elapsed_time(b) / 40 * 1e3)
-print(f"{os.environ.get('FASTLLAMA_HIP_LIB', 'default')}: K.Q + soft_max + V.P {np.median(ts):.1f} us (min {min(ts):.1f}, max {max(ts):.1f})", flush=True)
+print(f"{os.environ.get('FASTLLAMA_HIP_LIB', 'default')} {' '.join(sys.argv[1:])}: K.Q + soft_max + V.P {np.median(ts):.1f} us (min {min(ts):.1f}, max {max(ts):.1f})", flush=True)

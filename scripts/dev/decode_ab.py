@@ -29,7 +29,7 @@ def run(tag):
     dt = (time.perf_counter() - t0) / steps
     print(f"[{tag}] {name} qtype={QT} n_past={past}: {dt*1e3:.3f} ms/token  {1/dt:.1f} tok/s", flush=True)
 # variants: name -> (fl_debug_set(6, .) value, fl_model_set_graph mode)
-VARS = {"head": (-1, 1), "no_kv_prefetch": (-1, 1 | 512), "round5": (1 << 30, 1), "stream_all": (1, 1)}
+VARS = {"head": (-1, 1), "no_kv_prefetch": (-1, 1 | 512), "round5": (1 << 30, 1), "stream_all": (1, 1), "stream300": (300, 1), "stream500": (500, 1)}
 names = os.environ.get("AB", "head,round5").split(",")
 for r in range(reps):
     for tag in names:

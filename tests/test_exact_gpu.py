@@ -618,13 +618,18 @@ def test_exact_prefill_attention_mfma_forms(torch, ops, port, D, H, N, n_past):
     scale = np.float32(1.0) / np.sqrt(np.float32(D))
     outs = []
     compact_forms = ((2,) if 512 < P <= 2048 else ()) + ((3,) if 512 < P <= 1024 else ())
-    for which in compact_forms + (0, 1):
+    # (beyond 512 keys V.P has two forms -- eight waves per workgroup, the default, and four: 12 / 11 stand for 2 / 1 with the four-wave form)
+    four_wave = ((12,) if 512 < P <= 2048 else ()) + ((11,) if P > 512 else ())
+    for which in four_wave + compact_forms + (0, 1):
+        L.fl_debug_set(8, 4 if which >= 10 else 8)
+        which %= 10
         att = torch.full((H, N, n_ctx), float("nan"), device="cuda")
         ao = torch.full((N, E), 3.0, device="cuda")
         hip.check(L.fl_debug_attn_exact(qd.data_ptr(), 3 * E, D, H, N, n_past, n_ctx, E, kd.data_ptr(), vd.data_ptr(), ed.data_ptr(),
                                         float(scale), att.data_ptr(), ao.data_ptr(), which, None))
         torch.cuda.synchronize()
         outs.append(ao.cpu().numpy())
+    L.fl_debug_set(8, 8)
     for o in outs[:-1]:
         assert np.array_equal(bits(o), bits(outs[-1])), int((bits(o) != bits(outs[-1])).sum())
     outs = outs[-2:]
