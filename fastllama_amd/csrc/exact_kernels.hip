@@ -1224,7 +1224,6 @@ __global__ __launch_bounds__(256) void attn_pv_exact_kernel(const float *__restr
     };
     auto nothing = [](auto) {};
     constexpr std::integral_constant<int, 1> one_sum{};
-    constexpr std::integral_constant<int, 2> two_sums{};
     if constexpr (one_piece) {
     for (int d0 = 0; d0 < D; d0 += 32) {
         v16f tw;
