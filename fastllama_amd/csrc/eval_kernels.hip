@@ -1195,7 +1195,7 @@ hipError_t softmax_rows(float *S, int ld, int64_t sz, int N, int P, int n_past, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// decode attention (N = 1), one workgroup per head: rope(q, k) -> KV store -> KQ*scale -> soft_max (fp16 table,
+// decode attention (N = 1), one workgroup per head (round 6: two per 128-feature head, see the kernel): rope(q, k) -> KV store -> KQ*scale -> soft_max (fp16 table,
 // f64 sum) -> KQV -> quantize_row_q8_0 of the head's 128 outputs straight into the QA1 workspace of the wo matmul.
 // Replaces five launches (rope_kv, 2 x gemm_f32_abt, softmax_rows, quantize_q8) of the generic path; same op
 // semantics, f32 dots in plain k order.  The position is read from device memory when dyn_past != null.
@@ -1545,7 +1545,7 @@ hipError_t decode_attention(const float *qkv, int E, int D, int H, int n_past, i
 // decode attention for long contexts: the same arithmetic in TWO launches that spread one head over many CUs.
 // One workgroup per head streams 8 KiB of K/V per cached position through a single CU -- beyond a few hundred
 // positions that dominates the token (7B, n_past 1900: 95 us of a 133 us layer).
-//   decode_scores_kernel  grid (heads, 256-position slices): rope(q) [+ rope(k), KV store in the slice that owns the
+//   decode_scores_kernel  grid (heads, 64-position slices): rope(q) [+ rope(k), KV store in the slice that owns the
 //                         fresh position], scaled K.q of the slice -> scores[head][p] in HBM
 //   decode_pv_kernel      grid (heads, D/32): soft_max of the head's score row in LDS (every workgroup repeats it: P
 //                         table lookups), KQV for 32 output features, Q8_0 block of those 32 features
