@@ -60,7 +60,7 @@ int ensure_device() {
 
 }  // namespace fl
 
-namespace fl { extern int g_gemm_force_cfg; extern int g_gemv_force_waves; extern int g_stream_min_groups; extern int g_stream_force_nw; extern int g_pv_waves; }
+namespace fl { extern int g_gemm_force_cfg; extern int g_gemv_force_waves; extern int g_stream_min_groups; extern int g_stream_force_nw; extern int g_pv_waves; extern int g_stream_helpers; }
 using namespace fl;
 
 #define FL_HIP(call)                                   \
@@ -627,6 +627,6 @@ extern "C" const fl::InternalTable *fl_internal_table(void) {
 #define X(name) &fl::name,
         FL_INTERNAL_FUNCS(X)
 #undef X
-        &fl::g_gemm_force_cfg, &fl::g_gemv_force_waves, &fl::g_op_mode, &fl::g_stream_min_groups, &fl::g_stream_force_nw, &fl::g_pv_waves};
+        &fl::g_gemm_force_cfg, &fl::g_gemv_force_waves, &fl::g_op_mode, &fl::g_stream_min_groups, &fl::g_stream_force_nw, &fl::g_pv_waves, &fl::g_stream_helpers};
     return &t;
 }

@@ -64,13 +64,15 @@ struct StreamPrefetch {
     int E, D, H, n_ctx;
 };
 thread_local StreamPrefetch stream_pending_prefetch = {nullptr, nullptr, nullptr, 0, 0, 0, 0};
+int g_stream_helpers = 2;        // fl_debug_set(9, .): prologue-only waves in front of the streaming ones -- 0 never, 1 where a workgroup has its CU to itself, 2 also two eight-wave workgroups per CU
 
 // EPI 0: y[row] = dot (+ resid[row]); 1: woven w1|w3 -> f32 silu(w1 x) * (w3 x); 2: woven w1|w3 -> the Q8_0 blocks (QA1 planes) of those features
 // nw <= MAXW: the waves of a workgroup that stream a row group each (workgroup b: row groups b nw .. b nw + nw - 1); the workgroup has 64 MAXW threads,
 // the others only help with the prologue.  Four by default; launches that would not be resident at four take one workgroup per CU with equal shares
 // (launch_stream below).
 template <int TYPE, int PRO, int EPI, int U, int MAXW, int TAIL>
-__global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void gemv1_q4_exact_stream_kernel(
+// (second bound: waves per SIMD -- two four-wave or two eight-wave workgroups per CU where the launch has more workgroups than CUs)
+__global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : (MAXW == 8 && U == 8) ? 4 : 1) void gemv1_q4_exact_stream_kernel(
     int M, int groups, int nw, int KB, const uint32_t *__restrict__ qwd, const float *__restrict__ dW, const float *__restrict__ xf,
     const void *__restrict__ aux, const float *__restrict__ mW, const int8_t *__restrict__ xq, const float *__restrict__ xd,
     const float *__restrict__ xs, float *__restrict__ y, const float *__restrict__ resid, float *__restrict__ ynorm,
@@ -93,8 +95,13 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void gemv1_q4_exact_s
     GP_DECL(PRO);
     GemvPrologue<PRO, NT, true>::issue(pv, pw, psl, psb, xf, aux, KB, 0);
 
-    const bool active = wave < nw && (int)blockIdx.x * nw + wave < groups;   // (wave-uniform) this wave streams a row group; the others help with the prologue
-    const int grp = min((int)blockIdx.x * nw + wave, groups - 1);
+    // The LAST nw waves of the workgroup stream a row group each (streaming index sw); the waves in front of them only work on the prologue.  With four
+    // such waves (MAXW = nw + 4: the rms_norm prologue is written for the first 256 threads) the prologue is computed by waves whose memory queue is
+    // not full of weight requests: a streaming wave issues its 32 requests for ~3.5 us (the queue fills, the first bytes have to return) and only then
+    // reached the norm -- prologue done 4.7 us into an 11 us launch of LLaMA-7B's wq|wk|wv (profiles/r06_decode_timeline.md).
+    const int sw = wave - (MAXW - nw);
+    const bool active = sw >= 0 && (int)blockIdx.x * nw + sw < groups;       // (wave-uniform) this wave streams a row group
+    const int grp = min((int)blockIdx.x * nw + max(sw, 0), groups - 1);
     const bool live = active;
     const int r = lane >> 2, g = lane & 3;
     // buffer loads: the wave-uniform part (row group, quad) in the scalar offset, one lane offset register per plane; bytes past a plane read as zero
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void gemv1_q4_exact_s
 
 #ifdef LLC_TIMING
     asm volatile("" :: "v"(a0), "v"(a1));
-    if (lane == 0 && wave < 4) tlw_[wave] = wall_clock64();
+    if (lane == 0 && sw >= 0 && sw < 4) tlw_[sw] = wall_clock64();
 #endif
     // ---- the row: ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)) over the quad of lanes that holds it (lane g: accumulators 2g, 2g+1)
     float e = a0, o = a1;
@@ -280,12 +287,12 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void gemv1_q4_exact_s
             put_y(y + row, v);
         }
     } else {
-        if (g == 0) ex[wave][r] = v;
+        if (g == 0 && sw >= 0) ex[sw][r] = v;
         __syncthreads();
         // the workgroup's nw / 4 blocks of 32 features: the first wave of a block's four finishes it
-        const int blk = (int)blockIdx.x * (nw >> 2) + (wave >> 2);
-        if ((wave & 3) == 0 && active) {                                     // feature f of the block in lanes f and f + 32 (both halves compute, the lower stores)
-            const int f = lane & 31, p2 = wave + (f >> 4) * 2;
+        const int blk = (int)blockIdx.x * (nw >> 2) + (max(sw, 0) >> 2);
+        if (sw >= 0 && (sw & 3) == 0 && active) {                            // feature f of the block in lanes f and f + 32 (both halves compute, the lower stores)
+            const int f = lane & 31, p2 = sw + (f >> 4) * 2;
             const float h1 = ex[p2][f & 15], h3 = ex[p2 + 1][f & 15];
             const uint16_t hx = __half_as_ushort(__float2half_rn(h1));                // GGML_FP32_TO_FP16
             const float sl = __half2float(__ushort_as_half(silu_tab[hx]));           // table_silu_f16
@@ -369,10 +376,16 @@ static bool launch_stream(const fl_qtensor &W, const fl_qact *xq, float *y, hipS
         if (g_stream_force_nw > 0) nw = EPI == 0 ? g_stream_force_nw : (g_stream_force_nw + 3) / 4 * 4;
         nw = std::min(nw, 12);
     }
-    const int maxw = nw <= 4 ? 4 : nw <= 8 ? 8 : 12;
+    int maxw = nw <= 4 ? 4 : nw <= 8 ? 8 : 12;
+    // four prologue-only waves in front of four streaming ones, where every workgroup has a CU of its own anyway (wq|wk|wv: 192 workgroups)
+    bool two_per_cu = false;
+    if (g_stream_helpers && PRO == 1 && nw == 4 && (EPI == 0 || g_stream_helpers > 1)) {
+        if ((groups + 3) / 4 <= n_cus) maxw = 8;
+        else if ((groups + 3) / 4 <= 2 * n_cus && g_stream_helpers > 1) maxw = 8, two_per_cu = true;      // (two eight-wave workgroups per CU: 8 quads in flight, 122 registers)
+    }
     // quads in flight per wave: 16 (20 KB per wave, ~170 registers) when that divides the row (K = 4096, 8192) and the workgroup has at most 8 waves
     // (two per SIMD); else 8
-    const bool u16 = (NQ % 16 == 0 || NQ % 16 >= 13) && maxw <= 8;
+    const bool u16 = (NQ % 16 == 0 || NQ % 16 >= 13) && maxw <= 8 && !two_per_cu;
     const int U = u16 ? 16 : 8, NQP = (NQ + U - 1) / U * U;
     const size_t lds = (size_t)NQP * 160;
     if (lds > 60 * 1024) return false;

@@ -27,6 +27,7 @@ int check_mm(const fl_qtensor *W, const fl_qact_impl *a, const float *y, int ldy
 int mul_mat_q_which(const fl_qtensor *W, const fl_qact *a, float *y, int ldy, int which, void *stream);
 // kernel-selection overrides (tuning sweeps and tests; -1 / 0 = automatic): gemm_q4_mfma.hip, q4_kernels.hip
 extern int g_gemm_force_cfg, g_gemv_force_waves;
+extern int g_stream_helpers;              // gemv1_q4_exact_stream.hip: prologue-only waves in wq|wk|wv-sized launches (1 / 0)
 extern int g_pv_waves;                     // exact_kernels.hip: waves per workgroup of the reference-order V.P kernel behind a deep context (8 / 4)
 extern int g_stream_force_nw;              // gemv1_q4_exact_stream.hip: streaming waves per workgroup (0: automatic -- one workgroup per CU)
 extern int g_stream_min_groups;            // gemv1_q4_exact_stream.hip: row groups from which a matrix takes the one-wave-per-row-group form (-1: automatic)
@@ -85,7 +86,7 @@ struct InternalTable {
 #define X(name) decltype(&fl::name) name;
     FL_INTERNAL_FUNCS(X)
 #undef X
-    int *g_gemm_force_cfg, *g_gemv_force_waves, *g_op_mode, *g_stream_min_groups, *g_stream_force_nw, *g_pv_waves;
+    int *g_gemm_force_cfg, *g_gemv_force_waves, *g_op_mode, *g_stream_min_groups, *g_stream_force_nw, *g_pv_waves, *g_stream_helpers;
 };
 }  // namespace fl
 extern "C" __attribute__((visibility("default"))) const fl::InternalTable *fl_internal_table(void);
