@@ -64,7 +64,7 @@ struct StreamPrefetch {
     int E, D, H, n_ctx;
 };
 thread_local StreamPrefetch stream_pending_prefetch = {nullptr, nullptr, nullptr, 0, 0, 0, 0};
-int g_stream_helpers = 2;        // fl_debug_set(9, .): prologue-only waves in front of the streaming ones -- 0 never, 1 where a workgroup has its CU to itself, 2 also two eight-wave workgroups per CU
+int g_stream_helpers = 1;        // fl_debug_set(9, 0 / 1): prologue-only waves in front of the streaming ones (launches of at most two workgroups per CU)
 
 // EPI 0: y[row] = dot (+ resid[row]); 1: woven w1|w3 -> f32 silu(w1 x) * (w3 x); 2: woven w1|w3 -> the Q8_0 blocks (QA1 planes) of those features
 // nw <= MAXW: the waves of a workgroup that stream a row group each (workgroup b: row groups b nw .. b nw + nw - 1); the workgroup has 64 MAXW threads,
@@ -378,14 +378,14 @@ static bool launch_stream(const fl_qtensor &W, const fl_qact *xq, float *y, hipS
     }
     int maxw = nw <= 4 ? 4 : nw <= 8 ? 8 : 12;
     // four prologue-only waves in front of four streaming ones, where every workgroup has a CU of its own anyway (wq|wk|wv: 192 workgroups)
-    bool two_per_cu = false;
-    if (g_stream_helpers && PRO == 1 && nw == 4 && (EPI == 0 || g_stream_helpers > 1)) {
-        if ((groups + 3) / 4 <= n_cus) maxw = 8;
-        else if ((groups + 3) / 4 <= 2 * n_cus && g_stream_helpers > 1) maxw = 8, two_per_cu = true;      // (two eight-wave workgroups per CU: 8 quads in flight, 122 registers)
-    }
+    // (more workgroups than CUs: two eight-wave workgroups per CU at 8 quads in flight, 122-128 registers)
+    if (g_stream_helpers && PRO == 1 && nw == 4 && (groups + 3) / 4 <= 2 * n_cus) maxw = 8;
     // quads in flight per wave: 16 (20 KB per wave, ~170 registers) when that divides the row (K = 4096, 8192) and the workgroup has at most 8 waves
     // (two per SIMD); else 8
-    const bool u16 = (NQ % 16 == 0 || NQ % 16 >= 13) && maxw <= 8 && !two_per_cu;
+    // ... and with the prologue-only waves: 8 -- the streaming waves reach the barrier behind the prologue sooner (wq|wk|wv: 1.529 -> 1.507 ms per token;
+    // 4 quads: 1.60)
+    const bool helpers = maxw == 8 && nw == 4;
+    const bool u16 = (NQ % 16 == 0 || NQ % 16 >= 13) && maxw <= 8 && !helpers;
     const int U = u16 ? 16 : 8, NQP = (NQ + U - 1) / U * U;
     const size_t lds = (size_t)NQP * 160;
     if (lds > 60 * 1024) return false;

@@ -87,7 +87,7 @@ int fl_debug_set(int what, int value) {
     if (what == 0) g_gemm_force_cfg = value;
     if (what == 1) g_gemv_force_waves = value;   // 0 = automatic, else 4 / 8 / 16 waves per 16-row group
     if (what == 2) g_debug_exact = value;            // the single-token test hooks (fl_debug_gemv_*, fl_debug_decode_attention*) in exact mode
-    if (what == 9) g_stream_helpers = value;    // prologue-only waves in front of the streaming ones (wq|wk|wv-sized launches of the one-wave-per-row-group form)
+    if (what == 9) g_stream_helpers = value != 0;    // prologue-only waves in front of the streaming ones (wq|wk|wv-sized launches of the one-wave-per-row-group form)
     if (what == 8) g_pv_waves = value == 4 ? 4 : 8;  // waves per workgroup of the reference-order V.P kernel behind a deep context
     if (what == 7) g_stream_force_nw = value;        // ... and its row groups per workgroup (0 automatic; rounded up to whole 32-feature blocks for the woven forms)
     if (what == 6) g_stream_min_groups = value;      // reference-order N = 1 matmuls: row groups from which the one-wave-per-row-group form runs (-1 automatic, 1 always, 1 << 30 never)

@@ -70,7 +70,7 @@ int fl_debug_mul_mat_q(const fl_qtensor *W, const fl_qact *a, float *y_dev, int 
                        void *stream);
 int fl_debug_qact_layout(const fl_qact *a); /* 16 = QA16, 1 = QA1 */
 int fl_debug_gemm_mixed_split(int row_groups, int col_groups, int *n_a, int *mg_split, int *n_b);  /* host logic of the two-tile-shape launch */
-int fl_debug_set(int what, int value);      /* what 0: force GEMM tile configuration id (-1 = automatic); 1: GEMV waves per row group (0 = automatic); 2: the single-token hooks run the reference-order kernels; 4: = fl_set_op_mode; 5: the form of the reference-order w1|w3 kernel fl_debug_gemv_norm_silu runs (1 / 2, 0 automatic); 6: row groups from which a reference-order N = 1 matmul takes the one-wave-per-row-group form (-1 automatic, 1 always, 1 << 30 never); 7: row groups per workgroup of that form (0 automatic: one workgroup per CU); 8: waves per workgroup of the reference-order V.P kernel behind a deep context (8, the default: two waves per SIMD; 4: the one-wave-per-SIMD form); 9: prologue-only waves in front of the streaming ones of the one-wave-per-row-group form (0 never, 1 where a workgroup has its CU to itself, 2 = the default: also as two eight-wave workgroups per CU) */
+int fl_debug_set(int what, int value);      /* what 0: force GEMM tile configuration id (-1 = automatic); 1: GEMV waves per row group (0 = automatic); 2: the single-token hooks run the reference-order kernels; 4: = fl_set_op_mode; 5: the form of the reference-order w1|w3 kernel fl_debug_gemv_norm_silu runs (1 / 2, 0 automatic); 6: row groups from which a reference-order N = 1 matmul takes the one-wave-per-row-group form (-1 automatic, 1 always, 1 << 30 never); 7: row groups per workgroup of that form (0 automatic: one workgroup per CU); 8: waves per workgroup of the reference-order V.P kernel behind a deep context (8, the default: two waves per SIMD; 4: the one-wave-per-SIMD form); 9: prologue-only waves in front of the streaming ones of the one-wave-per-row-group form (1, the default / 0) */
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

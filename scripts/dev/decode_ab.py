@@ -29,13 +29,13 @@ def run(tag):
     dt = (time.perf_counter() - t0) / steps
     print(f"[{tag}] {name} qtype={QT} n_past={past}: {dt*1e3:.3f} ms/token  {1/dt:.1f} tok/s", flush=True)
 # variants: name -> (fl_debug_set(6, .) value, fl_model_set_graph mode)
-VARS = {"head": (-1, 1), "no_kv_prefetch": (-1, 1 | 512), "round5": (1 << 30, 1), "stream_all": (1, 1), "stream300": (300, 1), "no_helpers": (-1, 1, 0), "helpers_qkv": (-1, 1, 1)}
+VARS = {"head": (-1, 1), "no_kv_prefetch": (-1, 1 | 512), "round5": (1 << 30, 1), "stream_all": (1, 1), "stream300": (300, 1), "no_helpers": (-1, 1, 0)}
 names = os.environ.get("AB", "head,round5").split(",")
 for r in range(reps):
     for tag in names:
         v, mode = VARS[tag][:2]
         L.fl_debug_set(6, v)
-        L.fl_debug_set(9, VARS[tag][2] if len(VARS[tag]) > 2 else 2)
+        L.fl_debug_set(9, VARS[tag][2] if len(VARS[tag]) > 2 else 1)
         L.fl_model_set_graph(m.h, mode ^ 2)   # (the fuse bit flips twice: the captured graph is dropped and the next eval captures the selected kernels)
         L.fl_model_set_graph(m.h, mode)
         run(tag)
