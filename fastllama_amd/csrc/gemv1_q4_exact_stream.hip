@@ -72,7 +72,7 @@ int g_stream_helpers = 1;        // fl_debug_set(9, 0 / 1): prologue-only waves 
 // (launch_stream below).
 template <int TYPE, int PRO, int EPI, int U, int MAXW, int TAIL>
 // (second bound: waves per SIMD -- two four-wave or two eight-wave workgroups per CU where the launch has more workgroups than CUs)
-__global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : (MAXW == 8 && U == 8) ? 4 : 1) void gemv1_q4_exact_stream_kernel(
+__global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : (MAXW == 8 && U == 8) || MAXW == 16 ? 4 : 1) void gemv1_q4_exact_stream_kernel(
     int M, int groups, int nw, int KB, const uint32_t *__restrict__ qwd, const float *__restrict__ dW, const float *__restrict__ xf,
     const void *__restrict__ aux, const float *__restrict__ mW, const int8_t *__restrict__ xq, const float *__restrict__ xd,
     const float *__restrict__ xs, float *__restrict__ y, const float *__restrict__ resid, float *__restrict__ ynorm,
@@ -380,6 +380,7 @@ static bool launch_stream(const fl_qtensor &W, const fl_qact *xq, float *y, hipS
     // four prologue-only waves in front of four streaming ones, where every workgroup has a CU of its own anyway (wq|wk|wv: 192 workgroups)
     // (more workgroups than CUs: two eight-wave workgroups per CU at 8 quads in flight, 122-128 registers)
     if (g_stream_helpers && PRO == 1 && nw == 4 && (groups + 3) / 4 <= 2 * n_cus) maxw = 8;
+    else if (g_stream_helpers && PRO == 1 && nw > 8) maxw = 16;            // (one workgroup per CU with up to twelve streaming waves: LLaMA-65B's w1|w3)
     // quads in flight per wave: 16 (20 KB per wave, ~170 registers) when that divides the row (K = 4096, 8192) and the workgroup has at most 8 waves
     // (two per SIMD); else 8
     // ... and with the prologue-only waves: 8 -- the streaming waves reach the barrier behind the prologue sooner (wq|wk|wv: 1.529 -> 1.507 ms per token;
@@ -406,7 +407,8 @@ static bool launch_stream(const fl_qtensor &W, const fl_qact *xq, float *y, hipS
     if constexpr (PRO == 1) {
         if (maxw == 4) { if (u16) FL_ST_TL(16, 4); else FL_ST_TL(8, 4); }
         else if (maxw == 8) { if (u16) FL_ST_TL(16, 8); else FL_ST_TL(8, 8); }
-        else FL_ST_TL(8, 12);
+        else if (maxw == 12) FL_ST_TL(8, 12);
+        else FL_ST_TL(8, 16);
     } else {
         if (u16) FL_ST_TL(16, 4); else FL_ST_TL(8, 4);
     }
