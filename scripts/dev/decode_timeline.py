@@ -54,7 +54,7 @@ def one_token(graph):
     if len(sraw):
         srec[:, 0:3] = sraw[:, 0:3]
         srec[:, 3] = sraw[:, 3:7].max(axis=1); srec[:, 4] = sraw[:, 7]; srec[:, 5] = sraw[:, 8]; srec[:, 6] = sraw[:, 2]
-        srec[:, 7] = (((sraw[:, 9] >> 32) + 1000) << 32) | (sraw[:, 9] & 0xffffffff)
+        srec[:, 7] = ((((sraw[:, 9] >> 32) | 1) + 1000) << 32) | (sraw[:, 9] & 0xffffffff)      # (| 1: the same row whether the launch runs 8 or 16 quads in flight)
     rec = np.concatenate([fetch(lib.fl_debug_llc_timeline, 1 << 17, 12), fetch(lib.fl_debug_da_timeline, 1 << 14, 8), srec])
     rec = rec[np.argsort(rec[:, 0], kind="stable")]
     kid = rec[:, 7] >> 32
